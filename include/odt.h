@@ -1,0 +1,182 @@
+/*
+ * odt.h -- C ABI of libodt_hip.so, the MI355X (gfx950) implementation of the
+ * per-frame detection + appearance-feature + cosine-matching hot path of
+ * JunweiLiang/Object_Detection_Tracking.
+ *
+ * The reference has no native code and no FFI: the boundary it crosses once
+ * per frame is `sess.run([final_boxes, final_labels, final_probs,
+ * fpn_box_feat], feed_dict)` (reference obj_detect_tracking.py:610-635,
+ * obj_detect_tracking_multi.py:460-466) plus the numpy call
+ * `metric.distance(features, targets)` inside the tracker (reference
+ * deep_sort/tracker.py:94-99 -> deep_sort/nn_matching.py:156-177).  Each entry
+ * point below names the reference interface it replaces.  Plain pointers and
+ * sizes only; every function returns 0 on success, non-zero on error, and
+ * never aborts the process (odt_last_error() gives the message).
+ *
+ * Layouts: frames are HWC BGR (uint8 or float32 0..255) exactly as the
+ * reference feeds them; outputs use the reference's layouts (boxes x1,y1,x2,y2
+ * in resized-image coordinates, features NCHW [R,256,7,7]).
+ */
+#ifndef ODT_H_
+#define ODT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct odt_model* odt_handle;
+
+#define ODT_DTYPE_U8 0
+#define ODT_DTYPE_F32 1
+
+/* graph semantics: the reference ships two different inference graphs */
+#define ODT_GRAPH_SINGLE 0 /* Mask_RCNN_FPN        (models.py:488-973)   b = 1 */
+#define ODT_GRAPH_MULTI 1  /* Mask_RCNN_FPN_multi  (models.py:2058-2408) b = B */
+
+/* Mirrors the fields of the reference's `args`/config namespace that the
+ * inference graph reads (obj_detect_tracking.py:303-387). */
+typedef struct odt_config {
+  int32_t graph;            /* ODT_GRAPH_SINGLE / ODT_GRAPH_MULTI             */
+  int32_t batch;            /* im_batch_size                                  */
+  int32_t height, width;    /* resized frame size fed to forward              */
+  int32_t num_class;        /* incl. background (15)                          */
+  int32_t num_blocks[4];    /* resnet_num_block (3,4,23,3)                    */
+  int32_t use_dilations;    /* model version >= 3                             */
+  int32_t fpn_channels;     /* fpn_num_channel (256)                          */
+  int32_t head_dim;         /* fpn_frcnn_fc_head_dim (1024)                   */
+  int32_t rpn_topk;         /* rpn_test_post_nms_topk (<= 1024)               */
+  int32_t result_per_im;    /* 100                                            */
+  int32_t anchor_field;     /* ceil(max_size/stride0): side of level-0 anchor grid */
+  float rpn_nms_thresh;     /* rpn_proposal_nms_thres (0.7)                   */
+  float rpn_decode_clip;    /* bbox_decode_clip = log(max_size/16)            */
+  float head_decode_clip;   /* log(1333/16) (nn.py:1518 default)              */
+  float bbox_reg_weights[4];/* fastrcnn_bbox_reg_weights (10,10,5,5)          */
+  float result_score_thresh;/* result_score_thres (1e-4)                      */
+  float head_nms_thresh;    /* fastrcnn_nms_iou_thres (0.5)                   */
+} odt_config;
+
+/* Caller-owned host output buffers (capacities in elements of the row type).
+ * Replaces the numpy arrays sess.run returns (models.py:965-973 / :2311-2320).
+ *   boxes  [batch, result_per_im, 4] float32
+ *   probs  [batch, result_per_im]    float32
+ *   labels [batch, result_per_im]    int32 (1-based class id)
+ *   valid  [batch]                   int32 number of detections per frame
+ *   feats  [sum(valid), C, 7, 7]     float32 (may be NULL)   fpn_box_feat
+ *   pooled [sum(valid), C]           float32 (may be NULL)   7x7 mean of feats
+ *                                    (deep_sort/utils.py:27-28 done on device)
+ */
+typedef struct odt_outputs {
+  float* boxes;
+  float* probs;
+  int32_t* labels;
+  int32_t* valid;
+  float* feats;
+  float* pooled;
+} odt_outputs;
+
+const char* odt_last_error(void);
+int odt_device_count(int* count);
+
+/* get_model(config, gpuid) (models.py:97-119): build the static execution
+ * plan, allocate weights + workspace on `device`. */
+int odt_create(const odt_config* cfg, int device, odt_handle* out);
+int odt_destroy(odt_handle h);
+
+/* initialize(config, sess) .npz branch (obj_detect_tracking.py:417-435): load
+ * one variable by its reference name ("conv0/W", "group2/block5/conv2/bn/gamma",
+ * "fastrcnn/fc6/W", ...) in the reference layout (conv HWIO, dense [in,out]).
+ * "anchors/lvl<i>" [S,S,A,4] carries the host-precomputed anchor field. */
+int odt_load_tensor(odt_handle h, const char* name, const float* data,
+                    const int64_t* shape, int rank);
+/* fold BN into conv weights, re-layout to [Cout][kh][kw][Cin], upload. */
+int odt_finalize_weights(odt_handle h);
+
+/* sess.run([final_boxes, final_labels, final_probs, fpn_box_feat], feed)
+ * (obj_detect_tracking.py:632-635).  frames: [batch,H,W,3] BGR; on_device != 0
+ * means `frames` is a device pointer (HBM-resident input).  stream: hipStream_t
+ * to run on (NULL = the handle's own stream).  Blocks until outputs are on the
+ * host. */
+int odt_forward(odt_handle h, const void* frames, int dtype, int on_device,
+                void* stream, odt_outputs* out);
+/* Same, but only enqueues the device work (no D2H, no sync): used to time the
+ * device path with inputs resident in HBM. */
+int odt_forward_async(odt_handle h, const void* frames, int dtype,
+                      int on_device, void* stream);
+int odt_synchronize(odt_handle h);
+
+/* Debug / parity taps: copy a named stage tensor (device layout: NHWC) to the
+ * host.  shape_out receives up to 4 dims.  Names: "image_pad", "conv0",
+ * "pool0", "c2".."c5", "p2".."p6", "rpn2".."rpn6" (15 ch: 3 logits + 12
+ * deltas), "proposals", "nproposals", "roi_feat", "fc7", "head_out",
+ * "decoded_boxes", "label_probs". */
+int odt_tap(odt_handle h, const char* name, float* dst, size_t cap_elems,
+            int64_t* shape_out, int* rank_out);
+
+/* Per-launch timing of the implicit-GEMM conv kernel family, measured with
+ * HIP events on the launch stream (for bench.py's roofline object). */
+int odt_profile_enable(odt_handle h, int enable);
+int odt_profile_read(odt_handle h, double* conv_ms, double* conv_flops,
+                     int* conv_launches, double* total_ms);
+
+/* NearestNeighborDistanceMetric.distance (deep_sort/nn_matching.py:156-177,
+ * _nn_cosine_distance :78-96): gallery [G,D] float32 rows of all tracks
+ * concatenated, seg_offsets [T+1] row ranges per track, dets [N,D];
+ * cost [T,N] float64 = min over a track's rows of 1 - cos.  Host pointers. */
+int odt_nn_cosine(int device, const float* gallery, const int32_t* seg_offsets,
+                  int T, const float* dets, int N, int D, double* cost);
+
+/* ---- stand-alone op entry points (host pointers), used by the staged parity
+ * tests; each runs exactly the kernels odt_forward uses. ------------------- */
+
+/* conv2d (nn.py:337-381) + folded BN + optional residual + ReLU.
+ * in [B,H,W,ldc] NHWC (first Cin channels used), wt HWIO [kh,kw,Cin,Cout],
+ * out [B,Ho+oy,Wo+ox,Cout] written at offset (oy,ox) (rest zero).
+ * res_mode 0 none, 1 same-shape [B,Ho,Wo,Cout], 2 nearest-2x of
+ * [B,ceil(Ho/2),ceil(Wo/2),Cout]. */
+int odt_op_conv2d(int device, const float* in, int B, int H, int W, int Cin,
+                  const float* wt, const float* bias, int kh, int kw, int Cout,
+                  int stride, int dil, int pad_t, int pad_l, int Ho, int Wo,
+                  int oy, int ox, const float* res, int res_mode, int relu,
+                  float* out);
+/* image preprocess (models.py:340-355) + zero pad -> [B,Hp,Wp,4] */
+int odt_op_preprocess(int device, const void* frames, int dtype, int B, int H,
+                      int W, int pad_t, int pad_l, int Hp, int Wp, float* out);
+/* 3x3 stride-2 max pool after zero pad top/left 1 (nn.py:890-896), NHWC */
+int odt_op_maxpool(int device, const float* in, int B, int H, int W, int C,
+                   float* out);
+/* tf.nn.top_k canonical (score desc, index asc) */
+int odt_op_topk(int device, const float* scores, int n, int k, int32_t* idx_out);
+/* tf.image.non_max_suppression (ties: lower index first) */
+int odt_op_nms(int device, const float* boxes, const float* scores, int n,
+               int max_out, float iou_thresh, int32_t* idx_out, int* n_out);
+/* generate_fpn_proposals (models.py:402-436 / :2458-2522): rpn [L][B,h,w,15],
+ * anchors [L][S_l,S_l,3,4]; out props [B,K,4], nprops [B]. */
+int odt_op_proposals(int device, int graph, int B, int L, const int* hs,
+                     const int* ws, const int* fields, const float* const* rpn,
+                     const float* const* anchors, int img_h, int img_w, int K,
+                     float nms_thresh, float decode_clip, float* props,
+                     int32_t* nprops);
+/* multilevel_roi_align (models.py:465-485): feats[4] NHWC [B,h_l,w_l,C];
+ * boxes [R,4] image coords, box_ind [R]; out NCHW [R,C,7,7], pooled [R,C]. */
+int odt_op_roi_align(int device, int B, int C, const int* hs, const int* ws,
+                     const float* const* feats, const float* strides,
+                     const float* boxes, const int32_t* box_ind, int R,
+                     float* out_nchw, float* pooled);
+/* inference tail (models.py:828-843 + fastrcnn_predictions :1258-1304 or
+ * fastrcnn_predictions_multibatch :2924-2976).  cls_logits [B*K,C],
+ * box_logits [B*K,C,4] (class 0 present, ignored), props [B,K,4], nprops [B]. */
+int odt_op_detections(int device, int graph, int B, int K, int C,
+                      const float* cls_logits, const float* box_logits,
+                      const float* props, const int32_t* nprops, int img_h,
+                      int img_w, const float* reg_weights, float decode_clip,
+                      float score_thresh, float nms_thresh, int per_im,
+                      float* boxes, float* probs, int32_t* labels,
+                      int32_t* valid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODT_H_ */

@@ -1,0 +1,143 @@
+// HBM-bound elementwise kernels of the detector front end (gfx950).
+//   preprocess : reference models.py:340-355 ((x*(1/255) - mean_bgr)/std_bgr) fused with
+//                the zero pad of nn.py:871-878 and an HWC3 -> HWC4 repack so conv0 can read
+//                its 7x(8 taps x 4 ch) rows as contiguous 128-byte slices.
+//   maxpool    : reference nn.py:890-896 (zero pad top/left 1, 3x3 stride-2 VALID max).
+#include "odt_common.hpp"
+
+namespace odt {
+namespace {
+
+template <typename T>
+__global__ void __launch_bounds__(256) preprocess_kernel(const T* __restrict__ frames, int B, int H,
+                                                         int W, int pad_t, int pad_l, int Hp, int Wp,
+                                                         float* __restrict__ out) {
+  const long total = (long)B * Hp * Wp;
+  // BGR mean / std (models.py:343-351: RGB constants reversed)
+  const float mean0 = 0.406f, mean1 = 0.456f, mean2 = 0.485f;
+  const float std0 = 0.225f, std1 = 0.224f, std2 = 0.229f;
+  const float inv255 = (float)(1.0 / 255);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wp);
+    const long t = i / Wp;
+    const int y = (int)(t % Hp);
+    const int b = (int)(t / Hp);
+    const int sy = y - pad_t, sx = x - pad_l;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) {
+      const T* src = frames + (((long)b * H + sy) * W + sx) * 3;
+      v[0] = ((float)src[0] * inv255 - mean0) / std0;
+      v[1] = ((float)src[1] * inv255 - mean1) / std1;
+      v[2] = ((float)src[2] * inv255 - mean2) / std2;
+    }
+    *reinterpret_cast<f32x4*>(out + i * 4) = v;
+  }
+}
+
+// one thread per (pixel, 4-channel group); channels contiguous -> 16-byte accesses
+__global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const float* __restrict__ in, int B, int H,
+                                                           int W, int C, float* __restrict__ out,
+                                                           int Ho, int Wo) {
+  const int c4n = C >> 2;
+  const long total = (long)B * Ho * Wo * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    long t = i / c4n;
+    const int xo = (int)(t % Wo);
+    t /= Wo;
+    const int yo = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    bool any_pad = false;
+    f32x4 m = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int y = 2 * yo + dy - 1;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int x = 2 * xo + dx - 1;
+        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+          const f32x4 v =
+              *reinterpret_cast<const f32x4*>(in + (((long)b * H + y) * W + x) * C + c4 * 4);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], v[k]);
+        } else {
+          any_pad = true;   // tf.pad zeros take part in the max
+        }
+      }
+    }
+    if (any_pad) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(out + i * 4) = m;
+  }
+}
+
+// P6 = 1x1 max-pool stride 2 of P5 (nn.py:1011-1013) == [::2, ::2]
+__global__ void __launch_bounds__(256) subsample2_kernel(const float* __restrict__ in, int B, int H,
+                                                         int W, int C, float* __restrict__ out, int Ho,
+                                                         int Wo) {
+  const int c4n = C >> 2;
+  const long total = (long)B * Ho * Wo * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    long t = i / c4n;
+    const int xo = (int)(t % Wo);
+    t /= Wo;
+    const int yo = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    *reinterpret_cast<f32x4*>(out + i * 4) =
+        *reinterpret_cast<const f32x4*>(in + (((long)b * H + 2 * yo) * W + 2 * xo) * C + c4 * 4);
+  }
+}
+
+inline unsigned grid_for(long total) {
+  long g = (total + 255) / 256;
+  if (g > 256 * 8) g = 256 * 8;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+int launch_preprocess(const void* frames, int dtype, int B, int H, int W, int pad_t, int pad_l,
+                      int Hp, int Wp, float* out, hipStream_t stream) {
+  const long total = (long)B * Hp * Wp;
+  if (dtype == 0) {
+    hipLaunchKernelGGL(preprocess_kernel<unsigned char>, dim3(grid_for(total)), dim3(256), 0, stream,
+                       (const unsigned char*)frames, B, H, W, pad_t, pad_l, Hp, Wp, out);
+  } else if (dtype == 1) {
+    hipLaunchKernelGGL(preprocess_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream,
+                       (const float*)frames, B, H, W, pad_t, pad_l, Hp, Wp, out);
+  } else {
+    set_error("preprocess: dtype must be ODT_DTYPE_U8 or ODT_DTYPE_F32");
+    return 1;
+  }
+  ODT_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_subsample2(const float* in, int B, int H, int W, int C, float* out, int Ho, int Wo,
+                      hipStream_t stream) {
+  ODT_CHECK(C % 4 == 0, "subsample2: C must be a multiple of 4");
+  const long total = (long)B * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(subsample2_kernel, dim3(grid_for(total)), dim3(256), 0, stream, in, B, H, W, C, out,
+                     Ho, Wo);
+  ODT_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_maxpool3x3s2(const float* in, int B, int H, int W, int C, float* out, int Ho, int Wo,
+                        hipStream_t stream) {
+  ODT_CHECK(C % 4 == 0, "maxpool: C must be a multiple of 4");
+  const long total = (long)B * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, stream, in, B, H, W, C,
+                     out, Ho, Wo);
+  ODT_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace odt

@@ -1,0 +1,890 @@
+// libodt_hip.so -- C ABI (include/odt.h) over the gfx950 kernels: static execution plan of the
+// reference's inference graph, weight ingest (BN folding, layout
+// change to [Cout][kh][kw][Cin]), workspace, forward, taps and the stand-alone op entry points.
+// Host code only; every device kernel lives in the sibling .hip files.
+#include "../../include/odt.h"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "odt_common.hpp"
+
+namespace odt {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+int launch_subsample2(const float* in, int B, int H, int W, int C, float* out, int Ho, int Wo,
+                      hipStream_t stream);
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int alloc(size_t n) {
+    bytes = n;
+    if (n == 0) n = 256;
+    ODT_HIP(hipMalloc(&p, n));
+    return 0;
+  }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+};
+
+struct Tensor {      // NHWC device tensor; (h,w) = logical (possibly sliced) dims
+  float* d = nullptr;
+  int B = 0, H = 0, W = 0, C = 0;   // allocation dims (C = pixel stride)
+  int h = 0, w = 0, c = 0;          // logical dims
+  size_t elems() const { return (size_t)B * H * W * C; }
+};
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+};
+
+struct ConvOp {
+  ConvParams p;
+  std::string name;
+};
+
+enum OpKind { OP_PRE, OP_CONV, OP_POOL, OP_SUB2, OP_PROPOSALS, OP_ROI_HEAD, OP_DETECT, OP_ROI_FINAL };
+struct Op {
+  OpKind kind;
+  int conv = -1;        // index into convs
+  Tensor in, out;
+};
+
+}  // namespace
+}  // namespace odt
+
+using namespace odt;
+
+struct odt_model {
+  odt_config cfg;
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  bool finalized = false;
+  std::map<std::string, HostTensor> host_w;
+  std::vector<std::unique_ptr<DevBuf>> bufs;
+  std::map<std::string, Tensor> taps;
+  std::vector<ConvOp> convs;
+  std::vector<Op> ops;
+  // geometry
+  int Hp = 0, Wp = 0;
+  // proposal / head / detection state
+  ProposalParams prop{};
+  RoiAlignParams roi_head{}, roi_final{};
+  DetectParams det{};
+  Tensor image_pad, frames_dev;
+  float* anchors_dev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* final_feat = nullptr;    // [B*per_im, C, 7, 7] packed
+  float* final_pooled = nullptr;  // [B*per_im, C]
+  size_t frames_bytes = 0;
+  // profiling
+  bool profile = false;
+  std::vector<hipEvent_t> ev;
+  hipEvent_t ev_total[2] = {nullptr, nullptr};
+  double prof_conv_ms = 0, prof_conv_flops = 0, prof_total_ms = 0;
+  int prof_launches = 0;
+
+  float* alloc_f(size_t elems, bool zero) {
+    bufs.emplace_back(new DevBuf());
+    if (bufs.back()->alloc(elems * sizeof(float))) return nullptr;
+    if (zero && hipMemset(bufs.back()->p, 0, elems * sizeof(float)) != hipSuccess) return nullptr;
+    return (float*)bufs.back()->p;
+  }
+};
+
+namespace {
+
+int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+int make_tensor(odt_model* m, const std::string& name, int B, int H, int W, int C, Tensor* t,
+                bool zero = false) {
+  t->B = B; t->H = H; t->W = W; t->C = C; t->h = H; t->w = W; t->c = C;
+  t->d = m->alloc_f(t->elems(), zero);
+  ODT_CHECK(t->d != nullptr, "device allocation failed for " + name + ": " + g_err);
+  if (!name.empty()) m->taps[name] = *t;
+  return 0;
+}
+
+const HostTensor* find_w(odt_model* m, const std::string& name) {
+  auto it = m->host_w.find(name);
+  return it == m->host_w.end() ? nullptr : &it->second;
+}
+
+// Upload conv weights in [Cout][kh][kw][Cin] with optional folded BN; returns device ptrs.
+int upload_conv(odt_model* m, const std::string& scope, int kh, int kw, int cin, int cout,
+                bool has_bn, const float** wt_out, const float** bias_out) {
+  const HostTensor* W = find_w(m, scope + "/W");
+  ODT_CHECK(W != nullptr, "missing weight " + scope + "/W");
+  ODT_CHECK(W->data.size() == (size_t)kh * kw * cin * cout,
+            "bad shape for " + scope + "/W");
+  std::vector<double> scale(cout, 1.0), shift(cout, 0.0);
+  if (has_bn) {
+    const HostTensor* g = find_w(m, scope + "/bn/gamma");
+    const HostTensor* b = find_w(m, scope + "/bn/beta");
+    const HostTensor* mu = find_w(m, scope + "/bn/mean/EMA");
+    const HostTensor* var = find_w(m, scope + "/bn/variance/EMA");
+    ODT_CHECK(g && b && mu && var, "missing BN variables for " + scope);
+    for (int o = 0; o < cout; ++o) {   // tf.nn.batch_normalization, eps 1e-5 (nn.py:1771-1774)
+      const double inv = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
+      scale[o] = inv;
+      shift[o] = (double)b->data[o] - (double)mu->data[o] * inv;
+    }
+  } else {
+    const HostTensor* b = find_w(m, scope + "/b");
+    ODT_CHECK(b != nullptr, "missing bias " + scope + "/b");
+    for (int o = 0; o < cout; ++o) shift[o] = b->data[o];
+  }
+  std::vector<float> wt((size_t)cout * kh * kw * cin), bias(cout);
+  for (int y = 0; y < kh; ++y)
+    for (int x = 0; x < kw; ++x)
+      for (int i = 0; i < cin; ++i)
+        for (int o = 0; o < cout; ++o)
+          wt[(((size_t)o * kh + y) * kw + x) * cin + i] =
+              (float)((double)W->data[(((size_t)y * kw + x) * cin + i) * cout + o] * scale[o]);
+  for (int o = 0; o < cout; ++o) bias[o] = (float)shift[o];
+  float* dw = m->alloc_f(wt.size(), false);
+  float* db = m->alloc_f(bias.size(), false);
+  ODT_CHECK(dw && db, "device allocation failed for weights of " + scope);
+  ODT_HIP(hipMemcpy(dw, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+  ODT_HIP(hipMemcpy(db, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+  *wt_out = dw; *bias_out = db;
+  return 0;
+}
+
+int upload_raw(odt_model* m, const std::vector<float>& v, const float** out) {
+  float* d = m->alloc_f(v.size(), false);
+  ODT_CHECK(d != nullptr, "device allocation failed");
+  ODT_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+  *out = d;
+  return 0;
+}
+
+// Append a conv op.  `in` logical dims (h,w) bound the reads; output tensor is created here
+// unless `out_existing` is given.
+int add_conv(odt_model* m, const std::string& name, const Tensor& in, int cin, const float* wt,
+             const float* bias, int kh, int kw, int cout, int stride, int dil, int pad_t, int pad_l,
+             int Ho, int Wo, int oy, int ox, const Tensor* res, int res_mode, bool relu,
+             int out_ldc, Tensor* out, const std::string& tap) {
+  ConvOp c;
+  c.name = name;
+  ConvParams& p = c.p;
+  std::memset(&p, 0, sizeof(p));
+  if (out->d == nullptr) {
+    if (make_tensor(m, tap, in.B, Ho + oy, Wo + ox, out_ldc, out, oy != 0 || ox != 0 || out_ldc != cout))
+      return 1;
+    out->c = cout;
+  }
+  p.in = in.d; p.wt = wt; p.bias = bias; p.out = out->d;
+  p.res = res ? res->d : nullptr;
+  p.B = in.B; p.H = in.h; p.W = in.w; p.Cin = cin; p.in_ldc = in.C;
+  p.in_Ha = in.H; p.in_Wa = in.W;   // sliced views keep the allocation pitch
+  p.Ho = Ho; p.Wo = Wo; p.Cout = cout;
+  p.kh = kh; p.kw = kw; p.stride = stride; p.dil = dil; p.pad_t = pad_t; p.pad_l = pad_l;
+  p.out_H = out->H; p.out_W = out->W; p.out_oy = oy; p.out_ox = ox; p.out_ldc = out->C;
+  p.res_mode = res ? res_mode : 0;
+  if (res) { p.res_H = res->H; p.res_W = res->W; p.res_ldc = res->C; }
+  p.relu = relu ? 1 : 0;
+  m->convs.push_back(c);
+  Op op;
+  op.kind = OP_CONV;
+  op.conv = (int)m->convs.size() - 1;
+  m->ops.push_back(op);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* odt_last_error(void) { return g_err.c_str(); }
+
+int odt_device_count(int* count) {
+  ODT_CHECK(count != nullptr, "null argument");
+  ODT_HIP(hipGetDeviceCount(count));
+  return 0;
+}
+
+int odt_create(const odt_config* cfg, int device, odt_handle* out) {
+  ODT_CHECK(cfg && out, "odt_create: null argument");
+  ODT_CHECK(cfg->batch >= 1 && cfg->height >= 64 && cfg->width >= 64, "odt_create: bad geometry");
+  ODT_CHECK(cfg->rpn_topk >= 1 && cfg->rpn_topk <= kMaxTopK, "odt_create: rpn_topk must be in [1,1024]");
+  ODT_CHECK(cfg->fpn_channels % 32 == 0 && cfg->head_dim % 32 == 0, "odt_create: channel counts must be multiples of 32");
+  ODT_CHECK(cfg->graph == ODT_GRAPH_SINGLE || cfg->graph == ODT_GRAPH_MULTI, "odt_create: bad graph");
+  ODT_CHECK(cfg->graph == ODT_GRAPH_MULTI || cfg->batch == 1,
+            "odt_create: the Mask_RCNN_FPN graph is single-image (obj_detect_tracking.py:241-242)");
+  int n = 0;
+  ODT_HIP(hipGetDeviceCount(&n));
+  ODT_CHECK(device >= 0 && device < n, "odt_create: no such device");
+  ODT_HIP(hipSetDevice(device));
+  std::unique_ptr<odt_model> m(new odt_model());
+  m->cfg = *cfg;
+  m->device = device;
+  ODT_HIP(hipStreamCreate(&m->own_stream));
+  *out = m.release();
+  return 0;
+}
+
+int odt_destroy(odt_handle h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  for (auto e : h->ev) (void)hipEventDestroy(e);
+  for (auto e : h->ev_total) if (e) (void)hipEventDestroy(e);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+  return 0;
+}
+
+int odt_load_tensor(odt_handle h, const char* name, const float* data, const int64_t* shape, int rank) {
+  ODT_CHECK(h && name && data && shape && rank >= 1 && rank <= 4, "odt_load_tensor: bad argument");
+  ODT_CHECK(!h->finalized, "odt_load_tensor: weights already finalized");
+  HostTensor t;
+  size_t n = 1;
+  for (int i = 0; i < rank; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+  t.data.assign(data, data + n);
+  h->host_w[name] = std::move(t);
+  return 0;
+}
+
+}  // extern "C"
+
+namespace {
+
+// Build the whole static plan (called from odt_finalize_weights).
+int build_plan(odt_model* m) {
+  const odt_config& cfg = m->cfg;
+  const int B = cfg.batch, H = cfg.height, W = cfg.width;
+  const int FC = cfg.fpn_channels;
+  // ---- front end geometry (nn.py:860-896; tf_pad_reverse => pad [3, 2 + pad_to_32])
+  const int ph = ceil_div(H, 32) * 32 - H, pw = ceil_div(W, 32) * 32 - W;
+  const int Hp = 3 + H + 2 + ph, Wpl = 3 + W + 2 + pw;
+  const int Ho0 = (Hp - 7) / 2 + 1, Wo0 = (Wpl - 7) / 2 + 1;
+  const int Wp = 2 * Wo0 + 8;          // room for the 8th (zero-weight) tap of the last window
+  m->Hp = Hp; m->Wp = Wp;
+  if (make_tensor(m, "image_pad", B, Hp, Wp, 4, &m->image_pad)) return 1;
+  m->frames_bytes = (size_t)B * H * W * 3 * sizeof(float);
+  { m->bufs.emplace_back(new DevBuf()); if (m->bufs.back()->alloc(m->frames_bytes)) return 1;
+    m->frames_dev.d = (float*)m->bufs.back()->p; }
+  { Op op; op.kind = OP_PRE; m->ops.push_back(op); }
+
+  // ---- conv0: 7x7 s2 VALID as a 7x1 conv over 8-tap x 4-channel rows (K = 7*32)
+  const float *wt = nullptr, *bias = nullptr;
+  {
+    const HostTensor* W0 = find_w(m, "conv0/W");
+    ODT_CHECK(W0 && W0->data.size() == (size_t)7 * 7 * 3 * 64, "missing/bad conv0/W");
+    HostTensor v;   // virtual HWIO [7,1,32,64]
+    v.data.assign((size_t)7 * 32 * 64, 0.f);
+    for (int y = 0; y < 7; ++y)
+      for (int x = 0; x < 7; ++x)
+        for (int c = 0; c < 3; ++c)
+          for (int o = 0; o < 64; ++o)
+            v.data[((size_t)y * 32 + x * 4 + c) * 64 + o] = W0->data[(((size_t)y * 7 + x) * 3 + c) * 64 + o];
+    m->host_w["__conv0v/W"] = v;
+    for (const char* s : {"gamma", "beta", "mean/EMA", "variance/EMA"}) {
+      const HostTensor* t = find_w(m, std::string("conv0/bn/") + s);
+      ODT_CHECK(t != nullptr, std::string("missing conv0/bn/") + s);
+      m->host_w[std::string("__conv0v/bn/") + s] = *t;
+    }
+    if (upload_conv(m, "__conv0v", 7, 1, 32, 64, true, &wt, &bias)) return 1;
+  }
+  Tensor x{};
+  if (add_conv(m, "conv0", m->image_pad, 32, wt, bias, 7, 1, 64, 2, 1, 0, 0, Ho0, Wo0, 0, 0, nullptr, 0,
+               true, 64, &x, "conv0")) return 1;
+  // ---- pool0: pad top/left 1, 3x3 s2 VALID max
+  Tensor pool{};
+  const int Hq = (Ho0 + 1 - 3) / 2 + 1, Wq = (Wo0 + 1 - 3) / 2 + 1;
+  if (make_tensor(m, "pool0", B, Hq, Wq, 64, &pool)) return 1;
+  { Op op; op.kind = OP_POOL; op.in = x; op.out = pool; m->ops.push_back(op); }
+  x = pool;
+
+  // ---- ResNet groups (nn.py:459-588, 898-936)
+  Tensor cfeat[4];
+  const int feats[4] = {64, 128, 256, 512};
+  int cin = 64;
+  for (int g = 0; g < 4; ++g) {
+    const int cnt = cfg.num_blocks[g], ch = feats[g];
+    for (int i = 0; i < cnt; ++i) {
+      const std::string pre = "group" + std::to_string(g) + "/block" + std::to_string(i);
+      const int stride = (i == 0 && g > 0) ? 2 : 1;
+      const int dil = (g == 3 && cfg.use_dilations && i >= cnt - 3) ? 2 : 1;
+      Tensor t1{}, t2{}, sc = x, y{};
+      if (upload_conv(m, pre + "/conv1", 1, 1, cin, ch, true, &wt, &bias)) return 1;
+      if (add_conv(m, pre + "/conv1", x, cin, wt, bias, 1, 1, ch, 1, 1, 0, 0, x.h, x.w, 0, 0, nullptr, 0,
+                   true, ch, &t1, "")) return 1;
+      if (upload_conv(m, pre + "/conv2", 3, 3, ch, ch, true, &wt, &bias)) return 1;
+      int Ho, Wo;
+      if (stride == 2) {
+        const int keff = 2 * dil + 1;
+        const int h2 = (x.h + 1 - keff) / 2 + 1, w2 = (x.w + 1 - keff) / 2 + 1;
+        const int off = dil != 1 ? 1 : 0;       // nn.py:493-497 second pad, after BN+ReLU
+        if (add_conv(m, pre + "/conv2", t1, ch, wt, bias, 3, 3, ch, 2, dil, 1, 1, h2, w2, off, off,
+                     nullptr, 0, true, ch, &t2, "")) return 1;
+        Ho = h2 + off; Wo = w2 + off;
+      } else {
+        if (add_conv(m, pre + "/conv2", t1, ch, wt, bias, 3, 3, ch, 1, dil, dil, dil, x.h, x.w, 0, 0,
+                     nullptr, 0, true, ch, &t2, "")) return 1;
+        Ho = x.h; Wo = x.w;
+      }
+      if (cin != ch * 4) {
+        if (upload_conv(m, pre + "/convshortcut", 1, 1, cin, ch * 4, true, &wt, &bias)) return 1;
+        Tensor s{};
+        if (stride == 2) {
+          Tensor xc = x;              // shortcut[:, :, :-1, :-1] (nn.py:555-556)
+          xc.h = x.h - 1; xc.w = x.w - 1;
+          const int hs = (xc.h - 1) / 2 + 1, ws = (xc.w - 1) / 2 + 1;
+          ODT_CHECK(hs == Ho && ws == Wo, "shortcut / conv2 geometry mismatch in " + pre);
+          if (add_conv(m, pre + "/convshortcut", xc, cin, wt, bias, 1, 1, ch * 4, 2, 1, 0, 0, hs, ws, 0, 0,
+                       nullptr, 0, false, ch * 4, &s, "")) return 1;
+        } else {
+          if (add_conv(m, pre + "/convshortcut", x, cin, wt, bias, 1, 1, ch * 4, 1, 1, 0, 0, x.h, x.w, 0,
+                       0, nullptr, 0, false, ch * 4, &s, "")) return 1;
+        }
+        sc = s;
+      }
+      if (upload_conv(m, pre + "/conv3", 1, 1, ch, ch * 4, true, &wt, &bias)) return 1;
+      const std::string tap = (i == cnt - 1) ? "c" + std::to_string(g + 2) : (i == 0 ? pre : "");
+      if (add_conv(m, pre + "/conv3", t2, ch, wt, bias, 1, 1, ch * 4, 1, 1, 0, 0, Ho, Wo, 0, 0, &sc, 1,
+                   true, ch * 4, &y, tap)) return 1;
+      x = y;
+      cin = ch * 4;
+    }
+    cfeat[g] = x;
+  }
+
+  // ---- FPN (nn.py:947-1014): lateral 1x1 (+ nearest-2x top-down add), posthoc 3x3, P6
+  Tensor lat[4], P[5];
+  for (int l = 3; l >= 0; --l) {
+    const std::string sc = "fpn/lateral_1x1_c" + std::to_string(l + 2);
+    if (upload_conv(m, sc, 1, 1, cfeat[l].c, FC, false, &wt, &bias)) return 1;
+    const Tensor* res = l < 3 ? &lat[l + 1] : nullptr;
+    if (res) ODT_CHECK(res->H * 2 == cfeat[l].h && res->W * 2 == cfeat[l].w, "FPN levels are not exact 2x");
+    lat[l] = Tensor{};
+    if (add_conv(m, sc, cfeat[l], cfeat[l].c, wt, bias, 1, 1, FC, 1, 1, 0, 0, cfeat[l].h, cfeat[l].w, 0, 0,
+                 res, 2, false, FC, &lat[l], "")) return 1;
+  }
+  for (int l = 0; l < 4; ++l) {
+    const std::string sc = "fpn/posthoc_3x3_p" + std::to_string(l + 2);
+    if (upload_conv(m, sc, 3, 3, FC, FC, false, &wt, &bias)) return 1;
+    P[l] = Tensor{};
+    if (add_conv(m, sc, lat[l], FC, wt, bias, 3, 3, FC, 1, 1, 1, 1, lat[l].h, lat[l].w, 0, 0, nullptr, 0,
+                 false, FC, &P[l], "")) return 1;
+  }
+  {
+    const int h6 = (P[3].h - 1) / 2 + 1, w6 = (P[3].w - 1) / 2 + 1;
+    if (make_tensor(m, "p6", B, h6, w6, FC, &P[4])) return 1;
+    Op op; op.kind = OP_SUB2; op.in = P[3]; op.out = P[4]; m->ops.push_back(op);
+  }
+  // slice_feature_and_anchors (models.py:372-400): P2..P4 cropped to ceil(H / stride)
+  const int strides[5] = {4, 8, 16, 32, 64};
+  for (int l = 0; l < 3; ++l) {
+    const int th = (int)std::ceil((float)H * (float)(1.0 / strides[l]));
+    const int tw = (int)std::ceil((float)W * (float)(1.0 / strides[l]));
+    ODT_CHECK(th <= P[l].H && tw <= P[l].W, "sliced feature larger than the feature map");
+    P[l].h = th; P[l].w = tw;
+  }
+  for (int l = 0; l < 5; ++l) m->taps["p" + std::to_string(l + 2)] = P[l];
+
+  // ---- RPN head (models.py:979-1009), class(3) + box(12) merged into one 15-channel 1x1
+  const float *w_r0, *b_r0, *w_r1, *b_r1;
+  if (upload_conv(m, "rpn/conv0", 3, 3, FC, FC, false, &w_r0, &b_r0)) return 1;
+  {
+    const HostTensor* wc = find_w(m, "rpn/class/W"); const HostTensor* bc = find_w(m, "rpn/class/b");
+    const HostTensor* wb = find_w(m, "rpn/box/W"); const HostTensor* bb = find_w(m, "rpn/box/b");
+    ODT_CHECK(wc && bc && wb && bb, "missing rpn/class or rpn/box variables");
+    ODT_CHECK(wc->data.size() == (size_t)FC * 3 && wb->data.size() == (size_t)FC * 12, "bad rpn head shapes");
+    HostTensor v, vb;
+    v.data.resize((size_t)FC * 15); vb.data.resize(15);
+    for (int i = 0; i < FC; ++i) {
+      for (int a = 0; a < 3; ++a) v.data[(size_t)i * 15 + a] = wc->data[(size_t)i * 3 + a];
+      for (int j = 0; j < 12; ++j) v.data[(size_t)i * 15 + 3 + j] = wb->data[(size_t)i * 12 + j];
+    }
+    for (int a = 0; a < 3; ++a) vb.data[a] = bc->data[a];
+    for (int j = 0; j < 12; ++j) vb.data[3 + j] = bb->data[j];
+    m->host_w["__rpnhead/W"] = v; m->host_w["__rpnhead/b"] = vb;
+    if (upload_conv(m, "__rpnhead", 1, 1, FC, 15, false, &w_r1, &b_r1)) return 1;
+  }
+  Tensor rpn_out[5];
+  for (int l = 0; l < 5; ++l) {
+    Tensor t{};
+    if (add_conv(m, "rpn/conv0@p" + std::to_string(l + 2), P[l], FC, w_r0, b_r0, 3, 3, FC, 1, 1, 1, 1,
+                 P[l].h, P[l].w, 0, 0, nullptr, 0, true, FC, &t, "")) return 1;
+    rpn_out[l] = Tensor{};
+    if (add_conv(m, "rpn/head@p" + std::to_string(l + 2), t, FC, w_r1, b_r1, 1, 1, 15, 1, 1, 0, 0, P[l].h,
+                 P[l].w, 0, 0, nullptr, 0, false, kRpnCh, &rpn_out[l], "rpn" + std::to_string(l + 2)))
+      return 1;
+  }
+
+  // ---- proposals
+  const int K = cfg.rpn_topk, L = 5;
+  ProposalParams& pp = m->prop;
+  pp.nlevels = L; pp.graph = cfg.graph; pp.B = B; pp.K = K; pp.img_h = H; pp.img_w = W;
+  pp.nms_thresh = cfg.rpn_nms_thresh; pp.decode_clip = cfg.rpn_decode_clip;
+  for (int l = 0; l < L; ++l) {
+    const HostTensor* a = find_w(m, "anchors/lvl" + std::to_string(l));
+    ODT_CHECK(a != nullptr && a->shape.size() == 4 && a->shape[2] == 3 && a->shape[3] == 4 &&
+              a->shape[0] == a->shape[1], "missing/bad anchors/lvl" + std::to_string(l));
+    ODT_CHECK(a->shape[0] >= rpn_out[l].h && a->shape[0] >= rpn_out[l].w, "anchor field smaller than feature map");
+    const float* d;
+    if (upload_raw(m, a->data, &d)) return 1;
+    pp.lvl[l].rpn = rpn_out[l].d; pp.lvl[l].anchors = d; pp.lvl[l].h = rpn_out[l].h; pp.lvl[l].w = rpn_out[l].w;
+    pp.lvl[l].field = (int)a->shape[0];
+    ODT_CHECK(rpn_out[l].H == rpn_out[l].h && rpn_out[l].W == rpn_out[l].w, "rpn output must be dense");
+  }
+  const size_t per = (size_t)B * L * K;
+  pp.cand_boxes = m->alloc_f(per * 4, true); pp.cand_scores = m->alloc_f(per, true);
+  pp.lvl_boxes = m->alloc_f(per * 4, true); pp.lvl_scores = m->alloc_f(per, true);
+  pp.cand_count = (int*)m->alloc_f((size_t)B * L, true); pp.lvl_count = (int*)m->alloc_f((size_t)B * L, true);
+  Tensor props{}; if (make_tensor(m, "proposals", 1, B, K, 4, &props, true)) return 1;
+  pp.props = props.d;
+  pp.nprops = (int*)m->alloc_f(B, true);
+  ODT_CHECK(pp.cand_boxes && pp.cand_scores && pp.lvl_boxes && pp.lvl_scores && pp.cand_count &&
+            pp.lvl_count && pp.nprops, "device allocation failed (proposals)");
+  { Op op; op.kind = OP_PROPOSALS; m->ops.push_back(op); }
+
+  // ---- ROIAlign over P2..P5 -> box head (models.py:465-485, 1030-1108)
+  Tensor roi{}; if (make_tensor(m, "roi_feat", 1, 1, B * K, 49 * FC, &roi, true)) return 1;
+  RoiAlignParams& rh = m->roi_head;
+  std::memset(&rh, 0, sizeof(rh));
+  for (int l = 0; l < 4; ++l) {
+    rh.feat[l] = P[l].d; rh.h[l] = P[l].h; rh.w[l] = P[l].w; rh.ldc[l] = P[l].C;
+    rh.alloc_h[l] = P[l].H; rh.alloc_w[l] = P[l].W; rh.inv_stride[l] = (float)(1.0 / strides[l]);
+  }
+  rh.C = FC; rh.boxes = props.d; rh.box_ind = nullptr; rh.per_image = K; rh.count = pp.nprops;
+  rh.R_cap = B * K; rh.out_nhwc = roi.d;
+  m->roi_final = rh;
+  { Op op; op.kind = OP_ROI_HEAD; m->ops.push_back(op); }
+
+  const int D = cfg.head_dim, C = cfg.num_class;
+  {   // fc6: rows of W are flattened NCHW (c*49 + h*7 + w, nn.py:736-738); our RoI rows are (h,w,c)
+    const HostTensor* w6 = find_w(m, "fastrcnn/fc6/W");
+    ODT_CHECK(w6 && w6->data.size() == (size_t)FC * 49 * D, "missing/bad fastrcnn/fc6/W");
+    HostTensor v; v.data.resize(w6->data.size());
+    for (int c = 0; c < FC; ++c)
+      for (int s = 0; s < 49; ++s)
+        std::memcpy(&v.data[((size_t)s * FC + c) * D], &w6->data[((size_t)c * 49 + s) * D], sizeof(float) * D);
+    m->host_w["__fc6/W"] = v;
+    const HostTensor* b6 = find_w(m, "fastrcnn/fc6/b"); ODT_CHECK(b6 != nullptr, "missing fastrcnn/fc6/b");
+    m->host_w["__fc6/b"] = *b6;
+  }
+  Tensor h6{}, h7{}, hout{};
+  if (upload_conv(m, "__fc6", 1, 1, 49 * FC, D, false, &wt, &bias)) return 1;
+  // compacted rows: only the first nprops[b] rows of each image are meaningful
+  if (add_conv(m, "fastrcnn/fc6", roi, 49 * FC, wt, bias, 1, 1, D, 1, 1, 0, 0, 1, B * K, 0, 0, nullptr, 0, true,
+               D, &h6, "fc6")) return 1;
+  if (upload_conv(m, "fastrcnn/fc7", 1, 1, D, D, false, &wt, &bias)) return 1;
+  if (add_conv(m, "fastrcnn/fc7", h6, D, wt, bias, 1, 1, D, 1, 1, 0, 0, 1, B * K, 0, 0, nullptr, 0, true, D,
+               &h7, "fc7")) return 1;
+  {
+    const HostTensor* wc = find_w(m, "fastrcnn/outputs/class/W"); const HostTensor* bc = find_w(m, "fastrcnn/outputs/class/b");
+    const HostTensor* wb = find_w(m, "fastrcnn/outputs/box/W"); const HostTensor* bb = find_w(m, "fastrcnn/outputs/box/b");
+    ODT_CHECK(wc && bc && wb && bb, "missing fastrcnn/outputs variables");
+    ODT_CHECK(wc->data.size() == (size_t)D * C && wb->data.size() == (size_t)D * C * 4, "bad fastrcnn/outputs shapes");
+    HostTensor v, vb; v.data.resize((size_t)D * C * 5); vb.data.resize((size_t)C * 5);
+    for (int i = 0; i < D; ++i) {
+      for (int c = 0; c < C; ++c) v.data[(size_t)i * C * 5 + c] = wc->data[(size_t)i * C + c];
+      for (int j = 0; j < 4 * C; ++j) v.data[(size_t)i * C * 5 + C + j] = wb->data[(size_t)i * 4 * C + j];
+    }
+    for (int c = 0; c < C; ++c) vb.data[c] = bc->data[c];
+    for (int j = 0; j < 4 * C; ++j) vb.data[C + j] = bb->data[j];
+    m->host_w["__headout/W"] = v; m->host_w["__headout/b"] = vb;
+    if (upload_conv(m, "__headout", 1, 1, D, C * 5, false, &wt, &bias)) return 1;
+  }
+  const int ld = (C * 5 + 3) / 4 * 4;
+  if (add_conv(m, "fastrcnn/outputs", h7, D, wt, bias, 1, 1, C * 5, 1, 1, 0, 0, 1, B * K, 0, 0, nullptr, 0,
+               false, ld, &hout, "head_out")) return 1;
+
+  // ---- detection tail
+  DetectParams& dp = m->det;
+  std::memset(&dp, 0, sizeof(dp));
+  dp.graph = cfg.graph; dp.B = B; dp.K = K; dp.C = C; dp.head_out = hout.d; dp.ld = hout.C;
+  dp.props = props.d; dp.nprops = pp.nprops; dp.img_h = H; dp.img_w = W;
+  for (int i = 0; i < 4; ++i) dp.reg_w[i] = cfg.bbox_reg_weights[i];
+  dp.decode_clip = cfg.head_decode_clip; dp.score_thresh = cfg.result_score_thresh;
+  dp.nms_thresh = cfg.head_nms_thresh; dp.per_im = cfg.result_per_im;
+  const int per_im = cfg.result_per_im;
+  Tensor dec{}, prb{};
+  if (make_tensor(m, "decoded_boxes", 1, B * K, C - 1, 4, &dec, true)) return 1;
+  if (make_tensor(m, "label_probs", 1, 1, B * K, C, &prb, true)) return 1;
+  dp.dec_boxes = dec.d; dp.probs = prb.d;
+  dp.cls_keep = (int*)m->alloc_f((size_t)B * (C - 1) * per_im, true);
+  dp.cls_count = (int*)m->alloc_f((size_t)B * (C - 1), true);
+  dp.out_boxes = m->alloc_f((size_t)B * per_im * 4, true);
+  dp.out_probs = m->alloc_f((size_t)B * per_im, true);
+  dp.out_labels = (int*)m->alloc_f((size_t)B * per_im, true);
+  dp.out_valid = (int*)m->alloc_f(B, true);
+  ODT_CHECK(dp.cls_keep && dp.cls_count && dp.out_boxes && dp.out_probs && dp.out_labels && dp.out_valid,
+            "device allocation failed (detections)");
+  { Op op; op.kind = OP_DETECT; m->ops.push_back(op); }
+
+  // ---- appearance features: ROIAlign of the final boxes (models.py:971-973) + 7x7 mean
+  m->final_feat = m->alloc_f((size_t)B * per_im * FC * 49, true);
+  m->final_pooled = m->alloc_f((size_t)B * per_im * FC, true);
+  ODT_CHECK(m->final_feat && m->final_pooled, "device allocation failed (features)");
+  RoiAlignParams& rf = m->roi_final;
+  rf.boxes = dp.out_boxes; rf.per_image = per_im; rf.count = dp.out_valid; rf.R_cap = B * per_im;
+  rf.out_nhwc = nullptr; rf.out_nchw = m->final_feat; rf.pooled = m->final_pooled;
+  { Op op; op.kind = OP_ROI_FINAL; m->ops.push_back(op); }
+  return 0;
+}
+
+int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStream_t st) {
+  const odt_config& cfg = m->cfg;
+  ODT_CHECK(m->finalized, "odt_forward: call odt_finalize_weights first");
+  ODT_CHECK(frames != nullptr, "odt_forward: null frames");
+  ODT_CHECK(dtype == ODT_DTYPE_U8 || dtype == ODT_DTYPE_F32, "odt_forward: bad dtype");
+  ODT_HIP(hipSetDevice(m->device));
+  const void* src = frames;
+  if (!on_device) {
+    const size_t n = (size_t)cfg.batch * cfg.height * cfg.width * 3 * (dtype == ODT_DTYPE_U8 ? 1 : 4);
+    ODT_HIP(hipMemcpyAsync(m->frames_dev.d, frames, n, hipMemcpyHostToDevice, st));
+    src = m->frames_dev.d;
+  }
+  size_t ev_i = 0;
+  if (m->profile) {
+    while (m->ev.size() < 2 * m->convs.size()) { hipEvent_t e; ODT_HIP(hipEventCreate(&e)); m->ev.push_back(e); }
+    for (int i = 0; i < 2; ++i) if (!m->ev_total[i]) ODT_HIP(hipEventCreate(&m->ev_total[i]));
+    ODT_HIP(hipEventRecord(m->ev_total[0], st));
+  }
+  for (const Op& op : m->ops) {
+    switch (op.kind) {
+      case OP_PRE:
+        if (launch_preprocess(src, dtype, cfg.batch, cfg.height, cfg.width, 3, 3, m->Hp, m->Wp, m->image_pad.d, st)) return 1;
+        break;
+      case OP_CONV: {
+        const ConvOp& c = m->convs[op.conv];
+        if (m->profile) ODT_HIP(hipEventRecord(m->ev[ev_i++], st));
+        if (launch_conv(c.p, st)) { g_err = c.name + ": " + g_err; return 1; }
+        if (m->profile) ODT_HIP(hipEventRecord(m->ev[ev_i++], st));
+        break;
+      }
+      case OP_POOL:
+        if (launch_maxpool3x3s2(op.in.d, op.in.B, op.in.h, op.in.w, op.in.C, op.out.d, op.out.H, op.out.W, st)) return 1;
+        break;
+      case OP_SUB2:
+        if (launch_subsample2(op.in.d, op.in.B, op.in.H, op.in.W, op.in.C, op.out.d, op.out.H, op.out.W, st)) return 1;
+        break;
+      case OP_PROPOSALS:
+        if (launch_proposals(m->prop, st)) return 1;
+        break;
+      case OP_ROI_HEAD:
+        if (launch_roi_align(m->roi_head, st)) return 1;
+        break;
+      case OP_DETECT:
+        if (launch_detections(m->det, st)) return 1;
+        break;
+      case OP_ROI_FINAL:
+        if (launch_roi_align(m->roi_final, st)) return 1;
+        break;
+    }
+  }
+  if (m->profile) {
+    ODT_HIP(hipEventRecord(m->ev_total[1], st));
+    ODT_HIP(hipStreamSynchronize(st));
+    double ms = 0, fl = 0;
+    for (size_t i = 0; i < m->convs.size(); ++i) {
+      float t = 0;
+      ODT_HIP(hipEventElapsedTime(&t, m->ev[2 * i], m->ev[2 * i + 1]));
+      ms += t; fl += conv_flops(m->convs[i].p);
+    }
+    float tt = 0;
+    ODT_HIP(hipEventElapsedTime(&tt, m->ev_total[0], m->ev_total[1]));
+    m->prof_conv_ms += ms; m->prof_conv_flops += fl; m->prof_launches += (int)m->convs.size();
+    m->prof_total_ms += tt;
+  }
+  return 0;
+}
+
+template <typename T>
+struct Tmp {   // RAII device temp for the stand-alone ops
+  T* d = nullptr;
+  size_t n = 0;
+  int alloc(size_t count) { n = count; ODT_HIP(hipMalloc((void**)&d, (count ? count : 1) * sizeof(T))); return 0; }
+  int put(const T* h) { ODT_HIP(hipMemcpy(d, h, n * sizeof(T), hipMemcpyHostToDevice)); return 0; }
+  int get(T* h, size_t count) { ODT_HIP(hipMemcpy(h, d, count * sizeof(T), hipMemcpyDeviceToHost)); return 0; }
+  int zero() { ODT_HIP(hipMemset(d, 0, (n ? n : 1) * sizeof(T))); return 0; }
+  ~Tmp() { if (d) (void)hipFree(d); }
+};
+
+int set_dev(int device) {
+  int n = 0;
+  ODT_HIP(hipGetDeviceCount(&n));
+  ODT_CHECK(device >= 0 && device < n, "no such device");
+  ODT_HIP(hipSetDevice(device));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int odt_finalize_weights(odt_handle h) {
+  ODT_CHECK(h != nullptr, "null handle");
+  ODT_CHECK(!h->finalized, "weights already finalized");
+  ODT_HIP(hipSetDevice(h->device));
+  if (build_plan(h)) return 1;
+  ODT_HIP(hipDeviceSynchronize());
+  h->finalized = true;
+  h->host_w.clear();
+  return 0;
+}
+
+int odt_forward_async(odt_handle h, const void* frames, int dtype, int on_device, void* stream) {
+  ODT_CHECK(h != nullptr, "null handle");
+  hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
+  return run_plan(h, frames, dtype, on_device, st);
+}
+
+int odt_synchronize(odt_handle h) {
+  ODT_CHECK(h != nullptr, "null handle");
+  ODT_HIP(hipSetDevice(h->device));
+  ODT_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
+int odt_forward(odt_handle h, const void* frames, int dtype, int on_device, void* stream, odt_outputs* out) {
+  ODT_CHECK(h != nullptr && out != nullptr, "null argument");
+  hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
+  if (run_plan(h, frames, dtype, on_device, st)) return 1;
+  ODT_HIP(hipStreamSynchronize(st));
+  const odt_config& cfg = h->cfg;
+  const int B = cfg.batch, per = cfg.result_per_im, FC = cfg.fpn_channels;
+  std::vector<int> valid(B);
+  ODT_HIP(hipMemcpy(valid.data(), h->det.out_valid, B * sizeof(int), hipMemcpyDeviceToHost));
+  int total = 0;
+  for (int b = 0; b < B; ++b) total += valid[b];
+  if (out->valid) std::memcpy(out->valid, valid.data(), B * sizeof(int));
+  if (out->boxes) ODT_HIP(hipMemcpy(out->boxes, h->det.out_boxes, (size_t)B * per * 4 * sizeof(float), hipMemcpyDeviceToHost));
+  if (out->probs) ODT_HIP(hipMemcpy(out->probs, h->det.out_probs, (size_t)B * per * sizeof(float), hipMemcpyDeviceToHost));
+  if (out->labels) ODT_HIP(hipMemcpy(out->labels, h->det.out_labels, (size_t)B * per * sizeof(int), hipMemcpyDeviceToHost));
+  if (out->feats && total > 0)
+    ODT_HIP(hipMemcpy(out->feats, h->final_feat, (size_t)total * FC * 49 * sizeof(float), hipMemcpyDeviceToHost));
+  if (out->pooled && total > 0)
+    ODT_HIP(hipMemcpy(out->pooled, h->final_pooled, (size_t)total * FC * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int odt_tap(odt_handle h, const char* name, float* dst, size_t cap_elems, int64_t* shape_out, int* rank_out) {
+  ODT_CHECK(h && name && shape_out && rank_out, "odt_tap: null argument");
+  ODT_HIP(hipSetDevice(h->device));
+  if (std::string(name) == "nproposals") {
+    shape_out[0] = h->cfg.batch; *rank_out = 1;
+    if (dst) {
+      ODT_CHECK(cap_elems >= (size_t)h->cfg.batch, "odt_tap: buffer too small");
+      std::vector<int> v(h->cfg.batch);
+      ODT_HIP(hipMemcpy(v.data(), h->prop.nprops, v.size() * sizeof(int), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < v.size(); ++i) dst[i] = (float)v[i];
+    }
+    return 0;
+  }
+  auto it = h->taps.find(name);
+  ODT_CHECK(it != h->taps.end(), std::string("odt_tap: unknown stage ") + name);
+  const Tensor& t = it->second;
+  shape_out[0] = t.B; shape_out[1] = t.H; shape_out[2] = t.W; shape_out[3] = t.C; *rank_out = 4;
+  if (dst) {
+    ODT_CHECK(cap_elems >= t.elems(), "odt_tap: buffer too small");
+    ODT_HIP(hipDeviceSynchronize());
+    ODT_HIP(hipMemcpy(dst, t.d, t.elems() * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+int odt_profile_enable(odt_handle h, int enable) {
+  ODT_CHECK(h != nullptr, "null handle");
+  h->profile = enable != 0;
+  h->prof_conv_ms = h->prof_conv_flops = h->prof_total_ms = 0; h->prof_launches = 0;
+  return 0;
+}
+
+int odt_profile_read(odt_handle h, double* conv_ms, double* conv_flops, int* conv_launches, double* total_ms) {
+  ODT_CHECK(h != nullptr, "null handle");
+  if (conv_ms) *conv_ms = h->prof_conv_ms;
+  if (conv_flops) *conv_flops = h->prof_conv_flops;
+  if (conv_launches) *conv_launches = h->prof_launches;
+  if (total_ms) *total_ms = h->prof_total_ms;
+  return 0;
+}
+
+int odt_nn_cosine(int device, const float* gallery, const int32_t* seg_offsets, int T, const float* dets,
+                  int N, int D, double* cost) {
+  ODT_CHECK(T >= 0 && N >= 0 && D > 0, "odt_nn_cosine: bad sizes");
+  if (T == 0 || N == 0) return 0;
+  ODT_CHECK(gallery && seg_offsets && dets && cost, "odt_nn_cosine: null argument");
+  if (set_dev(device)) return 1;
+  const int G = seg_offsets[T];
+  ODT_CHECK(G > 0 && seg_offsets[0] == 0, "odt_nn_cosine: bad segment offsets");
+  for (int t = 0; t < T; ++t) ODT_CHECK(seg_offsets[t + 1] > seg_offsets[t], "odt_nn_cosine: empty track gallery");
+  Tmp<float> g, gn, d, dn; Tmp<int> s; Tmp<double> c;
+  if (g.alloc((size_t)G * D) || gn.alloc((size_t)G * D) || d.alloc((size_t)N * D) || dn.alloc((size_t)N * D) ||
+      s.alloc(T + 1) || c.alloc((size_t)T * N)) return 1;
+  if (g.put(gallery) || d.put(dets) || s.put(seg_offsets)) return 1;
+  if (launch_nn_cosine(g.d, G, s.d, T, d.d, N, D, gn.d, dn.d, c.d, nullptr)) return 1;
+  ODT_HIP(hipDeviceSynchronize());
+  return c.get(cost, (size_t)T * N);
+}
+
+int odt_op_conv2d(int device, const float* in, int B, int H, int W, int Cin, const float* wt_hwio,
+                  const float* bias, int kh, int kw, int Cout, int stride, int dil, int pad_t, int pad_l,
+                  int Ho, int Wo, int oy, int ox, const float* res, int res_mode, int relu, float* out) {
+  ODT_CHECK(in && wt_hwio && out, "odt_op_conv2d: null argument");
+  if (set_dev(device)) return 1;
+  const size_t nin = (size_t)B * H * W * Cin, nout = (size_t)B * (Ho + oy) * (Wo + ox) * Cout;
+  std::vector<float> w((size_t)Cout * kh * kw * Cin), bz(Cout, 0.f);
+  for (int y = 0; y < kh; ++y) for (int x = 0; x < kw; ++x) for (int i = 0; i < Cin; ++i) for (int o = 0; o < Cout; ++o)
+    w[(((size_t)o * kh + y) * kw + x) * Cin + i] = wt_hwio[(((size_t)y * kw + x) * Cin + i) * Cout + o];
+  const int rH = res_mode == 2 ? (Ho + 1) / 2 : Ho, rW = res_mode == 2 ? (Wo + 1) / 2 : Wo;
+  Tmp<float> di, dw, db, dr, dout;
+  if (di.alloc(nin) || dw.alloc(w.size()) || db.alloc(Cout) || dout.alloc(nout) || dout.zero()) return 1;
+  if (di.put(in) || dw.put(w.data()) || db.put(bias ? bias : bz.data())) return 1;
+  if (res && res_mode) { if (dr.alloc((size_t)B * rH * rW * Cout) || dr.put(res)) return 1; }
+  ConvParams p; std::memset(&p, 0, sizeof(p));
+  p.in = di.d; p.wt = dw.d; p.bias = db.d; p.res = (res && res_mode) ? dr.d : nullptr; p.out = dout.d;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.in_ldc = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
+  p.kh = kh; p.kw = kw; p.stride = stride; p.dil = dil; p.pad_t = pad_t; p.pad_l = pad_l;
+  p.out_H = Ho + oy; p.out_W = Wo + ox; p.out_oy = oy; p.out_ox = ox; p.out_ldc = Cout;
+  p.res_mode = p.res ? res_mode : 0; p.res_H = rH; p.res_W = rW; p.res_ldc = Cout; p.relu = relu;
+  p.in_Ha = H; p.in_Wa = W;
+  if (launch_conv(p, nullptr)) return 1;
+  ODT_HIP(hipDeviceSynchronize());
+  return dout.get(out, nout);
+}
+
+int odt_op_preprocess(int device, const void* frames, int dtype, int B, int H, int W, int pad_t, int pad_l,
+                      int Hp, int Wp, float* out) {
+  ODT_CHECK(frames && out, "odt_op_preprocess: null argument");
+  if (set_dev(device)) return 1;
+  const size_t nin = (size_t)B * H * W * 3 * (dtype == ODT_DTYPE_U8 ? 1 : 4);
+  Tmp<unsigned char> di; Tmp<float> dout;
+  if (di.alloc(nin) || di.put((const unsigned char*)frames) || dout.alloc((size_t)B * Hp * Wp * 4)) return 1;
+  if (launch_preprocess(di.d, dtype, B, H, W, pad_t, pad_l, Hp, Wp, dout.d, nullptr)) return 1;
+  ODT_HIP(hipDeviceSynchronize());
+  return dout.get(out, dout.n);
+}
+
+int odt_op_maxpool(int device, const float* in, int B, int H, int W, int C, float* out) {
+  ODT_CHECK(in && out, "odt_op_maxpool: null argument");
+  if (set_dev(device)) return 1;
+  const int Ho = (H + 1 - 3) / 2 + 1, Wo = (W + 1 - 3) / 2 + 1;
+  Tmp<float> di, dout;
+  if (di.alloc((size_t)B * H * W * C) || di.put(in) || dout.alloc((size_t)B * Ho * Wo * C)) return 1;
+  if (launch_maxpool3x3s2(di.d, B, H, W, C, dout.d, Ho, Wo, nullptr)) return 1;
+  ODT_HIP(hipDeviceSynchronize());
+  return dout.get(out, dout.n);
+}
+
+int odt_op_topk(int device, const float* scores, int n, int k, int32_t* idx_out) {
+  ODT_CHECK(scores && idx_out, "odt_op_topk: null argument");
+  if (set_dev(device)) return 1;
+  Tmp<float> ds; Tmp<int> di;
+  if (ds.alloc(n) || ds.put(scores) || di.alloc(k)) return 1;
+  if (launch_topk(ds.d, n, k, di.d, nullptr)) return 1;
+  ODT_HIP(hipDeviceSynchronize());
+  return di.get(idx_out, k);
+}
+
+int odt_op_nms(int device, const float* boxes, const float* scores, int n, int max_out, float iou_thresh,
+               int32_t* idx_out, int* n_out) {
+  ODT_CHECK(idx_out && n_out, "odt_op_nms: null argument");
+  if (n == 0) { *n_out = 0; return 0; }
+  ODT_CHECK(boxes && scores, "odt_op_nms: null argument");
+  if (set_dev(device)) return 1;
+  Tmp<float> db, ds; Tmp<int> di, dn;
+  if (db.alloc((size_t)n * 4) || db.put(boxes) || ds.alloc(n) || ds.put(scores) || di.alloc(n) || dn.alloc(1)) return 1;
+  if (launch_nms(db.d, ds.d, n, max_out, iou_thresh, di.d, dn.d, nullptr)) return 1;
+  ODT_HIP(hipDeviceSynchronize());
+  if (dn.get(n_out, 1)) return 1;
+  return di.get(idx_out, *n_out);
+}
+
+int odt_op_proposals(int device, int graph, int B, int L, const int* hs, const int* ws, const int* fields,
+                     const float* const* rpn, const float* const* anchors, int img_h, int img_w, int K,
+                     float nms_thresh, float decode_clip, float* props, int32_t* nprops) {
+  ODT_CHECK(L >= 1 && L <= 5 && hs && ws && fields && rpn && anchors && props && nprops, "odt_op_proposals: bad argument");
+  if (set_dev(device)) return 1;
+  ProposalParams p; std::memset(&p, 0, sizeof(p));
+  Tmp<float> dr[5], da[5];
+  for (int l = 0; l < L; ++l) {
+    if (dr[l].alloc((size_t)B * hs[l] * ws[l] * kRpnCh) || dr[l].put(rpn[l])) return 1;
+    if (da[l].alloc((size_t)fields[l] * fields[l] * 12) || da[l].put(anchors[l])) return 1;
+    p.lvl[l].rpn = dr[l].d; p.lvl[l].anchors = da[l].d; p.lvl[l].h = hs[l]; p.lvl[l].w = ws[l]; p.lvl[l].field = fields[l];
+  }
+  p.nlevels = L; p.graph = graph; p.B = B; p.K = K; p.img_h = img_h; p.img_w = img_w;
+  p.nms_thresh = nms_thresh; p.decode_clip = decode_clip;
+  const size_t per = (size_t)B * L * K;
+  Tmp<float> cb, cs, lb, ls, pr; Tmp<int> cc, lc, np;
+  if (cb.alloc(per * 4) || cs.alloc(per) || lb.alloc(per * 4) || ls.alloc(per) || pr.alloc((size_t)B * K * 4) ||
+      cc.alloc((size_t)B * L) || lc.alloc((size_t)B * L) || np.alloc(B)) return 1;
+  p.cand_boxes = cb.d; p.cand_scores = cs.d; p.lvl_boxes = lb.d; p.lvl_scores = ls.d;
+  p.cand_count = cc.d; p.lvl_count = lc.d; p.props = pr.d; p.nprops = np.d;
+  if (launch_proposals(p, nullptr)) return 1;
+  ODT_HIP(hipDeviceSynchronize());
+  if (pr.get(props, (size_t)B * K * 4)) return 1;
+  return np.get(nprops, B);
+}
+
+int odt_op_roi_align(int device, int B, int C, const int* hs, const int* ws, const float* const* feats,
+                     const float* strides, const float* boxes, const int32_t* box_ind, int R,
+                     float* out_nchw, float* pooled) {
+  ODT_CHECK(hs && ws && feats && strides && boxes && box_ind && out_nchw, "odt_op_roi_align: null argument");
+  if (R == 0) return 0;
+  if (set_dev(device)) return 1;
+  RoiAlignParams p; std::memset(&p, 0, sizeof(p));
+  Tmp<float> df[4], db, dout, dpool; Tmp<int> di;
+  for (int l = 0; l < 4; ++l) {
+    if (df[l].alloc((size_t)B * hs[l] * ws[l] * C) || df[l].put(feats[l])) return 1;
+    p.feat[l] = df[l].d; p.h[l] = p.alloc_h[l] = hs[l]; p.w[l] = p.alloc_w[l] = ws[l]; p.ldc[l] = C;
+    p.inv_stride[l] = (float)(1.0 / (double)strides[l]);
+  }
+  if (db.alloc((size_t)R * 4) || db.put(boxes) || di.alloc(R) || di.put(box_ind) ||
+      dout.alloc((size_t)R * C * 49) || dpool.alloc((size_t)R * C)) return 1;
+  p.C = C; p.boxes = db.d; p.box_ind = di.d; p.per_image = 0; p.count = nullptr; p.R_cap = R;
+  p.out_nchw = dout.d; p.pooled = pooled ? dpool.d : nullptr;
+  if (launch_roi_align(p, nullptr)) return 1;
+  ODT_HIP(hipDeviceSynchronize());
+  if (dout.get(out_nchw, dout.n)) return 1;
+  if (pooled) return dpool.get(pooled, dpool.n);
+  return 0;
+}
+
+int odt_op_detections(int device, int graph, int B, int K, int C, const float* cls_logits,
+                      const float* box_logits, const float* props, const int32_t* nprops, int img_h, int img_w,
+                      const float* reg_weights, float decode_clip, float score_thresh, float nms_thresh,
+                      int per_im, float* boxes, float* probs, int32_t* labels, int32_t* valid) {
+  ODT_CHECK(cls_logits && box_logits && props && nprops && reg_weights && boxes && probs && labels && valid,
+            "odt_op_detections: null argument");
+  if (set_dev(device)) return 1;
+  const int rows = B * K, ld = C * 5;
+  std::vector<float> ho((size_t)rows * ld);
+  for (int r = 0; r < rows; ++r) {
+    std::memcpy(&ho[(size_t)r * ld], &cls_logits[(size_t)r * C], sizeof(float) * C);
+    std::memcpy(&ho[(size_t)r * ld + C], &box_logits[(size_t)r * C * 4], sizeof(float) * C * 4);
+  }
+  DetectParams p; std::memset(&p, 0, sizeof(p));
+  Tmp<float> dh, dp, dd, dpr, ob, op; Tmp<int> dn, ck, cc, ol, ov;
+  if (dh.alloc(ho.size()) || dh.put(ho.data()) || dp.alloc((size_t)rows * 4) || dp.put(props) || dn.alloc(B) ||
+      dn.put(nprops) || dd.alloc((size_t)rows * (C - 1) * 4) || dpr.alloc((size_t)rows * C) ||
+      ck.alloc((size_t)B * (C - 1) * per_im) || cc.alloc((size_t)B * (C - 1)) || ob.alloc((size_t)B * per_im * 4) ||
+      op.alloc((size_t)B * per_im) || ol.alloc((size_t)B * per_im) || ov.alloc(B)) return 1;
+  p.graph = graph; p.B = B; p.K = K; p.C = C; p.head_out = dh.d; p.ld = ld; p.props = dp.d; p.nprops = dn.d;
+  p.img_h = img_h; p.img_w = img_w;
+  for (int i = 0; i < 4; ++i) p.reg_w[i] = reg_weights[i];
+  p.decode_clip = decode_clip; p.score_thresh = score_thresh; p.nms_thresh = nms_thresh; p.per_im = per_im;
+  p.dec_boxes = dd.d; p.probs = dpr.d; p.cls_keep = ck.d; p.cls_count = cc.d;
+  p.out_boxes = ob.d; p.out_probs = op.d; p.out_labels = ol.d; p.out_valid = ov.d;
+  if (launch_detections(p, nullptr)) return 1;
+  ODT_HIP(hipDeviceSynchronize());
+  if (ob.get(boxes, ob.n) || op.get(probs, op.n) || ol.get(labels, ol.n)) return 1;
+  return ov.get(valid, B);
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+// Shared declarations for libodt_hip.so (gfx950).  Kernel launch wrappers are
+// declared here and defined in the per-kernel .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+namespace odt {
+
+void set_error(const std::string& msg);
+
+#define ODT_HIP(expr)                                                          \
+  do {                                                                         \
+    hipError_t odt_e_ = (expr);                                                \
+    if (odt_e_ != hipSuccess) {                                                \
+      ::odt::set_error(std::string(#expr) + ": " + hipGetErrorString(odt_e_)); \
+      return 1;                                                                \
+    }                                                                          \
+  } while (0)
+
+#define ODT_CHECK(cond, msg)                 \
+  do {                                       \
+    if (!(cond)) {                           \
+      ::odt::set_error(std::string(msg));    \
+      return 1;                              \
+    }                                        \
+  } while (0)
+
+typedef float f32x4 __attribute__((vector_size(16)));
+typedef float f32x16 __attribute__((vector_size(64)));
+
+constexpr int kMaxTopK = 1024;   // rpn_test_post_nms_topk upper bound
+constexpr int kRoiOut = 7;       // ROIAlign output side (models.py:703)
+constexpr int kRpnCh = 16;       // 3 logits + 12 deltas (+1 pad) per pixel
+
+// ---------------------------------------------------------------- conv (K2+K3)
+// Implicit-GEMM convolution, NHWC fp32, exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
+//   out[n,ho+oy,wo+ox,co] = act( sum_{kh,kw,ci} in[n,ho*s+kh*d-pt, wo*s+kw*d-pl, ci]
+//                                * wt[co,kh,kw,ci] + bias[co] (+ residual) )
+struct ConvParams {
+  const float* in;     // [B,H,W,in_ldc]  (first Cin channels read)
+  const float* wt;     // [Cout][kh][kw][Cin]  (K contiguous), BN folded
+  const float* bias;   // [Cout]
+  const float* res;    // residual (see res_mode) or nullptr
+  float* out;          // [B,out_H,out_W,out_ldc]
+  int B, H, W, Cin, in_ldc;   // H,W: logical input extent (reads outside are zero)
+  int in_Ha, in_Wa;           // allocation extent of `in` (row pitch); >= H,W (sliced views)
+  int Ho, Wo, Cout;
+  int kh, kw, stride, dil, pad_t, pad_l;
+  int out_H, out_W, out_oy, out_ox, out_ldc;
+  int res_mode;        // 0 none | 1 same shape | 2 nearest-2x upsample of [B,res_H,res_W,*]
+  int res_H, res_W, res_ldc;
+  int relu;
+};
+int launch_conv(const ConvParams& p, hipStream_t stream);
+double conv_flops(const ConvParams& p);   // algorithmic 2*M*N*K
+
+// ------------------------------------------------------------ elementwise (K1,K4)
+int launch_preprocess(const void* frames, int dtype, int B, int H, int W, int pad_t, int pad_l,
+                      int Hp, int Wp, float* out, hipStream_t stream);
+int launch_maxpool3x3s2(const float* in, int B, int H, int W, int C, float* out, int Ho, int Wo,
+                        hipStream_t stream);
+
+// ------------------------------------------------------- proposals (K6,K7,K8)
+struct RpnLevel {
+  const float* rpn;      // [B,h,w,kRpnCh]: ch 0..2 logits, 3+a*4+c deltas
+  const float* anchors;  // [field,field,3,4]
+  int h, w, field;
+};
+struct ProposalParams {
+  RpnLevel lvl[5];
+  int nlevels;
+  int graph;             // ODT_GRAPH_SINGLE / MULTI semantics
+  int B, K;
+  int img_h, img_w;
+  float nms_thresh, decode_clip;
+  // workspace (device): per (b,level) sorted candidates and survivors
+  float* cand_boxes;     // [B,L,K,4]
+  float* cand_scores;    // [B,L,K]
+  int* cand_count;       // [B,L]
+  float* lvl_boxes;      // [B,L,K,4]
+  float* lvl_scores;     // [B,L,K]
+  int* lvl_count;        // [B,L]
+  // outputs
+  float* props;          // [B,K,4]
+  int* nprops;           // [B]
+};
+size_t proposal_workspace_bytes(int B, int L, int K);
+int launch_proposals(const ProposalParams& p, hipStream_t stream);
+int launch_topk(const float* scores, int n, int k, int* idx_out, hipStream_t stream);
+int launch_nms(const float* boxes, const float* scores, int n, int max_out, float thresh,
+               int* idx_out, int* n_out, hipStream_t stream);
+
+// --------------------------------------------------------------- ROIAlign (K9,K14)
+struct RoiAlignParams {
+  const float* feat[4];  // NHWC [B,h,w,C] (sliced dims h,w ; pixel stride ldc)
+  int h[4], w[4], ldc[4], alloc_h[4], alloc_w[4];
+  float inv_stride[4];
+  int C;
+  const float* boxes;    // [R_cap,4] image coords
+  const int* box_ind;    // [R_cap] or nullptr (then box r belongs to image r / per_image)
+  int per_image;         // rows per image when box_ind == nullptr
+  const int* count;      // device: number of valid rows per image [B] (nullptr: all R_cap)
+  int R_cap;
+  float* out_nhwc;       // [R_cap,7,7,C] or nullptr   (box-head input order h,w,c)
+  float* out_nchw;       // [R_cap,C,7,7] or nullptr   (fpn_box_feat)
+  float* pooled;         // [R_cap,C] or nullptr
+};
+int launch_roi_align(const RoiAlignParams& p, hipStream_t stream);
+
+// ------------------------------------------------------- detection tail (K11,K12,K13)
+struct DetectParams {
+  int graph, B, K, C;          // C = num_class incl. BG
+  const float* head_out;       // [B*K, ld] : cols [0,C) class logits, [C, C+4C) box logits
+  int ld;
+  const float* props;          // [B,K,4]
+  const int* nprops;           // [B]
+  int img_h, img_w;
+  float reg_w[4];
+  float decode_clip, score_thresh, nms_thresh;
+  int per_im;
+  // workspace
+  float* dec_boxes;            // [B*K, C-1, 4]
+  float* probs;                // [B*K, C]
+  int* cls_keep;               // [B, C-1, per_im]
+  int* cls_count;              // [B, C-1]
+  // outputs (device)
+  float* out_boxes;            // [B, per_im, 4]
+  float* out_probs;            // [B, per_im]
+  int* out_labels;             // [B, per_im]
+  int* out_valid;              // [B]
+};
+int launch_detections(const DetectParams& p, hipStream_t stream);
+
+// ----------------------------------------------------------------- tracker (K15)
+// gal_n / det_n: device scratch for the L2-normalised copies ([G,D] / [N,D])
+int launch_nn_cosine(const float* gallery, int G, const int* seg, int T, const float* dets, int N,
+                     int D, float* gal_n, float* det_n, double* cost, hipStream_t stream);
+
+}  // namespace odt

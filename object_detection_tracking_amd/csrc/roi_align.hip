@@ -1,0 +1,142 @@
+// Multilevel ROIAlign on gfx950 (gather / bilinear, L2-bound): FPN level assignment,
+// tf.image.crop_and_resize(14x14, bilinear, extrapolation 0) with the reference's box
+// transform, 2x2 average pool -> 7x7, plus the 7x7 mean ("DeepSORT appearance feature").
+//
+// Restates reference models.py:439-485 (fpn_map_rois_to_levels, multilevel_roi_align),
+// nn.py:1229-1335 (crop_and_resize, roi_align[_multi]) and deep_sort/utils.py:27-28 (mean).
+// Feature maps are NHWC, so each bilinear tap is one coalesced C*4-byte row read; one thread
+// per channel, one workgroup per (RoI, output row).  fp32, operand order of TF-1.15
+// crop_and_resize_op.cc (see oracle/tfops.py); built with -ffp-contract=off.
+#include "odt_common.hpp"
+
+namespace odt {
+namespace {
+
+__device__ __forceinline__ int fpn_level_of(float x0, float y0, float x1, float y1) {
+  // models.py:441-447: floor(4 + log(sqrt(area) * (1/224) + 1e-6) * (1/ln 2))
+  const float area = (y1 - y0) * (x1 - x0);
+  const float sq = sqrtf(area);
+  const float lv = floorf(4.0f + logf(sq * (float)(1. / 224) + 1e-6f) * (float)(1.0 / 0.6931471805599453));
+  if (!(lv > 2.0f)) return 0;     // also NaN (negative area)
+  if (lv >= 5.0f) return 3;
+  return (int)lv - 2;
+}
+
+__global__ void __launch_bounds__(256) roi_align_kernel(RoiAlignParams p, int B) {
+  const int r = blockIdx.x, oy = blockIdx.y;
+  int b, out_row = r;
+  if (p.box_ind != nullptr) {
+    b = p.box_ind[r];
+  } else {
+    b = r / p.per_image;
+    const int j = r - b * p.per_image;
+    if (p.count != nullptr) {
+      if (j >= p.count[b]) return;
+      int base = 0;
+      for (int q = 0; q < b; ++q) base += p.count[q];
+      out_row = base + j;          // outputs are packed over valid rows (reference [M,...])
+    }
+  }
+  (void)B;
+  const float* bx = p.boxes + (size_t)r * 4;
+  const float X0 = bx[0], Y0 = bx[1], X1 = bx[2], Y1 = bx[3];
+  const int L = fpn_level_of(X0, Y0, X1, Y1);
+  const float is = p.inv_stride[L];
+  const float x0 = X0 * is, y0 = Y0 * is, x1 = X1 * is, y1 = Y1 * is;
+  const int H = p.h[L], W = p.w[L];
+  const float fH1 = (float)(H - 1), fW1 = (float)(W - 1);
+  constexpr int CS = 2 * kRoiOut;                       // 14
+  // transform_fpcoor_for_tf (nn.py:1238-1271)
+  const float sw = (x1 - x0) / (float)CS, sh = (y1 - y0) / (float)CS;
+  const float nx0 = (x0 + sw / 2.0f - 0.5f) / fW1, ny0 = (y0 + sh / 2.0f - 0.5f) / fH1;
+  const float nw = sw * (float)(CS - 1) / fW1, nh = sh * (float)(CS - 1) / fH1;
+  const float by1 = ny0, bx1 = nx0, by2 = ny0 + nh, bx2 = nx0 + nw;
+  // crop_and_resize_op.cc
+  const float hs = (by2 - by1) * fH1 / (float)(CS - 1);
+  const float ws = (bx2 - bx1) * fW1 / (float)(CS - 1);
+  float yl[2];
+  int top[2], bot[2];
+  bool vy[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float in_y = by1 * fH1 + (float)(2 * oy + q) * hs;
+    vy[q] = !(in_y < 0.f || in_y > fH1);
+    const float iy = vy[q] ? in_y : 0.f;
+    top[q] = (int)floorf(iy);
+    bot[q] = (int)ceilf(iy);
+    yl[q] = iy - (float)top[q];
+  }
+  const float* feat = p.feat[L] + (size_t)b * p.alloc_h[L] * p.alloc_w[L] * p.ldc[L];
+  const int aw = p.alloc_w[L], ldc = p.ldc[L];
+  for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+    for (int ox = 0; ox < kRoiOut; ++ox) {
+      float v[2][2];
+#pragma unroll
+      for (int qx = 0; qx < 2; ++qx) {
+        const float in_x = bx1 * fW1 + (float)(2 * ox + qx) * ws;
+        const bool vx = !(in_x < 0.f || in_x > fW1);
+        const float ix = vx ? in_x : 0.f;
+        const int lef = (int)floorf(ix), rig = (int)ceilf(ix);
+        const float xl = ix - (float)lef;
+#pragma unroll
+        for (int qy = 0; qy < 2; ++qy) {
+          float val = 0.f;
+          if (vx && vy[qy]) {
+            const float tl = feat[((size_t)top[qy] * aw + lef) * ldc + c];
+            const float tr = feat[((size_t)top[qy] * aw + rig) * ldc + c];
+            const float bl = feat[((size_t)bot[qy] * aw + lef) * ldc + c];
+            const float br = feat[((size_t)bot[qy] * aw + rig) * ldc + c];
+            const float t = tl + (tr - tl) * xl;
+            const float bm = bl + (br - bl) * xl;
+            val = t + (bm - t) * yl[qy];
+          }
+          v[qy][qx] = val;
+        }
+      }
+      // 2x2 average pool (nn.py:1332): ((v00 + v01) + v10) + v11, * 0.25
+      const float o = (((v[0][0] + v[0][1]) + v[1][0]) + v[1][1]) * 0.25f;
+      if (p.out_nhwc) p.out_nhwc[(((size_t)out_row * kRoiOut + oy) * kRoiOut + ox) * p.C + c] = o;
+      if (p.out_nchw) p.out_nchw[(((size_t)out_row * p.C + c) * kRoiOut + oy) * kRoiOut + ox] = o;
+    }
+  }
+}
+
+// mean over the 7x7 window (deep_sort/utils.py:27-28 np.mean(feat, axis=(1,2)))
+__global__ void __launch_bounds__(256) roi_pool_mean_kernel(const float* nchw, int rows_cap,
+                                                            const int* count, int per_image, int B,
+                                                            int C, float* pooled) {
+  int rows = rows_cap;
+  if (count != nullptr) {
+    rows = 0;
+    for (int q = 0; q < B; ++q) rows += count[q];
+  }
+  (void)per_image;
+  const long total = (long)rows * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const float* src = nchw + i * (kRoiOut * kRoiOut);
+    float s = 0.f;
+    for (int q = 0; q < kRoiOut * kRoiOut; ++q) s += src[q];
+    pooled[i] = s / (float)(kRoiOut * kRoiOut);
+  }
+}
+
+}  // namespace
+
+int launch_roi_align(const RoiAlignParams& p, hipStream_t stream) {
+  ODT_CHECK(p.R_cap > 0, "roi_align: no rows");
+  ODT_CHECK(p.pooled == nullptr || p.out_nchw != nullptr, "roi_align: pooled needs out_nchw");
+  const int B = (p.box_ind == nullptr && p.per_image > 0) ? p.R_cap / p.per_image : 0;
+  hipLaunchKernelGGL(roi_align_kernel, dim3(p.R_cap, kRoiOut), dim3(256), 0, stream, p, B);
+  if (p.pooled) {
+    const long total = (long)p.R_cap * p.C;
+    unsigned g = (unsigned)((total + 255) / 256);
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(roi_pool_mean_kernel, dim3(g), dim3(256), 0, stream, (const float*)p.out_nchw,
+                       p.R_cap, p.count, p.per_image, B, p.C, p.pooled);
+  }
+  ODT_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace odt

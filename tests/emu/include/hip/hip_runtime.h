@@ -1,0 +1,298 @@
+// TEST INFRASTRUCTURE ONLY -- a minimal HIP-on-CPU *simulator*.
+//
+// There is no GPU in the build container, so the kernel sources under
+// object_detection_tracking_amd/csrc/ are additionally compiled with g++
+// against THIS header (it shadows <hip/hip_runtime.h>) into
+// tests/emu/libodt_emu.so, and the `-m "not gpu"` suite runs the very same
+// kernel code (same indexing, same LDS tiling, same MFMA fragment maps, same
+// shuffles) block by block on the host.  It is a simulator for tests, not a
+// backend: nothing under object_detection_tracking_amd/ can load it (the
+// product loader only opens libodt_hip.so and raises if it is missing), and
+// no performance number is ever taken from it.
+//
+// Model: one workgroup at a time per host worker thread; every HIP thread is a
+// ucontext fiber.  __syncthreads() and the wave-level primitives (shuffles,
+// ballots, MFMA) are fiber switch points.  Wave = 64 lanes.  Wave-level ops
+// must be reached by all 64 lanes of a wave in the same order (true of the
+// real hardware too).  MFMA fragment maps follow the gfx950 layout:
+//   v_mfma_f32_32x32x2_f32 : A[i=l&31][k=l>>5], B[k=l>>5][j=l&31],
+//                            D reg r -> row (r&3)+8*(r>>2)+4*(l>>5), col l&31
+//   v_mfma_f32_16x16x4_f32 : A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
+//                            D reg r -> row 4*(l>>4)+r, col l&15
+#pragma once
+#include <ucontext.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#define ODT_HIP_EMULATOR 1
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3_emu { unsigned x, y, z; };
+
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+static inline float2 make_float2(float a, float b) { return {a, b}; }
+static inline float4 make_float4(float a, float b, float c, float d) { return {a, b, c, d}; }
+static inline int2 make_int2(int a, int b) { return {a, b}; }
+static inline int4 make_int4(int a, int b, int c, int d) { return {a, b, c, d}; }
+static inline uint2 make_uint2(unsigned a, unsigned b) { return {a, b}; }
+static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return {a, b, c, d}; }
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+struct hipEvent_s { double t; };
+typedef hipEvent_s* hipEvent_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost,
+                     hipMemcpyDeviceToDevice, hipMemcpyDefault };
+struct hipDeviceProp_t { char name[256]; int multiProcessorCount; char gcnArchName[256]; };
+
+namespace hipemu {
+
+constexpr int kWave = 64;
+constexpr size_t kStack = 96 * 1024;
+
+struct WaveX {           // per-wave exchange area (double buffered)
+  uint64_t u[2][kWave];
+  float a[2][kWave], b[2][kWave];
+  int src[2][kWave];
+  unsigned long long seq[kWave];
+};
+
+struct Fiber {
+  ucontext_t ctx;
+  uint3_emu tid;
+  int linear;            // linear thread id in block
+  int state;             // 0 runnable, 1 at barrier, 2 done
+  unsigned long long wseq;  // number of wave ops issued
+  char* stack;
+};
+
+struct Worker {
+  ucontext_t sched;
+  std::vector<Fiber> fibers;
+  std::vector<WaveX> waves;
+  Fiber* cur = nullptr;
+  dim3 block_idx, block_dim, grid_dim;
+  int at_barrier = 0, live = 0;
+  const std::function<void()>* body = nullptr;
+};
+
+extern thread_local Worker* tl_worker;
+
+inline Worker& W() { return *tl_worker; }
+inline void yield_to_sched() { Worker& w = W(); swapcontext(&w.cur->ctx, &w.sched); }
+
+void launch(const std::function<void()>& body, dim3 grid, dim3 block);
+double now_ms();
+
+// ---- wave primitives ------------------------------------------------------
+inline int lane_id() { return W().cur->linear & (kWave - 1); }
+inline WaveX& wavex() { Worker& w = W(); return w.waves[w.cur->linear / kWave]; }
+
+// deposit + sync; returns parity slot to read from
+inline int wave_sync_begin() {
+  Fiber* f = W().cur;
+  return (int)(f->wseq & 1);
+}
+inline void wave_sync_end() {
+  Worker& w = W();
+  Fiber* f = w.cur;
+  WaveX& x = w.waves[f->linear / kWave];
+  x.seq[f->linear & (kWave - 1)] = ++f->wseq;
+  yield_to_sched();
+  // all lanes of this wave must have issued the same op
+  int base = (f->linear / kWave) * kWave;
+  int n = (int)w.fibers.size();
+  for (int l = 0; l < kWave && base + l < n; ++l) {
+    if (w.fibers[base + l].state == 2 || x.seq[l] < f->wseq) {
+      fprintf(stderr, "hipemu: divergent wave-level op (block %u,%u lane %d)\n",
+              w.block_idx.x, w.block_idx.y, f->linear);
+      abort();
+    }
+  }
+}
+
+}  // namespace hipemu
+
+#define threadIdx (hipemu::W().cur->tid)
+#define blockIdx (hipemu::W().block_idx)
+#define blockDim (hipemu::W().block_dim)
+#define gridDim (hipemu::W().grid_dim)
+static const int warpSize = 64;
+
+inline void __syncthreads() {
+  hipemu::Worker& w = hipemu::W();
+  w.cur->state = 1;
+  w.at_barrier++;
+  hipemu::yield_to_sched();
+}
+inline void __threadfence() {}
+inline void __threadfence_block() {}
+
+// ---- shuffles / votes -------------------------------------------------------
+template <typename T>
+inline T __shfl(T v, int src, int width = 64) {
+  static_assert(sizeof(T) <= 8, "shfl");
+  int s = hipemu::wave_sync_begin();
+  hipemu::WaveX& x = hipemu::wavex();
+  int l = hipemu::lane_id();
+  uint64_t raw = 0; memcpy(&raw, &v, sizeof(T));
+  x.u[s][l] = raw;
+  hipemu::wave_sync_end();
+  int base = l & ~(width - 1);
+  int sl = base + (src & (width - 1));
+  T out; memcpy(&out, &x.u[s][sl], sizeof(T));
+  return out;
+}
+template <typename T> inline T __shfl_xor(T v, int mask, int width = 64) {
+  int l = hipemu::lane_id(); return __shfl(v, (l ^ mask), width); }
+template <typename T> inline T __shfl_down(T v, unsigned d, int width = 64) {
+  int l = hipemu::lane_id(); int t = (l & (width - 1)) + (int)d;
+  T o = __shfl(v, t < width ? (l + (int)d) : l, 64); return o; }
+template <typename T> inline T __shfl_up(T v, unsigned d, int width = 64) {
+  int l = hipemu::lane_id(); int t = (l & (width - 1)) - (int)d;
+  T o = __shfl(v, t >= 0 ? (l - (int)d) : l, 64); return o; }
+inline unsigned long long __ballot(int pred) {
+  int s = hipemu::wave_sync_begin();
+  hipemu::WaveX& x = hipemu::wavex();
+  x.u[s][hipemu::lane_id()] = pred ? 1u : 0u;
+  hipemu::wave_sync_end();
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l) m |= (unsigned long long)(x.u[s][l] & 1u) << l;
+  return m;
+}
+inline int __any(int p) { return __ballot(p) != 0ull; }
+inline int __all(int p) { return __ballot(p) == ~0ull; }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }
+inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
+inline int __clz(unsigned v) { return v ? __builtin_clz(v) : 32; }
+
+// ---- MFMA -------------------------------------------------------------------
+typedef float hipemu_f32x16 __attribute__((vector_size(64)));
+typedef float hipemu_f32x4 __attribute__((vector_size(16)));
+
+inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, hipemu_f32x16 c,
+                                                          int, int, int) {
+  int s = hipemu::wave_sync_begin();
+  hipemu::WaveX& x = hipemu::wavex();
+  int l = hipemu::lane_id();
+  x.a[s][l] = a; x.b[s][l] = b;
+  hipemu::wave_sync_end();
+  int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = c[r];
+    for (int k = 0; k < 2; ++k)   // k-ordered fmaf chain (exact f32 semantics)
+      acc = fmaf(x.a[s][row + 32 * k], x.b[s][col + 32 * k], acc);
+    c[r] = acc;
+  }
+  return c;
+}
+inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipemu_f32x4 c,
+                                                         int, int, int) {
+  int s = hipemu::wave_sync_begin();
+  hipemu::WaveX& x = hipemu::wavex();
+  int l = hipemu::lane_id();
+  x.a[s][l] = a; x.b[s][l] = b;
+  hipemu::wave_sync_end();
+  int col = l & 15;
+  for (int r = 0; r < 4; ++r) {
+    int row = 4 * (l >> 4) + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k)
+      acc = fmaf(x.a[s][row + 16 * k], x.b[s][col + 16 * k], acc);
+    c[r] = acc;
+  }
+  return c;
+}
+inline void __builtin_amdgcn_s_setprio(int) {}
+inline void __builtin_amdgcn_sched_barrier(int) {}
+
+// ---- atomics / bit casts ----------------------------------------------------
+template <typename T> inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline float atomicAdd(float* p, float v) {
+  float old, nw; uint32_t* ip = (uint32_t*)p; uint32_t o = __atomic_load_n(ip, __ATOMIC_RELAXED), n;
+  do { memcpy(&old, &o, 4); nw = old + v; memcpy(&n, &nw, 4);
+  } while (!__atomic_compare_exchange_n(ip, &o, n, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+  return old;
+}
+template <typename T> inline T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+template <typename T> inline T atomicMax(T* p, T v) {
+  T o = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (o < v && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return o; }
+template <typename T> inline T atomicMin(T* p, T v) {
+  T o = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (o > v && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return o; }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
+inline float __fdividef(float a, float b) { return a / b; }
+inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+
+// ---- runtime API --------------------------------------------------------------
+inline const char* hipGetErrorString(hipError_t e) { return e == 0 ? "hipSuccess(emu)" : "hipError(emu)"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+  memset(p, 0, sizeof(*p)); strcpy(p->name, "hipemu-cpu-simulator"); strcpy(p->gcnArchName, "emu");
+  p->multiProcessorCount = 256; return hipSuccess; }
+inline hipError_t hipMalloc(void** p, size_t n) {
+  *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <typename T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = 0) {
+  memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = 0) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipEvent_s{0}; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = 0) { e->t = hipemu::now_ms(); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
+
+template <typename... KArgs, typename... Args>
+inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t /*shmem*/,
+                               hipStream_t /*stream*/, Args... args) {
+  std::function<void()> body = [=]() { kernel(static_cast<KArgs>(args)...); };
+  hipemu::launch(body, grid, block);
+}
