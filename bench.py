@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""Headline benchmark: detector FPS @1920x1080, batch 8, per MI355X (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (preprocess -> ResNet-101-dilated+FPN -> RPN -> proposals
+-> ROIAlign -> box head -> per-class NMS -> appearance-feature ROIAlign + 7x7 mean) over one
+batch of 8 synthetic 1920x1080 frames that are already resident in HBM (uint8).  One process
+per GPU, one video stream per GPU, weights replicated, no data-path collective (streams are
+independent: "weak" scaling; RCCL only carries the barrier and the max-over-ranks timing).
+Rank 0 prints ONE JSON line with the contract fields plus `roofline` (conv implicit-GEMM kernel
+family, HIP-event timed on its launch stream) and, at N=1, `cpu_baseline` (the oracle -- a CPU
+restatement of the reference's TF graph, kind "port" -- timed on the host cores over a bounded
+sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=10)
+  ap.add_argument("--warmup", type=int, default=2)
+  ap.add_argument("--batch", type=int, default=8)
+  ap.add_argument("--height", type=int, default=1080)
+  ap.add_argument("--width", type=int, default=1920)
+  ap.add_argument("--topk", type=int, default=300, help="rpn_test_post_nms_topk (BASELINE: 300)")
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--cpu-frames", type=int, default=2, help="frames in the bounded CPU sample")
+  ap.add_argument("--profile-steps", type=int, default=2)
+  args = ap.parse_args()
+
+  import torch
+  import torch.distributed as dist
+
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  if not torch.cuda.is_available():
+    raise SystemExit("bench.py needs a GPU: the product path is the HIP library only")
+  torch.cuda.set_device(local_rank)
+  if world > 1:
+    dist.init_process_group("nccl", rank=rank, world_size=world,
+                            device_id=torch.device("cuda", local_rank))
+
+  from object_detection_tracking_amd import models
+  from object_detection_tracking_amd._lib import ODT_DTYPE_U8
+  from object_detection_tracking_amd.config import make_config
+  from object_detection_tracking_amd.weights import synthetic_frames, synthetic_weights
+
+  B, H, W = args.batch, args.height, args.width
+  cfg = make_config(rpn_test_post_nms_topk=args.topk, im_batch_size=B, max_size=max(H, W),
+                    short_edge_size=min(H, W))
+  weights = synthetic_weights(cfg, seed=0)
+  model = models.get_model(cfg, local_rank, weights=weights, is_multi=True)
+  eng = model.engine(B, H, W)
+  # one video stream per GPU: each rank gets its own seeded frames
+  frames = synthetic_frames(B, H, W, seed=1234 + rank)
+  dev_frames = torch.from_numpy(frames).cuda(local_rank)          # HBM-resident uint8 input
+  torch.cuda.synchronize()
+
+  def step():
+    eng.forward_device_async(dev_frames.data_ptr(), ODT_DTYPE_U8)
+
+  def barrier():
+    if world > 1:
+      dist.barrier()
+
+  for _ in range(args.warmup):
+    step()
+  eng.synchronize()
+  torch.cuda.synchronize()
+  barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    step()
+  eng.synchronize()
+  torch.cuda.synchronize()
+  barrier()
+  dt = time.perf_counter() - t0
+  if world > 1:
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+  # roofline of the dominant kernel family (implicit-GEMM conv, ~99% of the FLOPs): HIP events
+  # around every launch on the launch stream, outside the timed region.
+  eng.profile(True)
+  for _ in range(max(1, args.profile_steps)):
+    step()
+  eng.synchronize()
+  prof = eng.profile_read()
+  eng.profile(False)
+  achieved = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12 if prof["conv_ms"] > 0 else 0.0
+
+  if rank == 0:
+    fps = world * B * args.steps / dt
+    out = {
+        "metric": "detector FPS @1920x1080 b=8 per MI355X",
+        "value": fps,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "ResNet-101-dilated+FPN detector + RoI appearance features, "
+                               "%dx%d, batch %d per GPU, rpn_post_nms_topk %d, 15 classes, "
+                               "random-init weights, frames resident in HBM (uint8)" %
+                               (W, H, B, args.topk),
+                   "graph": "Mask_RCNN_FPN_multi", "streams_per_gpu": 1},
+        "roofline": {
+            "bound": "mfma",
+            "kernel": "conv_igemm_kernel (v_mfma_f32_32x32x2_f32 implicit GEMM, %d launches/step)"
+                      % (prof["conv_launches"] // max(1, args.profile_steps)),
+            "achieved": achieved,
+            "peak": F32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+            "traffic": None,
+            "conv_ms_per_step": prof["conv_ms"] / max(1, args.profile_steps),
+            "step_ms_profiled": prof["total_ms"] / max(1, args.profile_steps),
+            "algorithmic_gflop_per_step": prof["conv_flops"] / max(1, args.profile_steps) / 1e9,
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      out["cpu_baseline"] = cpu_baseline(cfg, weights, frames, args.cpu_frames)
+    print(json.dumps(out), flush=True)
+  model.close()
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, weights, frames, nframes):
+  """Oracle (CPU restatement of the TF graph; NOT TensorFlow) on a bounded sample."""
+  import torch
+  from oracle.graph import OracleModel
+  n = max(1, min(nframes, frames.shape[0]))
+  om = OracleModel(cfg, weights)
+  t0 = time.perf_counter()
+  om.forward_multi(frames[:n])
+  dt = time.perf_counter() - t0
+  return {"value": n / dt, "unit": "frames/s", "cores": int(torch.get_num_threads()),
+          "kind": "port",
+          "sample": "%d of the step's %d frames through oracle.graph.OracleModel.forward_multi "
+                    "(torch-CPU fp32 conv/matmul + numpy selection ops), one pass, %.1f s"
+                    % (n, frames.shape[0], dt)}
+
+
+if __name__ == "__main__":
+  main()

@@ -1,0 +1,282 @@
+"""Host-side mirror of the reference's model surface for the hot path.
+
+The reference builds a TF1 graph once and exposes tensor *handles*
+(``model.final_boxes`` ...) that callers fetch with ``sess.run(handles,
+feed_dict)`` (reference models.py:97-119 ``get_model``, :965-973 output
+identities, :1629-1636 ``get_feed_dict_forward``, :3301
+``get_feed_dict_forward_multi``; call sites obj_detect_tracking.py:505-517,
+:610-635 and obj_detect_tracking_multi.py:460-467).  This module keeps exactly
+that surface -- same factory, same attribute names, same feed-dict methods,
+same output dtypes/shapes -- over the C ABI of libodt_hip.so, and adds the
+plain ``predict()`` / ``predict_batch()`` calls BASELINE.json asks for.
+
+There is no CPU path: constructing a model without the HIP library or without a
+GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (ODT_DTYPE_F32, ODT_DTYPE_U8, ODT_GRAPH_MULTI, ODT_GRAPH_SINGLE, OdtConfig,
+                   OdtOutputs, c_i64_p, f32, fptr, iptr)
+from .anchors import fpn_anchor_fields
+from .config import HEAD_DECODE_CLIP, finalize_config
+from .weights import load_npz
+
+
+class TensorHandle(object):
+  """Opaque stand-in for a TF tensor handle (fetch key for Session.run)."""
+
+  def __init__(self, model, name):
+    self.model = model
+    self.name = name
+
+  def __repr__(self):
+    return "<odt tensor %s:0>" % self.name
+
+
+class _Engine(object):
+  """One static plan (fixed batch, H, W) on one GPU."""
+
+  def __init__(self, lib, config, graph, batch, height, width, weights, device):
+    self.lib = lib
+    self.batch, self.height, self.width = batch, height, width
+    self.per_im = int(config.result_per_im)
+    self.channels = int(config.fpn_num_channel)
+    c = OdtConfig()
+    c.graph = graph; c.batch = batch; c.height = height; c.width = width
+    c.num_class = int(config.num_class)
+    for i, n in enumerate(config.resnet_num_block):
+      c.num_blocks[i] = int(n)
+    c.use_dilations = int(bool(config.use_dilations))
+    c.fpn_channels = self.channels
+    c.head_dim = int(config.fpn_frcnn_fc_head_dim)
+    c.rpn_topk = int(config.rpn_test_post_nms_topk)
+    c.result_per_im = self.per_im
+    c.anchor_field = int(np.ceil(config.max_size / config.anchor_strides[0]))
+    c.rpn_nms_thresh = float(config.rpn_proposal_nms_thres)
+    c.rpn_decode_clip = float(config.bbox_decode_clip)
+    c.head_decode_clip = HEAD_DECODE_CLIP
+    for i in range(4):
+      c.bbox_reg_weights[i] = float(config.fastrcnn_bbox_reg_weights[i])
+    c.result_score_thresh = float(config.result_score_thres)
+    c.head_nms_thresh = float(config.fastrcnn_nms_iou_thres)
+    self.h = C.c_void_p()
+    lib.check(lib.dll.odt_create(C.byref(c), device, C.byref(self.h)))
+    try:
+      for name, arr in weights.items():
+        self._load(name, arr)
+      for i, a in enumerate(fpn_anchor_fields(config)):
+        self._load("anchors/lvl%d" % i, a)
+      lib.check(lib.dll.odt_finalize_weights(self.h))
+    except Exception:
+      lib.dll.odt_destroy(self.h)
+      self.h = None
+      raise
+    B, P, Cn = batch, self.per_im, self.channels
+    self._boxes = np.zeros((B, P, 4), np.float32)
+    self._probs = np.zeros((B, P), np.float32)
+    self._labels = np.zeros((B, P), np.int32)
+    self._valid = np.zeros((B,), np.int32)
+    self._feats = np.zeros((B * P, Cn, 7, 7), np.float32)
+    self._pooled = np.zeros((B * P, Cn), np.float32)
+
+  def _load(self, name, arr):
+    a = f32(arr)
+    shape = (C.c_int64 * a.ndim)(*a.shape)
+    self.lib.check(self.lib.dll.odt_load_tensor(self.h, name.encode(), fptr(a),
+                                                C.cast(shape, c_i64_p), a.ndim))
+
+  def close(self):
+    if self.h is not None:
+      self.lib.dll.odt_destroy(self.h)
+      self.h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
+  def forward(self, frames, want_feats=True, want_pooled=False):
+    """frames: [B,H,W,3] uint8/float32 BGR host array.  Returns fresh arrays."""
+    fr = np.ascontiguousarray(frames)
+    if fr.dtype == np.uint8:
+      dt = ODT_DTYPE_U8
+    else:
+      fr = np.ascontiguousarray(fr, dtype=np.float32)
+      dt = ODT_DTYPE_F32
+    assert fr.shape == (self.batch, self.height, self.width, 3), fr.shape
+    out = OdtOutputs()
+    out.boxes = fptr(self._boxes); out.probs = fptr(self._probs)
+    out.labels = iptr(self._labels); out.valid = iptr(self._valid)
+    out.feats = fptr(self._feats) if want_feats else None
+    out.pooled = fptr(self._pooled) if want_pooled else None
+    self.lib.check(self.lib.dll.odt_forward(self.h, fr.ctypes.data_as(C.c_void_p), dt, 0, None,
+                                            C.byref(out)))
+    total = int(self._valid.sum())
+    return (self._boxes.copy(), self._labels.copy(), self._probs.copy(), self._valid.copy(),
+            self._feats[:total].copy() if want_feats else None,
+            self._pooled[:total].copy() if want_pooled else None)
+
+  def forward_device_async(self, dev_ptr, dtype, stream=None):
+    """Enqueue one forward on frames already resident in HBM (bench path)."""
+    self.lib.check(self.lib.dll.odt_forward_async(self.h, C.c_void_p(dev_ptr), dtype, 1,
+                                                  C.c_void_p(stream) if stream else None))
+
+  def synchronize(self):
+    self.lib.check(self.lib.dll.odt_synchronize(self.h))
+
+  def profile(self, enable):
+    self.lib.check(self.lib.dll.odt_profile_enable(self.h, int(enable)))
+
+  def profile_read(self):
+    ms = C.c_double(); fl = C.c_double(); n = C.c_int(); tot = C.c_double()
+    self.lib.check(self.lib.dll.odt_profile_read(self.h, C.byref(ms), C.byref(fl), C.byref(n),
+                                                 C.byref(tot)))
+    return dict(conv_ms=ms.value, conv_flops=fl.value, conv_launches=n.value, total_ms=tot.value)
+
+  def tap(self, name):
+    """Stage tensor in the device layout (NHWC), as numpy."""
+    shape = (C.c_int64 * 4)(); rank = C.c_int()
+    self.lib.check(self.lib.dll.odt_tap(self.h, name.encode(), None, 0, C.cast(shape, c_i64_p),
+                                        C.byref(rank)))
+    dims = [int(shape[i]) for i in range(rank.value)]
+    out = np.zeros(dims, np.float32)
+    self.lib.check(self.lib.dll.odt_tap(self.h, name.encode(), fptr(out), out.size,
+                                        C.cast(shape, c_i64_p), C.byref(rank)))
+    return out
+
+
+class _DetectorBase(object):
+  graph = ODT_GRAPH_SINGLE
+
+  def __init__(self, config, gpuid=0, weights=None, lib=None):
+    self.config = finalize_config(config)
+    self.gpuid = gpuid
+    self.lib = lib if lib is not None else _lib.get_lib()
+    if weights is None:
+      path = getattr(config, "model_path", None)
+      if not path or not str(path).endswith(".npz"):
+        raise ValueError("weights: pass a {name: array} dict or set config.model_path to a "
+                         "Tensorpack-style .npz (reference obj_detect_tracking.py:417-435)")
+      weights = load_npz(path)
+    self.weights = weights
+    self._engines = {}
+    # the reference's tensor handles / placeholders (models.py:282-283, 965-973)
+    self.image = TensorHandle(self, "image")
+    self.is_train = TensorHandle(self, "is_train")
+    self.final_boxes = TensorHandle(self, "final_boxes")
+    self.final_labels = TensorHandle(self, "final_labels")
+    self.final_probs = TensorHandle(self, "final_probs")
+    self.fpn_box_feat = TensorHandle(self, "fpn_box_feat")
+    self.final_valid_indices = TensorHandle(self, "final_valid_indices")
+
+  def engine(self, batch, height, width):
+    key = (batch, height, width)
+    if key not in self._engines:
+      self._engines[key] = _Engine(self.lib, self.config, self.graph, batch, height, width,
+                                   self.weights, self.gpuid)
+    return self._engines[key]
+
+  # reference models.py:1629-1636
+  def get_feed_dict_forward(self, imgdata):
+    return {self.image: imgdata, self.is_train: False}
+
+  def _fetch(self, fetches, feed_dict):
+    raise NotImplementedError
+
+  def close(self):
+    for e in self._engines.values():
+      e.close()
+    self._engines = {}
+
+
+class Mask_RCNN_FPN(_DetectorBase):
+  """b=1 graph (reference models.py:267-973)."""
+  graph = ODT_GRAPH_SINGLE
+
+  def predict(self, img, pooled=False):
+    """One frame [H,W,3] BGR -> (final_boxes [R,4] f32, final_labels [R] i64,
+    final_probs [R] f32, fpn_box_feat [R,256,7,7] f32 (or [R,256] if pooled))."""
+    img = np.asarray(img)
+    e = self.engine(1, img.shape[0], img.shape[1])
+    boxes, labels, probs, valid, feats, pl = e.forward(img[None], want_feats=not pooled,
+                                                       want_pooled=pooled)
+    r = int(valid[0])
+    return (boxes[0, :r].copy(), labels[0, :r].astype(np.int64), probs[0, :r].copy(),
+            pl if pooled else feats)
+
+  def _fetch(self, fetches, feed_dict):
+    boxes, labels, probs, feats = self.predict(feed_dict[self.image])
+    table = {"final_boxes": boxes, "final_labels": labels, "final_probs": probs,
+             "fpn_box_feat": feats,
+             "final_valid_indices": np.asarray([boxes.shape[0]], np.int32)}
+    return [table[f.name] for f in fetches]
+
+
+class Mask_RCNN_FPN_multi(_DetectorBase):
+  """b=B graph (reference models.py:1969-2408)."""
+  graph = ODT_GRAPH_MULTI
+
+  # reference models.py:3301
+  def get_feed_dict_forward_multi(self, imgdata_list):
+    return {self.image: np.stack(imgdata_list, axis=0), self.is_train: False}
+
+  def predict_batch(self, imgs, pooled=False):
+    """[B,H,W,3] -> (final_boxes [B,100,4], final_labels [B,100] f32, final_probs [B,100],
+    final_valid_indices [B] i32, fpn_box_feat [M,256,7,7]), M = sum(valid)."""
+    imgs = np.asarray(imgs)
+    e = self.engine(imgs.shape[0], imgs.shape[1], imgs.shape[2])
+    boxes, labels, probs, valid, feats, pl = e.forward(imgs, want_feats=not pooled,
+                                                       want_pooled=pooled)
+    return boxes, labels.astype(np.float32), probs, valid, (pl if pooled else feats)
+
+  def _fetch(self, fetches, feed_dict):
+    boxes, labels, probs, valid, feats = self.predict_batch(feed_dict[self.image])
+    table = {"final_boxes": boxes, "final_labels": labels, "final_probs": probs,
+             "final_valid_indices": valid, "fpn_box_feat": feats}
+    return [table[f.name] for f in fetches]
+
+
+class Session(object):
+  """Shim for the ``tf.Session`` the reference drivers use: ``run(fetches,
+  feed_dict)`` triggers ONE forward and returns numpy arrays in fetch order
+  (reference obj_detect_tracking.py:632-635)."""
+
+  def __init__(self, config=None):
+    pass
+
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *a):
+    return False
+
+  def run(self, fetches, feed_dict=None):
+    single = isinstance(fetches, TensorHandle)
+    fl = [fetches] if single else list(fetches)
+    model = fl[0].model
+    out = model._fetch(fl, feed_dict)
+    return out[0] if single else out
+
+
+def get_model(config, gpuid=0, task=0, controller="/cpu:0", is_multi=False, weights=None,
+              lib=None):
+  """reference models.py:97-119.  Dispatch is the reference's; the frozen-.pb and
+  EfficientDet branches are out of this path's scope."""
+  if getattr(config, "is_load_from_pb", False):
+    raise NotImplementedError("frozen .pb graphs need TensorFlow; use the .npz weight route")
+  if getattr(config, "is_efficientdet", False):
+    raise NotImplementedError("EfficientDet path is a 'next' row (SURVEY.md 8f)")
+  cls = Mask_RCNN_FPN_multi if is_multi else Mask_RCNN_FPN
+  return cls(config, gpuid=gpuid, weights=weights, lib=lib)
+
+
+def initialize(config, sess):
+  """reference obj_detect_tracking.py:392-448: weights are loaded when the model is
+  built, so this is a no-op kept for drop-in compatibility."""
+  return None

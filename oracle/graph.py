@@ -100,10 +100,10 @@ def backbone(img, weights, config, taps=None):
   l = TF.pad(img, (3, 2 + pw, 3, 2 + ph))
   l = conv2d(l, weights, "conv0", stride=2, padding="VALID")
   l = torch.relu(batch_norm(l, weights, "conv0/bn"))
-  if taps is not None: taps["conv0"] = l
+  if taps is not None: taps["conv0"] = l.numpy()
   l = pad_tl(l)
   l = TF.max_pool2d(l, 3, 2)
-  if taps is not None: taps["pool0"] = l
+  if taps is not None: taps["pool0"] = l.numpy()
   feats = []
   for g, (ch, cnt) in enumerate(zip((64, 128, 256, 512),
                                     config.resnet_num_block)):
@@ -114,7 +114,7 @@ def backbone(img, weights, config, taps=None):
         dil = 2                                     # nn.py:577-579,932-936
       l = bottleneck(l, weights, "group%d/block%d" % (g, i), ch, stride, dil)
       if taps is not None and i == 0:
-        taps["group%d/block0" % g] = l
+        taps["group%d/block0" % g] = l.numpy()
     feats.append(l)
   return feats
 

@@ -128,7 +128,7 @@ inline void wave_sync_end() {
   int base = (f->linear / kWave) * kWave;
   int n = (int)w.fibers.size();
   for (int l = 0; l < kWave && base + l < n; ++l) {
-    if (w.fibers[base + l].state == 2 || x.seq[l] < f->wseq) {
+    if (x.seq[l] < f->wseq) {
       fprintf(stderr, "hipemu: divergent wave-level op (block %u,%u lane %d)\n",
               w.block_idx.x, w.block_idx.y, f->linear);
       abort();

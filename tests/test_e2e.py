@@ -1,0 +1,154 @@
+"""End-to-end parity of the whole forward (libodt via the reference's model surface) against
+the oracle, stage by stage through the debug taps, for both reference graphs.
+
+Tolerances: the network is ~105 sequential fp32 conv/FC layers accumulated in a different order
+than torch/TF, so stage tensors are compared with a relative tolerance on their own scale and
+boxes with 1e-3 * (image side / 128) px (the north_star's 1e-3 is quoted at O(100) px
+coordinates).  Selection stages (top-k / NMS / level assignment) are discontinuous, so final
+detections are compared as matched sets with a reported mismatch count; the bit-exact index
+tests on identical inputs live in test_ops.py.
+"""
+import numpy as np
+import pytest
+
+from common import match_detections, small_config, weights_for
+from object_detection_tracking_amd import models
+from object_detection_tracking_amd.config import make_config
+from object_detection_tracking_amd.weights import synthetic_frames
+from oracle.graph import OracleModel
+
+
+def _rel(a, b):
+  return float(np.abs(a - b).max() / max(1e-6, np.abs(b).max()))
+
+
+def _check_trunk(e, ref, tol):
+  for name in ["conv0", "pool0", "c2", "c3", "c4", "c5"]:
+    assert _rel(e.tap(name).transpose(0, 3, 1, 2), ref[name]) < tol, name
+  for l in range(2, 7):
+    r = ref["p%d" % l]
+    t = e.tap("p%d" % l).transpose(0, 3, 1, 2)[:, :, :r.shape[2], :r.shape[3]]
+    assert _rel(t, r) < tol, "p%d" % l
+    rp = e.tap("rpn%d" % l)
+    assert _rel(rp[..., :3], ref["rpn_logits%d" % l]) < tol
+    assert _rel(rp[..., 3:15].reshape(rp.shape[:3] + (3, 4)), ref["rpn_deltas%d" % l]) < tol
+
+
+def _run_single(lib, cfg, H, W, tol=2e-5, box_tol=None):
+  w = weights_for(cfg)
+  fr = synthetic_frames(1, H, W)
+  ref = OracleModel(cfg, w).forward(fr[0])
+  m = models.get_model(cfg, 0, weights=w, lib=lib)
+  try:
+    boxes, labels, probs, feats = m.predict(fr[0])
+    e = m.engine(1, H, W)
+    _check_trunk(e, ref, tol)
+    box_tol = box_tol or 1e-3 * max(H, W) / 128
+    assert boxes.dtype == np.float32 and labels.dtype == np.int64 and probs.dtype == np.float32
+    assert feats.shape == (boxes.shape[0], 256, 7, 7)
+    n = int(e.tap("nproposals")[0])
+    assert n == ref["proposals"].shape[0]
+    pm, rm = match_detections(e.tap("proposals")[0, 0, :n], np.zeros(n), np.zeros(n),
+                              ref["proposals"], np.zeros(n), np.zeros(n), box_tol, 1)
+    assert pm + rm <= max(2, n // 50), "proposal sets differ: %d/%d of %d" % (pm, rm, n)
+    miss, extra = match_detections(boxes, labels, probs, ref["final_boxes"], ref["final_labels"],
+                                   ref["final_probs"], box_tol, 1e-4)
+    assert miss + extra <= max(2, len(ref["final_boxes"]) // 25), (miss, extra)
+    if miss + extra == 0 and np.array_equal(labels, ref["final_labels"]):
+      np.testing.assert_allclose(boxes, ref["final_boxes"], rtol=0, atol=box_tol)
+      assert _rel(feats, ref["fpn_box_feat"]) < 10 * tol
+    return miss, extra
+  finally:
+    m.close()
+
+
+def test_forward_single_small(backend):
+  name, lib = backend
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1] if name == "emu" else [1, 1, 2, 3])
+  miss, extra = _run_single(lib, cfg, 96, 128)
+  assert miss == 0 and extra == 0
+
+
+def _run_multi(lib, cfg, B, H, W, tol=2e-5):
+  w = weights_for(cfg)
+  fr = synthetic_frames(B, H, W)
+  ref = OracleModel(cfg, w).forward_multi(fr)
+  m = models.get_model(cfg, 0, weights=w, lib=lib, is_multi=True)
+  try:
+    boxes, labels, probs, valid, feats = m.predict_batch(fr)
+    e = m.engine(B, H, W)
+    _check_trunk(e, ref, tol)
+    assert labels.dtype == np.float32 and valid.dtype == np.int32
+    assert boxes.shape == (B, cfg.result_per_im, 4)
+    assert np.array_equal(valid, ref["final_valid_indices"])
+    assert feats.shape[0] == valid.sum()
+    box_tol = 1e-3 * max(H, W) / 128
+    tot = 0
+    for b in range(B):
+      v = valid[b]
+      miss, extra = match_detections(boxes[b, :v], labels[b, :v], probs[b, :v],
+                                     ref["final_boxes"][b, :v], ref["final_labels"][b, :v],
+                                     ref["final_probs"][b, :v], box_tol, 1e-4)
+      tot += miss + extra
+    assert tot <= max(2, int(valid.sum()) // 25), tot
+    if tot == 0 and np.array_equal(labels, ref["final_labels"]):
+      assert _rel(feats, ref["fpn_box_feat"]) < 10 * tol
+    return tot
+  finally:
+    m.close()
+
+
+def test_forward_multi_small(backend):
+  name, lib = backend
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1], im_batch_size=2, rpn_test_post_nms_topk=48)
+  assert _run_multi(lib, cfg, 2, 96, 128) == 0
+
+
+@pytest.mark.gpu
+def test_forward_single_r101_256x448(hip_lib):
+  cfg = make_config(rpn_test_post_nms_topk=300, max_size=448, short_edge_size=256)
+  _run_single(hip_lib, cfg, 256, 448)
+
+
+@pytest.mark.gpu
+def test_forward_single_r101_odd_size(hip_lib):
+  """Non multiple-of-32 frame: exercises pad-to-32, sliced P2..P4 and anchor slicing."""
+  cfg = make_config(rpn_test_post_nms_topk=200, max_size=400, short_edge_size=230)
+  _run_single(hip_lib, cfg, 230, 394)
+
+
+@pytest.mark.gpu
+def test_forward_multi_r101_b2_256x448(hip_lib):
+  cfg = make_config(rpn_test_post_nms_topk=300, max_size=448, short_edge_size=256,
+                    im_batch_size=2)
+  _run_multi(hip_lib, cfg, 2, 256, 448)
+
+
+@pytest.mark.gpu
+def test_forward_single_r101_1080p(hip_lib):
+  """BASELINE config #2: 1920x1080, b=1, K=300."""
+  cfg = make_config(rpn_test_post_nms_topk=300)
+  _run_single(hip_lib, cfg, 1080, 1920, tol=5e-5)
+
+
+@pytest.mark.gpu
+def test_determinism_and_size_independent_properties(hip_lib):
+  """Full-size properties that need no oracle: run-to-run bit-identical outputs; boxes inside
+  the frame; probs sorted within (0,1]; labels in range; features finite."""
+  cfg = make_config(rpn_test_post_nms_topk=300, im_batch_size=2)
+  w = weights_for(cfg)
+  fr = synthetic_frames(2, 1080, 1920, seed=7)
+  m = models.get_model(cfg, 0, weights=w, lib=hip_lib, is_multi=True)
+  try:
+    a = m.predict_batch(fr)
+    b = m.predict_batch(fr)
+    for x, y in zip(a, b):
+      assert np.array_equal(x, y)
+    boxes, labels, probs, valid, feats = a
+    assert np.all(valid == cfg.result_per_im)
+    assert boxes.min() >= 0 and boxes[..., 2].max() <= 1920 and boxes[..., 3].max() <= 1080
+    assert np.all(np.diff(probs, axis=1) <= 0) and probs.max() <= 1 and probs.min() >= 0
+    assert labels.min() >= 1 and labels.max() <= cfg.num_class - 1
+    assert np.isfinite(feats).all() and feats.shape == (int(valid.sum()), 256, 7, 7)
+  finally:
+    m.close()
