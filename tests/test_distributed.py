@@ -1,0 +1,60 @@
+"""N > 1 path on CPU: world_size-2 gloo processes exercising the stream sharding and the
+optional appearance-feature all-gather (the only exchange step)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from object_detection_tracking_amd.parallel import all_gather_reid_features, shard_streams
+
+
+def _free_port():
+  s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+  return p
+
+
+def _worker(rank, world, port, out):
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  try:
+    streams = ["cam%d.mp4" % i for i in range(5)]
+    mine = shard_streams(streams, rank, world)
+    rng = np.random.default_rng(100 + rank)
+    n = 3 + 4 * rank
+    feats = torch.from_numpy(rng.standard_normal((n, 256)).astype(np.float32))
+    boxes = torch.from_numpy(rng.uniform(0, 1000, (n, 4)).astype(np.float32))
+    gf, gb = all_gather_reid_features(feats, boxes, max_rows=100)
+    ok = len(gf) == world
+    for r in range(world):
+      rr = np.random.default_rng(100 + r)
+      nr = 3 + 4 * r
+      ef = rr.standard_normal((nr, 256)).astype(np.float32)
+      eb = rr.uniform(0, 1000, (nr, 4)).astype(np.float32)
+      ok = ok and np.array_equal(gf[r].numpy(), ef) and np.array_equal(gb[r].numpy(), eb)
+    # timing reduction used by bench.py: max over ranks
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok = ok and float(t.item()) == float(world)
+    out[rank] = (ok, mine)
+    dist.barrier()
+  finally:
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharding_and_feature_allgather():
+  world = 2
+  mgr = mp.Manager()
+  out = mgr.dict()
+  mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+  assert out[0][0] and out[1][0]
+  assert out[0][1] == ["cam0.mp4", "cam2.mp4", "cam4.mp4"] and out[1][1] == ["cam1.mp4", "cam3.mp4"]
+
+
+def test_allgather_is_identity_without_process_group():
+  f = torch.ones(2, 256); b = torch.zeros(2, 4)
+  gf, gb = all_gather_reid_features(f, b)
+  assert len(gf) == 1 and gf[0] is f and gb[0] is b

@@ -1,0 +1,183 @@
+"""Drop-in surface: the reference's driver code talks to `get_model()` handles through
+`sess.run(fetches, feed_dict)` and hands the results to deep_sort (reference
+obj_detect_tracking.py:505-517, :577-695).  These tests drive that exact call pattern.
+
+BASELINE config #1 ("plumbing"): the reference ships no test video and cv2/av are not
+installed, so the frame loop is driven by a synthetic in-memory reader exposing the
+cv2.VideoCapture methods the loop uses.  When /root/reference is present (build
+container) the UNMODIFIED reference Tracker consumes our Detections and our HIP-backed metric.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from common import small_config, weights_for
+from object_detection_tracking_amd import models
+from object_detection_tracking_amd.application_util import preprocessing
+from object_detection_tracking_amd.config import ACTEV_CLASSES
+from object_detection_tracking_amd.deep_sort import (Detection, NearestNeighborDistanceMetric,
+                                                     create_obj_infos)
+from object_detection_tracking_amd.weights import synthetic_frames
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REF = "/root/reference"
+
+
+def _reference_tracker_cls():
+  if not os.path.isdir(os.path.join(REF, "deep_sort")):
+    return None
+  np.float = float; np.int = int          # numpy-2 removed the aliases the reference uses
+  sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+  if REF not in sys.path:
+    sys.path.append(REF)
+  from deep_sort.tracker import Tracker
+  return Tracker
+
+
+class SyntheticCapture(object):
+  """cv2.VideoCapture look-alike over an in-memory frame array."""
+
+  def __init__(self, frames):
+    self.frames, self.i = frames, 0
+
+  def isOpened(self):
+    return True
+
+  def get(self, prop):
+    return float(len(self.frames))
+
+  def read(self):
+    if self.i >= len(self.frames):
+      return False, None
+    f = self.frames[self.i]; self.i += 1
+    return True, f
+
+
+def test_session_shim_single(backend):
+  name, lib = backend
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1])
+  m = models.get_model(cfg, 0, controller="/cpu:0", weights=weights_for(cfg), lib=lib)
+  try:
+    img = synthetic_frames(1, 96, 128)[0].astype("float32")     # the reference feeds float32
+    with models.Session() as sess:
+      models.initialize(cfg, sess)
+      feed = m.get_feed_dict_forward(img)
+      assert feed[m.is_train] is False
+      boxes, labels, probs, feats = sess.run(
+          [m.final_boxes, m.final_labels, m.final_probs, m.fpn_box_feat], feed_dict=feed)
+      only = sess.run(m.final_probs, feed_dict=feed)
+    assert boxes.dtype == np.float32 and boxes.shape[1] == 4 and boxes.shape[0] <= 100
+    assert labels.dtype == np.int64 and probs.dtype == np.float32
+    assert feats.shape == (len(boxes), 256, 7, 7) and len(feats) == len(boxes)
+    assert np.array_equal(only, probs)
+    boxes[:, 2] -= boxes[:, 0]                                   # caller mutates in place
+    u8 = m.predict(synthetic_frames(1, 96, 128)[0])              # uint8 feed is bit-identical
+    assert np.array_equal(u8[2], probs)
+    pooled = m.predict(synthetic_frames(1, 96, 128)[0], pooled=True)[3]
+    np.testing.assert_allclose(pooled, feats.mean(axis=(2, 3)), atol=2e-6)
+  finally:
+    m.close()
+
+
+def test_session_shim_multi(backend):
+  name, lib = backend
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1], im_batch_size=2, rpn_test_post_nms_topk=32)
+  m = models.get_model(cfg, 0, weights=weights_for(cfg), lib=lib, is_multi=True)
+  try:
+    fr = synthetic_frames(2, 96, 128)
+    feed = m.get_feed_dict_forward_multi([fr[0].astype("float32"), fr[1].astype("float32")])
+    sess = models.Session()
+    boxes, labels, probs, valid, feats = sess.run(
+        [m.final_boxes, m.final_labels, m.final_probs, m.final_valid_indices, m.fpn_box_feat],
+        feed_dict=feed)
+    assert boxes.shape == (2, 100, 4) and labels.shape == (2, 100) and labels.dtype == np.float32
+    assert valid.dtype == np.int32 and feats.shape[0] == valid.sum()   # obj_detect_tracking_multi.py:467
+  finally:
+    m.close()
+
+
+def test_plumbing_video_loop_with_tracker(emu_lib):
+  """config #1: frame loop (frame_gap) -> sess.run -> create_obj_infos -> tracker NMS ->
+  Tracker.predict/update, exactly the call sequence of obj_detect_tracking.py:577-695."""
+  Tracker = _reference_tracker_cls()
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1], rpn_test_post_nms_topk=32)
+  m = models.get_model(cfg, 0, weights=weights_for(cfg), lib=emu_lib)
+  id2class = {i: n for i, n in enumerate(ACTEV_CLASSES)}
+  base = synthetic_frames(1, 96, 128)[0]
+  video = np.stack([np.roll(base, 2 * i, axis=1) for i in range(9)])
+  vcap = SyntheticCapture(video)
+  frame_gap, min_conf = 4, 0.02           # random-init weights: use a reachable confidence
+  metric = NearestNeighborDistanceMetric("cosine", 0.5, 5, lib=emu_lib)
+  tracker = Tracker(metric, max_iou_distance=0.5) if Tracker else None
+  sess = models.Session()
+  cur_frame, n_runs, n_det = 0, 0, 0
+  try:
+    while cur_frame < int(vcap.get(7)):
+      suc, frame = vcap.read()
+      assert suc
+      if cur_frame % frame_gap != 0:
+        cur_frame += 1
+        continue
+      im = frame.astype("float32")
+      scale = 1.0
+      boxes, labels, probs, feats = sess.run(
+          [m.final_boxes, m.final_labels, m.final_probs, m.fpn_box_feat],
+          feed_dict=m.get_feed_dict_forward(im))
+      assert len(feats) == len(boxes)
+      n_runs += 1
+      objs = [id2class[int(l)] for l in labels[:1]]        # class of the top detection
+      for obj in objs:
+        dets = create_obj_infos(cur_frame, boxes, probs, labels, feats, id2class, [obj], min_conf,
+                                0, scale)
+        keep = preprocessing.non_max_suppression(np.array([d.tlwh for d in dets]).reshape(-1, 4),
+                                                 0.85, np.array([d.confidence for d in dets]))
+        dets = [dets[i] for i in keep]
+        n_det += len(dets)
+        assert all(isinstance(d, Detection) and d.feature.shape == (256,) for d in dets)
+        if tracker is not None and obj == objs[0]:
+          tracker.predict()
+          tracker.update(dets)
+      cur_frame += 1
+  finally:
+    m.close()
+  assert n_runs == 3
+  assert n_det > 0
+  if tracker is not None:
+    assert len(tracker.tracks) > 0
+
+
+def test_reference_tracker_with_hip_metric_reproduces_golden_tracks(emu_lib):
+  """The unmodified reference Tracker + our metric class == the reference end to end."""
+  Tracker = _reference_tracker_cls()
+  if Tracker is None:
+    pytest.skip("/root/reference not present (GPU box)")
+  g = np.load(os.path.join(G, "deep_sort_ref.npz"))
+  tracker = Tracker(NearestNeighborDistanceMetric("cosine", 0.5, budget=5, lib=emu_lib),
+                    max_iou_distance=0.5)
+  o = t = 0
+  for fr, (n, nt) in enumerate(zip(g["seq_n"], g["seq_tracks_n"])):
+    dets = [Detection(g["seq_tlwh"][o + i], 0.95, g["seq_feat"][o + i]) for i in range(n)]
+    o += n
+    tracker.predict(); tracker.update(dets)
+    got = np.asarray([[tr.track_id] + list(tr.to_tlwh()) for tr in tracker.tracks
+                      if tr.is_confirmed() and tr.time_since_update <= 1]).reshape(-1, 5)
+    want = g["seq_tracks"][t:t + nt]; t += nt
+    assert got.shape == want.shape, fr
+    assert np.array_equal(got[:, 0], want[:, 0]), fr
+    np.testing.assert_allclose(got[:, 1:], want[:, 1:], rtol=1e-9, atol=1e-6)
+
+
+def test_metric_class_bookkeeping():
+  """partial_fit budget trimming / active-target pruning like nn_matching.py:137-154."""
+  met = NearestNeighborDistanceMetric("cosine", 0.5, budget=2, lib=object())
+  f = np.eye(4, dtype=np.float32)
+  met.partial_fit(f, [1, 1, 1, 2], [1, 2])
+  assert len(met.samples[1]) == 2 and np.array_equal(met.samples[1][-1], f[2])
+  met.partial_fit(f[:1], [3], [3])
+  assert list(met.samples) == [3]
+  assert met.distance(np.zeros((0, 4), np.float32), [3]).shape == (1, 0)
+  with pytest.raises(ValueError):
+    NearestNeighborDistanceMetric("euclidean", 0.5)
