@@ -109,8 +109,8 @@ int odt_synchronize(odt_handle h);
 
 /* Debug / parity taps: copy a named stage tensor (device layout: NHWC) to the
  * host.  shape_out receives up to 4 dims.  Names: "image_pad", "conv0",
- * "pool0", "c2".."c5", "p2".."p6", "rpn2".."rpn6" (15 ch: 3 logits + 12
- * deltas), "proposals", "nproposals", "roi_feat", "fc7", "head_out",
+ * "pool0", "c2".."c5", "p2".."p6", "rpn2".."rpn6" (16 ch: 3 logits + 12
+ * deltas + 1 pad), "proposals", "nproposals", "roi_feat", "fc7", "head_out",
  * "decoded_boxes", "label_probs". */
 int odt_tap(odt_handle h, const char* name, float* dst, size_t cap_elems,
             int64_t* shape_out, int* rank_out);
@@ -120,6 +120,11 @@ int odt_tap(odt_handle h, const char* name, float* dst, size_t cap_elems,
 int odt_profile_enable(odt_handle h, int enable);
 int odt_profile_read(odt_handle h, double* conv_ms, double* conv_flops,
                      int* conv_launches, double* total_ms);
+/* Per-launch view of the same measurement: conv launch `index` of the plan (0 <=
+ * index < *count): layer name, algorithmic FLOPs, HIP-event milliseconds summed
+ * since odt_profile_enable, GEMM view M, N, K. */
+int odt_profile_layer(odt_handle h, int index, char* name, int name_cap,
+                      double* flops, double* ms, int64_t* mnk, int* count);
 
 /* NearestNeighborDistanceMetric.distance (deep_sort/nn_matching.py:156-177,
  * _nn_cosine_distance :78-96): gallery [G,D] float32 rows of all tracks
@@ -152,7 +157,8 @@ int odt_op_topk(int device, const float* scores, int n, int k, int32_t* idx_out)
 /* tf.image.non_max_suppression (ties: lower index first) */
 int odt_op_nms(int device, const float* boxes, const float* scores, int n,
                int max_out, float iou_thresh, int32_t* idx_out, int* n_out);
-/* generate_fpn_proposals (models.py:402-436 / :2458-2522): rpn [L][B,h,w,15],
+/* generate_fpn_proposals (models.py:402-436 / :2458-2522): rpn [L][B,h,w,16]
+ * (ch 0..2 logits, 3+4a+c deltas, ch 15 unused),
  * anchors [L][S_l,S_l,3,4]; out props [B,K,4], nprops [B]. */
 int odt_op_proposals(int device, int graph, int B, int L, const int* hs,
                      const int* ws, const int* fields, const float* const* rpn,

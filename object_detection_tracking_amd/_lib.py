@@ -72,7 +72,7 @@ class OdtLib(object):
       "odt_last_error", "odt_device_count", "odt_create", "odt_destroy",
       "odt_load_tensor", "odt_finalize_weights", "odt_forward",
       "odt_forward_async", "odt_synchronize", "odt_tap", "odt_profile_enable",
-      "odt_profile_read", "odt_nn_cosine", "odt_op_conv2d", "odt_op_preprocess",
+      "odt_profile_read", "odt_profile_layer", "odt_nn_cosine", "odt_op_conv2d", "odt_op_preprocess",
       "odt_op_maxpool", "odt_op_topk", "odt_op_nms", "odt_op_proposals",
       "odt_op_roi_align", "odt_op_detections",
   ]
@@ -101,6 +101,8 @@ class OdtLib(object):
     d.odt_profile_enable.argtypes = [C.c_void_p, C.c_int]
     d.odt_profile_read.argtypes = [C.c_void_p, c_double_p, c_double_p,
                                    C.POINTER(C.c_int), c_double_p]
+    d.odt_profile_layer.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, c_double_p,
+                                    c_double_p, c_i64_p, C.POINTER(C.c_int)]
     d.odt_nn_cosine.argtypes = [C.c_int, c_float_p, c_int_p, C.c_int, c_float_p, C.c_int,
                                 C.c_int, c_double_p]
     d.odt_op_conv2d.argtypes = [C.c_int, c_float_p] + [C.c_int] * 4 + [c_float_p, c_float_p] + \

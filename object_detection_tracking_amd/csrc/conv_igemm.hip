@@ -138,29 +138,81 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: D reg r of lane l -> row (r&3)+8*(r>>2)+4*(l>>5), col l&31
+  // ---- epilogue.  D reg r of lane l is C[row (r&3)+8*(r>>2)+4*(l>>5)][col l&31]: stage the
+  // block tile through LDS (the A/B stages are dead) so that HBM sees whole 16-byte-per-lane
+  // row segments: residual tile prefetched with independent 16-B loads, then bias + residual +
+  // ReLU and 16-B stores (a wave covers full 512-byte output rows).
+  constexpr int CS = BN + 4;                      // C-tile row stride (floats); +4 keeps b128 reads aligned
+  static_assert(BM * CS <= 2 * (BM + BN) * LS, "C tile must fit in the A/B stages");
+  float* Ct = &lds[0][0];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int m = m0 + row;
-      if (m >= M) continue;
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int col = wn * TN * 32 + j * 32 + (lane & 31);
+        Ct[row * CS + col] = acc[i][j][r];
+      }
+  __syncthreads();
+
+  constexpr int C4 = BN / 4;                      // 16-byte chunks per tile row
+  constexpr int NCH = BM * C4 / 256;              // chunks per thread
+  const bool vec_ok = (p.out_ldc & 3) == 0 && (p.res_mode == 0 || (p.res_ldc & 3) == 0);
+  f32x4 rv[NCH];
+  size_t oaddr[NCH];
+  int nval[NCH];
+#pragma unroll
+  for (int s2 = 0; s2 < NCH; ++s2) {
+    const int q = tid + 256 * s2;
+    const int row = q / C4, c4 = q - row * C4;
+    const int m = m0 + row, col = n0 + c4 * 4;
+    int nv = p.Cout - col;
+    nv = nv > 4 ? 4 : nv;
+    if (m >= M || nv < 0) nv = 0;
+    nval[s2] = nv;
+    rv[s2] = zero4;
+    oaddr[s2] = 0;
+    if (nv > 0) {
       const int n = m / HoWo, rr = m - n * HoWo;
       const int ho = rr / p.Wo, wo = rr - ho * p.Wo;
-      const size_t opix = ((size_t)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
-      size_t rpix = 0;
-      if (p.res_mode == 1) rpix = ((size_t)n * p.res_H + ho) * p.res_W + wo;
-      if (p.res_mode == 2) rpix = ((size_t)n * p.res_H + (ho >> 1)) * p.res_W + (wo >> 1);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
-        if (col >= p.Cout) continue;
-        float v = acc[i][j][r] + p.bias[col];
-        if (p.res_mode != 0) v += p.res[rpix * p.res_ldc + col];
-        if (p.relu) v = fmaxf(v, 0.f);
-        p.out[opix * p.out_ldc + col] = v;
+      oaddr[s2] = (((size_t)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox) * p.out_ldc + col;
+      if (p.res_mode != 0) {
+        const size_t rpix = p.res_mode == 1 ? ((size_t)n * p.res_H + ho) * p.res_W + wo
+                                            : ((size_t)n * p.res_H + (ho >> 1)) * p.res_W + (wo >> 1);
+        const float* rp = p.res + rpix * p.res_ldc + col;
+        if (nv == 4 && vec_ok) {
+          rv[s2] = *reinterpret_cast<const f32x4*>(rp);
+        } else {
+          for (int e = 0; e < nv; ++e) rv[s2][e] = rp[e];
+        }
       }
+    }
+  }
+#pragma unroll
+  for (int s2 = 0; s2 < NCH; ++s2) {
+    const int nv = nval[s2];
+    if (nv == 0) continue;
+    const int q = tid + 256 * s2;
+    const int row = q / C4, c4 = q - row * C4;
+    const int col = n0 + c4 * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[row * CS + c4 * 4]);
+    if (nv == 4) {
+      v += *reinterpret_cast<const f32x4*>(p.bias + col);
+    } else {
+      for (int e = 0; e < nv; ++e) v[e] += p.bias[col + e];
+    }
+    v += rv[s2];
+    if (p.relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    float* op = p.out + oaddr[s2];
+    if (nv == 4 && vec_ok) {
+      *reinterpret_cast<f32x4*>(op) = v;
+    } else {
+      for (int e = 0; e < nv; ++e) op[e] = v[e];
     }
   }
 }

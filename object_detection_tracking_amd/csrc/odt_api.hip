@@ -93,6 +93,7 @@ struct odt_model {
   std::vector<hipEvent_t> ev;
   hipEvent_t ev_total[2] = {nullptr, nullptr};
   double prof_conv_ms = 0, prof_conv_flops = 0, prof_total_ms = 0;
+  std::vector<double> prof_layer_ms;
   int prof_launches = 0;
 
   float* alloc_f(size_t elems, bool zero) {
@@ -596,6 +597,8 @@ int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStre
       float t = 0;
       ODT_HIP(hipEventElapsedTime(&t, m->ev[2 * i], m->ev[2 * i + 1]));
       ms += t; fl += conv_flops(m->convs[i].p);
+      if (m->prof_layer_ms.size() < m->convs.size()) m->prof_layer_ms.resize(m->convs.size(), 0.0);
+      m->prof_layer_ms[i] += t;
     }
     float tt = 0;
     ODT_HIP(hipEventElapsedTime(&tt, m->ev_total[0], m->ev_total[1]));
@@ -703,6 +706,20 @@ int odt_profile_enable(odt_handle h, int enable) {
   ODT_CHECK(h != nullptr, "null handle");
   h->profile = enable != 0;
   h->prof_conv_ms = h->prof_conv_flops = h->prof_total_ms = 0; h->prof_launches = 0;
+  h->prof_layer_ms.assign(h->convs.size(), 0.0);
+  return 0;
+}
+
+int odt_profile_layer(odt_handle h, int index, char* name, int name_cap, double* flops, double* ms,
+                      int64_t* mnk, int* count) {
+  ODT_CHECK(h != nullptr, "null handle");
+  if (count) *count = (int)h->convs.size();
+  if (index < 0 || index >= (int)h->convs.size()) return 0;
+  const ConvOp& c = h->convs[index];
+  if (name && name_cap > 0) { std::strncpy(name, c.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (flops) *flops = conv_flops(c.p);
+  if (ms) *ms = index < (int)h->prof_layer_ms.size() ? h->prof_layer_ms[index] : 0.0;
+  if (mnk) { mnk[0] = (int64_t)c.p.B * c.p.Ho * c.p.Wo; mnk[1] = c.p.Cout; mnk[2] = (int64_t)c.p.kh * c.p.kw * c.p.Cin; }
   return 0;
 }
 

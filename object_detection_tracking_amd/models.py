@@ -139,6 +139,20 @@ class _Engine(object):
                                                  C.byref(tot)))
     return dict(conv_ms=ms.value, conv_flops=fl.value, conv_launches=n.value, total_ms=tot.value)
 
+  def profile_layers(self):
+    """[(name, flops, ms, (M, N, K))] for every conv launch of the plan."""
+    cnt = C.c_int()
+    self.lib.check(self.lib.dll.odt_profile_layer(self.h, -1, None, 0, None, None, None,
+                                                  C.byref(cnt)))
+    out = []
+    for i in range(cnt.value):
+      name = C.create_string_buffer(128); fl = C.c_double(); ms = C.c_double()
+      mnk = (C.c_int64 * 3)()
+      self.lib.check(self.lib.dll.odt_profile_layer(self.h, i, name, 128, C.byref(fl), C.byref(ms),
+                                                    C.cast(mnk, c_i64_p), C.byref(cnt)))
+      out.append((name.value.decode(), fl.value, ms.value, (mnk[0], mnk[1], mnk[2])))
+    return out
+
   def tap(self, name):
     """Stage tensor in the device layout (NHWC), as numpy."""
     shape = (C.c_int64 * 4)(); rank = C.c_int()

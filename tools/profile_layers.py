@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Per-layer HIP-event timing of the conv launches of one forward (GPU only).
+  python tools/profile_layers.py [--batch 8] [--steps 3] [--tile N]
+Groups identical GEMM shapes and prints TFLOP/s vs the 157.3 TF f32-MFMA peak."""
+import argparse, os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--batch", type=int, default=8)
+  ap.add_argument("--steps", type=int, default=3)
+  ap.add_argument("--height", type=int, default=1080)
+  ap.add_argument("--width", type=int, default=1920)
+  a = ap.parse_args()
+  from object_detection_tracking_amd import models
+  from object_detection_tracking_amd.config import make_config
+  from object_detection_tracking_amd.weights import synthetic_frames, synthetic_weights
+  cfg = make_config(rpn_test_post_nms_topk=300, im_batch_size=a.batch)
+  m = models.get_model(cfg, 0, weights=synthetic_weights(cfg, 0), is_multi=True)
+  e = m.engine(a.batch, a.height, a.width)
+  fr = synthetic_frames(a.batch, a.height, a.width)
+  e.forward(fr)
+  e.profile(True)
+  for _ in range(a.steps):
+    e.forward(fr)
+  rows = e.profile_layers()
+  tot = e.profile_read()
+  groups = collections.OrderedDict()
+  for name, fl, ms, mnk in rows:
+    kind = name.split("/")[-1].split("@")[0] if not name.startswith("fpn") and not name.startswith("rpn") and not name.startswith("fastrcnn") else name
+    key = (mnk, kind if mnk[2] in (147, 224) else "")
+    g = groups.setdefault(mnk, [0, 0.0, 0.0, name])
+    g[0] += 1; g[1] += fl; g[2] += ms / a.steps
+  print("%-44s %5s %9s %7s %7s %9s %8s %7s" % ("first layer of shape", "n", "M", "N", "K", "ms/step", "TFLOP/s", "frac"))
+  for mnk, (n, fl, ms, name) in sorted(groups.items(), key=lambda kv: -kv[1][2]):
+    tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0
+    print("%-44s %5d %9d %7d %7d %9.3f %8.1f %7.3f" % (name[:44], n, mnk[0], mnk[1], mnk[2], ms, tf, tf / 157.3))
+  cms = tot["conv_ms"] / a.steps
+  print("conv total %.2f ms/step, %.1f TFLOP/s (%.3f of peak); step %.2f ms" %
+        (cms, tot["conv_flops"] / a.steps / (cms * 1e-3) / 1e12, tot["conv_flops"] / a.steps / (cms * 1e-3) / 1e12 / 157.3, tot["total_ms"] / a.steps))
+  m.close()
+
+if __name__ == "__main__":
+  main()
