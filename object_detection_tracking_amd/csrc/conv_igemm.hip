@@ -29,6 +29,9 @@ namespace {
 
 constexpr int LS = 36;  // LDS row stride in floats (32 + 4 pad)
 
+typedef unsigned int u32x4 __attribute__((vector_size(16)));
+constexpr unsigned kOOB = 0x80000000u;   // buffer offset that is out of range for every tensor (< 2 GiB)
+
 template <int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvParams p) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -48,46 +51,66 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvParams p) {
   const int cpt = p.Cin >> 5;               // 32-channel slices per tap
   const int nslices = p.kh * p.kw * cpt;
 
+  // Branch-free operand fetch: raw buffer loads (SRSRC descriptors built from kernel arguments,
+  // i.e. provably wave-uniform); rows that fall into the zero padding / past M / past Cout get an
+  // out-of-range offset and the hardware returns zeros.
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.in, 0, (int)((unsigned)p.B * p.in_Ha * p.in_Wa * p.in_ldc * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.wt, 0, (int)((unsigned)p.Cout * K * 4u), 0x00020000);
+
   // ---- loader role: thread -> (row lr + 32*j, 16-byte column lc)
   const int lc = tid & 7, lr = tid >> 3;
-  int a_hi0[RA], a_wi0[RA], a_img[RA];
-  bool a_ok[RA];
+  int a_hi0[RA], a_wi0[RA];
+  unsigned a_img[RA];          // byte offset of the image of this row (kOOB: row >= M)
 #pragma unroll
   for (int j = 0; j < RA; ++j) {
     const int m = m0 + lr + 32 * j;
-    a_ok[j] = m < M;
-    const int mm = a_ok[j] ? m : 0;
+    const bool ok = m < M;
+    const int mm = ok ? m : 0;
     const int n = mm / HoWo, r = mm - n * HoWo;
     const int ho = r / p.Wo, wo = r - ho * p.Wo;
     a_hi0[j] = ho * p.stride - p.pad_t;
     a_wi0[j] = wo * p.stride - p.pad_l;
-    a_img[j] = n * p.in_Ha * p.in_Wa;
+    a_img[j] = ok ? (unsigned)n * p.in_Ha * p.in_Wa * p.in_ldc * 4u + lc * 16u : kOOB;
   }
-  const float* b_ptr[RB];
-  bool b_ok[RB];
+  unsigned b_off[RB];
 #pragma unroll
   for (int j = 0; j < RB; ++j) {
     const int n = n0 + lr + 32 * j;
-    b_ok[j] = n < p.Cout;
-    b_ptr[j] = p.wt + (size_t)(b_ok[j] ? n : 0) * K + lc * 4;
+    b_off[j] = n < p.Cout ? (unsigned)n * K * 4u + lc * 16u : kOOB;
   }
+  const unsigned pix_bytes = (unsigned)p.in_ldc * 4u;
 
-  f32x4 ra[RA], rb[RB];
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-  auto load_slice = [&](int c) {
-    const int tap = c / cpt, cc = c - tap * cpt;
+  // load-stream state (runs up to two slices ahead of the MFMA stream)
+  int l_cc = 0, l_tap = 0;
+  unsigned l_k = 0;             // byte offset of the slice inside a weight row
+  unsigned a_row[RA];           // byte offset of this tap's pixel for each row (kOOB if padded)
+  auto set_tap = [&](int tap) {
     const int khh = tap / p.kw, kww = tap - khh * p.kw;
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
       const int hi = a_hi0[j] + khh * p.dil, wi = a_wi0[j] + kww * p.dil;
-      const bool v = a_ok[j] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-      const size_t off = (size_t)(a_img[j] + (v ? hi * p.in_Wa + wi : 0)) * p.in_ldc + cc * 32 + lc * 4;
-      ra[j] = v ? *reinterpret_cast<const f32x4*>(p.in + off) : zero4;
+      const bool v = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W && a_img[j] != kOOB;
+      a_row[j] = v ? a_img[j] + (unsigned)(hi * p.in_Wa + wi) * pix_bytes : kOOB;
     }
+  };
+  set_tap(0);
+
+  f32x4 ra[RA], rb[RB];
+  auto load_slice = [&]() {     // fetch the next slice of the stream into ra / rb
+#pragma unroll
+    for (int j = 0; j < RA; ++j)
+      ra[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(a_row[j] + (unsigned)l_cc * 128u), 0, 0);
 #pragma unroll
     for (int j = 0; j < RB; ++j)
-      rb[j] = b_ok[j] ? *reinterpret_cast<const f32x4*>(b_ptr[j] + (size_t)c * 32) : zero4;
+      rb[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_wt, (int)(b_off[j] + l_k), 0, 0);
+    l_k += 128u;
+    if (++l_cc == cpt) {
+      l_cc = 0;
+      ++l_tap;
+      set_tap(l_tap);           // harmless past the last tap (never loaded)
+    }
   };
   auto store_slice = [&](int buf) {
     float* A = lds[buf];
@@ -106,37 +129,53 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // MFMA fragments, double buffered over the four k-groups (g) of a slice.
   const int frag_off = (lane & 31) * LS + (lane >> 5) * 4;
-  auto compute = [&](int buf) {
-    const float* A = lds[buf] + (wm * TM * 32) * LS + frag_off;
-    const float* Bm = lds[buf] + BM * LS + (wn * TN * 32) * LS + frag_off;
+  f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+  auto read_frags = [&](int buf, int g, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
+    const float* A = lds[buf] + (wm * TM * 32) * LS + frag_off + g * 8;
+    const float* Bm = lds[buf] + BM * LS + (wn * TN * 32) * LS + frag_off + g * 8;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 a[TM], b[TN];
+    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(A + i * 32 * LS);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(A + i * 32 * LS + g * 8);
+    for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bm + j * 32 * LS);
+  };
+  auto mfma_group = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bm + j * 32 * LS + g * 8);
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
-    }
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
   };
 
-  load_slice(0);
+  // Software pipeline.  Per slice c (LDS stage c&1) the four k-groups run as
+  //   g0: read frags g1 | MFMA g0        g1: read frags g2 | MFMA g1
+  //   g2: read frags g3 | MFMA g2 | write slice c+1 (registers -> other LDS stage)
+  //   g3: barrier | read frags g0 of slice c+1 | fetch slice c+2 (global -> registers) | MFMA g3
+  // so every LDS / global access has >= one k-group (16*TM*TN MFMAs) of latency cover and the
+  // single barrier per slice sits in front of MFMAs whose operands are already in registers.
+  load_slice();
   store_slice(0);
   __syncthreads();
+  if (nslices > 1) load_slice();
+  read_frags(0, 0, fa0, fb0);
   for (int c = 0; c < nslices; ++c) {
-    const bool more = c + 1 < nslices;
-    if (more) load_slice(c + 1);
-    compute(c & 1);
-    if (more) store_slice((c + 1) & 1);
+    const int cur = c & 1;
+    read_frags(cur, 1, fa1, fb1);
+    mfma_group(fa0, fb0);
+    read_frags(cur, 2, fa0, fb0);
+    mfma_group(fa1, fb1);
+    read_frags(cur, 3, fa1, fb1);
+    mfma_group(fa0, fb0);
+    if (c + 1 < nslices) store_slice(cur ^ 1);
     __syncthreads();
+    if (c + 1 < nslices) read_frags(cur ^ 1, 0, fa0, fb0);
+    if (c + 2 < nslices) load_slice();
+    mfma_group(fa1, fb1);
   }
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   // ---- epilogue.  D reg r of lane l is C[row (r&3)+8*(r>>2)+4*(l>>5)][col l&31]: stage the
   // block tile through LDS (the A/B stages are dead) so that HBM sees whole 16-byte-per-lane
@@ -235,6 +274,9 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
   ODT_CHECK(p.Cin % 32 == 0, "conv: Cin must be a multiple of 32");
   ODT_CHECK(p.in_ldc % 4 == 0, "conv: input pixel stride must be a multiple of 4 floats");
   ODT_CHECK(p.B > 0 && p.Ho > 0 && p.Wo > 0 && p.Cout > 0, "conv: empty problem");
+  ODT_CHECK((double)p.B * p.in_Ha * p.in_Wa * p.in_ldc * 4.0 < 2147483648.0 &&
+            (double)p.Cout * p.kh * p.kw * p.Cin * 4.0 < 2147483648.0,
+            "conv: operand tensors must be smaller than 2 GiB (32-bit buffer offsets)");
   const long M = (long)p.B * p.Ho * p.Wo;
   const long tiles128 = ((M + 127) / 128) * ((p.Cout + 127) / 128);
   int tile = 0;   // 0 auto | 1: 128x64 | 2: 64x64 | 3: 128x128  (ODT_CONV_TILE: tuning / test knob)

@@ -232,6 +232,23 @@ inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipem
   }
   return c;
 }
+// ---- raw buffer loads (SRSRC descriptor; out-of-range dwords read as 0) ------------------------
+struct __amdgpu_buffer_rsrc_t { const char* base; unsigned num_records; };
+typedef unsigned int hipemu_u32x4 __attribute__((vector_size(16)));
+inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(const void* p, short /*stride*/,
+                                                                int num_records, int /*flags*/) {
+  return __amdgpu_buffer_rsrc_t{(const char*)p, (unsigned)num_records};
+}
+inline hipemu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int voffset,
+                                                          int soffset, int /*aux*/) {
+  hipemu_u32x4 v = {0u, 0u, 0u, 0u};
+  const unsigned long long off = (unsigned long long)(unsigned)voffset + (unsigned)soffset;
+  for (int d = 0; d < 4; ++d) {
+    const unsigned long long o = off + 4ull * d;
+    if (o + 4 <= r.num_records) { unsigned t; memcpy(&t, r.base + o, 4); v[d] = t; }
+  }
+  return v;
+}
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_sched_barrier(int) {}
 
