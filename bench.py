@@ -106,6 +106,26 @@ def main():
   eng.profile(False)
   achieved = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12 if prof["conv_ms"] > 0 else 0.0
 
+  # Not part of `value`: (a) the same step through the host boundary (pageable host frames ->
+  # odt_forward -> host outputs incl. [M,256,7,7] features): PCIe-inclusive rate; (b) the DeepSORT
+  # appearance matching kernel at BASELINE config #3 size (T=64 tracks x budget 5, N=100 dets).
+  extra = {}
+  if rank == 0:
+    from object_detection_tracking_amd import ops
+    t1 = time.perf_counter()
+    for _ in range(3):
+      eng.forward(frames)
+    extra["pcie_inclusive_fps"] = 3 * B / (time.perf_counter() - t1)
+    rng = np.random.default_rng(0)
+    gal = rng.standard_normal((320, 256)).astype(np.float32)
+    seg = (np.arange(65) * 5).astype(np.int32)
+    det = rng.standard_normal((100, 256)).astype(np.float32)
+    ops.nn_cosine(gal, seg, det, device=local_rank)
+    t1 = time.perf_counter()
+    for _ in range(20):
+      ops.nn_cosine(gal, seg, det, device=local_rank)
+    extra["nn_matching_ms_per_call_host_to_host"] = 1e3 * (time.perf_counter() - t1) / 20
+
   if rank == 0:
     fps = world * B * args.steps / dt
     out = {
@@ -140,6 +160,7 @@ def main():
             "algorithmic_gflop_per_step": prof["conv_flops"] / max(1, args.profile_steps) / 1e9,
         },
     }
+    out["extra"] = extra
     if world == 1 and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline(cfg, weights, frames, args.cpu_frames)
     print(json.dumps(out), flush=True)
