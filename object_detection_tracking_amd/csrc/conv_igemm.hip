@@ -33,7 +33,11 @@ typedef unsigned int u32x4 __attribute__((vector_size(16)));
 constexpr unsigned kOOB = 0x80000000u;   // buffer offset that is out of range for every tensor (< 2 GiB)
 
 template <int WM, int WN, int TM, int TN>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(ConvParams p) {
+__global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvParams* __restrict__ pp) {
+  // Parameters live in device memory (one record per conv of the plan): the by-value kernarg
+  // block sits in host-coherent memory and its cold scalar loads cost the first dispatch wave of
+  // every launch tens of microseconds.
+  const ConvParams p = *pp;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int RA = BM / 32, RB = BN / 32;
   static_assert(WM * WN == 4, "4 waves");
@@ -43,7 +47,21 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvParams p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int ntn = (p.Cout + BN - 1) / BN;
-  const int mt = blockIdx.x / ntn, nt = blockIdx.x - mt * ntn;
+  auto stamp = [&](int i) {
+    if (p.trace != nullptr && tid == 0) p.trace[(size_t)blockIdx.x * 8 + i] = wall_clock64();
+  };
+  stamp(0);
+  // XCD-aware tile order: the dispatcher places workgroup i on XCD i % 8, each XCD has its own
+  // L2.  Give every XCD one contiguous run of (m-tile, n-tile) pairs so that all N-tiles of an
+  // M-tile (same A rows) and neighbouring M-tiles (shared 3x3 halo rows) hit the same L2
+  // instead of pulling the A tile through the fabric once per XCD.  Bijective for any grid size;
+  // a different placement would only change speed.
+  int wg = (int)blockIdx.x;
+  if (!(p.debug & 128)) {
+    const int nwg = (int)gridDim.x, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  const int mt = wg / ntn, nt = wg - mt * ntn;
   const int m0 = mt * BM, n0 = nt * BN;
   const int HoWo = p.Ho * p.Wo;
   const int M = p.B * HoWo;
@@ -63,16 +81,26 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvParams p) {
   const int lc = tid & 7, lr = tid >> 3;
   int a_hi0[RA], a_wi0[RA];
   unsigned a_img[RA];          // byte offset of the image of this row (kOOB: row >= M)
+  // 1x1 / stride 1 / unpadded convs over a dense input (all bottleneck 1x1s, FPN laterals, FCs):
+  // input pixel == output row m, no (n,ho,wo) decomposition (saves the integer divisions)
+  const bool dense_in = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 &&
+                        p.H == p.in_Ha && p.W == p.in_Wa && p.Ho == p.H && p.Wo == p.W;
 #pragma unroll
   for (int j = 0; j < RA; ++j) {
     const int m = m0 + lr + 32 * j;
     const bool ok = m < M;
-    const int mm = ok ? m : 0;
-    const int n = mm / HoWo, r = mm - n * HoWo;
-    const int ho = r / p.Wo, wo = r - ho * p.Wo;
-    a_hi0[j] = ho * p.stride - p.pad_t;
-    a_wi0[j] = wo * p.stride - p.pad_l;
-    a_img[j] = ok ? (unsigned)n * p.in_Ha * p.in_Wa * p.in_ldc * 4u + lc * 16u : kOOB;
+    if (dense_in) {
+      a_hi0[j] = 0;
+      a_wi0[j] = 0;
+      a_img[j] = ok ? (unsigned)m * p.in_ldc * 4u + lc * 16u : kOOB;
+    } else {
+      const int mm = ok ? m : 0;
+      const int n = mm / HoWo, r = mm - n * HoWo;
+      const int ho = r / p.Wo, wo = r - ho * p.Wo;
+      a_hi0[j] = ho * p.stride - p.pad_t;
+      a_wi0[j] = wo * p.stride - p.pad_l;
+      a_img[j] = ok ? (unsigned)n * p.in_Ha * p.in_Wa * p.in_ldc * 4u + lc * 16u : kOOB;
+    }
   }
   unsigned b_off[RB];
 #pragma unroll
@@ -82,12 +110,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvParams p) {
   }
   const unsigned pix_bytes = (unsigned)p.in_ldc * 4u;
 
+  const int dbg = p.debug;
   // load-stream state (runs up to two slices ahead of the MFMA stream)
-  int l_cc = 0, l_tap = 0;
+  int l_cc = 0, l_kh = 0, l_kw = 0;
   unsigned l_k = 0;             // byte offset of the slice inside a weight row
   unsigned a_row[RA];           // byte offset of this tap's pixel for each row (kOOB if padded)
-  auto set_tap = [&](int tap) {
-    const int khh = tap / p.kw, kww = tap - khh * p.kw;
+  auto set_tap = [&](int khh, int kww) {
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
       const int hi = a_hi0[j] + khh * p.dil, wi = a_wi0[j] + kww * p.dil;
@@ -95,7 +123,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvParams p) {
       a_row[j] = v ? a_img[j] + (unsigned)(hi * p.in_Wa + wi) * pix_bytes : kOOB;
     }
   };
-  set_tap(0);
+  set_tap(0, 0);
 
   f32x4 ra[RA], rb[RB];
   auto load_slice = [&]() {     // fetch the next slice of the stream into ra / rb
@@ -108,8 +136,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvParams p) {
     l_k += 128u;
     if (++l_cc == cpt) {
       l_cc = 0;
-      ++l_tap;
-      set_tap(l_tap);           // harmless past the last tap (never loaded)
+      if (++l_kw == p.kw) { l_kw = 0; ++l_kh; }
+      set_tap(l_kh, l_kw);      // harmless past the last tap (never loaded)
     }
   };
   auto store_slice = [&](int buf) {
@@ -140,9 +168,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bm + j * 32 * LS);
   };
-  auto mfma_group = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) {
+  auto mfma_group = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN], int t0, int t1) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = t0; t < t1; ++t)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -156,26 +184,45 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvParams p) {
   //   g3: barrier | read frags g0 of slice c+1 | fetch slice c+2 (global -> registers) | MFMA g3
   // so every LDS / global access has >= one k-group (16*TM*TN MFMAs) of latency cover and the
   // single barrier per slice sits in front of MFMAs whose operands are already in registers.
+  // sched_barrier(0) fences pin this interleave (without them the scheduler sinks the fragment
+  // reads to just before their first use and lumps the LDS writes / barrier / fetches together).
+  stamp(6);
   load_slice();
   store_slice(0);
+  stamp(7);
   __syncthreads();
+  stamp(1);
   if (nslices > 1) load_slice();
   read_frags(0, 0, fa0, fb0);
   for (int c = 0; c < nslices; ++c) {
     const int cur = c & 1;
-    read_frags(cur, 1, fa1, fb1);
-    mfma_group(fa0, fb0);
-    read_frags(cur, 2, fa0, fb0);
-    mfma_group(fa1, fb1);
-    read_frags(cur, 3, fa1, fb1);
-    mfma_group(fa0, fb0);
-    if (c + 1 < nslices) store_slice(cur ^ 1);
-    __syncthreads();
-    if (c + 1 < nslices) read_frags(cur ^ 1, 0, fa0, fb0);
-    if (c + 2 < nslices) load_slice();
-    mfma_group(fa1, fb1);
+    const bool more = c + 1 < nslices;
+    if (!(dbg & 8)) read_frags(cur, 1, fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(dbg & 16)) mfma_group(fa0, fb0, 0, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(dbg & 8)) read_frags(cur, 2, fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(dbg & 16)) mfma_group(fa1, fb1, 0, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(dbg & 8)) read_frags(cur, 3, fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(dbg & 16)) mfma_group(fa0, fb0, 0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more && !(dbg & 2)) store_slice(cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(dbg & 16)) mfma_group(fa0, fb0, 2, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(dbg & 4)) __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (more && !(dbg & 8)) read_frags(cur ^ 1, 0, fa0, fb0);
+    if (c + 2 < nslices && !(dbg & 1)) load_slice();
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(dbg & 16)) mfma_group(fa1, fb1, 0, 4);
+    __builtin_amdgcn_sched_barrier(0);
   }
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  stamp(2);
 
   // ---- epilogue.  D reg r of lane l is C[row (r&3)+8*(r>>2)+4*(l>>5)][col l&31]: stage the
   // block tile through LDS (the A/B stages are dead) so that HBM sees whole 16-byte-per-lane
@@ -195,10 +242,66 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvParams p) {
         Ct[row * CS + col] = acc[i][j][r];
       }
   __syncthreads();
+  stamp(3);
 
   constexpr int C4 = BN / 4;                      // 16-byte chunks per tile row
   constexpr int NCH = BM * C4 / 256;              // chunks per thread
   const bool vec_ok = (p.out_ldc & 3) == 0 && (p.res_mode == 0 || (p.res_ldc & 3) == 0);
+  const bool dense_io = p.out_oy == 0 && p.out_ox == 0 && p.out_H == p.Ho && p.out_W == p.Wo &&
+                        (p.res_mode == 0 || (p.res_mode == 1 && p.res_H == p.Ho && p.res_W == p.Wo));
+  if (vec_ok && (p.Cout & 3) == 0) {
+    // ---- fast path (every layer of the model except the 15-channel RPN head): branch-free.
+    // Buffer loads/stores with out-of-range offsets for the masked chunks, so the compiler sees
+    // straight-line code and emits counted vmcnt waits instead of draining every store.
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.out, 0, (int)((unsigned)p.B * p.out_H * p.out_W * p.out_ldc * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.res_mode != 0 ? p.res : p.bias), 0,
+        (int)(p.res_mode != 0 ? (unsigned)p.B * p.res_H * p.res_W * p.res_ldc * 4u : 0u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_bias =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (int)((unsigned)p.Cout * 4u), 0x00020000);
+    const int c4 = tid % C4, row0 = tid / C4;        // chunk s2 of this thread: row0 + s2*(256/C4)
+    const int col = n0 + c4 * 4;
+    const bool col_ok = col < p.Cout;
+    unsigned ooff[NCH];
+    f32x4 rv[NCH];
+#pragma unroll
+    for (int s2 = 0; s2 < NCH; ++s2) {
+      const int m = m0 + row0 + s2 * (256 / C4);
+      const bool ok = col_ok && m < M;
+      unsigned opix, rpix;
+      if (dense_io) {
+        opix = (unsigned)m;
+        rpix = (unsigned)m;
+      } else {
+        const int mm = ok ? m : 0;
+        const int n = mm / HoWo, rr = mm - n * HoWo;
+        const int ho = rr / p.Wo, wo = rr - ho * p.Wo;
+        opix = ((unsigned)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
+        rpix = p.res_mode == 2 ? ((unsigned)n * p.res_H + (ho >> 1)) * p.res_W + (wo >> 1)
+                               : ((unsigned)n * p.res_H + ho) * p.res_W + wo;
+      }
+      ooff[s2] = ok ? (opix * p.out_ldc + col) * 4u : kOOB;
+      const unsigned roff = ok ? (rpix * p.res_ldc + col) * 4u : kOOB;
+      rv[s2] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)roff, 0, 0);   // 0 if no residual
+    }
+    const f32x4 bias4 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, col_ok ? col * 4 : (int)kOOB, 0, 0);
+    stamp(4);
+#pragma unroll
+    for (int s2 = 0; s2 < NCH; ++s2) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[(row0 + s2 * (256 / C4)) * CS + c4 * 4]);
+      v += bias4;
+      v += rv[s2];
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)ooff[s2], 0, 0);
+    }
+    stamp(5);
+    return;
+  }
+  // ---- generic path (Cout % 4 != 0 or unaligned pixel strides)
   f32x4 rv[NCH];
   size_t oaddr[NCH];
   int nval[NCH];
@@ -214,12 +317,20 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvParams p) {
     rv[s2] = zero4;
     oaddr[s2] = 0;
     if (nv > 0) {
-      const int n = m / HoWo, rr = m - n * HoWo;
-      const int ho = rr / p.Wo, wo = rr - ho * p.Wo;
-      oaddr[s2] = (((size_t)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox) * p.out_ldc + col;
+      size_t opix, rpix = 0;
+      if (dense_io) {                 // output (and residual) pixels are simply row m: no divisions
+        opix = (size_t)m;
+        rpix = (size_t)m;
+      } else {
+        const int n = m / HoWo, rr = m - n * HoWo;
+        const int ho = rr / p.Wo, wo = rr - ho * p.Wo;
+        opix = ((size_t)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
+        if (p.res_mode != 0)
+          rpix = p.res_mode == 1 ? ((size_t)n * p.res_H + ho) * p.res_W + wo
+                                 : ((size_t)n * p.res_H + (ho >> 1)) * p.res_W + (wo >> 1);
+      }
+      oaddr[s2] = opix * p.out_ldc + col;
       if (p.res_mode != 0) {
-        const size_t rpix = p.res_mode == 1 ? ((size_t)n * p.res_H + ho) * p.res_W + wo
-                                            : ((size_t)n * p.res_H + (ho >> 1)) * p.res_W + (wo >> 1);
         const float* rp = p.res + rpix * p.res_ldc + col;
         if (nv == 4 && vec_ok) {
           rv[s2] = *reinterpret_cast<const f32x4*>(rp);
@@ -229,19 +340,24 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvParams p) {
       }
     }
   }
+  // every chunk of a thread has the same column (256 % C4 == 0): fetch the bias once, BEFORE
+  // any store (a load issued after a store has to wait for that store's completion: vmcnt is
+  // in-order).
+  static_assert(256 % C4 == 0, "bias column must be chunk-invariant");
+  const int bcol = n0 + (tid % C4) * 4;
+  f32x4 bias4 = zero4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (bcol + e < p.Cout) bias4[e] = p.bias[bcol + e];
+  stamp(4);
 #pragma unroll
   for (int s2 = 0; s2 < NCH; ++s2) {
     const int nv = nval[s2];
     if (nv == 0) continue;
     const int q = tid + 256 * s2;
     const int row = q / C4, c4 = q - row * C4;
-    const int col = n0 + c4 * 4;
     f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[row * CS + c4 * 4]);
-    if (nv == 4) {
-      v += *reinterpret_cast<const f32x4*>(p.bias + col);
-    } else {
-      for (int e = 0; e < nv; ++e) v[e] += p.bias[col + e];
-    }
+    v += bias4;
     v += rv[s2];
     if (p.relu) {
 #pragma unroll
@@ -254,14 +370,15 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvParams p) {
       for (int e = 0; e < nv; ++e) op[e] = v[e];
     }
   }
+  stamp(5);
 }
 
 template <int WM, int WN, int TM, int TN>
-void launch_variant(const ConvParams& p, hipStream_t stream) {
+void launch_variant(const ConvParams& p, const ConvParams* dev, hipStream_t stream) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int M = p.B * p.Ho * p.Wo;
   const unsigned grid = (unsigned)(((M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN));
-  hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, TM, TN>), dim3(grid), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, TM, TN>), dim3(grid), dim3(256), 0, stream, dev);
 }
 
 }  // namespace
@@ -270,26 +387,45 @@ double conv_flops(const ConvParams& p) {
   return 2.0 * (double)p.B * p.Ho * p.Wo * (double)p.Cout * (double)(p.kh * p.kw * p.Cin);
 }
 
-int launch_conv(const ConvParams& p, hipStream_t stream) {
+int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_params) {
   ODT_CHECK(p.Cin % 32 == 0, "conv: Cin must be a multiple of 32");
   ODT_CHECK(p.in_ldc % 4 == 0, "conv: input pixel stride must be a multiple of 4 floats");
   ODT_CHECK(p.B > 0 && p.Ho > 0 && p.Wo > 0 && p.Cout > 0, "conv: empty problem");
   ODT_CHECK((double)p.B * p.in_Ha * p.in_Wa * p.in_ldc * 4.0 < 2147483648.0 &&
             (double)p.Cout * p.kh * p.kw * p.Cin * 4.0 < 2147483648.0,
             "conv: operand tensors must be smaller than 2 GiB (32-bit buffer offsets)");
+  ODT_CHECK((double)p.B * p.out_H * p.out_W * p.out_ldc * 4.0 < 2147483648.0 &&
+            (p.res_mode == 0 || (double)p.B * p.res_H * p.res_W * p.res_ldc * 4.0 < 2147483648.0),
+            "conv: output / residual tensors must be smaller than 2 GiB (32-bit buffer offsets)");
   const long M = (long)p.B * p.Ho * p.Wo;
   const long tiles128 = ((M + 127) / 128) * ((p.Cout + 127) / 128);
   int tile = 0;   // 0 auto | 1: 128x64 | 2: 64x64 | 3: 128x128  (ODT_CONV_TILE: tuning / test knob)
   if (const char* e = getenv("ODT_CONV_TILE")) tile = atoi(e);
+  ConvParams q = p;
+  bool modified = false;
+  if (const char* e = getenv("ODT_CONV_DEBUG")) {
+    if (atoi(e) != 0) { q.debug = atoi(e); modified = true; }
+  }
+  // stand-alone calls (tests, tuning) and debug overrides: stage the record in a temporary
+  ConvParams* tmp = nullptr;
+  if (dev_params == nullptr || modified) {
+    ODT_HIP(hipMalloc((void**)&tmp, sizeof(ConvParams)));
+    ODT_HIP(hipMemcpy(tmp, &q, sizeof(ConvParams), hipMemcpyHostToDevice));
+    dev_params = tmp;
+  }
   if (tile == 0) tile = p.Cout <= 64 ? 1 : (tiles128 < 384 ? 2 : 3);
   if (tile == 1) {
-    launch_variant<4, 1, 1, 2>(p, stream);       // 128 x 64
+    launch_variant<4, 1, 1, 2>(q, dev_params, stream);       // 128 x 64
   } else if (tile == 2) {
-    launch_variant<2, 2, 1, 1>(p, stream);       // 64 x 64: fill the 256 CUs on small M
+    launch_variant<2, 2, 1, 1>(q, dev_params, stream);       // 64 x 64: fill the 256 CUs on small M
   } else {
-    launch_variant<2, 2, 2, 2>(p, stream);       // 128 x 128
+    launch_variant<2, 2, 2, 2>(q, dev_params, stream);       // 128 x 128
   }
   ODT_HIP(hipGetLastError());
+  if (tmp != nullptr) {
+    ODT_HIP(hipStreamSynchronize(stream));
+    ODT_HIP(hipFree(tmp));
+  }
   return 0;
 }
 

@@ -5,6 +5,7 @@
 #include "../../include/odt.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -76,6 +77,7 @@ struct odt_model {
   std::vector<std::unique_ptr<DevBuf>> bufs;
   std::map<std::string, Tensor> taps;
   std::vector<ConvOp> convs;
+  ConvParams* convs_dev = nullptr;   // device copies of convs[i].p
   std::vector<Op> ops;
   // geometry
   int Hp = 0, Wp = 0;
@@ -536,6 +538,14 @@ int build_plan(odt_model* m) {
   rf.boxes = dp.out_boxes; rf.per_image = per_im; rf.count = dp.out_valid; rf.R_cap = B * per_im;
   rf.out_nhwc = nullptr; rf.out_nchw = m->final_feat; rf.pooled = m->final_pooled;
   { Op op; op.kind = OP_ROI_FINAL; m->ops.push_back(op); }
+  {   // conv parameter records in device memory
+    std::vector<ConvParams> recs;
+    for (const ConvOp& c : m->convs) recs.push_back(c.p);
+    m->bufs.emplace_back(new DevBuf());
+    if (m->bufs.back()->alloc(recs.size() * sizeof(ConvParams))) return 1;
+    m->convs_dev = (ConvParams*)m->bufs.back()->p;
+    ODT_HIP(hipMemcpy(m->convs_dev, recs.data(), recs.size() * sizeof(ConvParams), hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
@@ -565,7 +575,7 @@ int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStre
       case OP_CONV: {
         const ConvOp& c = m->convs[op.conv];
         if (m->profile) ODT_HIP(hipEventRecord(m->ev[ev_i++], st));
-        if (launch_conv(c.p, st)) { g_err = c.name + ": " + g_err; return 1; }
+        if (launch_conv(c.p, st, m->convs_dev + op.conv)) { g_err = c.name + ": " + g_err; return 1; }
         if (m->profile) ODT_HIP(hipEventRecord(m->ev[ev_i++], st));
         break;
       }
@@ -771,8 +781,55 @@ int odt_op_conv2d(int device, const float* in, int B, int H, int W, int Cin, con
   p.out_H = Ho + oy; p.out_W = Wo + ox; p.out_oy = oy; p.out_ox = ox; p.out_ldc = Cout;
   p.res_mode = p.res ? res_mode : 0; p.res_H = rH; p.res_W = rW; p.res_ldc = Cout; p.relu = relu;
   p.in_Ha = H; p.in_Wa = W;
+  Tmp<unsigned long long> tr;
+  const bool trace = getenv("ODT_CONV_TRACE") != nullptr;
+  const int max_blocks = 1 << 16;
+  if (trace) { if (tr.alloc((size_t)max_blocks * 8) || tr.zero()) return 1; p.trace = tr.d; }
+  if (launch_conv(p, nullptr)) return 1;      // warm
+  if (trace) { if (tr.zero()) return 1; }
   if (launch_conv(p, nullptr)) return 1;
   ODT_HIP(hipDeviceSynchronize());
+  if (trace) {   // tuning aid: per-phase wall-clock (100 MHz) statistics over the workgroups
+    std::vector<unsigned long long> t((size_t)max_blocks * 8);
+    if (tr.get(t.data(), t.size())) return 1;
+    unsigned long long t0 = ~0ull, t1 = 0; int nb = 0;
+    double ph[5] = {0, 0, 0, 0, 0};
+    for (int b = 0; b < max_blocks; ++b) {
+      const unsigned long long* q = &t[(size_t)b * 8];
+      if (q[0] == 0) continue;
+      ++nb; if (q[0] < t0) t0 = q[0]; if (q[5] > t1) t1 = q[5];
+      for (int i = 0; i < 5; ++i) ph[i] += (double)(q[i + 1] - q[i]);
+    }
+    printf("[conv trace] blocks=%d span=%.1f us | per block avg us: prologue %.2f  mainloop %.2f  acc->lds %.2f  "
+           "addr+res loads %.2f  stores %.2f | sum %.2f\n", nb, (t1 - t0) / 100.0, ph[0] / nb / 100, ph[1] / nb / 100,
+           ph[2] / nb / 100, ph[3] / nb / 100, ph[4] / nb / 100, (ph[0] + ph[1] + ph[2] + ph[3] + ph[4]) / nb / 100);
+    // concurrency: how many blocks are in the main loop at the midpoint of the launch
+    const unsigned long long mid = t0 + (t1 - t0) / 2; int in_main = 0, in_epi = 0, in_pro = 0;
+    for (int b = 0; b < max_blocks; ++b) {
+      const unsigned long long* q = &t[(size_t)b * 8];
+      if (q[0] == 0) continue;
+      if (mid >= q[0] && mid < q[1]) ++in_pro; else if (mid >= q[1] && mid < q[2]) ++in_main; else if (mid >= q[2] && mid < q[5]) ++in_epi;
+    }
+    {   // first dispatch wave vs the rest
+      double sa[3] = {0, 0, 0}, sb[3] = {0, 0, 0};
+      double pa = 0, pb = 0, ma = 0, mb = 0; int na = 0, nb2 = 0;
+      for (int b = 0; b < max_blocks; ++b) {
+        const unsigned long long* q = &t[(size_t)b * 8];
+        if (q[0] == 0) continue;
+        double* sx = (q[0] - t0 < 500) ? sa : sb;
+        sx[0] += (double)(q[6] - q[0]); sx[1] += (double)(q[7] - q[6]); sx[2] += (double)(q[1] - q[7]);
+        if (q[0] - t0 < 500) { pa += (double)(q[1] - q[0]); ma += (double)(q[2] - q[1]); ++na; }
+        else { pb += (double)(q[1] - q[0]); mb += (double)(q[2] - q[1]); ++nb2; }
+      }
+      printf("[conv trace] first wave (%d blocks): prologue %.2f us, mainloop %.2f us | later (%d blocks): prologue %.2f us, mainloop %.2f us\n",
+             na, na ? pa / na / 100 : 0.0, na ? ma / na / 100 : 0.0, nb2, nb2 ? pb / nb2 / 100 : 0.0, nb2 ? mb / nb2 / 100 : 0.0);
+      if (na && nb2)
+        printf("[conv trace] prologue split (setup / first loads+lds / barrier): first wave %.2f / %.2f / %.2f us, later %.2f / %.2f / %.2f us\n",
+               sa[0] / na / 100, sa[1] / na / 100, sa[2] / na / 100, sb[0] / nb2 / 100, sb[1] / nb2 / 100, sb[2] / nb2 / 100);
+    }
+    printf("[conv trace] at mid-launch: %d blocks in prologue, %d in main loop, %d in epilogue\n", in_pro, in_main, in_epi);
+    fflush(stdout);
+  }
   return dout.get(out, nout);
 }
 

@@ -249,8 +249,18 @@ inline hipemu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t
   }
   return v;
 }
+inline void __builtin_amdgcn_raw_buffer_store_b128(hipemu_u32x4 v, __amdgpu_buffer_rsrc_t r, int voffset,
+                                                   int soffset, int /*aux*/) {
+  const unsigned long long off = (unsigned long long)(unsigned)voffset + (unsigned)soffset;
+  for (int d = 0; d < 4; ++d) {
+    const unsigned long long o = off + 4ull * d;
+    if (o + 4 <= r.num_records) { unsigned t = v[d]; memcpy(const_cast<char*>(r.base) + o, &t, 4); }
+  }
+}
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_s_sleep(int) {}
+inline unsigned long long wall_clock64() { return (unsigned long long)(hipemu::now_ms() * 1e5); }
 
 // ---- atomics / bit casts ----------------------------------------------------
 template <typename T> inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
