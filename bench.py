@@ -154,7 +154,7 @@ def main():
             "peak": F32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / F32_MFMA_PEAK_TFLOPS,
-            "traffic": None,
+            "traffic": pmc_traffic(),
             "conv_ms_per_step": prof["conv_ms"] / max(1, args.profile_steps),
             "step_ms_profiled": prof["total_ms"] / max(1, args.profile_steps),
             "algorithmic_gflop_per_step": prof["conv_flops"] / max(1, args.profile_steps) / 1e9,
@@ -168,6 +168,17 @@ def main():
   if world > 1:
     dist.barrier()
     dist.destroy_process_group()
+
+
+def pmc_traffic():
+  """HBM bytes per conv launch from the separate rocprofv3 --pmc passes of this same command
+  (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; tools/pmc_summary.py), or None."""
+  path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+  try:
+    with open(path) as fh:
+      return float(json.load(fh)["conv_hbm_bytes_per_launch_fetch_x2"])
+  except Exception:
+    return None
 
 
 def cpu_baseline(cfg, weights, frames, nframes):
