@@ -30,6 +30,11 @@ namespace {
 constexpr int LS = 36;  // LDS row stride in floats (32 + 4 pad)
 
 typedef unsigned int u32x4 __attribute__((vector_size(16)));
+
+// exact n / d for n < 2^31 with the (mul, sh) pair made by conv_prepare (mul == 0: d == 1)
+__device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned sh) {
+  return mul ? (int)(__umulhi((unsigned)n, mul) >> sh) : n;
+}
 constexpr unsigned kOOB = 0x80000000u;   // buffer offset that is out of range for every tensor (< 2 GiB)
 
 template <int WM, int WN, int TM, int TN>
@@ -95,8 +100,8 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvParams* __
       a_img[j] = ok ? (unsigned)m * p.in_ldc * 4u + lc * 16u : kOOB;
     } else {
       const int mm = ok ? m : 0;
-      const int n = mm / HoWo, r = mm - n * HoWo;
-      const int ho = r / p.Wo, wo = r - ho * p.Wo;
+      const int n = fast_div(mm, p.div_howo_mul, p.div_howo_sh), r = mm - n * HoWo;
+      const int ho = fast_div(r, p.div_wo_mul, p.div_wo_sh), wo = r - ho * p.Wo;
       a_hi0[j] = ho * p.stride - p.pad_t;
       a_wi0[j] = wo * p.stride - p.pad_l;
       a_img[j] = ok ? (unsigned)n * p.in_Ha * p.in_Wa * p.in_ldc * 4u + lc * 16u : kOOB;
@@ -275,8 +280,8 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvParams* __
         rpix = (unsigned)m;
       } else {
         const int mm = ok ? m : 0;
-        const int n = mm / HoWo, rr = mm - n * HoWo;
-        const int ho = rr / p.Wo, wo = rr - ho * p.Wo;
+        const int n = fast_div(mm, p.div_howo_mul, p.div_howo_sh), rr = mm - n * HoWo;
+        const int ho = fast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
         opix = ((unsigned)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
         rpix = p.res_mode == 2 ? ((unsigned)n * p.res_H + (ho >> 1)) * p.res_W + (wo >> 1)
                                : ((unsigned)n * p.res_H + ho) * p.res_W + wo;
@@ -383,6 +388,20 @@ void launch_variant(const ConvParams& p, const ConvParams* dev, hipStream_t stre
 
 }  // namespace
 
+static void make_div(unsigned d, unsigned* mul, unsigned* sh) {
+  if (d <= 1) { *mul = 0; *sh = 0; return; }
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;                 // l = ceil(log2 d) >= 1
+  const unsigned pbits = 31 + l;               // floor(n * mul / 2^p) == n / d for all n < 2^31
+  *mul = (unsigned)(((1ull << pbits) + d - 1) / d);
+  *sh = pbits - 32;
+}
+
+void conv_prepare(ConvParams& p) {
+  make_div((unsigned)(p.Ho * p.Wo), &p.div_howo_mul, &p.div_howo_sh);
+  make_div((unsigned)p.Wo, &p.div_wo_mul, &p.div_wo_sh);
+}
+
 double conv_flops(const ConvParams& p) {
   return 2.0 * (double)p.B * p.Ho * p.Wo * (double)p.Cout * (double)(p.kh * p.kw * p.Cin);
 }
@@ -402,6 +421,7 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
   int tile = 0;   // 0 auto | 1: 128x64 | 2: 64x64 | 3: 128x128  (ODT_CONV_TILE: tuning / test knob)
   if (const char* e = getenv("ODT_CONV_TILE")) tile = atoi(e);
   ConvParams q = p;
+  conv_prepare(q);
   bool modified = false;
   if (const char* e = getenv("ODT_CONV_DEBUG")) {
     if (atoi(e) != 0) { q.debug = atoi(e); modified = true; }

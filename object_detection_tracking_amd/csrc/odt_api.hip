@@ -198,6 +198,7 @@ int add_conv(odt_model* m, const std::string& name, const Tensor& in, int cin, c
   p.res_mode = res ? res_mode : 0;
   if (res) { p.res_H = res->H; p.res_W = res->W; p.res_ldc = res->C; }
   p.relu = relu ? 1 : 0;
+  conv_prepare(p);
   m->convs.push_back(c);
   Op op;
   op.kind = OP_CONV;

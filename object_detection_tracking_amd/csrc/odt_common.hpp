@@ -53,9 +53,12 @@ struct ConvParams {
   int res_mode;        // 0 none | 1 same shape | 2 nearest-2x upsample of [B,res_H,res_W,*]
   int res_H, res_W, res_ldc;
   int relu;
+  unsigned div_howo_mul, div_howo_sh, div_wo_mul, div_wo_sh;   // exact m / (Ho*Wo), r / Wo by multiply-shift (conv_prepare)
   int debug;           // ablation bits for kernel tuning (0 in production; ODT_CONV_DEBUG)
   unsigned long long* trace;   // optional [grid][8] wall-clock phase stamps (tuning only)
 };
+// fills the derived fields (multiply-shift divisors); call before copying a record to the device
+void conv_prepare(ConvParams& p);
 // dev_params: device copy of `p` (plan-owned); nullptr = stage a temporary (stand-alone calls)
 int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_params = nullptr);
 double conv_flops(const ConvParams& p);   // algorithmic 2*M*N*K
