@@ -119,13 +119,20 @@ __global__ void __launch_bounds__(kSelThreads) final_select_kernel(DetectParams 
   }
   __syncthreads();
   const int nreal = total < per ? total : per;
+  // rank in the merged (prob desc, class asc, order asc) order: every class list is already
+  // sorted that way, so the rank is a sum of binary-search counts over the C-1 lists.
   for (int e = tid; e < total; e += blockDim.x) {
     const float my = s_prob[e];
     const int mc = s_code[e];
     int rank = 0;
-    for (int j = 0; j < total; ++j) {
-      const float o = s_prob[j];
-      rank += (o > my || (o == my && s_code[j] < mc)) ? 1 : 0;   // prob desc, class asc, order asc
+    for (int c2 = 0; c2 < Cm1; ++c2) {
+      int lo = s_off[c2], hi = s_off[c2 + 1];
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const float o = s_prob[mid];
+        if (o > my || (o == my && s_code[mid] < mc)) lo = mid + 1; else hi = mid;
+      }
+      rank += lo - s_off[c2];
     }
     if (rank < per) {
       const int c = mc / per, i = mc - c * per;

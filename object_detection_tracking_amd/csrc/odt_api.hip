@@ -452,8 +452,9 @@ int build_plan(odt_model* m) {
   Tensor props{}; if (make_tensor(m, "proposals", 1, B, K, 4, &props, true)) return 1;
   pp.props = props.d;
   pp.nprops = (int*)m->alloc_f(B, true);
+  pp.chunk_keys = (unsigned long long*)m->alloc_f((size_t)B * proposal_total_chunks(pp) * K * 2, true);
   ODT_CHECK(pp.cand_boxes && pp.cand_scores && pp.lvl_boxes && pp.lvl_scores && pp.cand_count &&
-            pp.lvl_count && pp.nprops, "device allocation failed (proposals)");
+            pp.lvl_count && pp.nprops && pp.chunk_keys, "device allocation failed (proposals)");
   { Op op; op.kind = OP_PROPOSALS; m->ops.push_back(op); }
 
   // ---- ROIAlign over P2..P5 -> box head (models.py:465-485, 1030-1108)
@@ -901,6 +902,9 @@ int odt_op_proposals(int device, int graph, int B, int L, const int* hs, const i
       cc.alloc((size_t)B * L) || lc.alloc((size_t)B * L) || np.alloc(B)) return 1;
   p.cand_boxes = cb.d; p.cand_scores = cs.d; p.lvl_boxes = lb.d; p.lvl_scores = ls.d;
   p.cand_count = cc.d; p.lvl_count = lc.d; p.props = pr.d; p.nprops = np.d;
+  Tmp<unsigned long long> ck;
+  if (ck.alloc((size_t)B * proposal_total_chunks(p) * K)) return 1;
+  p.chunk_keys = ck.d;
   if (launch_proposals(p, nullptr)) return 1;
   ODT_HIP(hipDeviceSynchronize());
   if (pr.get(props, (size_t)B * K * 4)) return 1;

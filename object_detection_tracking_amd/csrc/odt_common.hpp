@@ -34,6 +34,8 @@ typedef float f32x16 __attribute__((vector_size(64)));
 constexpr int kMaxTopK = 1024;   // rpn_test_post_nms_topk upper bound
 constexpr int kRoiOut = 7;       // ROIAlign output side (models.py:703)
 constexpr int kRpnCh = 16;       // 3 logits + 12 deltas (+1 pad) per pixel
+constexpr int kSelChunk = 32768; // logits per workgroup in stage 1 of the RPN top-k
+int proposal_total_chunks(const struct ProposalParams& p);
 
 // ---------------------------------------------------------------- conv (K2+K3)
 // Implicit-GEMM convolution, NHWC fp32, exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
@@ -89,6 +91,7 @@ struct ProposalParams {
   float* lvl_boxes;      // [B,L,K,4]
   float* lvl_scores;     // [B,L,K]
   int* lvl_count;        // [B,L]
+  unsigned long long* chunk_keys;   // [B, total_chunks, K] per-chunk top-K keys (stage 1 of the select)
   // outputs
   float* props;          // [B,K,4]
   int* nprops;           // [B]

@@ -14,23 +14,65 @@
 namespace odt {
 namespace {
 
-struct RpnScoreAt {
-  const float* base;   // rpn of this image: [h*w, kRpnCh]
-  __device__ __forceinline__ float operator()(int e) const {
-    const int pix = e / 3, a = e - pix * 3;
-    return base[(size_t)pix * kRpnCh + a];
+// ---- stage A1: per-chunk top-k.  A level's logits are split into chunks of kSelChunk so that
+// the big levels (P2: 388 800 logits at 1080p) spread over many CUs; the union of the chunk
+// winners contains the level's top-k.
+struct ChunkMap { int level, first, n; };
+__device__ __forceinline__ ChunkMap chunk_of(const ProposalParams& p, int chunk) {
+  ChunkMap m{0, 0, 0};
+  int c = chunk;
+  for (int l = 0; l < p.nlevels; ++l) {
+    const int n = p.lvl[l].h * p.lvl[l].w * 3;
+    const int nc = (n + kSelChunk - 1) / kSelChunk;
+    if (c < nc) {
+      m.level = l; m.first = c * kSelChunk;
+      m.n = n - m.first < kSelChunk ? n - m.first : kSelChunk;
+      return m;
+    }
+    c -= nc;
+  }
+  return m;
+}
+struct RpnChunkKeyAt {
+  const float* base;   // rpn of this image
+  int first;
+  __device__ __forceinline__ unsigned long long operator()(int e) const {
+    const int g = first + e;
+    const int pix = g / 3, a = g - pix * 3;
+    return make_key64(base[(size_t)pix * kRpnCh + a], (unsigned)g);
   }
 };
+__global__ void __launch_bounds__(kSelThreads) rpn_chunk_topk_kernel(ProposalParams p, int total_chunks) {
+  __shared__ TopkScratch s;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const ChunkMap cm = chunk_of(p, chunk);
+  const RpnLevel lv = p.lvl[cm.level];
+  const int k = cm.n < p.K ? cm.n : p.K;
+  RpnChunkKeyAt ka{lv.rpn + (size_t)b * lv.h * lv.w * kRpnCh, cm.first};
+  block_topk_keys(ka, cm.n, k, s);
+  unsigned long long* out = p.chunk_keys + ((size_t)b * total_chunks + chunk) * p.K;
+  for (int t = threadIdx.x; t < p.K; t += blockDim.x) out[t] = t < k ? s.keys_b[t] : 0ull;
+}
 
-// ---- stage A: top-k, decode, clip, (min-size filter), ordered compaction -----------------
-__global__ void __launch_bounds__(kSelThreads) rpn_select_kernel(ProposalParams p) {
+struct CandKeyAt {
+  const unsigned long long* keys;
+  __device__ __forceinline__ unsigned long long operator()(int e) const { return keys[e]; }
+};
+
+// ---- stage A2: merge the chunk winners, decode, clip, (min-size filter), ordered compaction ---
+__global__ void __launch_bounds__(kSelThreads) rpn_select_kernel(ProposalParams p, int total_chunks) {
   __shared__ TopkScratch s;
   const int l = blockIdx.x, b = blockIdx.y;
   const RpnLevel lv = p.lvl[l];
   const int n = lv.h * lv.w * 3;
   const int k = n < p.K ? n : p.K;
-  RpnScoreAt sc{lv.rpn + (size_t)b * lv.h * lv.w * kRpnCh};
-  block_topk(sc, n, k, s);
+  int first_chunk = 0;
+  for (int q = 0; q < l; ++q) first_chunk += (p.lvl[q].h * p.lvl[q].w * 3 + kSelChunk - 1) / kSelChunk;
+  const int nc = (n + kSelChunk - 1) / kSelChunk;
+  CandKeyAt ka{p.chunk_keys + ((size_t)b * total_chunks + first_chunk) * p.K};
+  // zero keys pad short chunks; real keys are > 0 and there are at least k of them
+  block_topk_keys(ka, nc * p.K, k, s);
+  const float* base = lv.rpn + (size_t)b * lv.h * lv.w * kRpnCh;
 
   const int tid = threadIdx.x;
   float bx[4] = {0.f, 0.f, 0.f, 0.f};
@@ -41,9 +83,9 @@ __global__ void __launch_bounds__(kSelThreads) rpn_select_kernel(ProposalParams 
     const int e = (int)key64_index(key);
     const int pix = e / 3, a = e - pix * 3;
     const int y = pix / lv.w, x = pix - y * lv.w;
-    const float* d = sc.base + (size_t)pix * kRpnCh + 3 + a * 4;
+    const float* d = base + (size_t)pix * kRpnCh + 3 + a * 4;
     const float* an = lv.anchors + ((size_t)(y * lv.field + x) * 3 + a) * 4;
-    score = sc.base[(size_t)pix * kRpnCh + a];
+    score = base[(size_t)pix * kRpnCh + a];
     // decode_bbox_target (nn.py:1518-1538), fp32, same operand order as the oracle
     const float wa = an[2] - an[0], ha = an[3] - an[1];
     const float xa = (an[2] + an[0]) * 0.5f, ya = (an[3] + an[1]) * 0.5f;
@@ -226,6 +268,12 @@ __global__ void __launch_bounds__(kSelThreads) nms_kernel(const float* boxes, co
 
 }  // namespace
 
+int proposal_total_chunks(const ProposalParams& p) {
+  int t = 0;
+  for (int l = 0; l < p.nlevels; ++l) t += (p.lvl[l].h * p.lvl[l].w * 3 + kSelChunk - 1) / kSelChunk;
+  return t;
+}
+
 size_t proposal_workspace_bytes(int B, int L, int K) {
   const size_t per = (size_t)B * L * K;
   return 2 * (per * 4 * sizeof(float) + per * sizeof(float)) + 2 * (size_t)B * L * sizeof(int) + 256;
@@ -234,7 +282,10 @@ size_t proposal_workspace_bytes(int B, int L, int K) {
 int launch_proposals(const ProposalParams& p, hipStream_t stream) {
   ODT_CHECK(p.K >= 1 && p.K <= kMaxTopK, "proposals: rpn_test_post_nms_topk must be in [1,1024]");
   ODT_CHECK(p.nlevels >= 1 && p.nlevels <= 5, "proposals: 1..5 levels");
-  hipLaunchKernelGGL(rpn_select_kernel, dim3(p.nlevels, p.B), dim3(kSelThreads), 0, stream, p);
+  const int tc = proposal_total_chunks(p);
+  ODT_CHECK(p.chunk_keys != nullptr, "proposals: chunk_keys workspace missing");
+  hipLaunchKernelGGL(rpn_chunk_topk_kernel, dim3(tc, p.B), dim3(kSelThreads), 0, stream, p, tc);
+  hipLaunchKernelGGL(rpn_select_kernel, dim3(p.nlevels, p.B), dim3(kSelThreads), 0, stream, p, tc);
   hipLaunchKernelGGL(rpn_nms_kernel, dim3(p.nlevels, p.B), dim3(kSelThreads), 0, stream, p);
   hipLaunchKernelGGL(rpn_merge_kernel, dim3(p.B), dim3(kSelThreads), 0, stream, p);
   ODT_HIP(hipGetLastError());

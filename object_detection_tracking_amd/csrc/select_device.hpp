@@ -69,10 +69,11 @@ struct TopkScratch {
   int misc[4];
 };
 
-// Exact top-k (k <= kMaxTopK, k <= n) of score_at(0..n-1).  On return s.keys_b[0..k) holds the
-// selected 64-bit keys sorted descending == (score desc, index asc).  Workgroup-uniform call.
-template <class ScoreAt>
-__device__ void block_topk(ScoreAt score_at, int n, int k, TopkScratch& s) {
+// Exact top-k (k <= kMaxTopK, k <= n) over n unique 64-bit keys key_at(0..n-1) (see make_key64:
+// score in the high word, inverted index in the low word).  On return s.keys_b[0..k) holds the
+// selected keys sorted descending == (score desc, index asc).  Workgroup-uniform call.
+template <class KeyAt>
+__device__ void block_topk_keys(KeyAt key_at, int n, int k, TopkScratch& s) {
   const int tid = threadIdx.x, nthr = blockDim.x;
   unsigned long long prefix = 0ull, mask = 0ull;
   int need = k;
@@ -83,7 +84,7 @@ __device__ void block_topk(ScoreAt score_at, int n, int k, TopkScratch& s) {
     for (int i = tid; i < nb; i += nthr) s.hist[i] = 0;
     __syncthreads();
     for (int e = tid; e < n; e += nthr) {
-      const unsigned long long key = make_key64(score_at(e), (unsigned)e);
+      const unsigned long long key = key_at(e);
       if ((key & mask) == prefix) atomicAdd(&s.hist[(int)((key >> shift) & (unsigned long long)(nb - 1))], 1);
     }
     __syncthreads();
@@ -120,7 +121,7 @@ __device__ void block_topk(ScoreAt score_at, int n, int k, TopkScratch& s) {
   if (tid == 0) s.misc[3] = 0;
   __syncthreads();
   for (int e = tid; e < n; e += nthr) {
-    const unsigned long long key = make_key64(score_at(e), (unsigned)e);
+    const unsigned long long key = key_at(e);
     if ((key & mask) >= prefix) {
       const int pos = atomicAdd(&s.misc[3], 1);
       if (pos < kMaxTopK) s.keys_a[pos] = key;
@@ -135,6 +136,20 @@ __device__ void block_topk(ScoreAt score_at, int n, int k, TopkScratch& s) {
     s.keys_b[rank] = my;
   }
   __syncthreads();
+}
+
+template <class ScoreAt>
+struct ScoreKeyAt {
+  ScoreAt score_at;
+  __device__ __forceinline__ unsigned long long operator()(int e) const {
+    return make_key64(score_at(e), (unsigned)e);
+  }
+};
+// top-k of score_at(0..n-1); keys carry the element index.
+template <class ScoreAt>
+__device__ void block_topk(ScoreAt score_at, int n, int k, TopkScratch& s) {
+  ScoreKeyAt<ScoreAt> ka{score_at};
+  block_topk_keys(ka, n, k, s);
 }
 
 // ---- NMS --------------------------------------------------------------------------------

@@ -230,6 +230,28 @@ def test_proposals_single(backend, K):
   np.testing.assert_allclose(props[0, :nprops[0]], ref, rtol=0, atol=1e-4)
 
 
+def test_proposals_multi_chunk_level(backend):
+  """A level larger than one top-k chunk (32768 logits): the per-chunk winners are merged."""
+  name, lib = backend
+  rng = np.random.default_rng(21)
+  img_hw = (512, 1024)
+  levels = [(128, 256), (4, 8)]                       # 98 304 logits (3 chunks) + a small level
+  K = 100
+  strides, sizes = (4, 128), (32, 256)
+  rpn, anchors, logits, deltas = [], [], [], []
+  for (h, w), st, sz in zip(levels, strides, sizes):
+    lg = (rng.standard_normal((1, h, w, 3)) * 1.5).astype(F)
+    lg.reshape(-1)[rng.integers(0, lg.size, 64)] = F(4.25)      # ties across chunk borders
+    dl = (rng.standard_normal((1, h, w, 3, 4)) * 0.4).astype(F)
+    an = all_anchors(st, [sz], (0.5, 1, 2), 1024)
+    rpn.append(ops.pack_rpn(lg, dl)); anchors.append(an); logits.append(lg); deltas.append(dl)
+  clip = float(np.log(1024 / 16.0))
+  props, nprops = ops.proposals(ODT_GRAPH_SINGLE, rpn, anchors, img_hw, K, 0.7, clip, lib=lib)
+  ref = _oracle_proposals_single(logits, deltas, anchors, img_hw, K, 0.7, clip)
+  assert nprops[0] == ref.shape[0]
+  np.testing.assert_allclose(props[0, :nprops[0]], ref, rtol=0, atol=1e-3)
+
+
 @pytest.mark.parametrize("neg_shift", [0.0, 2.5])
 def test_proposals_multi_zero_padding_quirk(backend, neg_shift):
   """Multibatch graph: NMS output is zero-padded to K per level and the padding (score 0)
