@@ -116,6 +116,13 @@ def main():
     for _ in range(3):
       eng.forward(frames)
     extra["pcie_inclusive_fps"] = 3 * B / (time.perf_counter() - t1)
+    # same, through the pipelined ingest (pinned double-buffered staging, H2D / D2H on copy
+    # streams overlapping the forward; odt_submit / odt_collect)
+    t1 = time.perf_counter()
+    n = 0
+    for _ in eng.forward_stream([frames] * 10):
+      n += 1
+    extra["pcie_inclusive_pipelined_fps"] = n * B / (time.perf_counter() - t1)
     rng = np.random.default_rng(0)
     gal = rng.standard_normal((320, 256)).astype(np.float32)
     seg = (np.arange(65) * 5).astype(np.int32)

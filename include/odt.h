@@ -107,6 +107,20 @@ int odt_forward_async(odt_handle h, const void* frames, int dtype,
                       int on_device, void* stream);
 int odt_synchronize(odt_handle h);
 
+/* Pipelined ingest (replaces the frame.astype(float32) + feed_dict copy of
+ * obj_detect_tracking.py:597-635 and the prefetch queue of enqueuer_thread.py:236-303 on the
+ * device side): two slots of pinned host staging + device input + pinned output staging.
+ * odt_submit copies `frames` (host, [batch,H,W,3], u8 or f32) into the slot's pinned buffer,
+ * enqueues H2D on a copy stream, the forward on the compute stream and the D2H of all outputs
+ * on a second copy stream, and returns immediately with a ticket; odt_collect waits for that
+ * ticket and fills `out`.  At most two tickets may be outstanding; with two in flight the H2D
+ * of batch i+1 and the D2H of batch i-1 overlap the forward of batch i.
+ * odt_ingest_buffer exposes the next slot's pinned input buffer so a decoder can write into
+ * it directly (pass frames == NULL to odt_submit to use what was written there). */
+int odt_submit(odt_handle h, const void* frames, int dtype, int* ticket);
+int odt_collect(odt_handle h, int ticket, odt_outputs* out);
+int odt_ingest_buffer(odt_handle h, int dtype, void** buffer, size_t* bytes);
+
 /* Debug / parity taps: copy a named stage tensor (device layout: NHWC) to the
  * host.  shape_out receives up to 4 dims.  Names: "image_pad", "conv0",
  * "pool0", "c2".."c5", "p2".."p6", "rpn2".."rpn6" (16 ch: 3 logits + 12

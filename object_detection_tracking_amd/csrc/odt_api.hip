@@ -90,6 +90,18 @@ struct odt_model {
   float* final_feat = nullptr;    // [B*per_im, C, 7, 7] packed
   float* final_pooled = nullptr;  // [B*per_im, C]
   size_t frames_bytes = 0;
+  // pipelined ingest: two slots
+  struct Slot {
+    void* pin_in = nullptr; size_t pin_in_bytes = 0;
+    void* dev_in = nullptr; size_t dev_in_bytes = 0;
+    float *pin_boxes = nullptr, *pin_probs = nullptr, *pin_feats = nullptr, *pin_pooled = nullptr;
+    int *pin_labels = nullptr, *pin_valid = nullptr;
+    hipEvent_t h2d_done = nullptr, fwd_done = nullptr, d2h_done = nullptr;
+    int ticket = -1;            // outstanding ticket or -1
+  } slot[2];
+  hipStream_t copy_in = nullptr, copy_out = nullptr;
+  int next_ticket = 0;
+  hipEvent_t wait_before_detect = nullptr;   // D2H of the previous batch must finish before the tail rewrites outputs
   // profiling
   bool profile = false;
   std::vector<hipEvent_t> ev;
@@ -245,6 +257,16 @@ int odt_destroy(odt_handle h) {
   (void)hipDeviceSynchronize();
   for (auto e : h->ev) (void)hipEventDestroy(e);
   for (auto e : h->ev_total) if (e) (void)hipEventDestroy(e);
+  for (auto& sl : h->slot) {
+    if (sl.pin_in) (void)hipHostFree(sl.pin_in);
+    if (sl.dev_in) (void)hipFree(sl.dev_in);
+    for (void* q : {(void*)sl.pin_boxes, (void*)sl.pin_probs, (void*)sl.pin_feats, (void*)sl.pin_pooled,
+                    (void*)sl.pin_labels, (void*)sl.pin_valid})
+      if (q) (void)hipHostFree(q);
+    for (hipEvent_t e : {sl.h2d_done, sl.fwd_done, sl.d2h_done}) if (e) (void)hipEventDestroy(e);
+  }
+  if (h->copy_in) (void)hipStreamDestroy(h->copy_in);
+  if (h->copy_out) (void)hipStreamDestroy(h->copy_out);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return 0;
@@ -594,6 +616,10 @@ int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStre
         if (launch_roi_align(m->roi_head, st)) return 1;
         break;
       case OP_DETECT:
+        if (m->wait_before_detect) {
+          ODT_HIP(hipStreamWaitEvent(st, m->wait_before_detect, 0));
+          m->wait_before_detect = nullptr;
+        }
         if (launch_detections(m->det, st)) return 1;
         break;
       case OP_ROI_FINAL:
@@ -686,6 +712,102 @@ int odt_forward(odt_handle h, const void* frames, int dtype, int on_device, void
     ODT_HIP(hipMemcpy(out->feats, h->final_feat, (size_t)total * FC * 49 * sizeof(float), hipMemcpyDeviceToHost));
   if (out->pooled && total > 0)
     ODT_HIP(hipMemcpy(out->pooled, h->final_pooled, (size_t)total * FC * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+static int slot_prepare(odt_handle h, odt_model::Slot& sl, size_t in_bytes) {
+  const odt_config& cfg = h->cfg;
+  const size_t B = cfg.batch, per = cfg.result_per_im, FC = cfg.fpn_channels;
+  if (!h->copy_in) ODT_HIP(hipStreamCreate(&h->copy_in));
+  if (!h->copy_out) ODT_HIP(hipStreamCreate(&h->copy_out));
+  if (sl.pin_in_bytes < in_bytes) {
+    if (sl.pin_in) ODT_HIP(hipHostFree(sl.pin_in));
+    if (sl.dev_in) ODT_HIP(hipFree(sl.dev_in));
+    ODT_HIP(hipHostMalloc(&sl.pin_in, in_bytes, 0));
+    ODT_HIP(hipMalloc(&sl.dev_in, in_bytes));
+    sl.pin_in_bytes = sl.dev_in_bytes = in_bytes;
+  }
+  if (!sl.pin_boxes) {
+    ODT_HIP(hipHostMalloc((void**)&sl.pin_boxes, B * per * 4 * sizeof(float), 0));
+    ODT_HIP(hipHostMalloc((void**)&sl.pin_probs, B * per * sizeof(float), 0));
+    ODT_HIP(hipHostMalloc((void**)&sl.pin_labels, B * per * sizeof(int), 0));
+    ODT_HIP(hipHostMalloc((void**)&sl.pin_valid, B * sizeof(int), 0));
+    ODT_HIP(hipHostMalloc((void**)&sl.pin_feats, B * per * FC * 49 * sizeof(float), 0));
+    ODT_HIP(hipHostMalloc((void**)&sl.pin_pooled, B * per * FC * sizeof(float), 0));
+    ODT_HIP(hipEventCreate(&sl.h2d_done));
+    ODT_HIP(hipEventCreate(&sl.fwd_done));
+    ODT_HIP(hipEventCreate(&sl.d2h_done));
+  }
+  return 0;
+}
+
+int odt_ingest_buffer(odt_handle h, int dtype, void** buffer, size_t* bytes) {
+  ODT_CHECK(h && buffer && bytes, "odt_ingest_buffer: null argument");
+  ODT_CHECK(dtype == ODT_DTYPE_U8 || dtype == ODT_DTYPE_F32, "odt_ingest_buffer: bad dtype");
+  ODT_HIP(hipSetDevice(h->device));
+  const size_t n = (size_t)h->cfg.batch * h->cfg.height * h->cfg.width * 3 * (dtype == ODT_DTYPE_U8 ? 1 : 4);
+  odt_model::Slot& sl = h->slot[h->next_ticket & 1];
+  ODT_CHECK(sl.ticket < 0, "odt_ingest_buffer: slot still in flight (collect its ticket first)");
+  if (slot_prepare(h, sl, n)) return 1;
+  *buffer = sl.pin_in; *bytes = n;
+  return 0;
+}
+
+int odt_submit(odt_handle h, const void* frames, int dtype, int* ticket) {
+  ODT_CHECK(h && ticket, "odt_submit: null argument");
+  ODT_CHECK(h->finalized, "odt_submit: call odt_finalize_weights first");
+  ODT_CHECK(dtype == ODT_DTYPE_U8 || dtype == ODT_DTYPE_F32, "odt_submit: bad dtype");
+  ODT_HIP(hipSetDevice(h->device));
+  const odt_config& cfg = h->cfg;
+  const size_t B = cfg.batch, per = cfg.result_per_im, FC = cfg.fpn_channels;
+  const size_t n = B * cfg.height * cfg.width * 3 * (dtype == ODT_DTYPE_U8 ? 1 : 4);
+  const int t = h->next_ticket;
+  odt_model::Slot& sl = h->slot[t & 1];
+  odt_model::Slot& prev = h->slot[(t & 1) ^ 1];
+  ODT_CHECK(sl.ticket < 0, "odt_submit: two tickets already outstanding (collect one first)");
+  if (slot_prepare(h, sl, n)) return 1;
+  if (frames != nullptr) std::memcpy(sl.pin_in, frames, n);
+  ODT_HIP(hipMemcpyAsync(sl.dev_in, sl.pin_in, n, hipMemcpyHostToDevice, h->copy_in));
+  ODT_HIP(hipEventRecord(sl.h2d_done, h->copy_in));
+  hipStream_t st = h->own_stream;
+  ODT_HIP(hipStreamWaitEvent(st, sl.h2d_done, 0));
+  // the previous ticket's D2H reads the (single) device output buffers: the tail of this forward
+  // must not overwrite them before that copy is done
+  h->wait_before_detect = (prev.ticket >= 0) ? prev.d2h_done : nullptr;
+  if (run_plan(h, sl.dev_in, dtype, 1, st)) return 1;
+  ODT_HIP(hipEventRecord(sl.fwd_done, st));
+  hipStream_t co = h->copy_out;
+  ODT_HIP(hipStreamWaitEvent(co, sl.fwd_done, 0));
+  ODT_HIP(hipMemcpyAsync(sl.pin_valid, h->det.out_valid, B * sizeof(int), hipMemcpyDeviceToHost, co));
+  ODT_HIP(hipMemcpyAsync(sl.pin_boxes, h->det.out_boxes, B * per * 4 * sizeof(float), hipMemcpyDeviceToHost, co));
+  ODT_HIP(hipMemcpyAsync(sl.pin_probs, h->det.out_probs, B * per * sizeof(float), hipMemcpyDeviceToHost, co));
+  ODT_HIP(hipMemcpyAsync(sl.pin_labels, h->det.out_labels, B * per * sizeof(int), hipMemcpyDeviceToHost, co));
+  ODT_HIP(hipMemcpyAsync(sl.pin_feats, h->final_feat, B * per * FC * 49 * sizeof(float), hipMemcpyDeviceToHost, co));
+  ODT_HIP(hipMemcpyAsync(sl.pin_pooled, h->final_pooled, B * per * FC * sizeof(float), hipMemcpyDeviceToHost, co));
+  ODT_HIP(hipEventRecord(sl.d2h_done, co));
+  sl.ticket = t;
+  *ticket = t;
+  h->next_ticket = t + 1;
+  return 0;
+}
+
+int odt_collect(odt_handle h, int ticket, odt_outputs* out) {
+  ODT_CHECK(h && out, "odt_collect: null argument");
+  odt_model::Slot& sl = h->slot[ticket & 1];
+  ODT_CHECK(ticket >= 0 && sl.ticket == ticket, "odt_collect: unknown or already collected ticket");
+  ODT_HIP(hipSetDevice(h->device));
+  ODT_HIP(hipEventSynchronize(sl.d2h_done));
+  const odt_config& cfg = h->cfg;
+  const size_t B = cfg.batch, per = cfg.result_per_im, FC = cfg.fpn_channels;
+  size_t total = 0;
+  for (size_t b = 0; b < B; ++b) total += (size_t)sl.pin_valid[b];
+  if (out->valid) std::memcpy(out->valid, sl.pin_valid, B * sizeof(int));
+  if (out->boxes) std::memcpy(out->boxes, sl.pin_boxes, B * per * 4 * sizeof(float));
+  if (out->probs) std::memcpy(out->probs, sl.pin_probs, B * per * sizeof(float));
+  if (out->labels) std::memcpy(out->labels, sl.pin_labels, B * per * sizeof(int));
+  if (out->feats) std::memcpy(out->feats, sl.pin_feats, total * FC * 49 * sizeof(float));
+  if (out->pooled) std::memcpy(out->pooled, sl.pin_pooled, total * FC * sizeof(float));
+  sl.ticket = -1;
   return 0;
 }
 

@@ -122,6 +122,44 @@ class _Engine(object):
             self._feats[:total].copy() if want_feats else None,
             self._pooled[:total].copy() if want_pooled else None)
 
+  def submit(self, frames):
+    """Pipelined ingest (odt_submit): enqueue H2D + forward + D2H for one batch of host
+    frames and return a ticket at once; at most two tickets may be outstanding."""
+    fr = np.ascontiguousarray(frames)
+    if fr.dtype == np.uint8:
+      dt = ODT_DTYPE_U8
+    else:
+      fr = np.ascontiguousarray(fr, dtype=np.float32)
+      dt = ODT_DTYPE_F32
+    assert fr.shape == (self.batch, self.height, self.width, 3), fr.shape
+    t = C.c_int()
+    self.lib.check(self.lib.dll.odt_submit(self.h, fr.ctypes.data_as(C.c_void_p), dt, C.byref(t)))
+    return t.value
+
+  def collect(self, ticket, want_feats=True, want_pooled=False):
+    """Wait for a ticket of :meth:`submit`; same return value as :meth:`forward`."""
+    out = OdtOutputs()
+    out.boxes = fptr(self._boxes); out.probs = fptr(self._probs)
+    out.labels = iptr(self._labels); out.valid = iptr(self._valid)
+    out.feats = fptr(self._feats) if want_feats else None
+    out.pooled = fptr(self._pooled) if want_pooled else None
+    self.lib.check(self.lib.dll.odt_collect(self.h, ticket, C.byref(out)))
+    total = int(self._valid.sum())
+    return (self._boxes.copy(), self._labels.copy(), self._probs.copy(), self._valid.copy(),
+            self._feats[:total].copy() if want_feats else None,
+            self._pooled[:total].copy() if want_pooled else None)
+
+  def forward_stream(self, batches, want_feats=True, want_pooled=False):
+    """Generator over an iterable of frame batches with two batches in flight: the H2D of
+    batch i+1 and the D2H of batch i-1 overlap the forward of batch i."""
+    pending = []
+    for fr in batches:
+      pending.append(self.submit(fr))
+      if len(pending) == 2:
+        yield self.collect(pending.pop(0), want_feats, want_pooled)
+    while pending:
+      yield self.collect(pending.pop(0), want_feats, want_pooled)
+
   def forward_device_async(self, dev_ptr, dtype, stream=None):
     """Enqueue one forward on frames already resident in HBM (bench path)."""
     self.lib.check(self.lib.dll.odt_forward_async(self.h, C.c_void_p(dev_ptr), dtype, 1,
