@@ -118,6 +118,13 @@ def test_forward_single_r101_odd_size(hip_lib):
 
 
 @pytest.mark.gpu
+def test_forward_single_r101_k1000(hip_lib):
+  """The reference script's default rpn_test_post_nms_topk = 1000 (obj_detect_tracking.py:132)."""
+  cfg = make_config(rpn_test_post_nms_topk=1000, max_size=640, short_edge_size=384)
+  _run_single(hip_lib, cfg, 384, 640)
+
+
+@pytest.mark.gpu
 def test_forward_multi_r101_b2_256x448(hip_lib):
   cfg = make_config(rpn_test_post_nms_topk=300, max_size=448, short_edge_size=256,
                     im_batch_size=2)
