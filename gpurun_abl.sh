@@ -1,1 +1,2 @@
-for d in 64 192; do echo "== debug $d"; ODT_CONV_DEBUG=$d python tools/profile_layers.py --batch 8 --steps 3 2>&1 | grep -E "group2/block0/conv2|group2/block0/conv3|group2/block1/conv1|posthoc_3x3_p2|group0/block0/convshortcut|group1/block0/conv3|conv total" ; done
+for st in 2 1; do ODT_CONV_STAGES=$st python tools/profile_layers.py --batch 8 --steps 3 > gpurun_out/layers_st$st.txt 2>&1; done
+for st in 2 1; do ODT_CONV_STAGES=$st python tools/profile_layers.py --batch 1 --steps 5 > gpurun_out/layers_b1_st$st.txt 2>&1; done

@@ -37,8 +37,12 @@ __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned sh) {
 }
 constexpr unsigned kOOB = 0x80000000u;   // buffer offset that is out of range for every tensor (< 2 GiB)
 
-template <int WM, int WN, int TM, int TN>
-__global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvParams* __restrict__ pp) {
+// ST = number of LDS stages.  ST == 2: double-buffered stages + rotated one-barrier pipeline
+// (2 workgroups per CU).  ST == 1: one stage (36.9 KB for the 128x128 tile, registers prefetch
+// one slice ahead, two barriers per slice) so that three workgroups fit on a CU and another
+// workgroup's MFMA stream covers this one's barriers, prologue and HBM-bound epilogue.
+template <int WM, int WN, int TM, int TN, int ST>
+__global__ void __launch_bounds__(256, ST == 1 ? 3 : 2) conv_igemm_kernel(const ConvParams* __restrict__ pp) {
   // Parameters live in device memory (one record per conv of the plan): the by-value kernarg
   // block sits in host-coherent memory and its cold scalar loads cost the first dispatch wave of
   // every launch tens of microseconds.
@@ -46,7 +50,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvParams* __
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int RA = BM / 32, RB = BN / 32;
   static_assert(WM * WN == 4, "4 waves");
-  __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LS];
+  __shared__ __attribute__((aligned(16))) float lds[ST][(BM + BN) * LS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -199,32 +203,63 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvParams* __
   stamp(1);
   if (nslices > 1) load_slice();
   read_frags(0, 0, fa0, fb0);
-  for (int c = 0; c < nslices; ++c) {
-    const int cur = c & 1;
-    const bool more = c + 1 < nslices;
-    if (!(dbg & 8)) read_frags(cur, 1, fa1, fb1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(dbg & 16)) mfma_group(fa0, fb0, 0, 4);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(dbg & 8)) read_frags(cur, 2, fa0, fb0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(dbg & 16)) mfma_group(fa1, fb1, 0, 4);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(dbg & 8)) read_frags(cur, 3, fa1, fb1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(dbg & 16)) mfma_group(fa0, fb0, 0, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    if (more && !(dbg & 2)) store_slice(cur ^ 1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(dbg & 16)) mfma_group(fa0, fb0, 2, 4);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(dbg & 4)) __syncthreads();
-    __builtin_amdgcn_sched_barrier(0);
-    if (more && !(dbg & 8)) read_frags(cur ^ 1, 0, fa0, fb0);
-    if (c + 2 < nslices && !(dbg & 1)) load_slice();
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(dbg & 16)) mfma_group(fa1, fb1, 0, 4);
-    __builtin_amdgcn_sched_barrier(0);
+  if constexpr (ST == 2) {
+    for (int c = 0; c < nslices; ++c) {
+      const int cur = c & 1;
+      const bool more = c + 1 < nslices;
+      if (!(dbg & 8)) read_frags(cur, 1, fa1, fb1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(dbg & 16)) mfma_group(fa0, fb0, 0, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(dbg & 8)) read_frags(cur, 2, fa0, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(dbg & 16)) mfma_group(fa1, fb1, 0, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(dbg & 8)) read_frags(cur, 3, fa1, fb1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(dbg & 16)) mfma_group(fa0, fb0, 0, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more && !(dbg & 2)) store_slice(cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(dbg & 16)) mfma_group(fa0, fb0, 2, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(dbg & 4)) __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      if (more && !(dbg & 8)) read_frags(cur ^ 1, 0, fa0, fb0);
+      if (c + 2 < nslices && !(dbg & 1)) load_slice();
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(dbg & 16)) mfma_group(fa1, fb1, 0, 4);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    // single LDS stage: g0..g2 as above; then barrier (all fragment reads of this slice done),
+    // registers -> LDS (slice c+1) with the g3 MFMAs covering the write, fetch slice c+2,
+    // barrier, first fragment read of the next slice.
+    for (int c = 0; c < nslices; ++c) {
+      const bool more = c + 1 < nslices;
+      read_frags(0, 1, fa1, fb1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group(fa0, fb0, 0, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(0, 2, fa0, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group(fa1, fb1, 0, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(0, 3, fa1, fb1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group(fa0, fb0, 0, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) store_slice(0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group(fa1, fb1, 0, 4);
+      if (c + 2 < nslices) load_slice();
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) read_frags(0, 0, fa0, fb0);
+    }
   }
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   stamp(2);
@@ -234,156 +269,139 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvParams* __
   // row segments: residual tile prefetched with independent 16-B loads, then bias + residual +
   // ReLU and 16-B stores (a wave covers full 512-byte output rows).
   constexpr int CS = BN + 4;                      // C-tile row stride (floats); +4 keeps b128 reads aligned
-  static_assert(BM * CS <= 2 * (BM + BN) * LS, "C tile must fit in the A/B stages");
+  // the single-stage variants stage the C tile in PASSES row blocks of RP rows (LDS is smaller)
+  constexpr int PASSES = (ST == 1 && BM > 64) ? BM / 64 : 1;
+  constexpr int RP = BM / PASSES;
+  static_assert(RP * CS <= ST * (BM + BN) * LS, "C tile pass must fit in the A/B stages");
+  static_assert(RP % (TM * 32) == 0, "a wave's rows must fall into one pass");
   float* Ct = &lds[0][0];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int col = wn * TN * 32 + j * 32 + (lane & 31);
-        Ct[row * CS + col] = acc[i][j][r];
-      }
-  __syncthreads();
-  stamp(3);
-
   constexpr int C4 = BN / 4;                      // 16-byte chunks per tile row
-  constexpr int NCH = BM * C4 / 256;              // chunks per thread
+  constexpr int NCH = RP * C4 / 256;              // chunks per thread and pass
+  static_assert(256 % C4 == 0, "bias column must be chunk-invariant");
   const bool vec_ok = (p.out_ldc & 3) == 0 && (p.res_mode == 0 || (p.res_ldc & 3) == 0);
   const bool dense_io = p.out_oy == 0 && p.out_ox == 0 && p.out_H == p.Ho && p.out_W == p.Wo &&
                         (p.res_mode == 0 || (p.res_mode == 1 && p.res_H == p.Ho && p.res_W == p.Wo));
-  if (vec_ok && (p.Cout & 3) == 0) {
-    // ---- fast path (every layer of the model except the 15-channel RPN head): branch-free.
-    // Buffer loads/stores with out-of-range offsets for the masked chunks, so the compiler sees
-    // straight-line code and emits counted vmcnt waits instead of draining every store.
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)p.out, 0, (int)((unsigned)p.B * p.out_H * p.out_W * p.out_ldc * 4u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.res_mode != 0 ? p.res : p.bias), 0,
-        (int)(p.res_mode != 0 ? (unsigned)p.B * p.res_H * p.res_W * p.res_ldc * 4u : 0u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_bias =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (int)((unsigned)p.Cout * 4u), 0x00020000);
-    const int c4 = tid % C4, row0 = tid / C4;        // chunk s2 of this thread: row0 + s2*(256/C4)
-    const int col = n0 + c4 * 4;
-    const bool col_ok = col < p.Cout;
-    unsigned ooff[NCH];
-    f32x4 rv[NCH];
-#pragma unroll
-    for (int s2 = 0; s2 < NCH; ++s2) {
-      const int m = m0 + row0 + s2 * (256 / C4);
-      const bool ok = col_ok && m < M;
-      unsigned opix, rpix;
-      if (dense_io) {
-        opix = (unsigned)m;
-        rpix = (unsigned)m;
-      } else {
-        const int mm = ok ? m : 0;
-        const int n = fast_div(mm, p.div_howo_mul, p.div_howo_sh), rr = mm - n * HoWo;
-        const int ho = fast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
-        opix = ((unsigned)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
-        rpix = p.res_mode == 2 ? ((unsigned)n * p.res_H + (ho >> 1)) * p.res_W + (wo >> 1)
-                               : ((unsigned)n * p.res_H + ho) * p.res_W + wo;
-      }
-      ooff[s2] = ok ? (opix * p.out_ldc + col) * 4u : kOOB;
-      const unsigned roff = ok ? (rpix * p.res_ldc + col) * 4u : kOOB;
-      rv[s2] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)roff, 0, 0);   // 0 if no residual
-    }
-    const f32x4 bias4 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, col_ok ? col * 4 : (int)kOOB, 0, 0);
-    stamp(4);
-#pragma unroll
-    for (int s2 = 0; s2 < NCH; ++s2) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[(row0 + s2 * (256 / C4)) * CS + c4 * 4]);
-      v += bias4;
-      v += rv[s2];
-      if (p.relu) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-      }
-      __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)ooff[s2], 0, 0);
-    }
-    stamp(5);
-    return;
-  }
-  // ---- generic path (Cout % 4 != 0 or unaligned pixel strides)
-  f32x4 rv[NCH];
-  size_t oaddr[NCH];
-  int nval[NCH];
-#pragma unroll
-  for (int s2 = 0; s2 < NCH; ++s2) {
-    const int q = tid + 256 * s2;
-    const int row = q / C4, c4 = q - row * C4;
-    const int m = m0 + row, col = n0 + c4 * 4;
-    int nv = p.Cout - col;
-    nv = nv > 4 ? 4 : nv;
-    if (m >= M || nv < 0) nv = 0;
-    nval[s2] = nv;
-    rv[s2] = zero4;
-    oaddr[s2] = 0;
-    if (nv > 0) {
-      size_t opix, rpix = 0;
-      if (dense_io) {                 // output (and residual) pixels are simply row m: no divisions
-        opix = (size_t)m;
-        rpix = (size_t)m;
-      } else {
-        const int n = m / HoWo, rr = m - n * HoWo;
-        const int ho = rr / p.Wo, wo = rr - ho * p.Wo;
-        opix = ((size_t)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
-        if (p.res_mode != 0)
-          rpix = p.res_mode == 1 ? ((size_t)n * p.res_H + ho) * p.res_W + wo
-                                 : ((size_t)n * p.res_H + (ho >> 1)) * p.res_W + (wo >> 1);
-      }
-      oaddr[s2] = opix * p.out_ldc + col;
-      if (p.res_mode != 0) {
-        const float* rp = p.res + rpix * p.res_ldc + col;
-        if (nv == 4 && vec_ok) {
-          rv[s2] = *reinterpret_cast<const f32x4*>(rp);
-        } else {
-          for (int e = 0; e < nv; ++e) rv[s2][e] = rp[e];
-        }
-      }
-    }
-  }
-  // every chunk of a thread has the same column (256 % C4 == 0): fetch the bias once, BEFORE
-  // any store (a load issued after a store has to wait for that store's completion: vmcnt is
-  // in-order).
-  static_assert(256 % C4 == 0, "bias column must be chunk-invariant");
-  const int bcol = n0 + (tid % C4) * 4;
+  const bool fast = vec_ok && (p.Cout & 3) == 0;
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.out, 0, (int)((unsigned)p.B * p.out_H * p.out_W * p.out_ldc * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.res_mode != 0 ? p.res : p.bias), 0,
+      (int)(p.res_mode != 0 ? (unsigned)p.B * p.res_H * p.res_W * p.res_ldc * 4u : 0u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_bias =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (int)((unsigned)p.Cout * 4u), 0x00020000);
+  const int c4 = tid % C4, row0 = tid / C4;          // chunk s2 of this thread: row0 + s2*(256/C4)
+  const int col = n0 + c4 * 4;
+  const bool col_ok = col < p.Cout;
+  // every chunk of a thread has the same column (256 % C4 == 0): fetch the bias once, BEFORE any
+  // store (a load issued after a store waits for that store's completion: vmcnt is in-order).
   f32x4 bias4 = zero4;
+  if (fast) {
+    bias4 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, col_ok ? col * 4 : (int)kOOB, 0, 0);
+  } else {
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
-    if (bcol + e < p.Cout) bias4[e] = p.bias[bcol + e];
-  stamp(4);
+    for (int e = 0; e < 4; ++e)
+      if (col + e < p.Cout) bias4[e] = p.bias[col + e];
+  }
+
 #pragma unroll
-  for (int s2 = 0; s2 < NCH; ++s2) {
-    const int nv = nval[s2];
-    if (nv == 0) continue;
-    const int q = tid + 256 * s2;
-    const int row = q / C4, c4 = q - row * C4;
-    f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[row * CS + c4 * 4]);
-    v += bias4;
-    v += rv[s2];
-    if (p.relu) {
+  for (int pass = 0; pass < PASSES; ++pass) {
+    if (pass > 0) __syncthreads();                  // previous pass finished reading Ct
+    if ((wm * TM * 32) / RP == pass) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) - pass * RP;
+            const int cc = wn * TN * 32 + j * 32 + (lane & 31);
+            Ct[row * CS + cc] = acc[i][j][r];
+          }
     }
-    float* op = p.out + oaddr[s2];
-    if (nv == 4 && vec_ok) {
-      *reinterpret_cast<f32x4*>(op) = v;
+    __syncthreads();
+    if (pass == 0) stamp(3);
+    if (fast) {
+      // ---- fast path (every layer of the model except the 15-channel RPN head): branch-free.
+      // Buffer loads/stores with out-of-range offsets for the masked chunks, so the compiler sees
+      // straight-line code and emits counted vmcnt waits instead of draining every store.
+      unsigned ooff[NCH];
+      f32x4 rv[NCH];
+#pragma unroll
+      for (int s2 = 0; s2 < NCH; ++s2) {
+        const int m = m0 + pass * RP + row0 + s2 * (256 / C4);
+        const bool ok = col_ok && m < M;
+        unsigned opix, rpix;
+        if (dense_io) {
+          opix = (unsigned)m;
+          rpix = (unsigned)m;
+        } else {
+          const int mm = ok ? m : 0;
+          const int n = fast_div(mm, p.div_howo_mul, p.div_howo_sh), rr = mm - n * HoWo;
+          const int ho = fast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
+          opix = ((unsigned)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
+          rpix = p.res_mode == 2 ? ((unsigned)n * p.res_H + (ho >> 1)) * p.res_W + (wo >> 1)
+                                 : ((unsigned)n * p.res_H + ho) * p.res_W + wo;
+        }
+        ooff[s2] = ok ? (opix * p.out_ldc + col) * 4u : kOOB;
+        const unsigned roff = ok ? (rpix * p.res_ldc + col) * 4u : kOOB;
+        rv[s2] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)roff, 0, 0);   // 0 if no residual
+      }
+      if (pass == 0) stamp(4);
+#pragma unroll
+      for (int s2 = 0; s2 < NCH; ++s2) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[(row0 + s2 * (256 / C4)) * CS + c4 * 4]);
+        v += bias4;
+        v += rv[s2];
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)ooff[s2], 0, 0);
+      }
     } else {
-      for (int e = 0; e < nv; ++e) op[e] = v[e];
+      // ---- generic path (Cout % 4 != 0 or unaligned pixel strides): scalar tails
+      for (int s2 = 0; s2 < NCH; ++s2) {
+        const int rl = row0 + s2 * (256 / C4);
+        const int m = m0 + pass * RP + rl;
+        int nv = p.Cout - col;
+        nv = nv > 4 ? 4 : nv;
+        if (m >= M || nv <= 0) continue;
+        size_t opix, rpix = 0;
+        if (dense_io) {
+          opix = (size_t)m;
+          rpix = (size_t)m;
+        } else {
+          const int n = fast_div(m, p.div_howo_mul, p.div_howo_sh), rr = m - n * HoWo;
+          const int ho = fast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
+          opix = ((size_t)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
+          if (p.res_mode != 0)
+            rpix = p.res_mode == 1 ? ((size_t)n * p.res_H + ho) * p.res_W + wo
+                                   : ((size_t)n * p.res_H + (ho >> 1)) * p.res_W + (wo >> 1);
+        }
+        f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[rl * CS + c4 * 4]);
+        v += bias4;
+        if (p.res_mode != 0) {
+          const float* rp = p.res + rpix * p.res_ldc + col;
+          for (int e = 0; e < nv; ++e) v[e] += rp[e];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        float* op = p.out + opix * p.out_ldc + col;
+        for (int e = 0; e < nv; ++e) op[e] = v[e];
+      }
     }
   }
   stamp(5);
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int ST>
 void launch_variant(const ConvParams& p, const ConvParams* dev, hipStream_t stream) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int M = p.B * p.Ho * p.Wo;
   const unsigned grid = (unsigned)(((M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN));
-  hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, TM, TN>), dim3(grid), dim3(256), 0, stream, dev);
+  hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, TM, TN, ST>), dim3(grid), dim3(256), 0, stream, dev);
 }
 
 }  // namespace
@@ -434,12 +452,23 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
     dev_params = tmp;
   }
   if (tile == 0) tile = p.Cout <= 64 ? 1 : (tiles128 < 384 ? 2 : 3);
-  if (tile == 1) {
-    launch_variant<4, 1, 1, 2>(q, dev_params, stream);       // 128 x 64
+  // LDS stages: the single-stage / 3-workgroups-per-CU variant wins everywhere (measured per
+  // layer, profiles/) except the long 1x1 reductions on the 128x128 tile (res4 conv1, K = 1024:
+  // every slice is fresh HBM data, the two-slice register+LDS prefetch of ST = 2 hides it better).
+  int stages = (tile == 3 && p.kh * p.kw == 1 && p.Cin >= 1024) ? 2 : 1;
+  if (const char* e = getenv("ODT_CONV_STAGES")) {     // tuning knob: force 1 or 2
+    if (atoi(e) == 1 || atoi(e) == 2) stages = atoi(e);
+  }
+  if (stages == 1) {
+    if (tile == 1) launch_variant<4, 1, 1, 2, 1>(q, dev_params, stream);
+    else if (tile == 2) launch_variant<2, 2, 1, 1, 1>(q, dev_params, stream);
+    else launch_variant<2, 2, 2, 2, 1>(q, dev_params, stream);
+  } else if (tile == 1) {
+    launch_variant<4, 1, 1, 2, 2>(q, dev_params, stream);       // 128 x 64
   } else if (tile == 2) {
-    launch_variant<2, 2, 1, 1>(q, dev_params, stream);       // 64 x 64: fill the 256 CUs on small M
+    launch_variant<2, 2, 1, 1, 2>(q, dev_params, stream);       // 64 x 64: fill the 256 CUs on small M
   } else {
-    launch_variant<2, 2, 2, 2>(q, dev_params, stream);       // 128 x 128
+    launch_variant<2, 2, 2, 2, 2>(q, dev_params, stream);       // 128 x 128
   }
   ODT_HIP(hipGetLastError());
   if (tmp != nullptr) {
