@@ -40,6 +40,10 @@ def main():
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--cpu-frames", type=int, default=2, help="frames in the bounded CPU sample")
   ap.add_argument("--profile-steps", type=int, default=2)
+  ap.add_argument("--dist-backend", default="nccl",
+                  help="nccl (= RCCL, the default) | gloo (debug: lets N ranks share one GPU)")
+  ap.add_argument("--device", type=int, default=None,
+                  help="debug: force every rank onto this GPU (with --dist-backend gloo)")
   args = ap.parse_args()
 
   import torch
@@ -50,10 +54,15 @@ def main():
   world = int(os.environ.get("WORLD_SIZE", "1"))
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs a GPU: the product path is the HIP library only")
+  if args.device is not None:
+    local_rank = args.device
   torch.cuda.set_device(local_rank)
   if world > 1:
-    dist.init_process_group("nccl", rank=rank, world_size=world,
-                            device_id=torch.device("cuda", local_rank))
+    if args.dist_backend == "nccl":
+      dist.init_process_group("nccl", rank=rank, world_size=world,
+                              device_id=torch.device("cuda", local_rank))
+    else:
+      dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
   from object_detection_tracking_amd import models
   from object_detection_tracking_amd._lib import ODT_DTYPE_U8
@@ -92,7 +101,8 @@ def main():
   barrier()
   dt = time.perf_counter() - t0
   if world > 1:
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt], dtype=torch.float64,
+                     device="cuda" if args.dist_backend == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 

@@ -41,9 +41,19 @@ __global__ void __launch_bounds__(256) roi_align_kernel(RoiAlignParams p, int B)
   const float* bx = p.boxes + (size_t)r * 4;
   const float X0 = bx[0], Y0 = bx[1], X1 = bx[2], Y1 = bx[3];
   const int L = fpn_level_of(X0, Y0, X1, Y1);
-  const float is = p.inv_stride[L];
+  // select this level's parameters with compares (a runtime-indexed kernel-argument array would
+  // be spilled to scratch / waterfall SGPR reads)
+  float is = p.inv_stride[0];
+  int H = p.h[0], W = p.w[0], aw = p.alloc_w[0], ah = p.alloc_h[0], ldc = p.ldc[0];
+  const float* fbase = p.feat[0];
+#pragma unroll
+  for (int q = 1; q < 4; ++q) {
+    if (L == q) {
+      is = p.inv_stride[q]; H = p.h[q]; W = p.w[q]; aw = p.alloc_w[q]; ah = p.alloc_h[q];
+      ldc = p.ldc[q]; fbase = p.feat[q];
+    }
+  }
   const float x0 = X0 * is, y0 = Y0 * is, x1 = X1 * is, y1 = Y1 * is;
-  const int H = p.h[L], W = p.w[L];
   const float fH1 = (float)(H - 1), fW1 = (float)(W - 1);
   constexpr int CS = 2 * kRoiOut;                       // 14
   // transform_fpcoor_for_tf (nn.py:1238-1271)
@@ -66,8 +76,7 @@ __global__ void __launch_bounds__(256) roi_align_kernel(RoiAlignParams p, int B)
     bot[q] = (int)ceilf(iy);
     yl[q] = iy - (float)top[q];
   }
-  const float* feat = p.feat[L] + (size_t)b * p.alloc_h[L] * p.alloc_w[L] * p.ldc[L];
-  const int aw = p.alloc_w[L], ldc = p.ldc[L];
+  const float* feat = fbase + (size_t)b * ah * aw * ldc;
   for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
     for (int ox = 0; ox < kRoiOut; ++ox) {
       float v[2][2];
