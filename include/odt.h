@@ -147,6 +147,26 @@ int odt_profile_layer(odt_handle h, int index, char* name, int name_cap,
 int odt_nn_cosine(int device, const float* gallery, const int32_t* seg_offsets,
                   int T, const float* dets, int N, int D, double* cost);
 
+/* ---- DeepSORT tracker core, float64 on the host + the HIP cosine kernel.
+ * Tracker(metric, max_iou_distance, max_age, n_init) / predict / update / tracks
+ * (deep_sort/tracker.py:40-138, track.py, kalman_filter.py, linear_assignment.py,
+ * iou_matching.py); scipy.optimize.linear_sum_assignment restated as odt_lsap. */
+typedef struct odt_tracker* odt_tracker_handle;
+int odt_tracker_create(double max_cosine_distance, int nn_budget, double max_iou_distance,
+                       int max_age, int n_init, int device, odt_tracker_handle* out);
+int odt_tracker_destroy(odt_tracker_handle t);
+int odt_tracker_predict(odt_tracker_handle t);
+/* detections of one frame: tlwh [N,4] float64, confidence [N] float64, features [N,D] float32 */
+int odt_tracker_update(odt_tracker_handle t, const double* tlwh, const double* conf,
+                       const float* feats, int N, int D);
+/* snapshot of the track table in list order; any output pointer may be NULL; *n = #tracks.
+ * state: 1 tentative, 2 confirmed.  mean [n,8], covariance [n,8,8]. */
+int odt_tracker_tracks(odt_tracker_handle t, int cap, int32_t* ids, int32_t* state,
+                       int32_t* time_since_update, int32_t* hits, int32_t* age, double* mean,
+                       double* covariance, int* n);
+/* scipy.optimize.linear_sum_assignment(cost[nr,nc]) -> n = min(nr,nc) (row, col) pairs by row */
+int odt_lsap(const double* cost, int nr, int nc, int32_t* rows, int32_t* cols, int* n);
+
 /* ---- stand-alone op entry points (host pointers), used by the staged parity
  * tests; each runs exactly the kernels odt_forward uses. ------------------- */
 

@@ -75,7 +75,8 @@ class OdtLib(object):
       "odt_ingest_buffer", "odt_tap", "odt_profile_enable",
       "odt_profile_read", "odt_profile_layer", "odt_nn_cosine", "odt_op_conv2d", "odt_op_preprocess",
       "odt_op_maxpool", "odt_op_topk", "odt_op_nms", "odt_op_proposals",
-      "odt_op_roi_align", "odt_op_detections",
+      "odt_op_roi_align", "odt_op_detections", "odt_tracker_create", "odt_tracker_destroy",
+      "odt_tracker_predict", "odt_tracker_update", "odt_tracker_tracks", "odt_lsap",
   ]
 
   def __init__(self, path):
@@ -123,6 +124,14 @@ class OdtLib(object):
     d.odt_op_roi_align.argtypes = [C.c_int, C.c_int, C.c_int, c_int_p, c_int_p,
                                    C.POINTER(c_float_p), c_float_p, c_float_p, c_int_p, C.c_int,
                                    c_float_p, c_float_p]
+    d.odt_tracker_create.argtypes = [C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
+                                     C.POINTER(C.c_void_p)]
+    d.odt_tracker_destroy.argtypes = [C.c_void_p]
+    d.odt_tracker_predict.argtypes = [C.c_void_p]
+    d.odt_tracker_update.argtypes = [C.c_void_p, c_double_p, c_double_p, c_float_p, C.c_int, C.c_int]
+    d.odt_tracker_tracks.argtypes = [C.c_void_p, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p,
+                                     c_double_p, c_double_p, C.POINTER(C.c_int)]
+    d.odt_lsap.argtypes = [c_double_p, C.c_int, C.c_int, c_int_p, c_int_p, C.POINTER(C.c_int)]
     d.odt_op_detections.argtypes = [C.c_int] * 5 + [c_float_p, c_float_p, c_float_p, c_int_p,
                                                     C.c_int, C.c_int, c_float_p, C.c_float,
                                                     C.c_float, C.c_float, C.c_int, c_float_p,

@@ -1,0 +1,532 @@
+// DeepSORT tracker core, native (host C++ + the HIP cosine kernel): Kalman filter, gating,
+// matching cascade, IoU matching, rectangular assignment, track life cycle, appearance gallery.
+//
+// "Next" row 2 of SURVEY.md 8(f).  Restates, in float64 like the reference:
+//   deep_sort/kalman_filter.py:23-232   (constant-velocity filter on (x, y, a, h); chi2 gating)
+//   deep_sort/track.py:15-170           (Track state machine)
+//   deep_sort/iou_matching.py:8-84      (IoU cost)
+//   deep_sort/linear_assignment.py:12-194 (min_cost_matching, matching_cascade, gate_cost_matrix)
+//   deep_sort/tracker.py:40-138         (Tracker.predict / update / _match / _initiate_track)
+//   deep_sort/nn_matching.py:99-177     (gallery bookkeeping; the distance itself is the HIP
+//                                        kernel of tracker.hip)
+// and scipy.optimize.linear_sum_assignment (un-vendored dependency, scipy >= 1.4: the shortest
+// augmenting path algorithm of Crouse 2016 as implemented in rectangular_lsap.cpp, including
+// its tie rules: columns scanned from the highest index down, an unassigned column preferred
+// among equal reduced costs).  Results match the reference to summation-order rounding of the
+// 4x4 Cholesky solves (LAPACK in the reference), i.e. ~1e-12 relative; identities, match lists
+// and the order in which new track ids are handed out are reproduced exactly.
+#include "../../include/odt.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <limits>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "odt_common.hpp"
+
+namespace odt {
+
+// ------------------------------------------------------------------ assignment
+// scipy.optimize.linear_sum_assignment.  cost: nr x nc row-major.  Returns pairs sorted by row.
+int lsap(const double* cost_in, int nr, int nc, std::vector<int>* rows, std::vector<int>* cols) {
+  rows->clear(); cols->clear();
+  if (nr == 0 || nc == 0) return 0;
+  const bool transpose = nc < nr;
+  std::vector<double> ct;
+  const double* cost = cost_in;
+  int R = nr, Cn = nc;
+  if (transpose) {
+    ct.resize((size_t)nr * nc);
+    for (int i = 0; i < nr; ++i)
+      for (int j = 0; j < nc; ++j) ct[(size_t)j * nr + i] = cost_in[(size_t)i * nc + j];
+    cost = ct.data(); R = nc; Cn = nr;
+  }
+  for (size_t i = 0; i < (size_t)R * Cn; ++i)
+    if (cost[i] != cost[i] || cost[i] == -std::numeric_limits<double>::infinity()) {
+      set_error("lsap: cost matrix contains invalid numeric entries");
+      return 1;
+    }
+  const double INF = std::numeric_limits<double>::infinity();
+  std::vector<double> u(R, 0.0), v(Cn, 0.0), spc(Cn);
+  std::vector<int> path(Cn, -1), col4row(R, -1), row4col(Cn, -1), remaining(Cn);
+  std::vector<char> SR(R), SC(Cn);
+  for (int cur = 0; cur < R; ++cur) {
+    double minVal = 0.0;
+    int num_remaining = Cn;
+    for (int it = 0; it < Cn; ++it) remaining[it] = Cn - it - 1;
+    std::fill(SR.begin(), SR.end(), 0);
+    std::fill(SC.begin(), SC.end(), 0);
+    std::fill(spc.begin(), spc.end(), INF);
+    int sink = -1, i = cur;
+    while (sink == -1) {
+      int index = -1;
+      double lowest = INF;
+      SR[i] = 1;
+      for (int it = 0; it < num_remaining; ++it) {
+        const int j = remaining[it];
+        const double r = minVal + cost[(size_t)i * Cn + j] - u[i] - v[j];
+        if (r < spc[j]) { path[j] = i; spc[j] = r; }
+        if (spc[j] < lowest || (spc[j] == lowest && row4col[j] == -1)) { lowest = spc[j]; index = it; }
+      }
+      minVal = lowest;
+      if (minVal == INF) { set_error("lsap: cost matrix is infeasible"); return 1; }
+      const int j = remaining[index];
+      if (row4col[j] == -1) sink = j; else i = row4col[j];
+      SC[j] = 1;
+      remaining[index] = remaining[--num_remaining];
+    }
+    u[cur] += minVal;
+    for (int r2 = 0; r2 < R; ++r2)
+      if (SR[r2] && r2 != cur) u[r2] += minVal - spc[col4row[r2]];
+    for (int j = 0; j < Cn; ++j)
+      if (SC[j]) v[j] -= minVal - spc[j];
+    int j = sink;
+    for (;;) {
+      const int r2 = path[j];
+      row4col[j] = r2;
+      std::swap(col4row[r2], j);
+      if (r2 == cur) break;
+    }
+  }
+  if (transpose) {
+    std::vector<std::pair<int, int>> pr;
+    for (int r2 = 0; r2 < R; ++r2) pr.emplace_back(col4row[r2], r2);   // (original row, original col)
+    std::sort(pr.begin(), pr.end());
+    for (auto& q : pr) { rows->push_back(q.first); cols->push_back(q.second); }
+  } else {
+    for (int r2 = 0; r2 < R; ++r2) { rows->push_back(r2); cols->push_back(col4row[r2]); }
+  }
+  return 0;
+}
+
+namespace {
+
+// ---------------------------------------------------------------------- Kalman
+constexpr double kStdPos = 1.0 / 20, kStdVel = 1.0 / 160;
+constexpr double kChi2_4 = 9.4877;           // kalman_filter.py:11-20 chi2inv95[4]
+constexpr double kInftyCost = 1e+5;          // linear_assignment.py:9
+
+inline double sq(double x) { return x * x; }
+
+void kf_initiate(const double* z, double* mean, double* cov) {      // kalman_filter.py:57-86
+  for (int i = 0; i < 4; ++i) { mean[i] = z[i]; mean[4 + i] = 0.0; }
+  const double h = z[3];
+  const double std_[8] = {2 * kStdPos * h, 2 * kStdPos * h, 1e-2, 2 * kStdPos * h,
+                          10 * kStdVel * h, 10 * kStdVel * h, 1e-5, 10 * kStdVel * h};
+  std::memset(cov, 0, 64 * sizeof(double));
+  for (int i = 0; i < 8; ++i) cov[i * 8 + i] = sq(std_[i]);
+}
+
+void kf_predict(double* mean, double* cov) {                         // kalman_filter.py:88-124
+  const double h = mean[3];
+  const double q[8] = {sq(kStdPos * h), sq(kStdPos * h), sq(1e-2), sq(kStdPos * h),
+                       sq(kStdVel * h), sq(kStdVel * h), sq(1e-5), sq(kStdVel * h)};
+  for (int i = 0; i < 4; ++i) mean[i] = mean[i] + mean[4 + i];
+  // F P F^T with F = [[I, I],[0, I]] (dt = 1): X = P F^T, then F X (only two non-zero terms per
+  // entry, so this equals numpy's multi_dot bit for bit)
+  double X[64];
+  for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 8; ++j) X[i * 8 + j] = j < 4 ? cov[i * 8 + j] + cov[i * 8 + j + 4] : cov[i * 8 + j];
+  for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 8; ++j) cov[i * 8 + j] = i < 4 ? X[i * 8 + j] + X[(i + 4) * 8 + j] : X[i * 8 + j];
+  for (int i = 0; i < 8; ++i) cov[i * 8 + i] += q[i];
+}
+
+void kf_project(const double* mean, const double* cov, double* pm, double* pc) {   // :126-154
+  const double h = mean[3];
+  const double r[4] = {sq(kStdPos * h), sq(kStdPos * h), sq(1e-1), sq(kStdPos * h)};
+  for (int i = 0; i < 4; ++i) {
+    pm[i] = mean[i];
+    for (int j = 0; j < 4; ++j) pc[i * 4 + j] = cov[i * 8 + j] + (i == j ? r[i] : 0.0);
+  }
+}
+
+bool chol4(const double* a, double* L) {          // lower Cholesky of a 4x4 SPD matrix
+  std::memset(L, 0, 16 * sizeof(double));
+  for (int j = 0; j < 4; ++j) {
+    double d = a[j * 4 + j];
+    for (int k = 0; k < j; ++k) d -= L[j * 4 + k] * L[j * 4 + k];
+    if (!(d > 0.0)) return false;
+    L[j * 4 + j] = std::sqrt(d);
+    for (int i = j + 1; i < 4; ++i) {
+      double s = a[i * 4 + j];
+      for (int k = 0; k < j; ++k) s -= L[i * 4 + k] * L[j * 4 + k];
+      L[i * 4 + j] = s / L[j * 4 + j];
+    }
+  }
+  return true;
+}
+
+bool kf_update(double* mean, double* cov, const double* z) {          // kalman_filter.py:156-189
+  double pm[4], S[16], L[16];
+  kf_project(mean, cov, pm, S);
+  if (!chol4(S, L)) return false;
+  // K^T = S^-1 (P H^T)^T : solve S x = b for the 8 right-hand sides b = row i of P[:, :4]
+  double K[32];                                   // [8][4]
+  for (int i = 0; i < 8; ++i) {
+    double y[4], x[4];
+    for (int r = 0; r < 4; ++r) {                 // forward: L y = b
+      double s = cov[i * 8 + r];
+      for (int k = 0; k < r; ++k) s -= L[r * 4 + k] * y[k];
+      y[r] = s / L[r * 4 + r];
+    }
+    for (int r = 3; r >= 0; --r) {                // backward: L^T x = y
+      double s = y[r];
+      for (int k = r + 1; k < 4; ++k) s -= L[k * 4 + r] * x[k];
+      x[r] = s / L[r * 4 + r];
+    }
+    for (int r = 0; r < 4; ++r) K[i * 4 + r] = x[r];
+  }
+  double innov[4];
+  for (int r = 0; r < 4; ++r) innov[r] = z[r] - pm[r];
+  for (int i = 0; i < 8; ++i) {
+    double s = 0.0;
+    for (int r = 0; r < 4; ++r) s += innov[r] * K[i * 4 + r];
+    mean[i] += s;
+  }
+  double SK[32];                                  // S K^T : [4][8]
+  for (int r = 0; r < 4; ++r)
+    for (int j = 0; j < 8; ++j) {
+      double s = 0.0;
+      for (int k = 0; k < 4; ++k) s += S[r * 4 + k] * K[j * 4 + k];
+      SK[r * 8 + j] = s;
+    }
+  for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 8; ++j) {
+      double s = 0.0;
+      for (int k = 0; k < 4; ++k) s += K[i * 4 + k] * SK[k * 8 + j];
+      cov[i * 8 + j] -= s;
+    }
+  return true;
+}
+
+// squared Mahalanobis distance of every measurement to the projected track state (:191-232)
+bool kf_gating(const double* mean, const double* cov, const double* meas, int n, double* out) {
+  double pm[4], S[16], L[16];
+  kf_project(mean, cov, pm, S);
+  if (!chol4(S, L)) return false;
+  for (int m = 0; m < n; ++m) {
+    double y[4], acc = 0.0;
+    for (int r = 0; r < 4; ++r) {
+      double s = meas[m * 4 + r] - pm[r];
+      for (int k = 0; k < r; ++k) s -= L[r * 4 + k] * y[k];
+      y[r] = s / L[r * 4 + r];
+      acc += y[r] * y[r];
+    }
+    out[m] = acc;
+  }
+  return true;
+}
+
+enum { kTentative = 1, kConfirmed = 2, kDeleted = 3 };
+
+struct Trk {
+  double mean[8], cov[64];
+  int id, hits, age, tsu, state;
+  std::vector<std::vector<float>> features;     // not yet flushed into the gallery
+  void tlwh(double* o) const {                  // track.py:71-84
+    o[0] = mean[0]; o[1] = mean[1]; o[2] = mean[2] * mean[3]; o[3] = mean[3];
+    o[0] -= o[2] / 2; o[1] -= o[3] / 2;
+  }
+};
+
+struct Det { double tlwh[4], xyah[4], conf; const float* feat; };
+
+}  // namespace
+}  // namespace odt
+
+using namespace odt;
+
+struct odt_tracker {
+  double max_cos, max_iou;
+  int budget, max_age, n_init, device, D = 0;
+  int next_id = 1;
+  std::vector<Trk> tracks;
+  std::map<int, std::deque<std::vector<float>>> samples;     // nn_matching.py:125-154
+  // device scratch for the cosine kernel
+  float *d_gal = nullptr, *d_gal_n = nullptr, *d_det = nullptr, *d_det_n = nullptr;
+  int* d_seg = nullptr; double* d_cost = nullptr;
+  size_t cap_gal = 0, cap_det = 0, cap_seg = 0, cap_cost = 0;
+  ~odt_tracker() {
+    for (void* p : {(void*)d_gal, (void*)d_gal_n, (void*)d_det, (void*)d_det_n, (void*)d_seg, (void*)d_cost})
+      if (p) (void)hipFree(p);
+  }
+};
+
+namespace {
+
+template <typename T>
+int ensure(T** p, size_t* cap, size_t n) {
+  if (*cap >= n) return 0;
+  if (*p) ODT_HIP(hipFree(*p));
+  *p = nullptr;
+  ODT_HIP(hipMalloc((void**)p, n * sizeof(T)));
+  *cap = n;
+  return 0;
+}
+
+// NearestNeighborDistanceMetric.distance over the gallery of `targets` (HIP kernel)
+int metric_distance(odt_tracker* t, const std::vector<Det>& dets, const std::vector<int>& det_idx,
+                    const std::vector<int>& target_ids, std::vector<double>* cost) {
+  const int T = (int)target_ids.size(), N = (int)det_idx.size(), D = t->D;
+  cost->assign((size_t)T * N, 0.0);
+  if (T == 0 || N == 0) return 0;
+  std::vector<float> gal, det((size_t)N * D);
+  std::vector<int> seg(1, 0);
+  for (int id : target_ids) {
+    auto it = t->samples.find(id);
+    ODT_CHECK(it != t->samples.end() && !it->second.empty(), "tracker: confirmed track without gallery samples");
+    for (const auto& f : it->second) gal.insert(gal.end(), f.begin(), f.end());
+    seg.push_back((int)(gal.size() / D));
+  }
+  for (int j = 0; j < N; ++j) std::memcpy(&det[(size_t)j * D], dets[det_idx[j]].feat, sizeof(float) * D);
+  const int G = seg.back();
+  ODT_HIP(hipSetDevice(t->device));
+  size_t c2 = t->cap_gal, c3 = t->cap_det;
+  if (ensure(&t->d_gal, &t->cap_gal, gal.size()) || ensure(&t->d_gal_n, &c2, gal.size())) return 1;
+  if (ensure(&t->d_det, &t->cap_det, det.size()) || ensure(&t->d_det_n, &c3, det.size())) return 1;
+  if (ensure(&t->d_seg, &t->cap_seg, seg.size()) || ensure(&t->d_cost, &t->cap_cost, cost->size())) return 1;
+  ODT_HIP(hipMemcpy(t->d_gal, gal.data(), gal.size() * sizeof(float), hipMemcpyHostToDevice));
+  ODT_HIP(hipMemcpy(t->d_det, det.data(), det.size() * sizeof(float), hipMemcpyHostToDevice));
+  ODT_HIP(hipMemcpy(t->d_seg, seg.data(), seg.size() * sizeof(int), hipMemcpyHostToDevice));
+  if (launch_nn_cosine(t->d_gal, G, t->d_seg, T, t->d_det, N, D, t->d_gal_n, t->d_det_n, t->d_cost, nullptr)) return 1;
+  ODT_HIP(hipDeviceSynchronize());
+  ODT_HIP(hipMemcpy(cost->data(), t->d_cost, cost->size() * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+typedef int (*CostFn)(odt_tracker*, const std::vector<Det>&, const std::vector<int>&, const std::vector<int>&,
+                      std::vector<double>*);
+
+// tracker.py:94-104 gated_metric
+int gated_metric_cost(odt_tracker* t, const std::vector<Det>& dets, const std::vector<int>& trk_idx,
+                      const std::vector<int>& det_idx, std::vector<double>* cost) {
+  std::vector<int> ids;
+  for (int k : trk_idx) ids.push_back(t->tracks[k].id);
+  if (metric_distance(t, dets, det_idx, ids, cost)) return 1;
+  const int N = (int)det_idx.size();
+  std::vector<double> meas((size_t)N * 4), g(N);
+  for (int j = 0; j < N; ++j) std::memcpy(&meas[(size_t)j * 4], dets[det_idx[j]].xyah, 4 * sizeof(double));
+  for (size_t r = 0; r < trk_idx.size(); ++r) {            // linear_assignment.py:148-194
+    const Trk& tr = t->tracks[trk_idx[r]];
+    ODT_CHECK(kf_gating(tr.mean, tr.cov, meas.data(), N, g.data()), "tracker: projected covariance not positive definite");
+    for (int j = 0; j < N; ++j)
+      if (g[j] > kChi2_4) (*cost)[r * N + j] = kInftyCost;
+  }
+  return 0;
+}
+
+// iou_matching.py:42-84
+int iou_cost(odt_tracker* t, const std::vector<Det>& dets, const std::vector<int>& trk_idx,
+             const std::vector<int>& det_idx, std::vector<double>* cost) {
+  const int N = (int)det_idx.size();
+  cost->assign(trk_idx.size() * (size_t)N, 0.0);
+  for (size_t r = 0; r < trk_idx.size(); ++r) {
+    const Trk& tr = t->tracks[trk_idx[r]];
+    if (tr.tsu > 1) {
+      for (int j = 0; j < N; ++j) (*cost)[r * N + j] = kInftyCost;
+      continue;
+    }
+    double b[4];
+    tr.tlwh(b);
+    const double bx2 = b[0] + b[2], by2 = b[1] + b[3], area_b = b[2] * b[3];
+    for (int j = 0; j < N; ++j) {
+      const double* c = dets[det_idx[j]].tlwh;
+      const double tlx = std::max(b[0], c[0]), tly = std::max(b[1], c[1]);
+      const double brx = std::min(bx2, c[0] + c[2]), bry = std::min(by2, c[1] + c[3]);
+      const double w = std::max(0.0, brx - tlx), h = std::max(0.0, bry - tly);
+      const double inter = w * h, area_c = c[2] * c[3];
+      (*cost)[r * N + j] = 1.0 - inter / (area_b + area_c - inter);
+    }
+  }
+  return 0;
+}
+
+struct Matching {
+  std::vector<std::pair<int, int>> matches;
+  std::vector<int> unmatched_tracks, unmatched_dets;
+};
+
+// linear_assignment.py:12-79
+int min_cost_matching(odt_tracker* t, CostFn fn, double max_distance, const std::vector<Det>& dets,
+                      const std::vector<int>& trk_idx, const std::vector<int>& det_idx, Matching* out) {
+  out->matches.clear(); out->unmatched_tracks.clear(); out->unmatched_dets.clear();
+  if (det_idx.empty() || trk_idx.empty()) {
+    out->unmatched_tracks = trk_idx; out->unmatched_dets = det_idx;
+    return 0;
+  }
+  std::vector<double> cost;
+  if (fn(t, dets, trk_idx, det_idx, &cost)) return 1;
+  const int R = (int)trk_idx.size(), N = (int)det_idx.size();
+  for (double& c : cost)
+    if (c > max_distance) c = max_distance + 1e-5;
+  std::vector<int> rows, cols;
+  if (lsap(cost.data(), R, N, &rows, &cols)) return 1;
+  std::vector<char> col_used(N, 0), row_used(R, 0);
+  for (size_t q = 0; q < rows.size(); ++q) { row_used[rows[q]] = 1; col_used[cols[q]] = 1; }
+  for (int c = 0; c < N; ++c)
+    if (!col_used[c]) out->unmatched_dets.push_back(det_idx[c]);
+  for (int r = 0; r < R; ++r)
+    if (!row_used[r]) out->unmatched_tracks.push_back(trk_idx[r]);
+  for (size_t q = 0; q < rows.size(); ++q) {
+    const int ti = trk_idx[rows[q]], di = det_idx[cols[q]];
+    if (cost[(size_t)rows[q] * N + cols[q]] > max_distance) {
+      out->unmatched_tracks.push_back(ti);
+      out->unmatched_dets.push_back(di);
+    } else {
+      out->matches.emplace_back(ti, di);
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int odt_lsap(const double* cost, int nr, int nc, int32_t* rows, int32_t* cols, int* n) {
+  ODT_CHECK(rows && cols && n && (cost || nr * nc == 0), "odt_lsap: null argument");
+  std::vector<int> r, c;
+  if (lsap(cost, nr, nc, &r, &c)) return 1;
+  *n = (int)r.size();
+  for (size_t i = 0; i < r.size(); ++i) { rows[i] = r[i]; cols[i] = c[i]; }
+  return 0;
+}
+
+int odt_tracker_create(double max_cosine_distance, int nn_budget, double max_iou_distance, int max_age,
+                       int n_init, int device, odt_tracker_handle* out) {
+  ODT_CHECK(out != nullptr, "odt_tracker_create: null argument");
+  ODT_CHECK(max_age >= 1 && n_init >= 1, "odt_tracker_create: bad parameters");
+  odt_tracker* t = new odt_tracker();
+  t->max_cos = max_cosine_distance; t->budget = nn_budget; t->max_iou = max_iou_distance;
+  t->max_age = max_age; t->n_init = n_init; t->device = device;
+  *out = t;
+  return 0;
+}
+
+int odt_tracker_destroy(odt_tracker_handle t) {
+  delete t;
+  return 0;
+}
+
+int odt_tracker_predict(odt_tracker_handle t) {           // tracker.py:50-56, track.py:112-126
+  ODT_CHECK(t != nullptr, "null tracker");
+  for (Trk& tr : t->tracks) {
+    kf_predict(tr.mean, tr.cov);
+    tr.age += 1;
+    tr.tsu += 1;
+  }
+  return 0;
+}
+
+int odt_tracker_update(odt_tracker_handle t, const double* tlwh, const double* conf, const float* feats,
+                       int N, int D) {                    // tracker.py:57-138
+  ODT_CHECK(t != nullptr, "null tracker");
+  ODT_CHECK(N == 0 || (tlwh && conf && feats && D > 0), "odt_tracker_update: null argument");
+  if (N > 0) {
+    ODT_CHECK(t->D == 0 || t->D == D, "odt_tracker_update: feature dimension changed");
+    t->D = D;
+  }
+  std::vector<Det> dets(N);
+  for (int j = 0; j < N; ++j) {
+    Det& d = dets[j];
+    std::memcpy(d.tlwh, tlwh + (size_t)j * 4, 4 * sizeof(double));
+    d.xyah[0] = d.tlwh[0] + d.tlwh[2] / 2; d.xyah[1] = d.tlwh[1] + d.tlwh[3] / 2;    // detection.py:42-49
+    d.xyah[2] = d.tlwh[2] / d.tlwh[3]; d.xyah[3] = d.tlwh[3];
+    d.conf = conf[j]; d.feat = feats + (size_t)j * D;
+  }
+  // ---- _match (tracker.py:92-138)
+  std::vector<int> confirmed, unconfirmed;
+  for (int i = 0; i < (int)t->tracks.size(); ++i)
+    (t->tracks[i].state == kConfirmed ? confirmed : unconfirmed).push_back(i);
+  // matching_cascade (linear_assignment.py:82-145)
+  std::vector<int> unmatched_dets(N);
+  for (int j = 0; j < N; ++j) unmatched_dets[j] = j;
+  std::vector<std::pair<int, int>> matches;
+  for (int level = 0; level < t->max_age; ++level) {
+    if (unmatched_dets.empty()) break;
+    std::vector<int> lvl;
+    for (int k : confirmed)
+      if (t->tracks[k].tsu == 1 + level) lvl.push_back(k);
+    if (lvl.empty()) continue;
+    Matching m;
+    if (min_cost_matching(t, gated_metric_cost, t->max_cos, dets, lvl, unmatched_dets, &m)) return 1;
+    matches.insert(matches.end(), m.matches.begin(), m.matches.end());
+    unmatched_dets = m.unmatched_dets;
+  }
+  std::set<int> matched_a;
+  for (auto& pr : matches) matched_a.insert(pr.first);
+  std::vector<int> iou_cand = unconfirmed, unmatched_tracks;
+  for (int k : confirmed) {
+    if (matched_a.count(k)) continue;
+    if (t->tracks[k].tsu == 1) iou_cand.push_back(k); else unmatched_tracks.push_back(k);
+  }
+  Matching mb;
+  if (min_cost_matching(t, iou_cost, t->max_iou, dets, iou_cand, unmatched_dets, &mb)) return 1;
+  matches.insert(matches.end(), mb.matches.begin(), mb.matches.end());
+  unmatched_tracks.insert(unmatched_tracks.end(), mb.unmatched_tracks.begin(), mb.unmatched_tracks.end());
+  // ---- update track set (tracker.py:70-78)
+  for (auto& pr : matches) {
+    Trk& tr = t->tracks[pr.first];
+    const Det& d = dets[pr.second];
+    ODT_CHECK(kf_update(tr.mean, tr.cov, d.xyah), "tracker: innovation covariance not positive definite");
+    tr.features.emplace_back(d.feat, d.feat + D);
+    tr.hits += 1;
+    tr.tsu = 0;
+    if (tr.state == kTentative && tr.hits >= t->n_init) tr.state = kConfirmed;
+  }
+  for (int k : unmatched_tracks) {                       // track.py:147-153
+    Trk& tr = t->tracks[k];
+    if (tr.state == kTentative) tr.state = kDeleted;
+    else if (tr.tsu > t->max_age) tr.state = kDeleted;
+  }
+  for (int j : mb.unmatched_dets) {                      // tracker.py:133-138
+    Trk tr;
+    kf_initiate(dets[j].xyah, tr.mean, tr.cov);
+    tr.id = t->next_id++; tr.hits = 1; tr.age = 1; tr.tsu = 0; tr.state = kTentative;
+    tr.features.emplace_back(dets[j].feat, dets[j].feat + D);
+    t->tracks.push_back(std::move(tr));
+  }
+  t->tracks.erase(std::remove_if(t->tracks.begin(), t->tracks.end(),
+                                 [](const Trk& tr) { return tr.state == kDeleted; }), t->tracks.end());
+  // ---- metric.partial_fit (tracker.py:80-90, nn_matching.py:137-154)
+  std::set<int> active;
+  for (Trk& tr : t->tracks) {
+    if (tr.state != kConfirmed) continue;
+    active.insert(tr.id);
+    auto& bucket = t->samples[tr.id];
+    for (auto& f : tr.features) {
+      bucket.push_back(std::move(f));
+      if (t->budget > 0)
+        while ((int)bucket.size() > t->budget) bucket.pop_front();
+    }
+    tr.features.clear();
+  }
+  for (auto it = t->samples.begin(); it != t->samples.end();)
+    it = active.count(it->first) ? std::next(it) : t->samples.erase(it);
+  return 0;
+}
+
+int odt_tracker_tracks(odt_tracker_handle t, int cap, int32_t* ids, int32_t* state, int32_t* time_since_update,
+                       int32_t* hits, int32_t* age, double* mean, double* covariance, int* n) {
+  ODT_CHECK(t != nullptr && n != nullptr, "odt_tracker_tracks: null argument");
+  *n = (int)t->tracks.size();
+  for (int i = 0; i < *n && i < cap; ++i) {
+    const Trk& tr = t->tracks[i];
+    if (ids) ids[i] = tr.id;
+    if (state) state[i] = tr.state;
+    if (time_since_update) time_since_update[i] = tr.tsu;
+    if (hits) hits[i] = tr.hits;
+    if (age) age[i] = tr.age;
+    if (mean) std::memcpy(mean + (size_t)i * 8, tr.mean, 8 * sizeof(double));
+    if (covariance) std::memcpy(covariance + (size_t)i * 64, tr.cov, 64 * sizeof(double));
+  }
+  return 0;
+}
+
+}  // extern "C"
