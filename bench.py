@@ -146,7 +146,7 @@ def main():
   if rank == 0:
     fps = world * B * args.steps / dt
     out = {
-        "metric": "detector FPS @1920x1080 b=8 per MI355X",
+        "metric": "detector FPS @%dx%d b=%d per MI355X" % (W, H, B),
         "value": fps,
         "unit": "frames/s",
         "n_gpus": world,
@@ -171,7 +171,7 @@ def main():
             "peak": F32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / F32_MFMA_PEAK_TFLOPS,
-            "traffic": pmc_traffic(),
+            "traffic": pmc_traffic() if (B, H, W) == (8, 1080, 1920) else None,
             "conv_ms_per_step": prof["conv_ms"] / max(1, args.profile_steps),
             "step_ms_profiled": prof["total_ms"] / max(1, args.profile_steps),
             "algorithmic_gflop_per_step": prof["conv_flops"] / max(1, args.profile_steps) / 1e9,
