@@ -24,7 +24,7 @@ from ._lib import (ODT_DTYPE_F32, ODT_DTYPE_U8, ODT_GRAPH_MULTI, ODT_GRAPH_SINGL
                    OdtOutputs, c_i64_p, f32, fptr, iptr)
 from .anchors import fpn_anchor_fields
 from .config import HEAD_DECODE_CLIP, finalize_config
-from .weights import load_npz
+from .weights import load_npz, select_partial_classes
 
 
 class TensorHandle(object):
@@ -41,14 +41,15 @@ class TensorHandle(object):
 class _Engine(object):
   """One static plan (fixed batch, H, W) on one GPU."""
 
-  def __init__(self, lib, config, graph, batch, height, width, weights, device):
+  def __init__(self, lib, config, graph, batch, height, width, weights, device,
+               num_class=None):
     self.lib = lib
     self.batch, self.height, self.width = batch, height, width
     self.per_im = int(config.result_per_im)
     self.channels = int(config.fpn_num_channel)
     c = OdtConfig()
     c.graph = graph; c.batch = batch; c.height = height; c.width = width
-    c.num_class = int(config.num_class)
+    c.num_class = int(num_class if num_class is not None else config.num_class)
     for i, n in enumerate(config.resnet_num_block):
       c.num_blocks[i] = int(n)
     c.use_dilations = int(bool(config.use_dilations))
@@ -216,6 +217,12 @@ class _DetectorBase(object):
         raise ValueError("weights: pass a {name: array} dict or set config.model_path to a "
                          "Tensorpack-style .npz (reference obj_detect_tracking.py:417-435)")
       weights = load_npz(path)
+    # --use_partial_classes (reference models.py:807-829): class-subset head
+    self.head_num_class = int(self.config.num_class)
+    if getattr(self.config, "use_partial_classes", False):
+      ids = [self.config.classname2id[name] for name in self.config.partial_classes]
+      weights = select_partial_classes(weights, ids, self.head_num_class)
+      self.head_num_class = len(ids) + 1
     self.weights = weights
     self._engines = {}
     # the reference's tensor handles / placeholders (models.py:282-283, 965-973)
@@ -231,7 +238,7 @@ class _DetectorBase(object):
     key = (batch, height, width)
     if key not in self._engines:
       self._engines[key] = _Engine(self.lib, self.config, self.graph, batch, height, width,
-                                   self.weights, self.gpuid)
+                                   self.weights, self.gpuid, num_class=self.head_num_class)
     return self._engines[key]
 
   # reference models.py:1629-1636

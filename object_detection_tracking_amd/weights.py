@@ -133,3 +133,23 @@ def synthetic_frames(batch, height, width, seed=1234):
       img[y:y + rh, x:x + rw] = col + rng.normal(0, 6.0, (rh, rw, 3))
     out[b] = np.clip(np.rint(img), 0, 255).astype(np.uint8)
   return out
+
+
+def select_partial_classes(weights, class_ids, num_class):
+  """``--use_partial_classes`` (reference models.py:807-829, multi :2267-2287): the graph gathers
+  label logits ``[0] + ids`` and box logits ``ids - 1`` (after the BG box was dropped).  Both are
+  columns of a linear layer, so gathering the columns of ``fastrcnn/outputs/{class,box}`` once at
+  load time yields the identical dot products; the head then runs with ``len(ids) + 1`` classes.
+  Returns a new dict (the input is not modified)."""
+  cols = np.asarray([0] + [int(i) for i in class_ids], np.int64)
+  if cols.min() < 0 or cols.max() >= num_class:
+    raise ValueError("partial class id outside [0, %d)" % num_class)
+  out = dict(weights)
+  W = np.asarray(weights["fastrcnn/outputs/class/W"]); b = np.asarray(weights["fastrcnn/outputs/class/b"])
+  out["fastrcnn/outputs/class/W"] = np.ascontiguousarray(W[:, cols])
+  out["fastrcnn/outputs/class/b"] = np.ascontiguousarray(b[cols])
+  W = np.asarray(weights["fastrcnn/outputs/box/W"]); b = np.asarray(weights["fastrcnn/outputs/box/b"])
+  W = W.reshape(W.shape[0], num_class, 4)[:, cols, :]
+  out["fastrcnn/outputs/box/W"] = np.ascontiguousarray(W.reshape(W.shape[0], -1))
+  out["fastrcnn/outputs/box/b"] = np.ascontiguousarray(b.reshape(num_class, 4)[cols].reshape(-1))
+  return out

@@ -232,7 +232,7 @@ def multilevel_roi_align(features, boxes, box_ind, strides, out=7):
   return res
 
 
-def box_head(roi_feat, weights, num_class):
+def box_head(roi_feat, weights, num_class, partial_ids=None):
   """reference models.py:1030-1108 (fc6/fc7 ReLU, class, box[:,1:])."""
   x = torch.from_numpy(roi_feat.reshape(roi_feat.shape[0], -1))
   h = torch.relu(x @ _w(weights, "fastrcnn/fc6/W") + _w(weights, "fastrcnn/fc6/b"))
@@ -242,7 +242,13 @@ def box_head(roi_feat, weights, num_class):
   box = h @ _w(weights, "fastrcnn/outputs/box/W") + \
       _w(weights, "fastrcnn/outputs/box/b")
   box = box.reshape(-1, num_class, 4)[:, 1:, :]
-  return cls.numpy(), np.ascontiguousarray(box.numpy())
+  cls, box = cls.numpy(), np.ascontiguousarray(box.numpy())
+  if partial_ids is not None:
+    # reference models.py:807-829 (multi :2267-2287): gather label logits [0]+ids, box logits ids-1
+    ids = [int(i) for i in partial_ids]
+    cls = np.ascontiguousarray(cls[:, [0] + ids])
+    box = np.ascontiguousarray(box[:, [i - 1 for i in ids], :])
+  return cls, box
 
 
 def head_decode(rcnn_boxes, box_logits, cls_logits, hw, reg_weights):
@@ -282,6 +288,9 @@ class OracleModel(object):
     self.config = config
     self.weights = weights
     self.anchors = all_anchors_fpn(config)
+    self.partial_ids = None
+    if getattr(config, "use_partial_classes", False):
+      self.partial_ids = [config.classname2id[n] for n in config.partial_classes]
 
   # -- shared trunk ---------------------------------------------------------
   def trunk(self, images, taps):
@@ -334,7 +343,7 @@ class OracleModel(object):
     zeros = np.zeros((props.shape[0],), np.int32)
     rf = multilevel_roi_align(p[:4], props, zeros, cfg.anchor_strides)
     taps["roi_feat"] = rf
-    cls, box = box_head(rf, self.weights, cfg.num_class)
+    cls, box = box_head(rf, self.weights, cfg.num_class, self.partial_ids)
     taps["cls_logits"] = cls; taps["box_logits"] = box
     dec, probs = head_decode(props, box, cls, hw, cfg.fastrcnn_bbox_reg_weights)
     taps["decoded_boxes"] = dec; taps["label_probs"] = probs
@@ -391,7 +400,7 @@ class OracleModel(object):
     bidx = props[:, 0].astype(np.int32); rb = props[:, 1:]
     rf = multilevel_roi_align(p[:4], rb, bidx, cfg.anchor_strides)
     taps["roi_feat"] = rf
-    cls, box = box_head(rf, self.weights, cfg.num_class)
+    cls, box = box_head(rf, self.weights, cfg.num_class, self.partial_ids)
     dec, probs = head_decode(rb, box, cls, hw, cfg.fastrcnn_bbox_reg_weights)
     taps["decoded_boxes"] = dec; taps["label_probs"] = probs
     # fastrcnn_predictions_multibatch (models.py:2924-2976): scatter into

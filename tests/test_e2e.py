@@ -159,3 +159,25 @@ def test_determinism_and_size_independent_properties(hip_lib):
     assert np.isfinite(feats).all() and feats.shape == (int(valid.sum()), 256, 7, 7)
   finally:
     m.close()
+
+
+def test_forward_coco_v2_partial_classes(backend):
+  """Model-zoo variant (reference obj_detect_tracking.py:233-239,263-290): version 2 = no
+  dilations, 81 COCO classes, --use_partial_classes keeps a class subset of the head
+  (models.py:807-829).  The oracle gathers logits as the graph does; the product gathers the
+  weight columns once at load time."""
+  name, lib = backend
+  names = ["BG"] + ["c%d" % i for i in range(1, 81)]
+  part = ["c1", "c3", "c4", "c6", "c8", "c17", "c80"]
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1], version=2, use_dilations=False, num_class=81,
+                     is_coco_model=True, use_partial_classes=True, partial_classes=part,
+                     classname2id={n: i for i, n in enumerate(names)})
+  miss, extra = _run_single(lib, cfg, 96, 128)
+  assert miss == 0 and extra == 0
+  m = models.get_model(cfg, 0, weights=weights_for(cfg), lib=lib)
+  try:
+    assert m.head_num_class == 8
+    _, labels, _, _ = m.predict(synthetic_frames(1, 96, 128)[0])
+    assert labels.size and labels.min() >= 1 and labels.max() <= 7   # 1..num_partial (ref :637-641)
+  finally:
+    m.close()
