@@ -20,6 +20,7 @@
 // MFMAs on slice c, written to the other LDS stage after them; one barrier
 // per slice.
 #include <cstdlib>
+#include <type_traits>
 
 #include "odt_common.hpp"
 
@@ -57,9 +58,13 @@ __global__ void __launch_bounds__(256, ST == 1 ? 3 : 2) conv_igemm_kernel(const 
   const int wm = wave / WN, wn = wave % WN;
   const int ntn = (p.Cout + BN - 1) / BN;
   auto stamp = [&](int i) {
-    if (p.trace != nullptr && tid == 0) p.trace[(size_t)blockIdx.x * 8 + i] = wall_clock64();
+    if (p.trace != nullptr && tid == 0) p.trace[(size_t)blockIdx.x * 16 + i] = wall_clock64();
   };
   stamp(0);
+  if (p.trace != nullptr && tid == 0) {       // placement: HW_ID (cu/sh/se/tg slot) and XCC_ID
+    p.trace[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    p.trace[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+  }
   // XCD-aware tile order: the dispatcher places workgroup i on XCD i % 8, each XCD has its own
   // L2.  Give every XCD one contiguous run of (m-tile, n-tile) pairs so that all N-tiles of an
   // M-tile (same A rows) and neighbouring M-tiles (shared 3x3 halo rows) hit the same L2
@@ -237,28 +242,40 @@ __global__ void __launch_bounds__(256, ST == 1 ? 3 : 2) conv_igemm_kernel(const 
     // barrier, first fragment read of the next slice.
     for (int c = 0; c < nslices; ++c) {
       const bool more = c + 1 < nslices;
-      read_frags(0, 1, fa1, fb1);
+      if (!(dbg & 8)) read_frags(0, 1, fa1, fb1);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_group(fa0, fb0, 0, 4);
+      if (!(dbg & 16)) mfma_group(fa0, fb0, 0, 4);
       __builtin_amdgcn_sched_barrier(0);
-      read_frags(0, 2, fa0, fb0);
+      if (!(dbg & 8)) read_frags(0, 2, fa0, fb0);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_group(fa1, fb1, 0, 4);
+      if (!(dbg & 16)) mfma_group(fa1, fb1, 0, 4);
       __builtin_amdgcn_sched_barrier(0);
-      read_frags(0, 3, fa1, fb1);
+      if (!(dbg & 8)) read_frags(0, 3, fa1, fb1);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_group(fa0, fb0, 0, 4);
+      if (!(dbg & 16)) mfma_group(fa0, fb0, 0, 4);
       __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
+      if (!(dbg & 4)) __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
-      if (more) store_slice(0);
+      if (more && !(dbg & 2)) store_slice(0);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_group(fa1, fb1, 0, 4);
-      if (c + 2 < nslices) load_slice();
+#ifdef ODT_AB_NOROT
+      if (!(dbg & 16)) mfma_group(fa1, fb1, 0, 4);
+      if (c + 2 < nslices && !(dbg & 1)) load_slice();
       __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
+      if (!(dbg & 4)) __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
-      if (more) read_frags(0, 0, fa0, fb0);
+      if (more && !(dbg & 8)) read_frags(0, 0, fa0, fb0);
+#else
+      if (!(dbg & 16)) mfma_group(fa1, fb1, 0, 2);
+      if (c + 2 < nslices && !(dbg & 1)) load_slice();
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(dbg & 4)) __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      if (more && !(dbg & 8)) read_frags(0, 0, fa0, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(dbg & 16)) mfma_group(fa1, fb1, 2, 4);    // covers the first fragment read of slice c+1
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     }
   }
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -303,8 +320,45 @@ __global__ void __launch_bounds__(256, ST == 1 ? 3 : 2) conv_igemm_kernel(const 
       if (col + e < p.Cout) bias4[e] = p.bias[col + e];
   }
 
+  // Output / residual pixel of tile row m (dense tensors: the row index itself).
+  auto out_pix = [&](int m, bool ok, unsigned& opix, unsigned& rpix) {
+    if (dense_io) {
+      opix = (unsigned)m;
+      rpix = (unsigned)m;
+    } else {
+      const int mm = ok ? m : 0;
+      const int n = fast_div(mm, p.div_howo_mul, p.div_howo_sh), rr = mm - n * HoWo;
+      const int ho = fast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
+      opix = ((unsigned)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
+      rpix = p.res_mode == 2 ? ((unsigned)n * p.res_H + (ho >> 1)) * p.res_W + (wo >> 1)
+                             : ((unsigned)n * p.res_H + ho) * p.res_W + wo;
+    }
+  };
+  // The residual tile of ALL passes is fetched here, before the first store and before the C
+  // tile is staged: vmcnt retires in order, so a load issued after a store would wait for that
+  // store's write acknowledgement -- with the loads up front the passes below only read LDS and
+  // fire stores, and the residual latency hides behind the staging.
+  f32x4 rv[PASSES][NCH];
 #pragma unroll
-  for (int pass = 0; pass < PASSES; ++pass) {
+  for (int pass = 0; pass < PASSES; ++pass)
+#pragma unroll
+    for (int s2 = 0; s2 < NCH; ++s2) rv[pass][s2] = zero4;
+  if (fast && p.res_mode != 0) {
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass)
+#pragma unroll
+      for (int s2 = 0; s2 < NCH; ++s2) {
+        const int m = m0 + pass * RP + row0 + s2 * (256 / C4);
+        const bool ok = col_ok && m < M;
+        unsigned opix, rpix;
+        out_pix(m, ok, opix, rpix);
+        const unsigned roff = ok ? (rpix * p.res_ldc + col) * 4u : kOOB;
+        rv[pass][s2] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)roff, 0, 0);
+      }
+  }
+
+  // acc -> LDS C tile of one pass (row block of RP rows), with the barriers around it
+  auto stage_pass = [&](int pass) {
     if (pass > 0) __syncthreads();                  // previous pass finished reading Ct
     if ((wm * TM * 32) / RP == pass) {
 #pragma unroll
@@ -319,47 +373,43 @@ __global__ void __launch_bounds__(256, ST == 1 ? 3 : 2) conv_igemm_kernel(const 
           }
     }
     __syncthreads();
-    if (pass == 0) stamp(3);
-    if (fast) {
-      // ---- fast path (every layer of the model except the 15-channel RPN head): branch-free.
-      // Buffer loads/stores with out-of-range offsets for the masked chunks, so the compiler sees
-      // straight-line code and emits counted vmcnt waits instead of draining every store.
-      unsigned ooff[NCH];
-      f32x4 rv[NCH];
+  };
+
+  if (fast) {
+    // ---- fast path (every layer of the model except the 15-channel RPN head): straight-line,
+    // buffer stores with out-of-range offsets for the masked chunks.  The relu flag is
+    // unswitched so that the pass bodies have no control flow (the waitcnt placement stays
+    // exact: one vmcnt wait for the residual tile, none between the stores).
+    auto run = [&](auto relu_c) {
+      constexpr bool RELU = decltype(relu_c)::value;
 #pragma unroll
-      for (int s2 = 0; s2 < NCH; ++s2) {
-        const int m = m0 + pass * RP + row0 + s2 * (256 / C4);
-        const bool ok = col_ok && m < M;
-        unsigned opix, rpix;
-        if (dense_io) {
-          opix = (unsigned)m;
-          rpix = (unsigned)m;
-        } else {
-          const int mm = ok ? m : 0;
-          const int n = fast_div(mm, p.div_howo_mul, p.div_howo_sh), rr = mm - n * HoWo;
-          const int ho = fast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
-          opix = ((unsigned)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
-          rpix = p.res_mode == 2 ? ((unsigned)n * p.res_H + (ho >> 1)) * p.res_W + (wo >> 1)
-                                 : ((unsigned)n * p.res_H + ho) * p.res_W + wo;
+      for (int pass = 0; pass < PASSES; ++pass) {
+        stage_pass(pass);
+        if (pass == 0) stamp(3);
+#pragma unroll
+        for (int s2 = 0; s2 < NCH; ++s2) {
+          const int m = m0 + pass * RP + row0 + s2 * (256 / C4);
+          const bool ok = col_ok && m < M;
+          unsigned opix, rpix;
+          out_pix(m, ok, opix, rpix);
+          const unsigned ooff = (ok && !(dbg & 64)) ? (opix * p.out_ldc + col) * 4u : kOOB;
+          f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[(row0 + s2 * (256 / C4)) * CS + c4 * 4]);
+          v += bias4;
+          v += rv[pass][s2];
+          if (RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)ooff, 0, 0);
         }
-        ooff[s2] = ok ? (opix * p.out_ldc + col) * 4u : kOOB;
-        const unsigned roff = ok ? (rpix * p.res_ldc + col) * 4u : kOOB;
-        rv[s2] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)roff, 0, 0);   // 0 if no residual
+        if (pass == 0) stamp(4);
       }
-      if (pass == 0) stamp(4);
-#pragma unroll
-      for (int s2 = 0; s2 < NCH; ++s2) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[(row0 + s2 * (256 / C4)) * CS + c4 * 4]);
-        v += bias4;
-        v += rv[s2];
-        if (p.relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)ooff[s2], 0, 0);
-      }
-    } else {
-      // ---- generic path (Cout % 4 != 0 or unaligned pixel strides): scalar tails
+    };
+    if (p.relu) run(std::true_type{}); else run(std::false_type{});
+  } else {
+    // ---- generic path (Cout % 4 != 0 or unaligned pixel strides): scalar tails
+    for (int pass = 0; pass < PASSES; ++pass) {
+      stage_pass(pass);
       for (int s2 = 0; s2 < NCH; ++s2) {
         const int rl = row0 + s2 * (256 / C4);
         const int m = m0 + pass * RP + rl;

@@ -4,6 +4,7 @@
 // Host code only; every device kernel lives in the sibling .hip files.
 #include "../../include/odt.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -908,29 +909,29 @@ int odt_op_conv2d(int device, const float* in, int B, int H, int W, int Cin, con
   Tmp<unsigned long long> tr;
   const bool trace = getenv("ODT_CONV_TRACE") != nullptr;
   const int max_blocks = 1 << 16;
-  if (trace) { if (tr.alloc((size_t)max_blocks * 8) || tr.zero()) return 1; p.trace = tr.d; }
+  if (trace) { if (tr.alloc((size_t)max_blocks * 16) || tr.zero()) return 1; p.trace = tr.d; }
   if (launch_conv(p, nullptr)) return 1;      // warm
   if (trace) { if (tr.zero()) return 1; }
   if (launch_conv(p, nullptr)) return 1;
   ODT_HIP(hipDeviceSynchronize());
   if (trace) {   // tuning aid: per-phase wall-clock (100 MHz) statistics over the workgroups
-    std::vector<unsigned long long> t((size_t)max_blocks * 8);
+    std::vector<unsigned long long> t((size_t)max_blocks * 16);
     if (tr.get(t.data(), t.size())) return 1;
     unsigned long long t0 = ~0ull, t1 = 0; int nb = 0;
     double ph[5] = {0, 0, 0, 0, 0};
     for (int b = 0; b < max_blocks; ++b) {
-      const unsigned long long* q = &t[(size_t)b * 8];
+      const unsigned long long* q = &t[(size_t)b * 16];
       if (q[0] == 0) continue;
       ++nb; if (q[0] < t0) t0 = q[0]; if (q[5] > t1) t1 = q[5];
       for (int i = 0; i < 5; ++i) ph[i] += (double)(q[i + 1] - q[i]);
     }
-    printf("[conv trace] blocks=%d span=%.1f us | per block avg us: prologue %.2f  mainloop %.2f  acc->lds %.2f  "
-           "addr+res loads %.2f  stores %.2f | sum %.2f\n", nb, (t1 - t0) / 100.0, ph[0] / nb / 100, ph[1] / nb / 100,
+    printf("[conv trace] blocks=%d span=%.1f us | per block avg us: prologue %.2f  mainloop %.2f  res-issue+stage0 %.2f  "
+           "pass0 lds->stores %.2f  pass1 %.2f | sum %.2f\n", nb, (t1 - t0) / 100.0, ph[0] / nb / 100, ph[1] / nb / 100,
            ph[2] / nb / 100, ph[3] / nb / 100, ph[4] / nb / 100, (ph[0] + ph[1] + ph[2] + ph[3] + ph[4]) / nb / 100);
     // concurrency: how many blocks are in the main loop at the midpoint of the launch
     const unsigned long long mid = t0 + (t1 - t0) / 2; int in_main = 0, in_epi = 0, in_pro = 0;
     for (int b = 0; b < max_blocks; ++b) {
-      const unsigned long long* q = &t[(size_t)b * 8];
+      const unsigned long long* q = &t[(size_t)b * 16];
       if (q[0] == 0) continue;
       if (mid >= q[0] && mid < q[1]) ++in_pro; else if (mid >= q[1] && mid < q[2]) ++in_main; else if (mid >= q[2] && mid < q[5]) ++in_epi;
     }
@@ -938,7 +939,7 @@ int odt_op_conv2d(int device, const float* in, int B, int H, int W, int Cin, con
       double sa[3] = {0, 0, 0}, sb[3] = {0, 0, 0};
       double pa = 0, pb = 0, ma = 0, mb = 0; int na = 0, nb2 = 0;
       for (int b = 0; b < max_blocks; ++b) {
-        const unsigned long long* q = &t[(size_t)b * 8];
+        const unsigned long long* q = &t[(size_t)b * 16];
         if (q[0] == 0) continue;
         double* sx = (q[0] - t0 < 500) ? sa : sb;
         sx[0] += (double)(q[6] - q[0]); sx[1] += (double)(q[7] - q[6]); sx[2] += (double)(q[1] - q[7]);
@@ -952,6 +953,44 @@ int odt_op_conv2d(int device, const float* in, int B, int H, int W, int Cin, con
                sa[0] / na / 100, sa[1] / na / 100, sa[2] / na / 100, sb[0] / nb2 / 100, sb[1] / nb2 / 100, sb[2] / nb2 / 100);
     }
     printf("[conv trace] at mid-launch: %d blocks in prologue, %d in main loop, %d in epilogue\n", in_pro, in_main, in_epi);
+    {   // placement and per-CU concurrency: for every CU, the fraction of its busy time with 0 / 1 / 2 / 3+
+        // resident workgroups inside the main loop (lockstep shows up as time with 0 in the loop)
+      std::map<unsigned, std::vector<int>> cu_blocks;
+      for (int b = 0; b < max_blocks; ++b) {
+        const unsigned long long* q = &t[(size_t)b * 16];
+        if (q[0] == 0) continue;
+        const unsigned hw = (unsigned)q[8], xcc = (unsigned)q[9] & 0xf;
+        const unsigned cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 1, se = (hw >> 13) & 0x7;
+        cu_blocks[(xcc << 12) | (se << 8) | (sh << 4) | cu].push_back(b);
+      }
+      double frac[4] = {0, 0, 0, 0}; double busy = 0;
+      for (auto& kv : cu_blocks) {
+        std::vector<std::pair<unsigned long long, int>> ev;   // (time, +1/-1) for main-loop occupancy
+        unsigned long long lo = ~0ull, hi = 0;
+        for (int b : kv.second) {
+          const unsigned long long* q = &t[(size_t)b * 16];
+          ev.push_back({q[1], +1}); ev.push_back({q[2], -1});
+          if (q[0] < lo) lo = q[0]; if (q[5] > hi) hi = q[5];
+        }
+        std::sort(ev.begin(), ev.end());
+        unsigned long long prev = lo; int n = 0;
+        for (auto& e : ev) {
+          frac[n > 3 ? 3 : n] += (double)(e.first - prev); prev = e.first; n += e.second;
+        }
+        frac[0] += (double)(hi - prev); busy += (double)(hi - lo);
+      }
+      printf("[conv trace] %zu CUs seen; time share per CU with k workgroups in the main loop: k=0 %.3f  k=1 %.3f  k=2 %.3f  k>=3 %.3f\n",
+             cu_blocks.size(), frac[0] / busy, frac[1] / busy, frac[2] / busy, frac[3] / busy);
+      // dispatch order on XCD 0: which CU did the first blocks land on
+      printf("[conv trace] XCD0 first blocks -> (se,cu,tg): ");
+      for (int b = 0; b < 8 * 40 && b < max_blocks; b += 8) {
+        const unsigned long long* q = &t[(size_t)b * 16];
+        if (q[0] == 0) break;
+        const unsigned hw = (unsigned)q[8];
+        printf("%u.%u.%u ", (hw >> 13) & 7, (hw >> 8) & 0xf, (hw >> 16) & 0xf);
+      }
+      printf("\n");
+    }
     fflush(stdout);
   }
   return dout.get(out, nout);

@@ -249,6 +249,13 @@ inline hipemu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t
   }
   return v;
 }
+inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, int voffset, int soffset,
+                                                    int /*aux*/) {
+  const unsigned long long o = (unsigned long long)(unsigned)voffset + (unsigned)soffset;
+  unsigned t = 0;
+  if (o + 4 <= r.num_records) memcpy(&t, r.base + o, 4);
+  return t;
+}
 inline void __builtin_amdgcn_raw_buffer_store_b128(hipemu_u32x4 v, __amdgpu_buffer_rsrc_t r, int voffset,
                                                    int soffset, int /*aux*/) {
   const unsigned long long off = (unsigned long long)(unsigned)voffset + (unsigned)soffset;
@@ -258,6 +265,7 @@ inline void __builtin_amdgcn_raw_buffer_store_b128(hipemu_u32x4 v, __amdgpu_buff
   }
 }
 inline void __builtin_amdgcn_s_setprio(int) {}
+inline unsigned __builtin_amdgcn_s_getreg(int) { return 0; }
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_s_sleep(int) {}
 inline unsigned long long wall_clock64() { return (unsigned long long)(hipemu::now_ms() * 1e5); }

@@ -7,7 +7,11 @@ import numpy as np
 os.environ["ODT_CONV_TRACE"] = "1"
 from object_detection_tracking_amd import ops
 shapes = {"conv3": (8, 68, 120, 256, 1024, 1, True), "conv2": (8, 68, 120, 256, 256, 3, False),
-          "conv1": (8, 68, 120, 1024, 256, 1, False), "short0": (2, 272, 480, 64, 256, 1, False)}
+          "conv1": (8, 68, 120, 1024, 256, 1, False), "short0": (2, 272, 480, 64, 256, 1, False),
+          "conv3b1": (1, 68, 120, 256, 1024, 1, True), "conv3b2": (2, 68, 120, 256, 1024, 1, True),
+          "conv3nores": (8, 68, 120, 256, 1024, 1, False),
+          "e1": (1, 32, 128, 2304, 1024, 1, False), "e2": (1, 64, 128, 2304, 1024, 1, False),
+          "e3": (1, 96, 128, 2304, 1024, 1, False), "e4": (1, 128, 128, 2304, 1024, 1, False)}
 for name in sys.argv[1:]:
   B, H, W, Cin, Cout, k, res = shapes[name]
   rng = np.random.default_rng(0)
