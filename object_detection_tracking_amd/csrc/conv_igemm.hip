@@ -42,7 +42,7 @@ constexpr unsigned kOOB = 0x80000000u;   // buffer offset that is out of range f
 // (2 workgroups per CU).  ST == 1: one stage (36.9 KB for the 128x128 tile, registers prefetch
 // one slice ahead, two barriers per slice) so that three workgroups fit on a CU and another
 // workgroup's MFMA stream covers this one's barriers, prologue and HBM-bound epilogue.
-template <int WM, int WN, int TM, int TN, int ST>
+template <int WM, int WN, int TM, int TN, int ST, bool FINE>
 __global__ void __launch_bounds__(256, ST == 1 ? 3 : 2) conv_igemm_kernel(const ConvParams* __restrict__ pp) {
   // Parameters live in device memory (one record per conv of the plan): the by-value kernarg
   // block sits in host-coherent memory and its cold scalar loads cost the first dispatch wave of
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(256, ST == 1 ? 3 : 2) conv_igemm_kernel(const 
 
   // ---- loader role: thread -> (row lr + 32*j, 16-byte column lc)
   const int lc = tid & 7, lr = tid >> 3;
-  int a_hi0[RA], a_wi0[RA];
+  int a_hw0[RA];               // (hi0 << 16) | (wi0 & 0xffff): input row / column of tap (0,0), 16-bit signed each
   unsigned a_img[RA];          // byte offset of the image of this row (kOOB: row >= M)
   // 1x1 / stride 1 / unpadded convs over a dense input (all bottleneck 1x1s, FPN laterals, FCs):
   // input pixel == output row m, no (n,ho,wo) decomposition (saves the integer divisions)
@@ -104,15 +104,13 @@ __global__ void __launch_bounds__(256, ST == 1 ? 3 : 2) conv_igemm_kernel(const 
     const int m = m0 + lr + 32 * j;
     const bool ok = m < M;
     if (dense_in) {
-      a_hi0[j] = 0;
-      a_wi0[j] = 0;
+      a_hw0[j] = 0;
       a_img[j] = ok ? (unsigned)m * p.in_ldc * 4u + lc * 16u : kOOB;
     } else {
       const int mm = ok ? m : 0;
       const int n = fast_div(mm, p.div_howo_mul, p.div_howo_sh), r = mm - n * HoWo;
       const int ho = fast_div(r, p.div_wo_mul, p.div_wo_sh), wo = r - ho * p.Wo;
-      a_hi0[j] = ho * p.stride - p.pad_t;
-      a_wi0[j] = wo * p.stride - p.pad_l;
+      a_hw0[j] = (int)(((unsigned)(ho * p.stride - p.pad_t) << 16) | ((unsigned)(wo * p.stride - p.pad_l) & 0xffffu));
       a_img[j] = ok ? (unsigned)n * p.in_Ha * p.in_Wa * p.in_ldc * 4u + lc * 16u : kOOB;
     }
   }
@@ -125,6 +123,13 @@ __global__ void __launch_bounds__(256, ST == 1 ? 3 : 2) conv_igemm_kernel(const 
   const unsigned pix_bytes = (unsigned)p.in_ldc * 4u;
 
   const int dbg = p.debug;
+  // tuning ablations (ODT_CONV_DEBUG bits: 1 no global loads, 2 no LDS writes, 4 no barriers, 8 no
+  // fragment reads, 16 no MFMAs) exist only in -DODT_CONV_ABLATE builds (tools/ab_build.sh)
+#ifdef ODT_CONV_ABLATE
+#define ABL(bit) (!(dbg & (bit)))
+#else
+#define ABL(bit) true
+#endif
   // load-stream state (runs up to two slices ahead of the MFMA stream)
   int l_cc = 0, l_kh = 0, l_kw = 0;
   unsigned l_k = 0;             // byte offset of the slice inside a weight row
@@ -132,7 +137,7 @@ __global__ void __launch_bounds__(256, ST == 1 ? 3 : 2) conv_igemm_kernel(const 
   auto set_tap = [&](int khh, int kww) {
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
-      const int hi = a_hi0[j] + khh * p.dil, wi = a_wi0[j] + kww * p.dil;
+      const int hi = (a_hw0[j] >> 16) + khh * p.dil, wi = (int)(short)(a_hw0[j] & 0xffff) + kww * p.dil;
       const bool v = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W && a_img[j] != kOOB;
       a_row[j] = v ? a_img[j] + (unsigned)(hi * p.in_Wa + wi) * pix_bytes : kOOB;
     }
@@ -143,10 +148,10 @@ __global__ void __launch_bounds__(256, ST == 1 ? 3 : 2) conv_igemm_kernel(const 
   auto load_slice = [&]() {     // fetch the next slice of the stream into ra / rb
 #pragma unroll
     for (int j = 0; j < RA; ++j)
-      ra[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(a_row[j] + (unsigned)l_cc * 128u), 0, 0);
+      ra[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)a_row[j], l_cc * 128, 0);
 #pragma unroll
     for (int j = 0; j < RB; ++j)
-      rb[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_wt, (int)(b_off[j] + l_k), 0, 0);
+      rb[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_wt, (int)b_off[j], (int)l_k, 0);
     l_k += 128u;
     if (++l_cc == cpt) {
       l_cc = 0;
@@ -208,32 +213,138 @@ __global__ void __launch_bounds__(256, ST == 1 ? 3 : 2) conv_igemm_kernel(const 
   stamp(1);
   if (nslices > 1) load_slice();
   read_frags(0, 0, fa0, fb0);
+  if constexpr (FINE) {
+  // ---- fine-grained interleave.  A wave issues in order, so whatever follows a run of MFMAs
+  // (global-load issue + address math, LDS writes, fragment reads) is exposed unless ANOTHER wave
+  // on the SIMD has MFMAs ready.  Here every non-MFMA instruction of a slice is placed right
+  // after one MFMA (64 pipe cycles each), one or two per MFMA, pinned with sched_barrier fences:
+  // a lone workgroup on a CU keeps the matrix pipe busy through the whole slice.
+#define ODT_FENCE() __builtin_amdgcn_sched_barrier(0)
+  constexpr int GM = TM * TN;          // MFMAs per k-step
+  auto mfma_at = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN], int idx) {
+    const int t = idx / GM, ij = idx % GM, i = ij / TN, j = ij % TN;
+    if (ABL(16)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+  };
+  auto read_one = [&](int buf, int g, int s2, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
+    if (!ABL(8)) return;
+    if (s2 < TM)
+      fa[s2] = *reinterpret_cast<const f32x4*>(lds[buf] + (wm * TM * 32 + s2 * 32) * LS + frag_off + g * 8);
+    else
+      fb[s2 - TM] = *reinterpret_cast<const f32x4*>(lds[buf] + BM * LS + (wn * TN * 32 + (s2 - TM) * 32) * LS +
+                                                    frag_off + g * 8);
+  };
+  auto write_one = [&](int buf, int j) {
+    if (!ABL(2)) return;
+    if (j < RA) *reinterpret_cast<f32x4*>(&lds[buf][(lr + 32 * j) * LS + lc * 4]) = ra[j];
+    else *reinterpret_cast<f32x4*>(&lds[buf][BM * LS + (lr + 32 * (j - RA)) * LS + lc * 4]) = rb[j - RA];
+  };
+  auto gload_one = [&](int j) {        // j == RA + RB: advance the load stream to the next slice
+    if (!ABL(1)) return;
+    if (j < RA) {
+      ra[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)a_row[j], l_cc * 128, 0);
+    } else if (j < RA + RB) {
+      rb[j - RA] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_wt, (int)b_off[j - RA], (int)l_k, 0);
+    } else {
+      l_k += 128u;
+      if (++l_cc == cpt) {
+        l_cc = 0;
+        if (++l_kw == p.kw) { l_kw = 0; ++l_kh; }
+        set_tap(l_kh, l_kw);
+      }
+    }
+  };
+  // MFMAs [i0, i1) of a group, with side(0..nside-1) spread evenly behind them
+  auto run = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN], auto I0, auto I1, auto NS, auto&& side) {
+    constexpr int i0 = decltype(I0)::value, n = decltype(I1)::value - i0, nside = decltype(NS)::value;
+    constexpr int per = (nside + n - 1) / n;
+#pragma unroll
+    for (int m = 0; m < n; ++m) {
+      mfma_at(fa, fb, i0 + m);
+      ODT_FENCE();
+#pragma unroll
+      for (int q = 0; q < per; ++q)
+        if (m * per + q < nside) { side(m * per + q); ODT_FENCE(); }
+    }
+  };
+  using Z = std::integral_constant<int, 0>;
+  using NF_ = std::integral_constant<int, TM + TN>;
+  using NL_ = std::integral_constant<int, RA + RB>;
+  using NA_ = std::integral_constant<int, TM + TN + RA + RB + 1>;
+  using G4_ = std::integral_constant<int, 4 * GM>;
+  using G2_ = std::integral_constant<int, 2 * GM>;
+  constexpr int NF = TM + TN;
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  // One K slice.  NEXT: slice c+1 exists (write it to LDS, read its first fragments); PRE: slice
+  // c+2 exists (fetch it).  The K loop is peeled into (all but two) x full slice, one without
+  // the fetch, one without anything behind it, so MFMAs never sit inside a conditional arm (that costs a second accumulator copy).
+  auto slice = [&](int c, auto NEXT, auto NW, auto NG) {
+    constexpr bool next = decltype(NEXT)::value;
+    using NW_ = decltype(NW);           // LDS writes of slice c+1 (0 on the last slice)
+    using NG_ = decltype(NG);           // fragment reads of slice c+1 + global fetch of slice c+2
+    if constexpr (ST == 2) {
+      // stage c&1 holds slice c; registers -> other stage behind the second half of g2; barrier;
+      // first fragments of slice c+1 and the global prefetch of slice c+2 behind g3.
+      const int cur = c & 1;
+      run(fa0, fb0, Z{}, G4_{}, NF_{}, [&](int q) { read_one(cur, 1, q, fa1, fb1); });
+      run(fa1, fb1, Z{}, G4_{}, NF_{}, [&](int q) { read_one(cur, 2, q, fa0, fb0); });
+      run(fa0, fb0, Z{}, G2_{}, NF_{}, [&](int q) { read_one(cur, 3, q, fa1, fb1); });
+      run(fa0, fb0, G2_{}, G4_{}, NW_{}, [&](int q) { write_one(cur ^ 1, q); });
+      if (ABL(4)) __syncthreads();
+      ODT_FENCE();
+      run(fa1, fb1, Z{}, G4_{}, NG_{}, [&](int q) {
+        if (next && q < NF) read_one(cur ^ 1, 0, q, fa0, fb0); else gload_one(q - (next ? NF : 0));
+      });
+    } else {
+      // single LDS stage: barrier after the last fragment read of slice c, registers -> LDS behind
+      // the first half of g3, barrier, first fragments of slice c+1 + global prefetch of slice
+      // c+2 behind the second half.
+      run(fa0, fb0, Z{}, G4_{}, NF_{}, [&](int q) { read_one(0, 1, q, fa1, fb1); });
+      run(fa1, fb1, Z{}, G4_{}, NF_{}, [&](int q) { read_one(0, 2, q, fa0, fb0); });
+      run(fa0, fb0, Z{}, G4_{}, NF_{}, [&](int q) { read_one(0, 3, q, fa1, fb1); });
+      if (ABL(4)) __syncthreads();
+      ODT_FENCE();
+      run(fa1, fb1, Z{}, G2_{}, NW_{}, [&](int q) { write_one(0, q); });
+      if (ABL(4)) __syncthreads();
+      ODT_FENCE();
+      run(fa1, fb1, G2_{}, G4_{}, NG_{}, [&](int q) {
+        if (next && q < NF) read_one(0, 0, q, fa0, fb0); else gload_one(q - (next ? NF : 0));
+      });
+    }
+  };
+  {
+    int c = 0;
+    for (; c + 2 < nslices; ++c) slice(c, T_{}, NL_{}, NA_{});
+    if (c + 1 < nslices) { slice(c, T_{}, NL_{}, NF_{}); ++c; }
+    slice(c, F_{}, Z{}, Z{});
+  }
+  } else {
   if constexpr (ST == 2) {
     for (int c = 0; c < nslices; ++c) {
       const int cur = c & 1;
       const bool more = c + 1 < nslices;
-      if (!(dbg & 8)) read_frags(cur, 1, fa1, fb1);
+      if (ABL(8)) read_frags(cur, 1, fa1, fb1);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(dbg & 16)) mfma_group(fa0, fb0, 0, 4);
+      if (ABL(16)) mfma_group(fa0, fb0, 0, 4);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(dbg & 8)) read_frags(cur, 2, fa0, fb0);
+      if (ABL(8)) read_frags(cur, 2, fa0, fb0);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(dbg & 16)) mfma_group(fa1, fb1, 0, 4);
+      if (ABL(16)) mfma_group(fa1, fb1, 0, 4);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(dbg & 8)) read_frags(cur, 3, fa1, fb1);
+      if (ABL(8)) read_frags(cur, 3, fa1, fb1);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(dbg & 16)) mfma_group(fa0, fb0, 0, 2);
+      if (ABL(16)) mfma_group(fa0, fb0, 0, 2);
       __builtin_amdgcn_sched_barrier(0);
-      if (more && !(dbg & 2)) store_slice(cur ^ 1);
+      if (more && ABL(2)) store_slice(cur ^ 1);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(dbg & 16)) mfma_group(fa0, fb0, 2, 4);
+      if (ABL(16)) mfma_group(fa0, fb0, 2, 4);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(dbg & 4)) __syncthreads();
+      if (ABL(4)) __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
-      if (more && !(dbg & 8)) read_frags(cur ^ 1, 0, fa0, fb0);
-      if (c + 2 < nslices && !(dbg & 1)) load_slice();
+      if (more && ABL(8)) read_frags(cur ^ 1, 0, fa0, fb0);
+      if (c + 2 < nslices && ABL(1)) load_slice();
       __builtin_amdgcn_sched_barrier(0);
-      if (!(dbg & 16)) mfma_group(fa1, fb1, 0, 4);
+      if (ABL(16)) mfma_group(fa1, fb1, 0, 4);
       __builtin_amdgcn_sched_barrier(0);
     }
   } else {
@@ -242,42 +353,35 @@ __global__ void __launch_bounds__(256, ST == 1 ? 3 : 2) conv_igemm_kernel(const 
     // barrier, first fragment read of the next slice.
     for (int c = 0; c < nslices; ++c) {
       const bool more = c + 1 < nslices;
-      if (!(dbg & 8)) read_frags(0, 1, fa1, fb1);
+      if (ABL(8)) read_frags(0, 1, fa1, fb1);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(dbg & 16)) mfma_group(fa0, fb0, 0, 4);
+      if (ABL(16)) mfma_group(fa0, fb0, 0, 4);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(dbg & 8)) read_frags(0, 2, fa0, fb0);
+      if (ABL(8)) read_frags(0, 2, fa0, fb0);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(dbg & 16)) mfma_group(fa1, fb1, 0, 4);
+      if (ABL(16)) mfma_group(fa1, fb1, 0, 4);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(dbg & 8)) read_frags(0, 3, fa1, fb1);
+      if (ABL(8)) read_frags(0, 3, fa1, fb1);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(dbg & 16)) mfma_group(fa0, fb0, 0, 4);
+      if (ABL(16)) mfma_group(fa0, fb0, 0, 4);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(dbg & 4)) __syncthreads();
+      if (ABL(4)) __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
-      if (more && !(dbg & 2)) store_slice(0);
+      if (more && ABL(2)) store_slice(0);
       __builtin_amdgcn_sched_barrier(0);
-#ifdef ODT_AB_NOROT
-      if (!(dbg & 16)) mfma_group(fa1, fb1, 0, 4);
-      if (c + 2 < nslices && !(dbg & 1)) load_slice();
+      if (ABL(16)) mfma_group(fa1, fb1, 0, 2);
+      if (c + 2 < nslices && ABL(1)) load_slice();
       __builtin_amdgcn_sched_barrier(0);
-      if (!(dbg & 4)) __syncthreads();
+      if (ABL(4)) __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
-      if (more && !(dbg & 8)) read_frags(0, 0, fa0, fb0);
-#else
-      if (!(dbg & 16)) mfma_group(fa1, fb1, 0, 2);
-      if (c + 2 < nslices && !(dbg & 1)) load_slice();
+      if (more && ABL(8)) read_frags(0, 0, fa0, fb0);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(dbg & 4)) __syncthreads();
+      if (ABL(16)) mfma_group(fa1, fb1, 2, 4);    // covers the first fragment read of slice c+1
       __builtin_amdgcn_sched_barrier(0);
-      if (more && !(dbg & 8)) read_frags(0, 0, fa0, fb0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (!(dbg & 16)) mfma_group(fa1, fb1, 2, 4);    // covers the first fragment read of slice c+1
-      __builtin_amdgcn_sched_barrier(0);
-#endif
     }
   }
+  }
+#undef ODT_FENCE
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   stamp(2);
 
@@ -446,12 +550,12 @@ __global__ void __launch_bounds__(256, ST == 1 ? 3 : 2) conv_igemm_kernel(const 
   stamp(5);
 }
 
-template <int WM, int WN, int TM, int TN, int ST>
+template <int WM, int WN, int TM, int TN, int ST, bool FINE>
 void launch_variant(const ConvParams& p, const ConvParams* dev, hipStream_t stream) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int M = p.B * p.Ho * p.Wo;
   const unsigned grid = (unsigned)(((M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN));
-  hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, TM, TN, ST>), dim3(grid), dim3(256), 0, stream, dev);
+  hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, TM, TN, ST, FINE>), dim3(grid), dim3(256), 0, stream, dev);
 }
 
 }  // namespace
@@ -478,6 +582,8 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
   ODT_CHECK(p.Cin % 32 == 0, "conv: Cin must be a multiple of 32");
   ODT_CHECK(p.in_ldc % 4 == 0, "conv: input pixel stride must be a multiple of 4 floats");
   ODT_CHECK(p.B > 0 && p.Ho > 0 && p.Wo > 0 && p.Cout > 0, "conv: empty problem");
+  ODT_CHECK((long)p.Ho * p.stride + (long)p.kh * p.dil < 32000 && (long)p.Wo * p.stride + (long)p.kw * p.dil < 32000 &&
+            p.pad_t < 32000 && p.pad_l < 32000, "conv: spatial extent must fit 16-bit tap coordinates");
   ODT_CHECK((double)p.B * p.in_Ha * p.in_Wa * p.in_ldc * 4.0 < 2147483648.0 &&
             (double)p.Cout * p.kh * p.kw * p.Cin * 4.0 < 2147483648.0,
             "conv: operand tensors must be smaller than 2 GiB (32-bit buffer offsets)");
@@ -509,16 +615,30 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
   if (const char* e = getenv("ODT_CONV_STAGES")) {     // tuning knob: force 1 or 2
     if (atoi(e) == 1 || atoi(e) == 2) stages = atoi(e);
   }
+  // Loop style (measured per layer, profiles/r01_conv_fine_vs_coarse*.txt): the fine-grained
+  // interleave keeps the matrix pipe of a CU busy when few workgroups share it (single-round
+  // launches: everything at b=1) and on long reductions; on short reductions with several rounds
+  // the workgroups in prologue / epilogue need the issue slots that a never-stalling main loop
+  // takes, and the coarse loop wins.
+  const int BMt = tile == 2 ? 64 : 128, BNt = tile == 3 ? 128 : 64;
+  const long tiles = ((M + BMt - 1) / BMt) * ((p.Cout + BNt - 1) / BNt);
+  const long slots = 256L * (stages == 2 ? 2 : (tile == 3 ? 3 : 4));
+  const int Kred = p.kh * p.kw * p.Cin;
+  bool fine = stages == 2 || (tile != 2 && (tiles <= slots || tile == 1 || (Kred >= 1024 && tiles >= 2 * slots)));
+  if (tile == 2) fine = tiles >= 384 && tiles <= slots;
+  if (const char* e = getenv("ODT_CONV_FINE")) {       // tuning knob: force 0 or 1
+    if (e[0] == '0' || e[0] == '1') fine = e[0] == '1';
+  }
   if (stages == 1) {
-    if (tile == 1) launch_variant<4, 1, 1, 2, 1>(q, dev_params, stream);
-    else if (tile == 2) launch_variant<2, 2, 1, 1, 1>(q, dev_params, stream);
-    else launch_variant<2, 2, 2, 2, 1>(q, dev_params, stream);
-  } else if (tile == 1) {
-    launch_variant<4, 1, 1, 2, 2>(q, dev_params, stream);       // 128 x 64
-  } else if (tile == 2) {
-    launch_variant<2, 2, 1, 1, 2>(q, dev_params, stream);       // 64 x 64: fill the 256 CUs on small M
-  } else {
-    launch_variant<2, 2, 2, 2, 2>(q, dev_params, stream);       // 128 x 128
+    if (tile == 1) { if (fine) launch_variant<4, 1, 1, 2, 1, true>(q, dev_params, stream); else launch_variant<4, 1, 1, 2, 1, false>(q, dev_params, stream); }
+    else if (tile == 2) { if (fine) launch_variant<2, 2, 1, 1, 1, true>(q, dev_params, stream); else launch_variant<2, 2, 1, 1, 1, false>(q, dev_params, stream); }
+    else { if (fine) launch_variant<2, 2, 2, 2, 1, true>(q, dev_params, stream); else launch_variant<2, 2, 2, 2, 1, false>(q, dev_params, stream); }
+  } else if (tile == 1) {                                        // 128 x 64
+    if (fine) launch_variant<4, 1, 1, 2, 2, true>(q, dev_params, stream); else launch_variant<4, 1, 1, 2, 2, false>(q, dev_params, stream);
+  } else if (tile == 2) {                                        // 64 x 64: fill the 256 CUs on small M
+    if (fine) launch_variant<2, 2, 1, 1, 2, true>(q, dev_params, stream); else launch_variant<2, 2, 1, 1, 2, false>(q, dev_params, stream);
+  } else {                                                       // 128 x 128
+    if (fine) launch_variant<2, 2, 2, 2, 2, true>(q, dev_params, stream); else launch_variant<2, 2, 2, 2, 2, false>(q, dev_params, stream);
   }
   ODT_HIP(hipGetLastError());
   if (tmp != nullptr) {
