@@ -42,6 +42,9 @@ def main():
   ap.add_argument("--profile-steps", type=int, default=2)
   ap.add_argument("--dist-backend", default="nccl",
                   help="nccl (= RCCL, the default) | gloo (debug: lets N ranks share one GPU)")
+  ap.add_argument("--streams", type=int, default=1,
+                  help="video streams (independent handles, one HIP stream each) per GPU; each step runs "
+                       "one batch on every stream")
   ap.add_argument("--device", type=int, default=None,
                   help="debug: force every rank onto this GPU (with --dist-backend gloo)")
   args = ap.parse_args()
@@ -73,15 +76,24 @@ def main():
   cfg = make_config(rpn_test_post_nms_topk=args.topk, im_batch_size=B, max_size=max(H, W),
                     short_edge_size=min(H, W))
   weights = synthetic_weights(cfg, seed=0)
-  model = models.get_model(cfg, local_rank, weights=weights, is_multi=True)
-  eng = model.engine(B, H, W)
-  # one video stream per GPU: each rank gets its own seeded frames
+  S = max(1, args.streams)
+  all_models = [models.get_model(cfg, local_rank, weights=weights, is_multi=True) for _ in range(S)]
+  engs = [m.engine(B, H, W) for m in all_models]
+  model, eng = all_models[0], engs[0]
+  # one video stream per handle: each gets its own seeded frames
   frames = synthetic_frames(B, H, W, seed=1234 + rank)
-  dev_frames = torch.from_numpy(frames).cuda(local_rank)          # HBM-resident uint8 input
+  all_frames = [frames] + [synthetic_frames(B, H, W, seed=1234 + rank + 1000 * i) for i in range(1, S)]
+  dev_all = [torch.from_numpy(f).cuda(local_rank) for f in all_frames]      # HBM-resident uint8 input
+  dev_frames = dev_all[0]
   torch.cuda.synchronize()
 
   def step():
-    eng.forward_device_async(dev_frames.data_ptr(), ODT_DTYPE_U8)
+    for e, d in zip(engs, dev_all):
+      e.forward_device_async(d.data_ptr(), ODT_DTYPE_U8)
+
+  def sync_all():
+    for e in engs:
+      e.synchronize()
 
   def barrier():
     if world > 1:
@@ -89,14 +101,14 @@ def main():
 
   for _ in range(args.warmup):
     step()
-  eng.synchronize()
+  sync_all()
   torch.cuda.synchronize()
   barrier()
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   for _ in range(args.steps):
     step()
-  eng.synchronize()
+  sync_all()
   torch.cuda.synchronize()
   barrier()
   dt = time.perf_counter() - t0
@@ -110,7 +122,7 @@ def main():
   # around every launch on the launch stream, outside the timed region.
   eng.profile(True)
   for _ in range(max(1, args.profile_steps)):
-    step()
+    eng.forward_device_async(dev_frames.data_ptr(), ODT_DTYPE_U8)
   eng.synchronize()
   prof = eng.profile_read()
   eng.profile(False)
@@ -133,6 +145,20 @@ def main():
     for _ in eng.forward_stream([frames] * 10):
       n += 1
     extra["pcie_inclusive_pipelined_fps"] = n * B / (time.perf_counter() - t1)
+    if world == 1 and S == 1:
+      # (c) two independent video streams (two handles, one HIP stream each) sharing the GPU: the
+      # tails / low-occupancy layers of one forward overlap with the other stream's kernels
+      m2 = models.get_model(cfg, local_rank, weights=weights, is_multi=True)
+      e2 = m2.engine(B, H, W)
+      d2 = torch.from_numpy(synthetic_frames(B, H, W, seed=99)).cuda(local_rank)
+      for k in range(2 + 6):
+        if k == 2:
+          eng.synchronize(); e2.synchronize(); t1 = time.perf_counter()
+        eng.forward_device_async(dev_frames.data_ptr(), ODT_DTYPE_U8)
+        e2.forward_device_async(d2.data_ptr(), ODT_DTYPE_U8)
+      eng.synchronize(); e2.synchronize()
+      extra["two_streams_per_gpu_fps"] = 2 * 6 * B / (time.perf_counter() - t1)
+      m2.close()
     rng = np.random.default_rng(0)
     gal = rng.standard_normal((320, 256)).astype(np.float32)
     seg = (np.arange(65) * 5).astype(np.int32)
@@ -144,7 +170,7 @@ def main():
     extra["nn_matching_ms_per_call_host_to_host"] = 1e3 * (time.perf_counter() - t1) / 20
 
   if rank == 0:
-    fps = world * B * args.steps / dt
+    fps = world * S * B * args.steps / dt
     out = {
         "metric": "detector FPS @%dx%d b=%d per MI355X" % (W, H, B),
         "value": fps,
@@ -162,7 +188,7 @@ def main():
                                "%dx%d, batch %d per GPU, rpn_post_nms_topk %d, 15 classes, "
                                "random-init weights, frames resident in HBM (uint8)" %
                                (W, H, B, args.topk),
-                   "graph": "Mask_RCNN_FPN_multi", "streams_per_gpu": 1},
+                   "graph": "Mask_RCNN_FPN_multi", "streams_per_gpu": S},
         "roofline": {
             "bound": "mfma",
             "kernel": "conv_igemm_kernel (v_mfma_f32_32x32x2_f32 implicit GEMM, %d launches/step)"
@@ -181,7 +207,8 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline(cfg, weights, frames, args.cpu_frames)
     print(json.dumps(out), flush=True)
-  model.close()
+  for m in all_models:
+    m.close()
   if world > 1:
     dist.barrier()
     dist.destroy_process_group()
