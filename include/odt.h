@@ -107,6 +107,15 @@ int odt_forward_async(odt_handle h, const void* frames, int dtype,
                       int on_device, void* stream);
 int odt_synchronize(odt_handle h);
 
+/* Source frames of a different size than the plan's input (reference obj_detect_tracking.py:597-608:
+ * frame.astype("float32") -> resizeImage(frame, short_edge_size, max_size) = cv2.resize(...,
+ * INTER_LINEAR), nn.py:1540-1560, on the host for every frame).  After this call odt_forward /
+ * odt_forward_async / odt_submit take frames of [batch, src_height, src_width, 3] and the bilinear
+ * resize to [height, width] runs on the device, fused with the normalisation (so a 720p or 4K
+ * stream crosses PCIe at its native uint8 size).  Boxes come back in resized-image coordinates as
+ * in the reference.  Pass the plan's own size to switch back.  No tickets may be in flight. */
+int odt_set_source_size(odt_handle h, int src_height, int src_width);
+
 /* Pipelined ingest (replaces the frame.astype(float32) + feed_dict copy of
  * obj_detect_tracking.py:597-635 and the prefetch queue of enqueuer_thread.py:236-303 on the
  * device side): two slots of pinned host staging + device input + pinned output staging.

@@ -72,7 +72,7 @@ class OdtLib(object):
       "odt_last_error", "odt_device_count", "odt_create", "odt_destroy",
       "odt_load_tensor", "odt_finalize_weights", "odt_forward",
       "odt_forward_async", "odt_synchronize", "odt_submit", "odt_collect",
-      "odt_ingest_buffer", "odt_tap", "odt_profile_enable",
+      "odt_ingest_buffer", "odt_set_source_size", "odt_tap", "odt_profile_enable",
       "odt_profile_read", "odt_profile_layer", "odt_nn_cosine", "odt_op_conv2d", "odt_op_preprocess",
       "odt_op_maxpool", "odt_op_topk", "odt_op_nms", "odt_op_proposals",
       "odt_op_roi_align", "odt_op_detections", "odt_tracker_create", "odt_tracker_destroy",
@@ -100,6 +100,7 @@ class OdtLib(object):
     d.odt_synchronize.argtypes = [C.c_void_p]
     d.odt_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     d.odt_collect.argtypes = [C.c_void_p, C.c_int, C.POINTER(OdtOutputs)]
+    d.odt_set_source_size.argtypes = [C.c_void_p, C.c_int, C.c_int]
     d.odt_ingest_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p),
                                     C.POINTER(C.c_size_t)]
     d.odt_tap.argtypes = [C.c_void_p, C.c_char_p, c_float_p, C.c_size_t, c_i64_p,

@@ -34,7 +34,8 @@ struct DevBuf {
     ODT_HIP(hipMalloc(&p, n));
     return 0;
   }
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+  ~DevBuf() { release(); }
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
@@ -87,6 +88,8 @@ struct odt_model {
   RoiAlignParams roi_head{}, roi_final{};
   DetectParams det{};
   Tensor image_pad, frames_dev;
+  int src_h = 0, src_w = 0;          // source frame size (== cfg.height/width unless odt_set_source_size)
+  DevBuf frames_src;                 // device staging for source frames larger than the plan's input
   float* anchors_dev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float* final_feat = nullptr;    // [B*per_im, C, 7, 7] packed
   float* final_pooled = nullptr;  // [B*per_im, C]
@@ -301,6 +304,7 @@ int build_plan(odt_model* m) {
   m->Hp = Hp; m->Wp = Wp;
   if (make_tensor(m, "image_pad", B, Hp, Wp, 4, &m->image_pad)) return 1;
   m->frames_bytes = (size_t)B * H * W * 3 * sizeof(float);
+  m->src_h = H; m->src_w = W;
   { m->bufs.emplace_back(new DevBuf()); if (m->bufs.back()->alloc(m->frames_bytes)) return 1;
     m->frames_dev.d = (float*)m->bufs.back()->p; }
   { Op op; op.kind = OP_PRE; m->ops.push_back(op); }
@@ -574,6 +578,10 @@ int build_plan(odt_model* m) {
   return 0;
 }
 
+static size_t input_bytes(const odt_model* m, int dtype) {
+  return (size_t)m->cfg.batch * m->src_h * m->src_w * 3 * (dtype == ODT_DTYPE_U8 ? 1 : 4);
+}
+
 int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStream_t st) {
   const odt_config& cfg = m->cfg;
   ODT_CHECK(m->finalized, "odt_forward: call odt_finalize_weights first");
@@ -582,9 +590,10 @@ int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStre
   ODT_HIP(hipSetDevice(m->device));
   const void* src = frames;
   if (!on_device) {
-    const size_t n = (size_t)cfg.batch * cfg.height * cfg.width * 3 * (dtype == ODT_DTYPE_U8 ? 1 : 4);
-    ODT_HIP(hipMemcpyAsync(m->frames_dev.d, frames, n, hipMemcpyHostToDevice, st));
-    src = m->frames_dev.d;
+    const size_t n = input_bytes(m, dtype);
+    void* stage = n <= m->frames_bytes ? (void*)m->frames_dev.d : m->frames_src.p;
+    ODT_HIP(hipMemcpyAsync(stage, frames, n, hipMemcpyHostToDevice, st));
+    src = stage;
   }
   size_t ev_i = 0;
   if (m->profile) {
@@ -595,7 +604,12 @@ int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStre
   for (const Op& op : m->ops) {
     switch (op.kind) {
       case OP_PRE:
-        if (launch_preprocess(src, dtype, cfg.batch, cfg.height, cfg.width, 3, 3, m->Hp, m->Wp, m->image_pad.d, st)) return 1;
+        if (m->src_h == cfg.height && m->src_w == cfg.width) {
+          if (launch_preprocess(src, dtype, cfg.batch, cfg.height, cfg.width, 3, 3, m->Hp, m->Wp, m->image_pad.d, st)) return 1;
+        } else if (launch_preprocess_resize(src, dtype, cfg.batch, m->src_h, m->src_w, cfg.height, cfg.width, 3, 3,
+                                            m->Hp, m->Wp, m->image_pad.d, st)) {
+          return 1;
+        }
         break;
       case OP_CONV: {
         const ConvOp& c = m->convs[op.conv];
@@ -742,11 +756,27 @@ static int slot_prepare(odt_handle h, odt_model::Slot& sl, size_t in_bytes) {
   return 0;
 }
 
+int odt_set_source_size(odt_handle h, int src_height, int src_width) {
+  ODT_CHECK(h, "odt_set_source_size: null handle");
+  ODT_CHECK(src_height > 0 && src_width > 0 && src_height < 32768 && src_width < 32768,
+            "odt_set_source_size: bad size");
+  ODT_CHECK(h->slot[0].ticket < 0 && h->slot[1].ticket < 0, "odt_set_source_size: tickets in flight");
+  ODT_HIP(hipSetDevice(h->device));
+  const size_t need = (size_t)h->cfg.batch * src_height * src_width * 3 * sizeof(float);
+  if (need > h->frames_bytes && need > h->frames_src.bytes) {
+    ODT_HIP(hipStreamSynchronize(h->own_stream));
+    h->frames_src.release();
+    if (h->frames_src.alloc(need)) return 1;
+  }
+  h->src_h = src_height; h->src_w = src_width;
+  return 0;
+}
+
 int odt_ingest_buffer(odt_handle h, int dtype, void** buffer, size_t* bytes) {
   ODT_CHECK(h && buffer && bytes, "odt_ingest_buffer: null argument");
   ODT_CHECK(dtype == ODT_DTYPE_U8 || dtype == ODT_DTYPE_F32, "odt_ingest_buffer: bad dtype");
   ODT_HIP(hipSetDevice(h->device));
-  const size_t n = (size_t)h->cfg.batch * h->cfg.height * h->cfg.width * 3 * (dtype == ODT_DTYPE_U8 ? 1 : 4);
+  const size_t n = input_bytes(h, dtype);
   odt_model::Slot& sl = h->slot[h->next_ticket & 1];
   ODT_CHECK(sl.ticket < 0, "odt_ingest_buffer: slot still in flight (collect its ticket first)");
   if (slot_prepare(h, sl, n)) return 1;
@@ -761,7 +791,7 @@ int odt_submit(odt_handle h, const void* frames, int dtype, int* ticket) {
   ODT_HIP(hipSetDevice(h->device));
   const odt_config& cfg = h->cfg;
   const size_t B = cfg.batch, per = cfg.result_per_im, FC = cfg.fpn_channels;
-  const size_t n = B * cfg.height * cfg.width * 3 * (dtype == ODT_DTYPE_U8 ? 1 : 4);
+  const size_t n = input_bytes(h, dtype);
   const int t = h->next_ticket;
   odt_model::Slot& sl = h->slot[t & 1];
   odt_model::Slot& prev = h->slot[(t & 1) ^ 1];

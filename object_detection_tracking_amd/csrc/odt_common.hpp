@@ -68,6 +68,8 @@ double conv_flops(const ConvParams& p);   // algorithmic 2*M*N*K
 // ------------------------------------------------------------ elementwise (K1,K4)
 int launch_preprocess(const void* frames, int dtype, int B, int H, int W, int pad_t, int pad_l,
                       int Hp, int Wp, float* out, hipStream_t stream);
+int launch_preprocess_resize(const void* frames, int dtype, int B, int Hs, int Ws, int H, int W, int pad_t,
+                             int pad_l, int Hp, int Wp, float* out, hipStream_t stream);
 int launch_maxpool3x3s2(const float* in, int B, int H, int W, int C, float* out, int Ho, int Wo,
                         hipStream_t stream);
 

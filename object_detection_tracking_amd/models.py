@@ -24,6 +24,7 @@ from ._lib import (ODT_DTYPE_F32, ODT_DTYPE_U8, ODT_GRAPH_MULTI, ODT_GRAPH_SINGL
                    OdtOutputs, c_i64_p, f32, fptr, iptr)
 from .anchors import fpn_anchor_fields
 from .config import HEAD_DECODE_CLIP, finalize_config
+from .nn import get_new_hw
 from .weights import load_npz, select_partial_classes
 
 
@@ -45,6 +46,7 @@ class _Engine(object):
                num_class=None):
     self.lib = lib
     self.batch, self.height, self.width = batch, height, width
+    self.src_height, self.src_width = height, width
     self.per_im = int(config.result_per_im)
     self.channels = int(config.fpn_num_channel)
     c = OdtConfig()
@@ -85,6 +87,13 @@ class _Engine(object):
     self._feats = np.zeros((B * P, Cn, 7, 7), np.float32)
     self._pooled = np.zeros((B * P, Cn), np.float32)
 
+  def set_source_size(self, src_height, src_width):
+    """Frames of [B, src_height, src_width, 3] from now on; the bilinear resize to the plan's
+    [height, width] (reference resizeImage, nn.py:1540-1560) runs on the device."""
+    if (src_height, src_width) != (self.src_height, self.src_width):
+      self.lib.check(self.lib.dll.odt_set_source_size(self.h, int(src_height), int(src_width)))
+      self.src_height, self.src_width = int(src_height), int(src_width)
+
   def _load(self, name, arr):
     a = f32(arr)
     shape = (C.c_int64 * a.ndim)(*a.shape)
@@ -110,7 +119,7 @@ class _Engine(object):
     else:
       fr = np.ascontiguousarray(fr, dtype=np.float32)
       dt = ODT_DTYPE_F32
-    assert fr.shape == (self.batch, self.height, self.width, 3), fr.shape
+    assert fr.shape == (self.batch, self.src_height, self.src_width, 3), fr.shape
     out = OdtOutputs()
     out.boxes = fptr(self._boxes); out.probs = fptr(self._probs)
     out.labels = iptr(self._labels); out.valid = iptr(self._valid)
@@ -132,7 +141,7 @@ class _Engine(object):
     else:
       fr = np.ascontiguousarray(fr, dtype=np.float32)
       dt = ODT_DTYPE_F32
-    assert fr.shape == (self.batch, self.height, self.width, 3), fr.shape
+    assert fr.shape == (self.batch, self.src_height, self.src_width, 3), fr.shape
     t = C.c_int()
     self.lib.check(self.lib.dll.odt_submit(self.h, fr.ctypes.data_as(C.c_void_p), dt, C.byref(t)))
     return t.value
@@ -234,12 +243,25 @@ class _DetectorBase(object):
     self.fpn_box_feat = TensorHandle(self, "fpn_box_feat")
     self.final_valid_indices = TensorHandle(self, "final_valid_indices")
 
-  def engine(self, batch, height, width):
-    key = (batch, height, width)
+  def engine(self, batch, height, width, src_hw=None):
+    key = (batch, height, width) if src_hw is None else (batch, height, width) + tuple(src_hw)
     if key not in self._engines:
       self._engines[key] = _Engine(self.lib, self.config, self.graph, batch, height, width,
                                    self.weights, self.gpuid, num_class=self.head_num_class)
+      if src_hw is not None:
+        self._engines[key].set_source_size(*src_hw)
     return self._engines[key]
+
+  def engine_for_raw(self, batch, src_height, src_width):
+    """Engine for frames as they come off the decoder: (engine, scale) with the plan sized by
+    the reference's rule (get_new_hw, nn.py:1548-1560, short_edge_size / max_size of the config)
+    and the resize done on the device; ``scale`` is what the drivers divide boxes by
+    (obj_detect_tracking.py:607-608)."""
+    neww, newh = get_new_hw(src_height, src_width, self.config.short_edge_size, self.config.max_size)
+    scale = (newh * 1.0 / src_height + neww * 1.0 / src_width) / 2.0
+    if (newh, neww) == (src_height, src_width):
+      return self.engine(batch, newh, neww), scale
+    return self.engine(batch, newh, neww, src_hw=(src_height, src_width)), scale
 
   # reference models.py:1629-1636
   def get_feed_dict_forward(self, imgdata):
@@ -269,6 +291,20 @@ class Mask_RCNN_FPN(_DetectorBase):
     return (boxes[0, :r].copy(), labels[0, :r].astype(np.int64), probs[0, :r].copy(),
             pl if pooled else feats)
 
+  def predict_raw(self, frame, pooled=False):
+    """Decoder-sized frame [H0,W0,3] (uint8 or float32 BGR): the reference's
+    ``resizeImage(frame.astype("float32"), short_edge_size, max_size)`` step
+    (obj_detect_tracking.py:597-608) runs on the device.  Returns (boxes, labels, probs, feats,
+    scale) with boxes in resized-image coordinates, exactly what ``sess.run`` returns after the
+    host-side resize."""
+    frame = np.asarray(frame)
+    e, scale = self.engine_for_raw(1, frame.shape[0], frame.shape[1])
+    boxes, labels, probs, valid, feats, pl = e.forward(frame[None], want_feats=not pooled,
+                                                       want_pooled=pooled)
+    r = int(valid[0])
+    return (boxes[0, :r].copy(), labels[0, :r].astype(np.int64), probs[0, :r].copy(),
+            pl if pooled else feats, scale)
+
   def _fetch(self, fetches, feed_dict):
     boxes, labels, probs, feats = self.predict(feed_dict[self.image])
     table = {"final_boxes": boxes, "final_labels": labels, "final_probs": probs,
@@ -293,6 +329,15 @@ class Mask_RCNN_FPN_multi(_DetectorBase):
     boxes, labels, probs, valid, feats, pl = e.forward(imgs, want_feats=not pooled,
                                                        want_pooled=pooled)
     return boxes, labels.astype(np.float32), probs, valid, (pl if pooled else feats)
+
+  def predict_batch_raw(self, frames, pooled=False):
+    """[B,H0,W0,3] decoder-sized frames; device-side resize (see Mask_RCNN_FPN.predict_raw).
+    Returns predict_batch's tuple + scale."""
+    frames = np.asarray(frames)
+    e, scale = self.engine_for_raw(frames.shape[0], frames.shape[1], frames.shape[2])
+    boxes, labels, probs, valid, feats, pl = e.forward(frames, want_feats=not pooled,
+                                                       want_pooled=pooled)
+    return boxes, labels.astype(np.float32), probs, valid, (pl if pooled else feats), scale
 
   def _fetch(self, fetches, feed_dict):
     boxes, labels, probs, valid, feats = self.predict_batch(feed_dict[self.image])

@@ -37,3 +37,67 @@ def test_submit_collect_equals_forward(backend):
       e.collect(t0)
   finally:
     m.close()
+
+
+# ---- device-side frame resize (reference obj_detect_tracking.py:597-608: astype(float32) +
+# resizeImage on the host for every frame) ---------------------------------------------------------
+def _raw_vs_host_resize(lib, src_hw, dtype, short_edge, max_size):
+  from object_detection_tracking_amd.nn import get_new_hw, resizeImage
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1], short_edge_size=short_edge, max_size=max_size)
+  w = weights_for(cfg)
+  frame = synthetic_frames(1, src_hw[0], src_hw[1], seed=7)[0]
+  if dtype == np.float32:
+    frame = frame.astype(np.float32) + np.float32(0.25)
+  m = models.get_model(cfg, 0, weights=w, lib=lib)
+  try:
+    # reference order: float32 first, then bilinear resize on the host, then the forward
+    host = resizeImage(frame.astype(np.float32), short_edge, max_size)
+    neww, newh = get_new_hw(src_hw[0], src_hw[1], short_edge, max_size)
+    assert host.shape[:2] == (newh, neww) and (newh, neww) != tuple(src_hw)
+    b0, l0, p0, f0 = m.predict(host)
+    b1, l1, p1, f1, scale = m.predict_raw(frame)
+    assert np.isclose(scale, (newh / src_hw[0] + neww / src_hw[1]) / 2)
+    # the device resize follows the host restatement operation by operation: identical results
+    assert np.array_equal(b0, b1) and np.array_equal(l0, l1) and np.array_equal(p0, p1)
+    assert np.array_equal(f0, f1)
+    assert len(b0) > 0
+  finally:
+    m.close()
+
+
+def test_device_resize_matches_host_resize(backend):
+  name, lib = backend
+  _raw_vs_host_resize(lib, (48, 80), np.uint8, 64, 128)         # upscale 4/3 (720p -> 1080p style)
+  if name == "hip":                                             # (the simulator runs one case only)
+    _raw_vs_host_resize(lib, (72, 128), np.uint8, 96, 256)
+    _raw_vs_host_resize(lib, (150, 260), np.uint8, 96, 160)     # downscale, long edge bound by max_size
+    _raw_vs_host_resize(lib, (72, 128), np.float32, 96, 256)    # float32 feed
+    _raw_vs_host_resize(lib, (720, 1280), np.uint8, 1080, 1920)  # 720p stream into the 1080p plan
+
+
+def test_device_resize_batch_and_pipeline(backend):
+  from object_detection_tracking_amd.nn import resizeImage
+  name, lib = backend
+  if name == "emu":
+    pytest.skip("covered by test_device_resize_matches_host_resize on the simulator; full case on the GPU")
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1], im_batch_size=2, rpn_test_post_nms_topk=48,
+                     short_edge_size=96, max_size=256)
+  w = weights_for(cfg)
+  frames = synthetic_frames(2, 72, 128, seed=11)
+  m = models.get_model(cfg, 0, weights=w, lib=lib, is_multi=True)
+  try:
+    host = np.stack([resizeImage(f.astype(np.float32), 96, 256) for f in frames])
+    ref = m.predict_batch(host)
+    got = m.predict_batch_raw(frames)
+    for a, b in zip(ref, got[:5]):
+      assert np.array_equal(a, b)
+    # same frames through the pinned double-buffered ingest (odt_submit / odt_collect)
+    e, _ = m.engine_for_raw(2, 72, 128)
+    outs = list(e.forward_stream([frames, frames[::-1].copy(), frames]))
+    assert np.array_equal(outs[0][0], ref[0]) and np.array_equal(outs[2][0], ref[0])
+    assert np.array_equal(outs[1][0][::-1], ref[0])
+    # switching back to plan-sized frames on the same handle
+    e.set_source_size(e.height, e.width)
+    assert np.array_equal(e.forward(host)[0], ref[0])
+  finally:
+    m.close()
