@@ -1,4 +1,4 @@
-# per-layer in-network comparison of environment knobs: BATCH=8 bash gpurun_ab_layers_env.sh "ENV_A" "ENV_B" ...
+# per-layer in-network comparison of environment knobs: BATCH=8 bash tools/gpurun/ab_layers_env.sh "ENV_A" "ENV_B" ...
 i=0
 for v in "$@"; do
   env $v timeout 300 python tools/profile_layers.py --batch ${BATCH:-8} --steps 3 2>&1 | tail -40 > gpurun_out/layers_env_$i.txt

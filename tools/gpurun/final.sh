@@ -12,7 +12,7 @@ rm -rf $R/gpurun_out/prof_r01
 cd $R
 python tools/kernel_stats.py gpurun_out/prof_r01 > gpurun_out/kernel_stats_b8.txt 2>&1
 find gpurun_out/prof_r01 -name "*.db" -size +20M -delete
-bash gpurun_pmc.sh > gpurun_out/pmc_run.log 2>&1
+bash tools/gpurun/pmc.sh > gpurun_out/pmc_run.log 2>&1
 python tools/pmc_summary.py gpurun_out gpurun_out/pmc_summary > gpurun_out/pmc_summary.log 2>&1
 find gpurun_out -name "*.db" -size +20M -delete; find gpurun_out -name "*.csv" -size +20M -delete
 tail -3 gpurun_out/pytest_gpu.log; cat gpurun_out/smoke.log; cat gpurun_out/bench_n1.log; cat gpurun_out/bench_b1.log | cut -c1-200; head -8 gpurun_out/kernel_stats_b8.txt; cat gpurun_out/pmc_summary.txt 2>/dev/null | head -12

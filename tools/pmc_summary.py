@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Summarise rocprofv3 --pmc passes (separate passes: FETCH_SIZE | WRITE_SIZE | SQ MFMA counters)
-collected with gpurun_pmc.sh into profiles/<round>_pmc_summary.{txt,json}."""
+collected with tools/gpurun/pmc.sh into profiles/<round>_pmc_summary.{txt,json}."""
 import collections, csv, json, os, sys
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
 out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_pmc_summary"
