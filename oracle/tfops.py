@@ -132,10 +132,16 @@ def crop_and_resize(image, boxes, box_ind, crop_size):
   for k in range(K):
     y1, x1, y2, x2 = boxes[k]
     img = image[int(box_ind[k])]
-    hs = (y2 - y1) * F(H - 1) / F(ch - 1)
-    ws = (x2 - x1) * F(W - 1) / F(cw - 1)
-    in_y = y1 * F(H - 1) + ii * hs
-    in_x = x1 * F(W - 1) + ii * ws
+    if ch > 1:
+      hs = (y2 - y1) * F(H - 1) / F(ch - 1)
+      in_y = y1 * F(H - 1) + ii * hs
+    else:                                   # crop_and_resize_op.cc: single sample at the box centre
+      in_y = np.array([F(0.5) * (y1 + y2) * F(H - 1)], F)
+    if cw > 1:
+      ws = (x2 - x1) * F(W - 1) / F(cw - 1)
+      in_x = x1 * F(W - 1) + ii * ws
+    else:
+      in_x = np.array([F(0.5) * (x1 + x2) * F(W - 1)], F)
     vy = ~((in_y < 0) | (in_y > F(H - 1)))
     vx = ~((in_x < 0) | (in_x > F(W - 1)))
     if not vy.any() or not vx.any():
