@@ -25,6 +25,7 @@ from ._lib import (ODT_DTYPE_F32, ODT_DTYPE_U8, ODT_GRAPH_MULTI, ODT_GRAPH_SINGL
 from .anchors import fpn_anchor_fields
 from .config import HEAD_DECODE_CLIP, finalize_config
 from .nn import get_new_hw
+from .frozen_pb import load_frozen_pb
 from .weights import load_npz, select_partial_classes
 
 
@@ -221,11 +222,18 @@ class _DetectorBase(object):
     self.gpuid = gpuid
     self.lib = lib if lib is not None else _lib.get_lib()
     if weights is None:
-      path = getattr(config, "model_path", None)
-      if not path or not str(path).endswith(".npz"):
+      path = getattr(config, "load_from", None) if getattr(config, "is_load_from_pb", False) \
+          else getattr(config, "model_path", None)
+      path = path or getattr(config, "model_path", None)
+      if path and str(path).endswith(".pb"):
+        # frozen graph (reference --is_load_from_pb, models.py:198-263): Const payloads by name
+        weights = load_frozen_pb(path)
+      elif path and str(path).endswith(".npz"):
+        weights = load_npz(path)
+      else:
         raise ValueError("weights: pass a {name: array} dict or set config.model_path to a "
-                         "Tensorpack-style .npz (reference obj_detect_tracking.py:417-435)")
-      weights = load_npz(path)
+                         "Tensorpack-style .npz (reference obj_detect_tracking.py:417-435) or a "
+                         "frozen .pb (--is_load_from_pb)")
     # --use_partial_classes (reference models.py:807-829): class-subset head
     self.head_num_class = int(self.config.num_class)
     if getattr(self.config, "use_partial_classes", False):
@@ -370,10 +378,10 @@ class Session(object):
 
 def get_model(config, gpuid=0, task=0, controller="/cpu:0", is_multi=False, weights=None,
               lib=None):
-  """reference models.py:97-119.  Dispatch is the reference's; the frozen-.pb and
-  EfficientDet branches are out of this path's scope."""
-  if getattr(config, "is_load_from_pb", False):
-    raise NotImplementedError("frozen .pb graphs need TensorFlow; use the .npz weight route")
+  """reference models.py:97-119.  Dispatch is the reference's; frozen ``.pb`` files are read
+  without TensorFlow; the EfficientDet branch is a "next" row."""
+  # is_load_from_pb (reference models.py:102-108 -> Mask_RCNN_FPN_frozen): the frozen file is read
+  # as a weight container (frozen_pb.load_frozen_pb), the architecture comes from the config
   if getattr(config, "is_efficientdet", False):
     raise NotImplementedError("EfficientDet path is a 'next' row (SURVEY.md 8f)")
   cls = Mask_RCNN_FPN_multi if is_multi else Mask_RCNN_FPN

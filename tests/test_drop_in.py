@@ -199,3 +199,46 @@ def test_resize_helpers():
   # linear ramps stay linear under bilinear resampling away from the clamped border
   np.testing.assert_allclose(np.diff(up[2:6, 3, 0]), np.diff(up[2:6, 3, 0])[0], rtol=1e-5)
   np.testing.assert_allclose(up[0, 0], small[0, 0]); np.testing.assert_allclose(up[-1, -1], small[-1, -1])
+
+
+# ---- frozen .pb route (reference --is_load_from_pb, models.py:102-108,198-263) -----------------
+def test_frozen_pb_reader_roundtrip(tmp_path):
+  from object_detection_tracking_amd.frozen_pb import load_frozen_pb, write_frozen_pb
+  rng = np.random.default_rng(3)
+  w = {"conv0/W": rng.standard_normal((7, 7, 3, 64)).astype(np.float32),
+       "conv0/bn/gamma": rng.standard_normal((64,)).astype(np.float32),
+       "conv0/bn/mean/EMA": rng.standard_normal((64,)).astype(np.float32),
+       "fastrcnn/fc6/W": rng.standard_normal((96, 40)).astype(np.float32),
+       "fpn/lateral_1x1_c2/b": np.zeros((16,), np.float32)}
+  path = str(tmp_path / "frozen.pb")
+  write_frozen_pb(path, w, float_val_names=("conv0/bn/gamma",), half_names=("fastrcnn/fc6/W",))
+  got = load_frozen_pb(path)
+  assert set(got) == set(w)                       # int / scalar Consts, Identity, Placeholder skipped
+  for k in w:
+    want = w[k].astype(np.float16).astype(np.float32) if k == "fastrcnn/fc6/W" else w[k]
+    assert got[k].dtype == np.float32 and np.array_equal(got[k], want), k
+  with pytest.raises(ValueError):
+    open(path, "wb").write(b"\x0a\x02\x0a\x00")    # a GraphDef without any Const
+    load_frozen_pb(path)
+
+
+def test_get_model_from_frozen_pb(emu_lib, tmp_path):
+  """obj_detect_tracking.py --is_load_from_pb --model_path x.pb: same detections as the same
+  weights passed directly."""
+  from object_detection_tracking_amd.frozen_pb import write_frozen_pb
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1])
+  w = weights_for(cfg)
+  path = str(tmp_path / "obj_v3.pb")
+  write_frozen_pb(path, w)
+  fr = synthetic_frames(1, 64, 96)[0]
+  m0 = models.get_model(cfg, 0, weights=w, lib=emu_lib)
+  want = m0.predict(fr); m0.close()
+  cfg2 = small_config(resnet_num_block=[1, 1, 1, 1], is_load_from_pb=True, model_path=path,
+                      load_from=path)
+  m1 = models.get_model(cfg2, 0, lib=emu_lib)
+  try:
+    got = m1.predict(fr)
+    for a, b in zip(want, got):
+      assert np.array_equal(a, b)
+  finally:
+    m1.close()
