@@ -16,6 +16,7 @@ GPU raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -26,6 +27,7 @@ from .anchors import fpn_anchor_fields
 from .config import HEAD_DECODE_CLIP, finalize_config
 from .nn import get_new_hw
 from .frozen_pb import load_frozen_pb
+from .tf_checkpoint import load_checkpoint
 from .weights import load_npz, select_partial_classes
 
 
@@ -230,10 +232,15 @@ class _DetectorBase(object):
         weights = load_frozen_pb(path)
       elif path and str(path).endswith(".npz"):
         weights = load_npz(path)
+      elif path and (os.path.isdir(str(path)) or os.path.exists(str(path) + ".index") or
+                     str(path).endswith(".index")):
+        # TF checkpoint directory / prefix (reference obj_detect_tracking.py:404-416), read
+        # without TensorFlow
+        weights = load_checkpoint(str(path))
       else:
         raise ValueError("weights: pass a {name: array} dict or set config.model_path to a "
-                         "Tensorpack-style .npz (reference obj_detect_tracking.py:417-435) or a "
-                         "frozen .pb (--is_load_from_pb)")
+                         "Tensorpack-style .npz (reference obj_detect_tracking.py:417-435), a "
+                         "TF checkpoint directory / prefix, or a frozen .pb (--is_load_from_pb)")
     # --use_partial_classes (reference models.py:807-829): class-subset head
     self.head_num_class = int(self.config.num_class)
     if getattr(self.config, "use_partial_classes", False):

@@ -242,3 +242,43 @@ def test_get_model_from_frozen_pb(emu_lib, tmp_path):
       assert np.array_equal(a, b)
   finally:
     m1.close()
+
+
+# ---- TF checkpoint route (reference obj_detect_tracking.py:404-416; obj_v3_model.tgz is one) ----
+def test_tf_checkpoint_reader_roundtrip(tmp_path):
+  from object_detection_tracking_amd.tf_checkpoint import load_checkpoint, read_index, write_checkpoint
+  rng = np.random.default_rng(4)
+  v = {"group%d/block%d/conv%d/W" % (g, b, c): rng.standard_normal((1, 1, 8, 4)).astype(np.float32)
+       for g in range(3) for b in range(3) for c in (1, 2, 3)}          # shared prefixes, many blocks
+  v["conv0/bn/variance/EMA"] = rng.uniform(0.5, 1.5, (64,)).astype(np.float32)
+  v["fastrcnn/fc6/W"] = rng.standard_normal((96, 40)).astype(np.float16)
+  v["global_step"] = np.asarray(1234, np.int64)
+  v["conv0/W/Momentum"] = np.zeros((7, 7, 3, 64), np.float32)
+  prefix = str(tmp_path / "model-1234")
+  write_checkpoint(prefix, v)
+  assert set(read_index(prefix + ".index")) == set(v)
+  for where in (prefix, prefix + ".index", str(tmp_path)):              # prefix, index file, directory
+    got = load_checkpoint(where)
+    assert set(got) == {k for k in v if k not in ("global_step", "conv0/W/Momentum")}
+    for k, a in got.items():
+      assert a.dtype == np.float32 and np.array_equal(a, v[k].astype(np.float32)), k
+  open(prefix + ".index", "ab").write(b"x")
+  with pytest.raises(ValueError):
+    load_checkpoint(prefix)
+
+
+def test_get_model_from_tf_checkpoint_dir(emu_lib, tmp_path):
+  from object_detection_tracking_amd.tf_checkpoint import write_checkpoint
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1])
+  w = weights_for(cfg)
+  write_checkpoint(str(tmp_path / "model-77"), w)
+  fr = synthetic_frames(1, 64, 96)[0]
+  m0 = models.get_model(cfg, 0, weights=w, lib=emu_lib)
+  want = m0.predict(fr); m0.close()
+  m1 = models.get_model(small_config(resnet_num_block=[1, 1, 1, 1], model_path=str(tmp_path)), 0,
+                        lib=emu_lib)
+  try:
+    for a, b in zip(want, m1.predict(fr)):
+      assert np.array_equal(a, b)
+  finally:
+    m1.close()
