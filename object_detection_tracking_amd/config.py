@@ -72,6 +72,14 @@ def finalize_config(c):
   obj_detect_tracking.py:303-387 does (idempotent)."""
   d = c.__dict__
   d.setdefault("use_dilations", getattr(c, "version", 3) in (3, 4, 5))
+  # versions 4-6: class-agnostic box regression (obj_detect_tracking.py:272-280)
+  if getattr(c, "version", 3) in (4, 5, 6) and not d.get("_version_flags_applied", False):
+    c.use_frcnn_class_agnostic = True
+    if c.version in (4, 5):
+      c.use_dilations = True
+    if c.version == 6:
+      c.use_se = True
+    c._version_flags_applied = True
   c.is_train = False
   c.use_cpu_nms = False
   c.use_bg_score = False

@@ -28,7 +28,7 @@ from .config import HEAD_DECODE_CLIP, finalize_config
 from .nn import get_new_hw
 from .frozen_pb import load_frozen_pb
 from .tf_checkpoint import load_checkpoint
-from .weights import load_npz, select_partial_classes
+from .weights import expand_class_agnostic_box, load_npz, select_partial_classes
 
 
 class TensorHandle(object):
@@ -241,8 +241,17 @@ class _DetectorBase(object):
         raise ValueError("weights: pass a {name: array} dict or set config.model_path to a "
                          "Tensorpack-style .npz (reference obj_detect_tracking.py:417-435), a "
                          "TF checkpoint directory / prefix, or a frozen .pb (--is_load_from_pb)")
+    unsupported = [f for f in ("use_se", "use_gn", "use_resnext", "use_deformable", "add_relation_nn",
+                               "use_conv_frcnn_head", "use_att_frcnn_head", "add_mask",
+                               "use_small_object_head", "use_cascade_rcnn")
+                   if getattr(self.config, f, False)]
+    if unsupported:
+      raise NotImplementedError("graph variants not built on this path (SURVEY.md 8, out of scope): "
+                                + ", ".join(unsupported))
     # --use_partial_classes (reference models.py:807-829): class-subset head
     self.head_num_class = int(self.config.num_class)
+    if getattr(self.config, "use_frcnn_class_agnostic", False):
+      weights = expand_class_agnostic_box(weights, self.head_num_class)
     if getattr(self.config, "use_partial_classes", False):
       ids = [self.config.classname2id[name] for name in self.config.partial_classes]
       weights = select_partial_classes(weights, ids, self.head_num_class)

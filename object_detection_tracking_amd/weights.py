@@ -102,8 +102,9 @@ def synthetic_weights(config, seed=0):
   w["fastrcnn/fc7/b"] = normal((dim,), 0.02)
   w["fastrcnn/outputs/class/W"] = normal((dim, nc), 0.05)
   w["fastrcnn/outputs/class/b"] = normal((nc,), 0.02)
-  w["fastrcnn/outputs/box/W"] = normal((dim, nc * 4), 0.01)
-  w["fastrcnn/outputs/box/b"] = normal((nc * 4,), 0.002)
+  nb = 1 if getattr(config, "use_frcnn_class_agnostic", False) else nc   # models.py:1164
+  w["fastrcnn/outputs/box/W"] = normal((dim, nb * 4), 0.01)
+  w["fastrcnn/outputs/box/b"] = normal((nb * 4,), 0.002)
   return w
 
 
@@ -152,4 +153,20 @@ def select_partial_classes(weights, class_ids, num_class):
   W = W.reshape(W.shape[0], num_class, 4)[:, cols, :]
   out["fastrcnn/outputs/box/W"] = np.ascontiguousarray(W.reshape(W.shape[0], -1))
   out["fastrcnn/outputs/box/b"] = np.ascontiguousarray(b.reshape(num_class, 4)[cols].reshape(-1))
+  return out
+
+
+def expand_class_agnostic_box(weights, num_class):
+  """``use_frcnn_class_agnostic`` (model versions 4-6; reference models.py:1126-1170 and
+  :798-802): the head regresses ONE box per RoI (``fastrcnn/outputs/box`` is [dim, 4]) and the
+  graph tiles it over the ``num_class - 1`` foreground classes.  Tiling the four weight columns
+  over the classes once at load time yields the identical dot products for every class slot, so
+  the per-class plan runs unchanged.  Returns a new dict."""
+  W = np.asarray(weights["fastrcnn/outputs/box/W"]); b = np.asarray(weights["fastrcnn/outputs/box/b"])
+  if W.shape[1] != 4 or b.shape[0] != 4:
+    raise ValueError("class-agnostic box head expects fastrcnn/outputs/box/W of [dim, 4], got %s"
+                     % (W.shape,))
+  out = dict(weights)
+  out["fastrcnn/outputs/box/W"] = np.ascontiguousarray(np.tile(W, (1, num_class)))
+  out["fastrcnn/outputs/box/b"] = np.ascontiguousarray(np.tile(b, num_class))
   return out

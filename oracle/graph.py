@@ -232,7 +232,7 @@ def multilevel_roi_align(features, boxes, box_ind, strides, out=7):
   return res
 
 
-def box_head(roi_feat, weights, num_class, partial_ids=None):
+def box_head(roi_feat, weights, num_class, partial_ids=None, class_agnostic=False):
   """reference models.py:1030-1108 (fc6/fc7 ReLU, class, box[:,1:])."""
   x = torch.from_numpy(roi_feat.reshape(roi_feat.shape[0], -1))
   h = torch.relu(x @ _w(weights, "fastrcnn/fc6/W") + _w(weights, "fastrcnn/fc6/b"))
@@ -241,7 +241,11 @@ def box_head(roi_feat, weights, num_class, partial_ids=None):
       _w(weights, "fastrcnn/outputs/class/b")
   box = h @ _w(weights, "fastrcnn/outputs/box/W") + \
       _w(weights, "fastrcnn/outputs/box/b")
-  box = box.reshape(-1, num_class, 4)[:, 1:, :]
+  if class_agnostic:
+    # reference models.py:1164-1168 (one box per RoI) + :798-802 (tile over the foreground classes)
+    box = box.reshape(-1, 1, 4).repeat(1, num_class - 1, 1)
+  else:
+    box = box.reshape(-1, num_class, 4)[:, 1:, :]
   cls, box = cls.numpy(), np.ascontiguousarray(box.numpy())
   if partial_ids is not None:
     # reference models.py:807-829 (multi :2267-2287): gather label logits [0]+ids, box logits ids-1
@@ -343,7 +347,8 @@ class OracleModel(object):
     zeros = np.zeros((props.shape[0],), np.int32)
     rf = multilevel_roi_align(p[:4], props, zeros, cfg.anchor_strides)
     taps["roi_feat"] = rf
-    cls, box = box_head(rf, self.weights, cfg.num_class, self.partial_ids)
+    cls, box = box_head(rf, self.weights, cfg.num_class, self.partial_ids,
+                        getattr(cfg, "use_frcnn_class_agnostic", False))
     taps["cls_logits"] = cls; taps["box_logits"] = box
     dec, probs = head_decode(props, box, cls, hw, cfg.fastrcnn_bbox_reg_weights)
     taps["decoded_boxes"] = dec; taps["label_probs"] = probs
@@ -400,7 +405,8 @@ class OracleModel(object):
     bidx = props[:, 0].astype(np.int32); rb = props[:, 1:]
     rf = multilevel_roi_align(p[:4], rb, bidx, cfg.anchor_strides)
     taps["roi_feat"] = rf
-    cls, box = box_head(rf, self.weights, cfg.num_class, self.partial_ids)
+    cls, box = box_head(rf, self.weights, cfg.num_class, self.partial_ids,
+                        getattr(cfg, "use_frcnn_class_agnostic", False))
     dec, probs = head_decode(rb, box, cls, hw, cfg.fastrcnn_bbox_reg_weights)
     taps["decoded_boxes"] = dec; taps["label_probs"] = probs
     # fastrcnn_predictions_multibatch (models.py:2924-2976): scatter into

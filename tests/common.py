@@ -17,7 +17,7 @@ def small_config(**kw):
 
 
 def weights_for(cfg, seed=0):
-  key = (tuple(cfg.resnet_num_block), cfg.num_class, seed)
+  key = (tuple(cfg.resnet_num_block), cfg.num_class, seed, bool(getattr(cfg, "use_frcnn_class_agnostic", False)))
   if key not in _W:
     _W[key] = synthetic_weights(cfg, seed)
   return _W[key]

@@ -181,3 +181,17 @@ def test_forward_coco_v2_partial_classes(backend):
     assert labels.size and labels.min() >= 1 and labels.max() <= 7   # 1..num_partial (ref :637-641)
   finally:
     m.close()
+
+
+def test_forward_version5_class_agnostic(backend):
+  """obj_v4 / obj_v5 models (reference obj_detect_tracking.py:272-277): dilated res5 +
+  class-agnostic box regression (models.py:1126-1170, :798-802: one [K,1,4] regression tiled over
+  the foreground classes).  Product: the four box columns tiled at load time."""
+  name, lib = backend
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1], version=5)
+  assert cfg.use_frcnn_class_agnostic and cfg.use_dilations
+  assert weights_for(cfg)["fastrcnn/outputs/box/W"].shape[1] == 4
+  miss, extra = _run_single(lib, cfg, 96, 128)
+  assert miss == 0 and extra == 0
+  with pytest.raises(NotImplementedError):
+    models.get_model(small_config(version=6), 0, weights=weights_for(cfg), lib=lib)   # SE-ResNet
