@@ -139,6 +139,27 @@ def test_forward_single_r101_1080p(hip_lib):
 
 
 @pytest.mark.gpu
+def test_forward_multi_r101_b8_1080p(hip_lib):
+  """BASELINE config #3, the benchmark workload itself: 8 frames of 1920x1080 through the
+  batched graph, every stage tap and the final detections against the oracle."""
+  cfg = make_config(rpn_test_post_nms_topk=300, im_batch_size=8)
+  _run_multi(hip_lib, cfg, 8, 1080, 1920, tol=5e-5)
+
+
+@pytest.mark.gpu
+def test_forward_r50_coco_partial_1280x720(hip_lib):
+  """The README's released frozen model obj_coco_resnet50_partial_*_1280x720_rpn300: ResNet-50
+  FPN (blocks 3,4,6,3), version 2 (no dilation), 81 COCO classes reduced to a class subset."""
+  names = ["BG"] + ["c%d" % i for i in range(1, 81)]
+  part = ["c1", "c2", "c3", "c4", "c6", "c8", "c25", "c27"]
+  cfg = make_config(rpn_test_post_nms_topk=300, version=2, use_dilations=False, num_class=81,
+                    resnet_num_block=[3, 4, 6, 3], is_coco_model=True, use_partial_classes=True,
+                    partial_classes=part, classname2id={n: i for i, n in enumerate(names)},
+                    max_size=1280, short_edge_size=720)
+  _run_single(hip_lib, cfg, 720, 1280, tol=5e-5)
+
+
+@pytest.mark.gpu
 def test_determinism_and_size_independent_properties(hip_lib):
   """Full-size properties that need no oracle: run-to-run bit-identical outputs; boxes inside
   the frame; probs sorted within (0,1]; labels in range; features finite."""
