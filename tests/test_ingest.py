@@ -101,3 +101,50 @@ def test_device_resize_batch_and_pipeline(backend):
     assert np.array_equal(e.forward(host)[0], ref[0])
   finally:
     m.close()
+
+
+# ---- handle life cycle / threading (one handle per (GPU, stream), the
+# library is re-entrant across handles, ctypes releases the GIL during the forward) -----------------
+@pytest.mark.gpu
+def test_two_handles_in_two_threads_match_sequential(hip_lib):
+  import threading
+  cfg = small_config(resnet_num_block=[1, 1, 2, 3], im_batch_size=2, rpn_test_post_nms_topk=64,
+                     max_size=448)
+  w = weights_for(cfg)
+  frames = [synthetic_frames(2, 256, 448, seed=s) for s in (21, 22)]
+  ms = [models.get_model(cfg, 0, weights=w, lib=hip_lib, is_multi=True) for _ in range(2)]
+  try:
+    want = [ms[i].predict_batch(frames[i]) for i in range(2)]
+    got = [None, None]
+    def work(i):
+      for _ in range(5):
+        got[i] = ms[i].predict_batch(frames[i])
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]; [t.join() for t in th]
+    for i in range(2):
+      for a, b in zip(want[i], got[i]):
+        assert np.array_equal(a, b)
+  finally:
+    [m.close() for m in ms]
+
+
+@pytest.mark.gpu
+def test_create_destroy_does_not_leak_device_memory(hip_lib):
+  import torch
+  cfg = small_config(resnet_num_block=[1, 1, 2, 3], max_size=448)
+  w = weights_for(cfg)
+  fr = synthetic_frames(1, 256, 448)[0]
+  def cycle():
+    m = models.get_model(cfg, 0, weights=w, lib=hip_lib)
+    m.predict(fr)
+    e = m.engine(1, 256, 448)
+    list(e.forward_stream([fr[None]] * 3))          # allocates the pinned ingest slots too
+    m.close()
+  cycle(); cycle()
+  torch.cuda.synchronize()
+  free0 = torch.cuda.mem_get_info(0)[0]
+  for _ in range(6):
+    cycle()
+  torch.cuda.synchronize()
+  free1 = torch.cuda.mem_get_info(0)[0]
+  assert free0 - free1 < 8 << 20, "device memory shrank by %d bytes over 6 create/destroy cycles" % (free0 - free1)
