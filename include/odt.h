@@ -56,6 +56,8 @@ typedef struct odt_config {
   float bbox_reg_weights[4];/* fastrcnn_bbox_reg_weights (10,10,5,5)          */
   float result_score_thresh;/* result_score_thres (1e-4)                      */
   float head_nms_thresh;    /* fastrcnn_nms_iou_thres (0.5)                   */
+  int32_t add_mask;         /* --add_mask: Mask R-CNN head on the final boxes (models.py:932-962); single-image graph */
+  int32_t mask_dim;         /* mrcnn_head_dim (256)                           */
 } odt_config;
 
 /* Caller-owned host output buffers (capacities in elements of the row type).
@@ -67,6 +69,8 @@ typedef struct odt_config {
  *   feats  [sum(valid), C, 7, 7]     float32 (may be NULL)   fpn_box_feat
  *   pooled [sum(valid), C]           float32 (may be NULL)   7x7 mean of feats
  *                                    (deep_sort/utils.py:27-28 done on device)
+ *   masks  [result_per_im, 28, 28]   float32 (may be NULL; add_mask only) final_masks: sigmoid of the
+ *                                    mask logits of each detection's own class; rows >= valid[0] are 0
  */
 typedef struct odt_outputs {
   float* boxes;
@@ -75,6 +79,7 @@ typedef struct odt_outputs {
   int32_t* valid;
   float* feats;
   float* pooled;
+  float* masks;
 } odt_outputs;
 
 const char* odt_last_error(void);

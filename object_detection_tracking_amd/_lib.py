@@ -36,13 +36,14 @@ class OdtConfig(C.Structure):
       ("anchor_field", C.c_int32), ("rpn_nms_thresh", C.c_float),
       ("rpn_decode_clip", C.c_float), ("head_decode_clip", C.c_float),
       ("bbox_reg_weights", C.c_float * 4), ("result_score_thresh", C.c_float),
-      ("head_nms_thresh", C.c_float),
+      ("head_nms_thresh", C.c_float), ("add_mask", C.c_int32), ("mask_dim", C.c_int32),
   ]
 
 
 class OdtOutputs(C.Structure):
   _fields_ = [("boxes", c_float_p), ("probs", c_float_p), ("labels", c_int_p),
-              ("valid", c_int_p), ("feats", c_float_p), ("pooled", c_float_p)]
+              ("valid", c_int_p), ("feats", c_float_p), ("pooled", c_float_p),
+              ("masks", c_float_p)]
 
 
 def fptr(a):

@@ -94,6 +94,7 @@ def finalize_config(c):
                      c.fpn_resolution_requirement)
   c.fpn_num_channel = 256
   c.fpn_frcnn_fc_head_dim = 1024
+  d.setdefault("mrcnn_head_dim", 256)          # obj_detect_tracking.py:324
   d.setdefault("resnet_num_block", [3, 4, 23, 3])
   c.use_basic_block = False
   c.anchor_sizes = (32, 64, 128, 256, 512)
@@ -106,7 +107,7 @@ def finalize_config(c):
   c.rpn_test_pre_nms_topk = 6000   # dead in FPN mode (models.py:411-424)
   c.fastrcnn_nms_iou_thres = 0.5
   c.result_score_thres = getattr(c, "threshold_conf", 0.0001)
-  c.result_per_im = 100
+  d.setdefault("result_per_im", 100)           # obj_detect_tracking.py:375 (tests shrink it)
   if not hasattr(c, "classname2id"):
     names = ACTEV_CLASSES if c.num_class == 15 else \
         ["BG"] + ["class%d" % i for i in range(1, c.num_class)]

@@ -194,4 +194,32 @@ int launch_detections(const DetectParams& p, hipStream_t stream) {
   return 0;
 }
 
+namespace {
+// final_masks = sigmoid(mask_logits[r, label - 1]) on the 28x28 grid (reference models.py:951-962;
+// the 2x2-stride-2 transposed conv was computed as one 1x1 conv to (dy,dx,c) sub-pixel channels,
+// so the pixel shuffle happens here: (y, x) <- cell (y/2, x/2), sub-pixel (y%2, x%2)).
+__global__ void __launch_bounds__(256) mask_select_kernel(MaskSelectParams p) {
+  const int r = blockIdx.x;
+  const int b = r / p.per_image, j = r - b * p.per_image;
+  float* out = p.masks + (size_t)r * 784;
+  if (j >= p.valid[b]) {
+    for (int i = threadIdx.x; i < 784; i += blockDim.x) out[i] = 0.f;
+    return;
+  }
+  const int cls = p.labels[r] - 1;
+  for (int i = threadIdx.x; i < 784; i += blockDim.x) {
+    const int y = i / 28, x = i - y * 28;
+    const size_t cell = ((size_t)r * 14 + (y >> 1)) * 14 + (x >> 1);
+    const float v = p.logits[(cell * 4 + (y & 1) * 2 + (x & 1)) * p.ld + cls];
+    out[i] = 1.0f / (1.0f + expf(-v));
+  }
+}
+}  // namespace
+
+int launch_mask_select(const MaskSelectParams& p, hipStream_t stream) {
+  hipLaunchKernelGGL(mask_select_kernel, dim3(p.B * p.per_image), dim3(256), 0, stream, p);
+  ODT_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace odt

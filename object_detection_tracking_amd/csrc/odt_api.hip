@@ -58,7 +58,8 @@ struct ConvOp {
   std::string name;
 };
 
-enum OpKind { OP_PRE, OP_CONV, OP_POOL, OP_SUB2, OP_PROPOSALS, OP_ROI_HEAD, OP_DETECT, OP_ROI_FINAL };
+enum OpKind { OP_PRE, OP_CONV, OP_POOL, OP_SUB2, OP_PROPOSALS, OP_ROI_HEAD, OP_DETECT, OP_ROI_FINAL,
+              OP_ROI_MASK, OP_MASK_SELECT };
 struct Op {
   OpKind kind;
   int conv = -1;        // index into convs
@@ -85,7 +86,9 @@ struct odt_model {
   int Hp = 0, Wp = 0;
   // proposal / head / detection state
   ProposalParams prop{};
-  RoiAlignParams roi_head{}, roi_final{};
+  RoiAlignParams roi_head{}, roi_final{}, roi_mask{};
+  MaskSelectParams mask_sel{};
+  float* final_masks = nullptr;   // [B*per_im, 28, 28] (add_mask)
   DetectParams det{};
   Tensor image_pad, frames_dev;
   int src_h = 0, src_w = 0;          // source frame size (== cfg.height/width unless odt_set_source_size)
@@ -99,6 +102,7 @@ struct odt_model {
     void* pin_in = nullptr; size_t pin_in_bytes = 0;
     void* dev_in = nullptr; size_t dev_in_bytes = 0;
     float *pin_boxes = nullptr, *pin_probs = nullptr, *pin_feats = nullptr, *pin_pooled = nullptr;
+    float* pin_masks = nullptr;
     int *pin_labels = nullptr, *pin_valid = nullptr;
     hipEvent_t h2d_done = nullptr, fwd_done = nullptr, d2h_done = nullptr;
     int ticket = -1;            // outstanding ticket or -1
@@ -264,7 +268,7 @@ int odt_destroy(odt_handle h) {
   for (auto& sl : h->slot) {
     if (sl.pin_in) (void)hipHostFree(sl.pin_in);
     if (sl.dev_in) (void)hipFree(sl.dev_in);
-    for (void* q : {(void*)sl.pin_boxes, (void*)sl.pin_probs, (void*)sl.pin_feats, (void*)sl.pin_pooled,
+    for (void* q : {(void*)sl.pin_masks, (void*)sl.pin_boxes, (void*)sl.pin_probs, (void*)sl.pin_feats, (void*)sl.pin_pooled,
                     (void*)sl.pin_labels, (void*)sl.pin_valid})
       if (q) (void)hipHostFree(q);
     for (hipEvent_t e : {sl.h2d_done, sl.fwd_done, sl.d2h_done}) if (e) (void)hipEventDestroy(e);
@@ -567,6 +571,65 @@ int build_plan(odt_model* m) {
   rf.boxes = dp.out_boxes; rf.per_image = per_im; rf.count = dp.out_valid; rf.R_cap = B * per_im;
   rf.out_nhwc = nullptr; rf.out_nchw = m->final_feat; rf.pooled = m->final_pooled;
   { Op op; op.kind = OP_ROI_FINAL; m->ops.push_back(op); }
+
+  // ---- Mask R-CNN head on the final boxes (--add_mask; models.py:932-962, 1173-1199): 14x14
+  // ROIAlign, 4 x (3x3 conv + ReLU), 2x2 stride-2 transposed conv + ReLU, 1x1 conv to the
+  // foreground classes, sigmoid of each detection's own class.  The transposed conv has no
+  // overlap (kernel == stride), so it runs as ONE 1x1 conv to 4 * dim sub-pixel channels
+  // (dy, dx, co); the following 1x1 conv treats [R,14,14,4*dim] as [R,14,56,dim] pixels and the
+  // pixel shuffle to 28x28 happens in mask_select_kernel.
+  if (cfg.add_mask) {
+    ODT_CHECK(cfg.graph == ODT_GRAPH_SINGLE, "add_mask: built for the single-image graph only");
+    const int MD = cfg.mask_dim > 0 ? cfg.mask_dim : 256;
+    ODT_CHECK(MD % 32 == 0, "add_mask: mrcnn_head_dim must be a multiple of 32");
+    const int R = B * per_im;
+    Tensor mroi{};
+    if (make_tensor(m, "mask_roi", R, 14, 14, FC, &mroi, true)) return 1;
+    m->roi_mask = m->roi_final;
+    m->roi_mask.out_nhwc = mroi.d; m->roi_mask.out_nchw = nullptr; m->roi_mask.pooled = nullptr;
+    m->roi_mask.out_size = 14;
+    { Op op; op.kind = OP_ROI_MASK; m->ops.push_back(op); }
+    Tensor cur = mroi;
+    int cin = FC;
+    for (int k = 0; k < 4; ++k) {
+      const std::string sc = "maskrcnn/fcn" + std::to_string(k);
+      if (upload_conv(m, sc, 3, 3, cin, MD, false, &wt, &bias)) return 1;
+      Tensor nx{};
+      if (add_conv(m, sc, cur, cin, wt, bias, 3, 3, MD, 1, 1, 1, 1, 14, 14, 0, 0, nullptr, 0, true, MD, &nx,
+                   "mask_fcn" + std::to_string(k))) return 1;
+      cur = nx; cin = MD;
+    }
+    {   // Conv2DTranspose kernel [2,2,out,in] (nn.py:383-413) -> 1x1 conv [in][(dy,dx,out)]
+      const HostTensor* wd = find_w(m, "maskrcnn/deconv/W"); const HostTensor* bd = find_w(m, "maskrcnn/deconv/b");
+      ODT_CHECK(wd && bd, "missing maskrcnn/deconv variables");
+      ODT_CHECK(wd->data.size() == (size_t)4 * MD * MD && bd->data.size() == (size_t)MD, "bad maskrcnn/deconv shapes");
+      HostTensor v, vb; v.data.resize((size_t)MD * 4 * MD); vb.data.resize((size_t)4 * MD);
+      for (int q = 0; q < 4; ++q)
+        for (int co = 0; co < MD; ++co) {
+          vb.data[(size_t)q * MD + co] = bd->data[co];
+          for (int ci = 0; ci < MD; ++ci)
+            v.data[(size_t)ci * 4 * MD + (size_t)q * MD + co] = wd->data[((size_t)q * MD + co) * MD + ci];
+        }
+      m->host_w["__maskdeconv/W"] = v; m->host_w["__maskdeconv/b"] = vb;
+      if (upload_conv(m, "__maskdeconv", 1, 1, MD, 4 * MD, false, &wt, &bias)) return 1;
+    }
+    Tensor dc{};
+    if (add_conv(m, "maskrcnn/deconv", cur, MD, wt, bias, 1, 1, 4 * MD, 1, 1, 0, 0, 14, 14, 0, 0, nullptr, 0, true,
+                 4 * MD, &dc, "mask_deconv")) return 1;
+    Tensor dv = dc;                       // [R,14,14,4*MD] viewed as [R,14,56,MD]
+    dv.W = dv.w = 56; dv.C = MD; dv.c = MD;
+    if (upload_conv(m, "maskrcnn/conv", 1, 1, MD, C - 1, false, &wt, &bias)) return 1;
+    Tensor ml{};
+    const int mld = (C - 1 + 3) / 4 * 4;
+    if (add_conv(m, "maskrcnn/conv", dv, MD, wt, bias, 1, 1, C - 1, 1, 1, 0, 0, 14, 56, 0, 0, nullptr, 0, false, mld,
+                 &ml, "mask_logits")) return 1;
+    m->final_masks = m->alloc_f((size_t)R * 784, true);
+    ODT_CHECK(m->final_masks != nullptr, "device allocation failed (masks)");
+    MaskSelectParams& ms = m->mask_sel;
+    ms.logits = ml.d; ms.ld = ml.C; ms.labels = dp.out_labels; ms.valid = dp.out_valid; ms.B = B;
+    ms.per_image = per_im; ms.masks = m->final_masks;
+    { Op op; op.kind = OP_MASK_SELECT; m->ops.push_back(op); }
+  }
   {   // conv parameter records in device memory
     std::vector<ConvParams> recs;
     for (const ConvOp& c : m->convs) recs.push_back(c.p);
@@ -639,6 +702,12 @@ int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStre
         break;
       case OP_ROI_FINAL:
         if (launch_roi_align(m->roi_final, st)) return 1;
+        break;
+      case OP_ROI_MASK:
+        if (launch_roi_align(m->roi_mask, st)) return 1;
+        break;
+      case OP_MASK_SELECT:
+        if (launch_mask_select(m->mask_sel, st)) return 1;
         break;
     }
   }
@@ -727,6 +796,10 @@ int odt_forward(odt_handle h, const void* frames, int dtype, int on_device, void
     ODT_HIP(hipMemcpy(out->feats, h->final_feat, (size_t)total * FC * 49 * sizeof(float), hipMemcpyDeviceToHost));
   if (out->pooled && total > 0)
     ODT_HIP(hipMemcpy(out->pooled, h->final_pooled, (size_t)total * FC * sizeof(float), hipMemcpyDeviceToHost));
+  if (out->masks) {
+    ODT_CHECK(h->final_masks != nullptr, "odt_forward: masks requested but the model was built without add_mask");
+    ODT_HIP(hipMemcpy(out->masks, h->final_masks, (size_t)B * per * 784 * sizeof(float), hipMemcpyDeviceToHost));
+  }
   return 0;
 }
 
@@ -749,6 +822,7 @@ static int slot_prepare(odt_handle h, odt_model::Slot& sl, size_t in_bytes) {
     ODT_HIP(hipHostMalloc((void**)&sl.pin_valid, B * sizeof(int), 0));
     ODT_HIP(hipHostMalloc((void**)&sl.pin_feats, B * per * FC * 49 * sizeof(float), 0));
     ODT_HIP(hipHostMalloc((void**)&sl.pin_pooled, B * per * FC * sizeof(float), 0));
+    if (h->final_masks) ODT_HIP(hipHostMalloc((void**)&sl.pin_masks, B * per * 784 * sizeof(float), 0));
     ODT_HIP(hipEventCreate(&sl.h2d_done));
     ODT_HIP(hipEventCreate(&sl.fwd_done));
     ODT_HIP(hipEventCreate(&sl.d2h_done));
@@ -815,6 +889,8 @@ int odt_submit(odt_handle h, const void* frames, int dtype, int* ticket) {
   ODT_HIP(hipMemcpyAsync(sl.pin_labels, h->det.out_labels, B * per * sizeof(int), hipMemcpyDeviceToHost, co));
   ODT_HIP(hipMemcpyAsync(sl.pin_feats, h->final_feat, B * per * FC * 49 * sizeof(float), hipMemcpyDeviceToHost, co));
   ODT_HIP(hipMemcpyAsync(sl.pin_pooled, h->final_pooled, B * per * FC * sizeof(float), hipMemcpyDeviceToHost, co));
+  if (h->final_masks)
+    ODT_HIP(hipMemcpyAsync(sl.pin_masks, h->final_masks, B * per * 784 * sizeof(float), hipMemcpyDeviceToHost, co));
   ODT_HIP(hipEventRecord(sl.d2h_done, co));
   sl.ticket = t;
   *ticket = t;
@@ -838,6 +914,10 @@ int odt_collect(odt_handle h, int ticket, odt_outputs* out) {
   if (out->labels) std::memcpy(out->labels, sl.pin_labels, B * per * sizeof(int));
   if (out->feats) std::memcpy(out->feats, sl.pin_feats, total * FC * 49 * sizeof(float));
   if (out->pooled) std::memcpy(out->pooled, sl.pin_pooled, total * FC * sizeof(float));
+  if (out->masks) {
+    ODT_CHECK(sl.pin_masks != nullptr, "odt_collect: masks requested but the model was built without add_mask");
+    std::memcpy(out->masks, sl.pin_masks, (size_t)h->cfg.batch * h->cfg.result_per_im * 784 * sizeof(float));
+  }
   sl.ticket = -1;
   return 0;
 }

@@ -118,8 +118,20 @@ struct RoiAlignParams {
   float* out_nhwc;       // [R_cap,7,7,C] or nullptr   (box-head input order h,w,c)
   float* out_nchw;       // [R_cap,C,7,7] or nullptr   (fpn_box_feat)
   float* pooled;         // [R_cap,C] or nullptr
+  int out_size;          // 0 / 7: box head + features; 14: mask head (models.py:935-936)
 };
 int launch_roi_align(const RoiAlignParams& p, hipStream_t stream);
+
+// ------------------------------------------------------- mask head tail (models.py:951-962)
+struct MaskSelectParams {
+  const float* logits;   // [R_cap,14,14,4,ld]: deconv sub-pixel (dy,dx) major, class minor
+  int ld;                // padded class stride
+  const int* labels;     // [R_cap] 1-based foreground labels (device)
+  const int* valid;      // [B] rows per image
+  int B, per_image;
+  float* masks;          // [R_cap,28,28]
+};
+int launch_mask_select(const MaskSelectParams& p, hipStream_t stream);
 
 // ------------------------------------------------------- detection tail (K11,K12,K13)
 struct DetectParams {

@@ -22,6 +22,7 @@ __device__ __forceinline__ int fpn_level_of(float x0, float y0, float x1, float 
   return (int)lv - 2;
 }
 
+template <int OUT>
 __global__ void __launch_bounds__(256) roi_align_kernel(RoiAlignParams p, int B) {
   const int r = blockIdx.x, oy = blockIdx.y;
   int b, out_row = r;
@@ -55,7 +56,7 @@ __global__ void __launch_bounds__(256) roi_align_kernel(RoiAlignParams p, int B)
   }
   const float x0 = X0 * is, y0 = Y0 * is, x1 = X1 * is, y1 = Y1 * is;
   const float fH1 = (float)(H - 1), fW1 = (float)(W - 1);
-  constexpr int CS = 2 * kRoiOut;                       // 14
+  constexpr int CS = 2 * OUT;                           // 14 (box head, features) or 28 (mask head)
   // transform_fpcoor_for_tf (nn.py:1238-1271)
   const float sw = (x1 - x0) / (float)CS, sh = (y1 - y0) / (float)CS;
   const float nx0 = (x0 + sw / 2.0f - 0.5f) / fW1, ny0 = (y0 + sh / 2.0f - 0.5f) / fH1;
@@ -78,7 +79,7 @@ __global__ void __launch_bounds__(256) roi_align_kernel(RoiAlignParams p, int B)
   }
   const float* feat = fbase + (size_t)b * ah * aw * ldc;
   for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
-    for (int ox = 0; ox < kRoiOut; ++ox) {
+    for (int ox = 0; ox < OUT; ++ox) {
       float v[2][2];
 #pragma unroll
       for (int qx = 0; qx < 2; ++qx) {
@@ -104,8 +105,8 @@ __global__ void __launch_bounds__(256) roi_align_kernel(RoiAlignParams p, int B)
       }
       // 2x2 average pool (nn.py:1332): ((v00 + v01) + v10) + v11, * 0.25
       const float o = (((v[0][0] + v[0][1]) + v[1][0]) + v[1][1]) * 0.25f;
-      if (p.out_nhwc) p.out_nhwc[(((size_t)out_row * kRoiOut + oy) * kRoiOut + ox) * p.C + c] = o;
-      if (p.out_nchw) p.out_nchw[(((size_t)out_row * p.C + c) * kRoiOut + oy) * kRoiOut + ox] = o;
+      if (p.out_nhwc) p.out_nhwc[(((size_t)out_row * OUT + oy) * OUT + ox) * p.C + c] = o;
+      if (p.out_nchw) p.out_nchw[(((size_t)out_row * p.C + c) * OUT + oy) * OUT + ox] = o;
     }
   }
 }
@@ -136,7 +137,13 @@ int launch_roi_align(const RoiAlignParams& p, hipStream_t stream) {
   ODT_CHECK(p.R_cap > 0, "roi_align: no rows");
   ODT_CHECK(p.pooled == nullptr || p.out_nchw != nullptr, "roi_align: pooled needs out_nchw");
   const int B = (p.box_ind == nullptr && p.per_image > 0) ? p.R_cap / p.per_image : 0;
-  hipLaunchKernelGGL(roi_align_kernel, dim3(p.R_cap, kRoiOut), dim3(256), 0, stream, p, B);
+  const int out = p.out_size == 0 ? kRoiOut : p.out_size;
+  ODT_CHECK(out == kRoiOut || out == 2 * kRoiOut, "roi_align: output side must be 7 or 14");
+  ODT_CHECK(out == kRoiOut || p.pooled == nullptr, "roi_align: pooled features are 7x7 only");
+  if (out == kRoiOut)
+    hipLaunchKernelGGL(roi_align_kernel<kRoiOut>, dim3(p.R_cap, kRoiOut), dim3(256), 0, stream, p, B);
+  else
+    hipLaunchKernelGGL(roi_align_kernel<2 * kRoiOut>, dim3(p.R_cap, 2 * kRoiOut), dim3(256), 0, stream, p, B);
   if (p.pooled) {
     const long total = (long)p.R_cap * p.C;
     unsigned g = (unsigned)((total + 255) / 256);

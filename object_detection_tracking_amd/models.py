@@ -70,6 +70,9 @@ class _Engine(object):
       c.bbox_reg_weights[i] = float(config.fastrcnn_bbox_reg_weights[i])
     c.result_score_thresh = float(config.result_score_thres)
     c.head_nms_thresh = float(config.fastrcnn_nms_iou_thres)
+    self.add_mask = bool(getattr(config, "add_mask", False))
+    c.add_mask = int(self.add_mask)
+    c.mask_dim = int(getattr(config, "mrcnn_head_dim", 256))
     self.h = C.c_void_p()
     lib.check(lib.dll.odt_create(C.byref(c), device, C.byref(self.h)))
     try:
@@ -89,6 +92,7 @@ class _Engine(object):
     self._valid = np.zeros((B,), np.int32)
     self._feats = np.zeros((B * P, Cn, 7, 7), np.float32)
     self._pooled = np.zeros((B * P, Cn), np.float32)
+    self._masks = np.zeros((B * P, 28, 28), np.float32) if self.add_mask else None
 
   def set_source_size(self, src_height, src_width):
     """Frames of [B, src_height, src_width, 3] from now on; the bilinear resize to the plan's
@@ -128,6 +132,7 @@ class _Engine(object):
     out.labels = iptr(self._labels); out.valid = iptr(self._valid)
     out.feats = fptr(self._feats) if want_feats else None
     out.pooled = fptr(self._pooled) if want_pooled else None
+    out.masks = fptr(self._masks) if self.add_mask else None
     self.lib.check(self.lib.dll.odt_forward(self.h, fr.ctypes.data_as(C.c_void_p), dt, 0, None,
                                             C.byref(out)))
     total = int(self._valid.sum())
@@ -156,6 +161,7 @@ class _Engine(object):
     out.labels = iptr(self._labels); out.valid = iptr(self._valid)
     out.feats = fptr(self._feats) if want_feats else None
     out.pooled = fptr(self._pooled) if want_pooled else None
+    out.masks = fptr(self._masks) if self.add_mask else None
     self.lib.check(self.lib.dll.odt_collect(self.h, ticket, C.byref(out)))
     total = int(self._valid.sum())
     return (self._boxes.copy(), self._labels.copy(), self._probs.copy(), self._valid.copy(),
@@ -242,7 +248,7 @@ class _DetectorBase(object):
                          "Tensorpack-style .npz (reference obj_detect_tracking.py:417-435), a "
                          "TF checkpoint directory / prefix, or a frozen .pb (--is_load_from_pb)")
     unsupported = [f for f in ("use_se", "use_gn", "use_resnext", "use_deformable", "add_relation_nn",
-                               "use_conv_frcnn_head", "use_att_frcnn_head", "add_mask",
+                               "use_conv_frcnn_head", "use_att_frcnn_head",
                                "use_small_object_head", "use_cascade_rcnn")
                    if getattr(self.config, f, False)]
     if unsupported:
@@ -266,6 +272,10 @@ class _DetectorBase(object):
     self.final_probs = TensorHandle(self, "final_probs")
     self.fpn_box_feat = TensorHandle(self, "fpn_box_feat")
     self.final_valid_indices = TensorHandle(self, "final_valid_indices")
+    if getattr(self.config, "add_mask", False):       # reference models.py:959-962
+      if self.graph != ODT_GRAPH_SINGLE:
+        raise NotImplementedError("--add_mask is built for the single-image graph (Mask_RCNN_FPN)")
+      self.final_masks = TensorHandle(self, "final_masks")
 
   def engine(self, batch, height, width, src_hw=None):
     key = (batch, height, width) if src_hw is None else (batch, height, width) + tuple(src_hw)
@@ -312,6 +322,7 @@ class Mask_RCNN_FPN(_DetectorBase):
     boxes, labels, probs, valid, feats, pl = e.forward(img[None], want_feats=not pooled,
                                                        want_pooled=pooled)
     r = int(valid[0])
+    self.last_masks = e._masks[:r].copy() if e.add_mask else None    # final_masks [R,28,28]
     return (boxes[0, :r].copy(), labels[0, :r].astype(np.int64), probs[0, :r].copy(),
             pl if pooled else feats)
 
@@ -333,7 +344,8 @@ class Mask_RCNN_FPN(_DetectorBase):
     boxes, labels, probs, feats = self.predict(feed_dict[self.image])
     table = {"final_boxes": boxes, "final_labels": labels, "final_probs": probs,
              "fpn_box_feat": feats,
-             "final_valid_indices": np.asarray([boxes.shape[0]], np.int32)}
+             "final_valid_indices": np.asarray([boxes.shape[0]], np.int32),
+             "final_masks": self.last_masks}
     return [table[f.name] for f in fetches]
 
 

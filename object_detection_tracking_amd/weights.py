@@ -102,6 +102,17 @@ def synthetic_weights(config, seed=0):
   w["fastrcnn/fc7/b"] = normal((dim,), 0.02)
   w["fastrcnn/outputs/class/W"] = normal((dim, nc), 0.05)
   w["fastrcnn/outputs/class/b"] = normal((nc,), 0.02)
+  if getattr(config, "add_mask", False):           # maskrcnn_up4conv_head (models.py:1173-1199)
+    md = getattr(config, "mrcnn_head_dim", 256)
+    cin = ch
+    for k in range(4):
+      w["maskrcnn/fcn%d/W" % k] = normal((3, 3, cin, md), np.sqrt(2.0 / (9 * cin)))
+      w["maskrcnn/fcn%d/b" % k] = normal((md,), 0.02)
+      cin = md
+    w["maskrcnn/deconv/W"] = normal((2, 2, md, md), np.sqrt(2.0 / md))     # [kh, kw, out, in]
+    w["maskrcnn/deconv/b"] = normal((md,), 0.02)
+    w["maskrcnn/conv/W"] = normal((1, 1, md, nc - 1), np.sqrt(2.0 / md))
+    w["maskrcnn/conv/b"] = normal((nc - 1,), 0.02)
   nb = 1 if getattr(config, "use_frcnn_class_agnostic", False) else nc   # models.py:1164
   w["fastrcnn/outputs/box/W"] = normal((dim, nb * 4), 0.01)
   w["fastrcnn/outputs/box/b"] = normal((nb * 4,), 0.002)

@@ -255,6 +255,26 @@ def box_head(roi_feat, weights, num_class, partial_ids=None, class_agnostic=Fals
   return cls, box
 
 
+def mask_head(roi_feat14, weights, final_labels):
+  """reference models.py:1173-1199 (maskrcnn_up4conv_head: 4 x conv3x3+ReLU, Conv2DTranspose
+  2x2 stride 2 + ReLU, conv1x1 to num_class-1) and :951-962 (gather each detection's own class,
+  sigmoid) -> final_masks [R,28,28].  Conv2DTranspose kernel is [kh,kw,out,in] (nn.py:383-413),
+  torch wants [in,out,kh,kw]."""
+  import torch.nn.functional as TFn
+  x = torch.from_numpy(np.ascontiguousarray(roi_feat14))
+  with torch.no_grad():
+    for k in range(4):
+      W = _w(weights, "maskrcnn/fcn%d/W" % k).permute(3, 2, 0, 1).contiguous()
+      x = torch.relu(TFn.conv2d(x, W, _w(weights, "maskrcnn/fcn%d/b" % k), padding=1))
+    Wd = _w(weights, "maskrcnn/deconv/W").permute(3, 2, 0, 1).contiguous()
+    x = torch.relu(TFn.conv_transpose2d(x, Wd, _w(weights, "maskrcnn/deconv/b"), stride=2))
+    Wc = _w(weights, "maskrcnn/conv/W").permute(3, 2, 0, 1).contiguous()
+    logits = TFn.conv2d(x, Wc, _w(weights, "maskrcnn/conv/b")).numpy()        # [R,C-1,28,28]
+  idx = np.asarray(final_labels, np.int64) - 1
+  sel = logits[np.arange(logits.shape[0]), idx]
+  return (F(1.0) / (F(1.0) + np.exp(-sel))).astype(F), logits
+
+
 def head_decode(rcnn_boxes, box_logits, cls_logits, hw, reg_weights):
   """reference models.py:828-843: decode with /[10,10,5,5] and the DEFAULT clip
   log(1333/16) (nn.py:1518), clip to image, softmax."""
@@ -362,6 +382,10 @@ class OracleModel(object):
                                 cfg.anchor_strides)
     taps.update(final_boxes=fb, final_labels=fl, final_probs=fp,
                 fpn_box_feat=feat, pred_indices=pi)
+    if getattr(cfg, "add_mask", False):          # models.py:932-962
+      rf14 = multilevel_roi_align(p[:4], fb, np.zeros((fb.shape[0],), np.int32),
+                                  cfg.anchor_strides, out=14)
+      taps["final_masks"], taps["mask_logits"] = mask_head(rf14, self.weights, fl)
     return taps
 
   # -- b = B ----------------------------------------------------------------

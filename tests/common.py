@@ -17,7 +17,8 @@ def small_config(**kw):
 
 
 def weights_for(cfg, seed=0):
-  key = (tuple(cfg.resnet_num_block), cfg.num_class, seed, bool(getattr(cfg, "use_frcnn_class_agnostic", False)))
+  key = (tuple(cfg.resnet_num_block), cfg.num_class, seed, bool(getattr(cfg, "use_frcnn_class_agnostic", False)),
+         bool(getattr(cfg, "add_mask", False)), getattr(cfg, "mrcnn_head_dim", 256))
   if key not in _W:
     _W[key] = synthetic_weights(cfg, seed)
   return _W[key]

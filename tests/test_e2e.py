@@ -216,3 +216,29 @@ def test_forward_version5_class_agnostic(backend):
   assert miss == 0 and extra == 0
   with pytest.raises(NotImplementedError):
     models.get_model(small_config(version=6), 0, weights=weights_for(cfg), lib=lib)   # SE-ResNet
+
+
+def test_forward_single_with_mask_head(backend):
+  """--add_mask (reference models.py:932-962, 1173-1199): final_masks [R,28,28] next to the usual
+  outputs; fetched through the Session shim like obj_detect_tracking.py:626-631."""
+  name, lib = backend
+  small = dict(result_per_im=6, mrcnn_head_dim=64) if name == "emu" else {}   # simulator cost
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1], add_mask=True, rpn_test_post_nms_topk=32, **small)
+  w = weights_for(cfg)
+  fr = synthetic_frames(1, 96, 128)[0]
+  ref = OracleModel(cfg, w).forward(fr)
+  m = models.get_model(cfg, 0, weights=w, lib=lib)
+  try:
+    sess = models.Session()
+    boxes, labels, probs, feats, masks = sess.run(
+        [m.final_boxes, m.final_labels, m.final_probs, m.fpn_box_feat, m.final_masks],
+        feed_dict=m.get_feed_dict_forward(fr))
+    assert masks.shape == (boxes.shape[0], 28, 28) and masks.dtype == np.float32
+    assert np.array_equal(labels, ref["final_labels"])
+    np.testing.assert_allclose(boxes, ref["final_boxes"], rtol=0, atol=1e-3)
+    assert masks.min() >= 0 and masks.max() <= 1 and masks.std() > 1e-3
+    np.testing.assert_allclose(masks, ref["final_masks"], rtol=0, atol=2e-5)
+  finally:
+    m.close()
+  with pytest.raises(NotImplementedError):
+    models.get_model(small_config(add_mask=True, im_batch_size=2), 0, weights=w, lib=lib, is_multi=True)
