@@ -79,15 +79,19 @@ __global__ void __launch_bounds__(256, ST == 1 ? 3 : 2) conv_igemm_kernel(const 
   const int m0 = mt * BM, n0 = nt * BN;
   const int HoWo = p.Ho * p.Wo;
   const int M = p.B * HoWo;
-  const int K = p.kh * p.kw * p.Cin;
   const int cpt = p.Cin >> 5;               // 32-channel slices per tap
-  const int nslices = p.kh * p.kw * cpt;
+  const int cpt2 = p.in2 != nullptr ? p.Cin2 >> 5 : 0;     // slices of the second A source (1x1 only)
+  const int nslices = p.kh * p.kw * cpt + cpt2;
+  const int K = p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0);
 
   // Branch-free operand fetch: raw buffer loads (SRSRC descriptors built from kernel arguments,
   // i.e. provably wave-uniform); rows that fall into the zero padding / past M / past Cout get an
   // out-of-range offset and the hardware returns zeros.
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.in, 0, (int)((unsigned)p.B * p.in_Ha * p.in_Wa * p.in_ldc * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.in2 != nullptr ? p.in2 : p.in), 0,
+      (int)(p.in2 != nullptr ? (unsigned)p.B * p.in2_Ha * p.in2_Wa * p.in2_ldc * 4u : 0u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.wt, 0, (int)((unsigned)p.Cout * K * 4u), 0x00020000);
 
@@ -145,19 +149,46 @@ __global__ void __launch_bounds__(256, ST == 1 ? 3 : 2) conv_igemm_kernel(const 
   set_tap(0, 0);
 
   f32x4 ra[RA], rb[RB];
+  bool l_src2 = false;          // the load stream has moved on to the second A source
+  int l_cpt = cpt;
+  // second source: output row m reads pixel (n, ho * in2_stride, wo * in2_stride) of in2
+  auto set_src2 = [&]() {
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+      const int m = m0 + lr + 32 * j;
+      const bool ok = m < M;
+      const int mm = ok ? m : 0;
+      const int n = fast_div(mm, p.div_howo_mul, p.div_howo_sh), r = mm - n * HoWo;
+      const int ho = fast_div(r, p.div_wo_mul, p.div_wo_sh), wo = r - ho * p.Wo;
+      const unsigned pix = ((unsigned)n * p.in2_Ha + (unsigned)(ho * p.in2_stride)) * p.in2_Wa + (unsigned)(wo * p.in2_stride);
+      a_row[j] = ok ? pix * (unsigned)p.in2_ldc * 4u + lc * 16u : kOOB;
+    }
+  };
+  auto advance_stream = [&]() {  // next 32-channel slice of the K stream
+    l_k += 128u;
+    if (++l_cc == l_cpt) {
+      l_cc = 0;
+      if (!l_src2) {
+        if (++l_kw == p.kw) { l_kw = 0; ++l_kh; }
+        if (l_kh == p.kh && cpt2 > 0) {
+          l_src2 = true; l_cpt = cpt2;
+          set_src2();
+        } else {
+          set_tap(l_kh, l_kw);  // harmless past the last tap (never loaded)
+        }
+      }
+    }
+  };
+  auto load_a = [&](int j) {
+    return (f32x4)__builtin_amdgcn_raw_buffer_load_b128(l_src2 ? rs_in2 : rs_in, (int)a_row[j], l_cc * 128, 0);
+  };
   auto load_slice = [&]() {     // fetch the next slice of the stream into ra / rb
 #pragma unroll
-    for (int j = 0; j < RA; ++j)
-      ra[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)a_row[j], l_cc * 128, 0);
+    for (int j = 0; j < RA; ++j) ra[j] = load_a(j);
 #pragma unroll
     for (int j = 0; j < RB; ++j)
       rb[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_wt, (int)b_off[j], (int)l_k, 0);
-    l_k += 128u;
-    if (++l_cc == cpt) {
-      l_cc = 0;
-      if (++l_kw == p.kw) { l_kw = 0; ++l_kh; }
-      set_tap(l_kh, l_kw);      // harmless past the last tap (never loaded)
-    }
+    advance_stream();
   };
   auto store_slice = [&](int buf) {
     float* A = lds[buf];
@@ -241,16 +272,11 @@ __global__ void __launch_bounds__(256, ST == 1 ? 3 : 2) conv_igemm_kernel(const 
   auto gload_one = [&](int j) {        // j == RA + RB: advance the load stream to the next slice
     if (!ABL(1)) return;
     if (j < RA) {
-      ra[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)a_row[j], l_cc * 128, 0);
+      ra[j] = load_a(j);
     } else if (j < RA + RB) {
       rb[j - RA] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_wt, (int)b_off[j - RA], (int)l_k, 0);
     } else {
-      l_k += 128u;
-      if (++l_cc == cpt) {
-        l_cc = 0;
-        if (++l_kw == p.kw) { l_kw = 0; ++l_kh; }
-        set_tap(l_kh, l_kw);
-      }
+      advance_stream();
     }
   };
   // MFMAs [i0, i1) of a group, with side(0..nside-1) spread evenly behind them
@@ -575,17 +601,21 @@ void conv_prepare(ConvParams& p) {
 }
 
 double conv_flops(const ConvParams& p) {
-  return 2.0 * (double)p.B * p.Ho * p.Wo * (double)p.Cout * (double)(p.kh * p.kw * p.Cin);
+  return 2.0 * (double)p.B * p.Ho * p.Wo * (double)p.Cout *
+         (double)(p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0));
 }
 
 int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_params) {
   ODT_CHECK(p.Cin % 32 == 0, "conv: Cin must be a multiple of 32");
   ODT_CHECK(p.in_ldc % 4 == 0, "conv: input pixel stride must be a multiple of 4 floats");
   ODT_CHECK(p.B > 0 && p.Ho > 0 && p.Wo > 0 && p.Cout > 0, "conv: empty problem");
+  ODT_CHECK(p.in2 == nullptr || (p.kh == 1 && p.kw == 1 && p.Cin2 % 32 == 0 && p.in2_ldc % 4 == 0 &&
+                                 (double)p.B * p.in2_Ha * p.in2_Wa * p.in2_ldc * 4.0 < 2147483648.0),
+            "conv: a second A source needs a 1x1 conv, Cin2 % 32 == 0 and a tensor below 2 GiB");
   ODT_CHECK((long)p.Ho * p.stride + (long)p.kh * p.dil < 32000 && (long)p.Wo * p.stride + (long)p.kw * p.dil < 32000 &&
             p.pad_t < 32000 && p.pad_l < 32000, "conv: spatial extent must fit 16-bit tap coordinates");
   ODT_CHECK((double)p.B * p.in_Ha * p.in_Wa * p.in_ldc * 4.0 < 2147483648.0 &&
-            (double)p.Cout * p.kh * p.kw * p.Cin * 4.0 < 2147483648.0,
+            (double)p.Cout * (p.kh * p.kw * p.Cin + p.Cin2) * 4.0 < 2147483648.0,
             "conv: operand tensors must be smaller than 2 GiB (32-bit buffer offsets)");
   ODT_CHECK((double)p.B * p.out_H * p.out_W * p.out_ldc * 4.0 < 2147483648.0 &&
             (p.res_mode == 0 || (double)p.B * p.res_H * p.res_W * p.res_ldc * 4.0 < 2147483648.0),
@@ -623,7 +653,7 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
   const int BMt = tile == 2 ? 64 : 128, BNt = tile == 3 ? 128 : 64;
   const long tiles = ((M + BMt - 1) / BMt) * ((p.Cout + BNt - 1) / BNt);
   const long slots = 256L * (stages == 2 ? 2 : (tile == 3 ? 3 : 4));
-  const int Kred = p.kh * p.kw * p.Cin;
+  const int Kred = p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0);
   bool fine = stages == 2 || (tile != 2 && (tiles <= slots || tile == 1 || (Kred >= 1024 && tiles >= 2 * slots)));
   if (tile == 2) fine = tiles >= 384 && tiles <= slots;
   if (const char* e = getenv("ODT_CONV_FINE")) {       // tuning knob: force 0 or 1

@@ -185,6 +185,45 @@ int upload_conv(odt_model* m, const std::string& scope, int kh, int kw, int cin,
   return 0;
 }
 
+// conv3 + convshortcut of a stage-entry bottleneck as ONE 1x1 conv over the K-concatenated input
+// [t2 | x]: weights [cout][cin_a + cin_b] with each part's BN folded in, bias = shift_a + shift_b
+// (reference nn.py:503-521: conv3 -> BN, shortcut conv -> BN, add, ReLU).
+int upload_conv_cat(odt_model* m, const std::string& sa, int cin_a, const std::string& sb, int cin_b, int cout,
+                    const float** wt_out, const float** bias_out) {
+  std::vector<float> wt((size_t)cout * (cin_a + cin_b));
+  std::vector<double> shift(cout, 0.0);
+  const std::string scopes[2] = {sa, sb};
+  const int cins[2] = {cin_a, cin_b};
+  int koff = 0;
+  for (int part = 0; part < 2; ++part) {
+    const std::string& scope = scopes[part];
+    const int cin = cins[part];
+    const HostTensor* W = find_w(m, scope + "/W");
+    const HostTensor* g = find_w(m, scope + "/bn/gamma");
+    const HostTensor* b = find_w(m, scope + "/bn/beta");
+    const HostTensor* mu = find_w(m, scope + "/bn/mean/EMA");
+    const HostTensor* var = find_w(m, scope + "/bn/variance/EMA");
+    ODT_CHECK(W && g && b && mu && var, "missing variables for " + scope);
+    ODT_CHECK(W->data.size() == (size_t)cin * cout, "bad shape for " + scope + "/W");
+    for (int o = 0; o < cout; ++o) {
+      const double inv = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
+      shift[o] += (double)b->data[o] - (double)mu->data[o] * inv;
+      for (int i = 0; i < cin; ++i)
+        wt[(size_t)o * (cin_a + cin_b) + koff + i] = (float)((double)W->data[(size_t)i * cout + o] * inv);
+    }
+    koff += cin;
+  }
+  std::vector<float> bias(cout);
+  for (int o = 0; o < cout; ++o) bias[o] = (float)shift[o];
+  float* dw = m->alloc_f(wt.size(), false);
+  float* db = m->alloc_f(bias.size(), false);
+  ODT_CHECK(dw && db, "device allocation failed for weights of " + sa);
+  ODT_HIP(hipMemcpy(dw, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+  ODT_HIP(hipMemcpy(db, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+  *wt_out = dw; *bias_out = db;
+  return 0;
+}
+
 int upload_raw(odt_model* m, const std::vector<float>& v, const float** out) {
   float* d = m->alloc_f(v.size(), false);
   ODT_CHECK(d != nullptr, "device allocation failed");
@@ -371,6 +410,25 @@ int build_plan(odt_model* m) {
                      nullptr, 0, true, ch, &t2, "")) return 1;
         Ho = x.h; Wo = x.w;
       }
+      const std::string tap = (i == cnt - 1) ? "c" + std::to_string(g + 2) : (i == 0 ? pre : "");
+      static const bool fuse_shortcut = !(getenv("ODT_FUSE_SHORTCUT") && getenv("ODT_FUSE_SHORTCUT")[0] == '0');
+      if (cin != ch * 4 && fuse_shortcut) {
+        // stage entry: conv3(t2) + convshortcut(x[::stride]) as one K-concatenated GEMM -- saves the
+        // shortcut tensor's write + read and one launch (shortcut[:, :, :-1, :-1] of nn.py:555-556
+        // never matters: the stride-2 samples stop at 2 * (Ho - 1) <= h - 2)
+        if (stride == 2) {
+          const int hs = (x.h - 2) / 2 + 1, ws = (x.w - 2) / 2 + 1;
+          ODT_CHECK(hs == Ho && ws == Wo, "shortcut / conv2 geometry mismatch in " + pre);
+        }
+        if (upload_conv_cat(m, pre + "/conv3", ch, pre + "/convshortcut", cin, ch * 4, &wt, &bias)) return 1;
+        if (add_conv(m, pre + "/conv3+shortcut", t2, ch, wt, bias, 1, 1, ch * 4, 1, 1, 0, 0, Ho, Wo, 0, 0, nullptr, 0,
+                     true, ch * 4, &y, tap)) return 1;
+        ConvParams& cp = m->convs.back().p;
+        cp.in2 = x.d; cp.Cin2 = cin; cp.in2_ldc = x.C; cp.in2_Ha = x.H; cp.in2_Wa = x.W; cp.in2_stride = stride;
+        x = y;
+        cin = ch * 4;
+        continue;
+      }
       if (cin != ch * 4) {
         if (upload_conv(m, pre + "/convshortcut", 1, 1, cin, ch * 4, true, &wt, &bias)) return 1;
         Tensor s{};
@@ -388,7 +446,6 @@ int build_plan(odt_model* m) {
         sc = s;
       }
       if (upload_conv(m, pre + "/conv3", 1, 1, ch, ch * 4, true, &wt, &bias)) return 1;
-      const std::string tap = (i == cnt - 1) ? "c" + std::to_string(g + 2) : (i == 0 ? pre : "");
       if (add_conv(m, pre + "/conv3", t2, ch, wt, bias, 1, 1, ch * 4, 1, 1, 0, 0, Ho, Wo, 0, 0, &sc, 1,
                    true, ch * 4, &y, tap)) return 1;
       x = y;

@@ -55,6 +55,10 @@ struct ConvParams {
   int res_mode;        // 0 none | 1 same shape | 2 nearest-2x upsample of [B,res_H,res_W,*]
   int res_H, res_W, res_ldc;
   int relu;
+  // optional second A source, K-concatenated behind the first (1x1 convs only): the stage-entry
+  // bottleneck computes conv3(t2) + convshortcut(x) as ONE GEMM over [t2 | x(::stride2)]
+  const float* in2;    // [B,in2_Ha,in2_Wa,in2_ldc] or nullptr
+  int Cin2, in2_ldc, in2_Ha, in2_Wa, in2_stride;
   unsigned div_howo_mul, div_howo_sh, div_wo_mul, div_wo_sh;   // exact m / (Ho*Wo), r / Wo by multiply-shift (conv_prepare)
   int debug;           // ablation bits for kernel tuning (0 in production; ODT_CONV_DEBUG)
   unsigned long long* trace;   // optional [grid][8] wall-clock phase stamps (tuning only)
