@@ -194,6 +194,13 @@ int odt_op_conv2d(int device, const float* in, int B, int H, int W, int Cin,
                   int stride, int dil, int pad_t, int pad_l, int Ho, int Wo,
                   int oy, int ox, const float* res, int res_mode, int relu,
                   float* out);
+
+/* 1x1 conv over the K-concatenation of two inputs (the fused conv3 + convshortcut of a stage-entry
+ * bottleneck): out[b,y,x,:] = relu?( a[b,y,x,:] @ wa + b2[b, y*stride_b, x*stride_b, :] @ wb + bias ).
+ * a [B,Ho,Wo,Ca], b2 [B,Hb,Wb,Cb], wa [Ca,Cout], wb [Cb,Cout], out [B,Ho,Wo,Cout]. */
+int odt_op_conv2d_cat(int device, const float* a, int B, int Ho, int Wo, int Ca, const float* b2, int Hb,
+                      int Wb, int Cb, int stride_b, const float* wa, const float* wb, const float* bias,
+                      int Cout, int relu, float* out);
 /* image preprocess (models.py:340-355) + zero pad -> [B,Hp,Wp,4] */
 int odt_op_preprocess(int device, const void* frames, int dtype, int B, int H,
                       int W, int pad_t, int pad_l, int Hp, int Wp, float* out);

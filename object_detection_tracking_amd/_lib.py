@@ -74,7 +74,8 @@ class OdtLib(object):
       "odt_load_tensor", "odt_finalize_weights", "odt_forward",
       "odt_forward_async", "odt_synchronize", "odt_submit", "odt_collect",
       "odt_ingest_buffer", "odt_set_source_size", "odt_tap", "odt_profile_enable",
-      "odt_profile_read", "odt_profile_layer", "odt_nn_cosine", "odt_op_conv2d", "odt_op_preprocess",
+      "odt_profile_read", "odt_profile_layer", "odt_nn_cosine", "odt_op_conv2d", "odt_op_conv2d_cat",
+      "odt_op_preprocess",
       "odt_op_maxpool", "odt_op_topk", "odt_op_nms", "odt_op_proposals",
       "odt_op_roi_align", "odt_op_detections", "odt_tracker_create", "odt_tracker_destroy",
       "odt_tracker_predict", "odt_tracker_update", "odt_tracker_tracks", "odt_lsap",
@@ -115,6 +116,8 @@ class OdtLib(object):
                                 C.c_int, c_double_p]
     d.odt_op_conv2d.argtypes = [C.c_int, c_float_p] + [C.c_int] * 4 + [c_float_p, c_float_p] + \
         [C.c_int] * 11 + [c_float_p, C.c_int, C.c_int, c_float_p]
+    d.odt_op_conv2d_cat.argtypes = [C.c_int, c_float_p] + [C.c_int] * 4 + [c_float_p] + [C.c_int] * 4 + \
+        [c_float_p, c_float_p, c_float_p, C.c_int, C.c_int, c_float_p]
     d.odt_op_preprocess.argtypes = [C.c_int, C.c_void_p] + [C.c_int] * 8 + [c_float_p]
     d.odt_op_maxpool.argtypes = [C.c_int, c_float_p] + [C.c_int] * 4 + [c_float_p]
     d.odt_op_topk.argtypes = [C.c_int, c_float_p, C.c_int, C.c_int, c_int_p]

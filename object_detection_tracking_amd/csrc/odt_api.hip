@@ -1163,6 +1163,32 @@ int odt_op_conv2d(int device, const float* in, int B, int H, int W, int Cin, con
   return dout.get(out, nout);
 }
 
+int odt_op_conv2d_cat(int device, const float* a, int B, int Ho, int Wo, int Ca, const float* b2, int Hb,
+                      int Wb, int Cb, int stride_b, const float* wa, const float* wb, const float* bias,
+                      int Cout, int relu, float* out) {
+  ODT_CHECK(a && b2 && wa && wb && out, "odt_op_conv2d_cat: null argument");
+  ODT_CHECK((Ho - 1) * stride_b < Hb && (Wo - 1) * stride_b < Wb, "odt_op_conv2d_cat: second input too small");
+  if (set_dev(device)) return 1;
+  std::vector<float> w((size_t)Cout * (Ca + Cb)), bz(Cout, 0.f);
+  for (int o = 0; o < Cout; ++o) {
+    for (int i = 0; i < Ca; ++i) w[(size_t)o * (Ca + Cb) + i] = wa[(size_t)i * Cout + o];
+    for (int i = 0; i < Cb; ++i) w[(size_t)o * (Ca + Cb) + Ca + i] = wb[(size_t)i * Cout + o];
+  }
+  Tmp<float> da, db2, dw, dbias, dout;
+  const size_t na = (size_t)B * Ho * Wo * Ca, nb = (size_t)B * Hb * Wb * Cb, nout = (size_t)B * Ho * Wo * Cout;
+  if (da.alloc(na) || db2.alloc(nb) || dw.alloc(w.size()) || dbias.alloc(Cout) || dout.alloc(nout) || dout.zero()) return 1;
+  if (da.put(a) || db2.put(b2) || dw.put(w.data()) || dbias.put(bias ? bias : bz.data())) return 1;
+  ConvParams p; std::memset(&p, 0, sizeof(p));
+  p.in = da.d; p.wt = dw.d; p.bias = dbias.d; p.out = dout.d;
+  p.B = B; p.H = Ho; p.W = Wo; p.Cin = Ca; p.in_ldc = Ca; p.in_Ha = Ho; p.in_Wa = Wo;
+  p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.kh = 1; p.kw = 1; p.stride = 1; p.dil = 1;
+  p.out_H = Ho; p.out_W = Wo; p.out_ldc = Cout; p.relu = relu;
+  p.in2 = db2.d; p.Cin2 = Cb; p.in2_ldc = Cb; p.in2_Ha = Hb; p.in2_Wa = Wb; p.in2_stride = stride_b;
+  if (launch_conv(p, nullptr)) return 1;
+  ODT_HIP(hipDeviceSynchronize());
+  return dout.get(out, nout);
+}
+
 int odt_op_preprocess(int device, const void* frames, int dtype, int B, int H, int W, int pad_t, int pad_l,
                       int Hp, int Wp, float* out) {
   ODT_CHECK(frames && out, "odt_op_preprocess: null argument");

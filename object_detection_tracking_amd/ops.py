@@ -40,6 +40,22 @@ def conv2d(x_nhwc, w_hwio, bias=None, stride=1, dil=1, pad_t=0, pad_l=0, out_hw=
   return out
 
 
+def conv2d_cat(a, b2, wa, wb, bias=None, stride_b=1, relu=False, lib=None, device=0):
+  """1x1 conv over the K-concatenation [a | b2[:, ::stride_b, ::stride_b]] (fused conv3 +
+  convshortcut, reference nn.py:503-521)."""
+  lib = _L(lib)
+  a = f32(a); b2 = f32(b2); wa = f32(wa); wb = f32(wb)
+  B, Ho, Wo, Ca = a.shape
+  _, Hb, Wb, Cb = b2.shape
+  Cout = wa.shape[1]
+  out = np.zeros((B, Ho, Wo, Cout), np.float32)
+  bb = f32(bias) if bias is not None else None
+  lib.check(lib.dll.odt_op_conv2d_cat(device, fptr(a), B, Ho, Wo, Ca, fptr(b2), Hb, Wb, Cb, stride_b,
+                                      fptr(wa), fptr(wb), fptr(bb) if bb is not None else None, Cout,
+                                      int(relu), fptr(out)))
+  return out
+
+
 def preprocess(frames, pad_t, pad_l, Hp, Wp, lib=None, device=0):
   """reference models.py:340-355 + zero pad; returns [B,Hp,Wp,4]."""
   lib = _L(lib)

@@ -395,3 +395,74 @@ def test_nn_cosine(backend):
   assert got.dtype == np.float64
   np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6)
   assert ops.nn_cosine(gal, seg, np.zeros((0, D), F), lib=lib).shape == (T, 0)
+
+
+# ---- randomized conv coverage: every kernel instantiation (tile x stages x loop style) ----------
+def _fuzz_case(rng, lib, big):
+  B = int(rng.integers(1, 3)); k = int(rng.choice([1, 1, 3])); stride = int(rng.choice([1, 1, 2]))
+  dil = int(rng.choice([1, 1, 2])) if k == 3 else 1
+  lo, hi = (6, 20) if not big else (9, 70)
+  H, W = int(rng.integers(lo, hi)), int(rng.integers(lo, hi))
+  Cin = int(rng.choice([32, 64, 96] if not big else [32, 64, 96, 256]))
+  Cout = int(rng.choice([4, 8, 15, 32, 64, 72, 128, 200] if big else [4, 15, 32, 72]))
+  pad_t, pad_l = int(rng.integers(0, k)) * dil, int(rng.integers(0, k)) * dil
+  ke = (k - 1) * dil + 1
+  Ho = (H + pad_t + int(rng.integers(0, ke)) - ke) // stride + 1
+  Wo = (W + pad_l + int(rng.integers(0, ke)) - ke) // stride + 1
+  if Ho < 1 or Wo < 1:
+    return
+  oy, ox = (int(rng.integers(0, 2)), int(rng.integers(0, 2)))
+  res_mode = int(rng.choice([0, 0, 1, 2])) if (oy, ox) == (0, 0) else 0
+  relu = bool(rng.integers(0, 2))
+  x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+  w = (rng.standard_normal((k, k, Cin, Cout)) * (1.0 / np.sqrt(k * k * Cin))).astype(np.float32)
+  b = rng.standard_normal((Cout,)).astype(np.float32)
+  res = None
+  if res_mode == 1:
+    res = rng.standard_normal((B, Ho, Wo, Cout)).astype(np.float32)
+  elif res_mode == 2:
+    res = rng.standard_normal((B, (Ho + 1) // 2, (Wo + 1) // 2, Cout)).astype(np.float32)
+  want = torch_conv_nhwc(x, w, b, stride, dil, pad_t, pad_l, Ho, Wo)
+  if res_mode == 1:
+    want = want + res
+  elif res_mode == 2:
+    want = want + np.repeat(np.repeat(res, 2, 1), 2, 2)[:, :Ho, :Wo]
+  if relu:
+    want = np.maximum(want, 0)
+  got = ops.conv2d(x, w, b, stride=stride, dil=dil, pad_t=pad_t, pad_l=pad_l, out_hw=(Ho, Wo),
+                   out_off=(oy, ox), res=res, res_mode=res_mode, relu=relu, lib=lib)
+  assert np.all(got[:, :oy] == 0) and np.all(got[:, :, :ox] == 0)
+  np.testing.assert_allclose(got[:, oy:, ox:], want, rtol=2e-4, atol=2e-4)
+
+
+def test_conv_fuzz_all_variants(backend, monkeypatch):
+  name, lib = backend
+  rng = np.random.default_rng(2024)
+  n = 3 if name == "emu" else 12
+  for tile in ("1", "2", "3"):
+    for stages in ("1", "2"):
+      for fine in ("0", "1"):
+        monkeypatch.setenv("ODT_CONV_TILE", tile)
+        monkeypatch.setenv("ODT_CONV_STAGES", stages)
+        monkeypatch.setenv("ODT_CONV_FINE", fine)
+        for _ in range(n):
+          _fuzz_case(rng, lib, big=name == "hip")
+
+
+def test_conv_two_sources(backend, monkeypatch):
+  """conv3 + convshortcut as one K-concatenated GEMM (second source at stride 1 and 2)."""
+  name, lib = backend
+  rng = np.random.default_rng(7)
+  for fine in ("0", "1"):
+    monkeypatch.setenv("ODT_CONV_FINE", fine)
+    for stride_b, Ca, Cb, Cout in ((1, 64, 64, 256), (2, 128, 256, 512), (2, 32, 96, 40)):
+      B, Ho, Wo = 2, 9, 11
+      Hb, Wb = (Ho, Wo) if stride_b == 1 else (2 * Ho, 2 * Wo - 1)
+      a = rng.standard_normal((B, Ho, Wo, Ca)).astype(np.float32)
+      b2 = rng.standard_normal((B, Hb, Wb, Cb)).astype(np.float32)
+      wa = (rng.standard_normal((Ca, Cout)) / np.sqrt(Ca)).astype(np.float32)
+      wb = (rng.standard_normal((Cb, Cout)) / np.sqrt(Cb)).astype(np.float32)
+      bias = rng.standard_normal((Cout,)).astype(np.float32)
+      want = a @ wa + b2[:, ::stride_b, ::stride_b][:, :Ho, :Wo] @ wb + bias
+      got = ops.conv2d_cat(a, b2, wa, wb, bias, stride_b=stride_b, relu=True, lib=lib)
+      np.testing.assert_allclose(got, np.maximum(want, 0), rtol=2e-4, atol=2e-4)
