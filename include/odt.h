@@ -181,6 +181,24 @@ int odt_tracker_tracks(odt_tracker_handle t, int cap, int32_t* ids, int32_t* sta
 /* scipy.optimize.linear_sum_assignment(cost[nr,nc]) -> n = min(nr,nc) (row, col) pairs by row */
 int odt_lsap(const double* cost, int nr, int nc, int32_t* rows, int32_t* cols, int* n);
 
+/* ---- TMOT / JDE tracker core (reference tmot/multitracker.py JDETracker; driver
+ * obj_detect_tracking_multi_queuer_tmot.py:543-583, :707-714).  Host C++ like the DeepSORT core.
+ * id_counter is BaseTrack._count (basetrack.py:13,33-36): the reference shares it between all
+ * tracker instances of the process, so the caller owns it. ----------------------------------- */
+typedef struct odt_tmot* odt_tmot_handle;
+int odt_tmot_create(double conf_thres, double track_max_second_lost, double emb_max_dist, double iou_max_dist1,
+                    double iou_max_dist2, double emb_smooth_alpha, double frame_gap, double frame_rate,
+                    odt_tmot_handle* out);
+int odt_tmot_destroy(odt_tmot_handle t);
+int odt_tmot_reset(odt_tmot_handle t);
+/* JDETracker.update(detections): tlwh [n,4] f64, conf [n] f64, feats [n,dim] f32 -> n_out output tracks */
+int odt_tmot_update(odt_tmot_handle t, const double* tlwh, const double* conf, const float* feats, int n, int dim,
+                    int* id_counter, int* n_out);
+/* which: 0 output_stracks of the last update | 1 tracked | 2 lost | 3 removed; NULL arrays are skipped */
+int odt_tmot_tracks(odt_tmot_handle t, int which, int cap, int32_t* ids, int32_t* state, int32_t* activated,
+                    double* tlwh, double* det_tlwh, double* det_conf, double* score, int32_t* tracklet_len,
+                    int32_t* start_frame, int32_t* frame_id, int* n);
+
 /* ---- stand-alone op entry points (host pointers), used by the staged parity
  * tests; each runs exactly the kernels odt_forward uses. ------------------- */
 

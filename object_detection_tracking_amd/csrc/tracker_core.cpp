@@ -23,6 +23,7 @@
 #include <deque>
 #include <limits>
 #include <map>
+#include <memory>
 #include <set>
 #include <string>
 #include <vector>
@@ -525,6 +526,332 @@ int odt_tracker_tracks(odt_tracker_handle t, int cap, int32_t* ids, int32_t* sta
     if (age) age[i] = tr.age;
     if (mean) std::memcpy(mean + (size_t)i * 8, tr.mean, 8 * sizeof(double));
     if (covariance) std::memcpy(covariance + (size_t)i * 64, tr.cov, 64 * sizeof(double));
+  }
+  return 0;
+}
+
+}  // extern "C"
+
+
+// =================================================================================================
+// TMOT / JDE tracker core (reference tmot/multitracker.py, tmot/matching.py, tmot/kalman_filter.py,
+// tmot/basetrack.py; used by obj_detect_tracking_multi_queuer_tmot.py:543-583).  "Next" row 3b of
+// SURVEY.md 8(f).  Same Kalman model as deep_sort (the constants above); association: embedding
+// distance (Euclidean between the EMA-smoothed, L2-normalised track feature and the detection
+// feature) fused with the Mahalanobis gate, then two IoU stages; assignment = lap.lapjv(cost,
+// extend_cost=True, cost_limit=thresh), i.e. the cost matrix extended to (n+m)^2 with thresh/2 in
+// the off-diagonal blocks and 0 in the lower-right block, solved exactly (lap 0.4.0 _lapjv.pyx) --
+// here with the scipy-exact solver above; IoU = cython_bbox.bbox_overlaps ("+1" widths/heights).
+// =================================================================================================
+namespace odt {
+namespace {
+
+enum { kNew = 0, kTracked = 1, kLost = 2, kRemoved = 3 };       // basetrack.py:5-9
+
+struct STrk {
+  int id = 0, state = kNew;
+  bool activated = false, has_kf = false;
+  double mean[8], cov[64];
+  double tlwh0[4];                       // _tlwh
+  double score = 0.0;
+  int tracklet_len = 0, frame_id = 0, start_frame = 0;
+  std::vector<float> smooth, curr;
+  double det_tlwh[4], det_conf = 0.0;
+  float alpha = 0.9f;
+
+  void tlwh(double* o) const {           // multitracker.py:119-130
+    if (!has_kf) { for (int i = 0; i < 4; ++i) o[i] = tlwh0[i]; return; }
+    o[0] = mean[0]; o[1] = mean[1]; o[2] = mean[2] * mean[3]; o[3] = mean[3];
+    o[0] -= o[2] / 2; o[1] -= o[3] / 2;
+  }
+  void tlbr(double* o) const { tlwh(o); o[2] += o[0]; o[3] += o[1]; }
+};
+typedef std::shared_ptr<STrk> STrkP;
+
+void tlwh_to_xyah(const double* t, double* o) {                  // multitracker.py:143-151
+  o[0] = t[0] + t[2] / 2; o[1] = t[1] + t[3] / 2; o[2] = t[2] / t[3]; o[3] = t[3];
+}
+
+// feat /= np.linalg.norm(feat)  (float32 array; the norm is rounded to float32)
+void normalize_f32(std::vector<float>& f) {
+  double s = 0.0;
+  for (float x : f) s += (double)x * (double)x;
+  const float n = (float)std::sqrt(s);
+  for (float& x : f) x = x / n;
+}
+
+// STrack.update_features (multitracker.py:36-45), including its aliasing: on the first call
+// smooth_feat IS the feature array, so the final in-place normalisation hits curr_feat too
+void update_features(STrk& t, std::vector<float> feat, std::vector<float>* feat_inout) {
+  normalize_f32(feat);
+  if (feat_inout) *feat_inout = feat;    // the caller's array was normalised in place
+  t.curr = feat;
+  if (t.smooth.empty()) {
+    normalize_f32(t.curr);               // smooth_feat /= norm on the shared array
+    t.smooth = t.curr;
+    if (feat_inout) *feat_inout = t.curr;
+  } else {
+    const float a = t.alpha, b = (float)(1.0 - (double)t.alpha);
+    for (size_t i = 0; i < feat.size(); ++i) t.smooth[i] = a * t.smooth[i] + b * feat[i];
+    normalize_f32(t.smooth);
+  }
+}
+
+double iou_plus1(const double* a, const double* b) {             // cython_bbox.bbox_overlaps
+  const double iw = std::min(a[2], b[2]) - std::max(a[0], b[0]) + 1;
+  if (iw <= 0) return 0.0;
+  const double ih = std::min(a[3], b[3]) - std::max(a[1], b[1]) + 1;
+  if (ih <= 0) return 0.0;
+  const double ua = (a[2] - a[0] + 1) * (a[3] - a[1] + 1) + (b[2] - b[0] + 1) * (b[3] - b[1] + 1) - iw * ih;
+  return iw * ih / ua;
+}
+
+void iou_distance(const std::vector<STrkP>& a, const std::vector<STrkP>& b, std::vector<double>* cost) {
+  cost->assign(a.size() * b.size(), 0.0);                        // matching.py:61-79
+  for (size_t i = 0; i < a.size(); ++i) {
+    double ba[4]; a[i]->tlbr(ba);
+    for (size_t j = 0; j < b.size(); ++j) {
+      double bb[4]; b[j]->tlbr(bb);
+      (*cost)[i * b.size() + j] = 1.0 - iou_plus1(ba, bb);
+    }
+  }
+}
+
+// matching.linear_assignment (matching.py:26-37) = lap.lapjv(extend_cost=True, cost_limit=thresh)
+int linear_assignment(const std::vector<double>& cost, int nr, int nc, double thresh,
+                      std::vector<std::pair<int, int>>* matches, std::vector<int>* ua, std::vector<int>* ub) {
+  matches->clear(); ua->clear(); ub->clear();
+  if (nr == 0 || nc == 0) {
+    for (int i = 0; i < nr; ++i) ua->push_back(i);
+    for (int j = 0; j < nc; ++j) ub->push_back(j);
+    return 0;
+  }
+  const int n = nr + nc;
+  std::vector<double> ext((size_t)n * n, thresh / 2.0);
+  for (int i = nr; i < n; ++i)
+    for (int j = nc; j < n; ++j) ext[(size_t)i * n + j] = 0.0;
+  for (int i = 0; i < nr; ++i)
+    for (int j = 0; j < nc; ++j) ext[(size_t)i * n + j] = cost[(size_t)i * nc + j];
+  std::vector<int> rows, cols;
+  if (lsap(ext.data(), n, n, &rows, &cols)) return 1;
+  std::vector<int> x(nr, -1), y(nc, -1);
+  for (size_t k = 0; k < rows.size(); ++k) {
+    const int r = rows[k], c = cols[k];
+    if (r < nr && c < nc) { x[r] = c; y[c] = r; }
+  }
+  for (int i = 0; i < nr; ++i) { if (x[i] >= 0) matches->emplace_back(i, x[i]); else ua->push_back(i); }
+  for (int j = 0; j < nc; ++j) if (y[j] < 0) ub->push_back(j);
+  return 0;
+}
+
+std::vector<STrkP> joint_stracks(const std::vector<STrkP>& a, const std::vector<STrkP>& b) {   // :345-356
+  std::set<int> seen; std::vector<STrkP> r;
+  for (auto& t : a) { seen.insert(t->id); r.push_back(t); }
+  for (auto& t : b) if (!seen.count(t->id)) { seen.insert(t->id); r.push_back(t); }
+  return r;
+}
+
+std::vector<STrkP> sub_stracks(const std::vector<STrkP>& a, const std::vector<STrkP>& b) {     // :358-367
+  // dict keyed by track_id (insertion order kept; a later duplicate id replaces the VALUE in place)
+  std::vector<int> order; std::map<int, STrkP> d;
+  for (auto& t : a) { if (!d.count(t->id)) order.push_back(t->id); d[t->id] = t; }
+  for (auto& t : b) d.erase(t->id);
+  std::vector<STrkP> r;
+  for (int id : order) { auto it = d.find(id); if (it != d.end()) r.push_back(it->second); }
+  return r;
+}
+
+}  // namespace
+}  // namespace odt
+
+struct odt_tmot {
+  double det_thresh, max_frame_lost, emb_max_dist, iou1, iou2;
+  float alpha;
+  int frame_id = 0;
+  std::vector<odt::STrkP> tracked, lost, removed, output;
+};
+
+extern "C" {
+
+int odt_tmot_create(double conf_thres, double track_max_second_lost, double emb_max_dist, double iou_max_dist1,
+                    double iou_max_dist2, double emb_smooth_alpha, double frame_gap, double frame_rate,
+                    odt_tmot_handle* out) {
+  ODT_CHECK(out != nullptr && frame_gap > 0, "odt_tmot_create: bad argument");
+  odt_tmot* t = new odt_tmot();
+  t->det_thresh = conf_thres;
+  t->max_frame_lost = track_max_second_lost * frame_rate / frame_gap;      // multitracker.py:187
+  t->emb_max_dist = emb_max_dist; t->iou1 = iou_max_dist1; t->iou2 = iou_max_dist2;
+  t->alpha = (float)emb_smooth_alpha;
+  *out = t;
+  return 0;
+}
+
+int odt_tmot_destroy(odt_tmot_handle t) { delete t; return 0; }
+
+int odt_tmot_reset(odt_tmot_handle t) {                                      // multitracker.py:198-206
+  ODT_CHECK(t != nullptr, "odt_tmot_reset: null handle");
+  t->tracked.clear(); t->lost.clear(); t->removed.clear(); t->output.clear();
+  t->frame_id = 0;
+  return 0;
+}
+
+// JDETracker.update (multitracker.py:208-343).  id_counter: BaseTrack._count, owned by the caller
+// because the reference shares it between all tracker instances of the process.
+int odt_tmot_update(odt_tmot_handle t, const double* tlwh, const double* conf, const float* feats, int n, int dim,
+                    int* id_counter, int* n_out) {
+  using namespace odt;
+  ODT_CHECK(t != nullptr && id_counter != nullptr, "odt_tmot_update: null argument");
+  ODT_CHECK(n == 0 || (tlwh && conf && feats && dim > 0), "odt_tmot_update: null detections");
+  t->frame_id += 1;
+  std::vector<STrkP> activated, refind, lost_now, removed_now;
+  std::vector<STrkP> dets;
+  for (int i = 0; i < n; ++i) {                                               // STrack.__init__
+    STrkP d(new STrk());
+    for (int k = 0; k < 4; ++k) { d->tlwh0[k] = tlwh[i * 4 + k]; d->det_tlwh[k] = tlwh[i * 4 + k]; }
+    d->score = conf[i]; d->det_conf = conf[i]; d->alpha = t->alpha;
+    update_features(*d, std::vector<float>(feats + (size_t)i * dim, feats + (size_t)(i + 1) * dim), nullptr);
+    dets.push_back(d);
+  }
+  std::vector<STrkP> unconfirmed, tracked;
+  for (auto& tr : t->tracked) (tr->activated ? tracked : unconfirmed).push_back(tr);
+  // ---- step 2: first association, embedding + motion
+  std::vector<STrkP> pool = joint_stracks(tracked, t->lost);
+  for (auto& tr : pool) {                                                     // multi_predict (:53-66)
+    if (tr->state != kTracked) tr->mean[7] = 0;
+    kf_predict(tr->mean, tr->cov);
+  }
+  std::vector<double> cost((size_t)pool.size() * dets.size(), 0.0);
+  const size_t nd = dets.size();
+  if (!pool.empty() && nd) {
+    for (size_t i = 0; i < pool.size(); ++i)                                  // matching.embedding_distance
+      for (size_t j = 0; j < nd; ++j) {
+        double s = 0.0;
+        const std::vector<float>& a = pool[i]->smooth; const std::vector<float>& b = dets[j]->curr;
+        for (size_t k = 0; k < a.size(); ++k) { const double d = (double)a[k] - (double)b[k]; s += d * d; }
+        cost[i * nd + j] = std::max(0.0, std::sqrt(s));
+      }
+    std::vector<double> meas(nd * 4), gd(nd);                                 // matching.fuse_motion
+    for (size_t j = 0; j < nd; ++j) { double b[4]; dets[j]->tlwh(b); tlwh_to_xyah(b, &meas[j * 4]); }
+    for (size_t i = 0; i < pool.size(); ++i) {
+      ODT_CHECK(kf_gating(pool[i]->mean, pool[i]->cov, meas.data(), (int)nd, gd.data()),
+                "tmot: projected covariance is not positive definite");
+      for (size_t j = 0; j < nd; ++j) {
+        if (gd[j] > kChi2_4) cost[i * nd + j] = std::numeric_limits<double>::infinity();
+        cost[i * nd + j] = 0.98 * cost[i * nd + j] + (1 - 0.98) * gd[j];
+      }
+    }
+  }
+  std::vector<std::pair<int, int>> matches; std::vector<int> u_track, u_det;
+  if (linear_assignment(cost, (int)pool.size(), (int)nd, t->emb_max_dist, &matches, &u_track, &u_det)) return 1;
+  auto do_update = [&](STrkP& tr, STrkP& det) {                              // STrack.update (:96-117)
+    tr->frame_id = t->frame_id; tr->tracklet_len += 1;
+    double z[4], b[4]; det->tlwh(b); tlwh_to_xyah(b, z);
+    if (!kf_update(tr->mean, tr->cov, z)) return 1;
+    tr->state = kTracked; tr->activated = true; tr->score = det->score;
+    update_features(*tr, det->curr, &det->curr);
+    for (int k = 0; k < 4; ++k) tr->det_tlwh[k] = det->det_tlwh[k];
+    tr->det_conf = det->det_conf;
+    return 0;
+  };
+  auto do_reactivate = [&](STrkP& tr, STrkP& det) {                          // STrack.re_activate (:80-94)
+    double z[4], b[4]; det->tlwh(b); tlwh_to_xyah(b, z);
+    if (!kf_update(tr->mean, tr->cov, z)) return 1;
+    update_features(*tr, det->curr, &det->curr);
+    tr->tracklet_len = 0; tr->state = kTracked; tr->activated = true; tr->frame_id = t->frame_id;
+    for (int k = 0; k < 4; ++k) tr->det_tlwh[k] = det->det_tlwh[k];
+    tr->det_conf = det->det_conf;
+    return 0;
+  };
+  for (auto& m : matches) {
+    STrkP& tr = pool[m.first]; STrkP& det = dets[m.second];
+    if (tr->state == kTracked) { ODT_CHECK(!do_update(tr, det), "tmot: Kalman update failed"); activated.push_back(tr); }
+    else { ODT_CHECK(!do_reactivate(tr, det), "tmot: Kalman update failed"); refind.push_back(tr); }
+  }
+  // ---- step 3: second association, IoU, tracked-but-unmatched only
+  std::vector<STrkP> dets2; for (int j : u_det) dets2.push_back(dets[j]);
+  std::vector<STrkP> r_tracked; for (int i : u_track) if (pool[i]->state == kTracked) r_tracked.push_back(pool[i]);
+  iou_distance(r_tracked, dets2, &cost);
+  if (linear_assignment(cost, (int)r_tracked.size(), (int)dets2.size(), t->iou1, &matches, &u_track, &u_det)) return 1;
+  for (auto& m : matches) {
+    STrkP& tr = r_tracked[m.first]; STrkP& det = dets2[m.second];
+    if (tr->state == kTracked) { ODT_CHECK(!do_update(tr, det), "tmot: Kalman update failed"); activated.push_back(tr); }
+    else { ODT_CHECK(!do_reactivate(tr, det), "tmot: Kalman update failed"); refind.push_back(tr); }
+  }
+  for (int i : u_track) {
+    STrkP& tr = r_tracked[i];
+    if (tr->state != kLost) { tr->state = kLost; lost_now.push_back(tr); }
+  }
+  // ---- unconfirmed tracks (one beginning frame)
+  std::vector<STrkP> dets3; for (int j : u_det) dets3.push_back(dets2[j]);
+  iou_distance(unconfirmed, dets3, &cost);
+  std::vector<int> u_unc;
+  if (linear_assignment(cost, (int)unconfirmed.size(), (int)dets3.size(), t->iou2, &matches, &u_unc, &u_det)) return 1;
+  for (auto& m : matches) {
+    ODT_CHECK(!do_update(unconfirmed[m.first], dets3[m.second]), "tmot: Kalman update failed");
+    activated.push_back(unconfirmed[m.first]);
+  }
+  for (int i : u_unc) { unconfirmed[i]->state = kRemoved; removed_now.push_back(unconfirmed[i]); }
+  // ---- step 4: new tracks
+  for (int j : u_det) {
+    STrkP& d = dets3[j];
+    if (d->score < t->det_thresh) continue;
+    d->id = ++(*id_counter);                                                  // activate (:68-78)
+    double z[4]; tlwh_to_xyah(d->tlwh0, z);
+    kf_initiate(z, d->mean, d->cov); d->has_kf = true;
+    d->tracklet_len = 0; d->state = kTracked; d->frame_id = t->frame_id; d->start_frame = t->frame_id;
+    activated.push_back(d);
+  }
+  // ---- step 5: state update
+  for (auto& tr : t->lost)
+    if (t->frame_id - tr->frame_id > t->max_frame_lost) { tr->state = kRemoved; removed_now.push_back(tr); }
+  std::vector<STrkP> keep;
+  for (auto& tr : t->tracked) if (tr->state == kTracked) keep.push_back(tr);
+  t->tracked = joint_stracks(joint_stracks(keep, activated), refind);
+  t->lost = sub_stracks(t->lost, t->tracked);
+  t->lost.insert(t->lost.end(), lost_now.begin(), lost_now.end());
+  t->lost = sub_stracks(t->lost, t->removed);
+  t->removed.insert(t->removed.end(), removed_now.begin(), removed_now.end());
+  {   // remove_duplicate_stracks (:369-383)
+    iou_distance(t->tracked, t->lost, &cost);
+    std::set<int> dupa, dupb;
+    const size_t nl = t->lost.size();
+    for (size_t p2 = 0; p2 < t->tracked.size(); ++p2)
+      for (size_t q = 0; q < nl; ++q)
+        if (cost[p2 * nl + q] < 0.15) {
+          const int timep = t->tracked[p2]->frame_id - t->tracked[p2]->start_frame;
+          const int timeq = t->lost[q]->frame_id - t->lost[q]->start_frame;
+          if (timep > timeq) dupb.insert((int)q); else dupa.insert((int)p2);
+        }
+    std::vector<STrkP> ra, rb;
+    for (size_t i = 0; i < t->tracked.size(); ++i) if (!dupa.count((int)i)) ra.push_back(t->tracked[i]);
+    for (size_t i = 0; i < nl; ++i) if (!dupb.count((int)i)) rb.push_back(t->lost[i]);
+    t->tracked.swap(ra); t->lost.swap(rb);
+  }
+  t->output.clear();
+  for (auto& tr : t->tracked) if (tr->activated) t->output.push_back(tr);
+  if (n_out) *n_out = (int)t->output.size();
+  return 0;
+}
+
+// which: 0 output_stracks of the last update, 1 tracked_stracks, 2 lost_stracks, 3 removed_stracks
+int odt_tmot_tracks(odt_tmot_handle t, int which, int cap, int32_t* ids, int32_t* state, int32_t* activated,
+                    double* tlwh, double* det_tlwh, double* det_conf, double* score, int32_t* tracklet_len,
+                    int32_t* start_frame, int32_t* frame_id, int* n) {
+  ODT_CHECK(t != nullptr && n != nullptr && which >= 0 && which <= 3, "odt_tmot_tracks: bad argument");
+  const std::vector<odt::STrkP>& v = which == 0 ? t->output : which == 1 ? t->tracked : which == 2 ? t->lost : t->removed;
+  *n = (int)v.size();
+  for (int i = 0; i < *n && i < cap; ++i) {
+    const odt::STrk& k = *v[i];
+    if (ids) ids[i] = k.id;
+    if (state) state[i] = k.state;
+    if (activated) activated[i] = k.activated ? 1 : 0;
+    if (tlwh) k.tlwh(tlwh + i * 4);
+    if (det_tlwh) std::memcpy(det_tlwh + i * 4, k.det_tlwh, 4 * sizeof(double));
+    if (det_conf) det_conf[i] = k.det_conf;
+    if (score) score[i] = k.score;
+    if (tracklet_len) tracklet_len[i] = k.tracklet_len;
+    if (start_frame) start_frame[i] = k.start_frame;
+    if (frame_id) frame_id[i] = k.frame_id;
   }
   return 0;
 }

@@ -109,3 +109,64 @@ def test_native_tracker_in_lockstep_with_reference(emu_lib):
       np.testing.assert_allclose(y.mean, x.mean, rtol=1e-8, atol=1e-8)
       np.testing.assert_allclose(y.covariance, x.covariance, rtol=1e-8, atol=1e-10)
   assert max(t.track_id for t in nat.tracks) > nobj    # births after deletions happened
+
+
+# ---- TMOT / JDE tracker core (tracker half) ---------------------------------
+def _tmot_replay(lib):
+  from object_detection_tracking_amd.tmot import BaseTrack, JDETracker
+  g = np.load(os.path.join(G, "tmot_ref.npz"))
+  BaseTrack._count = 0
+  trk = JDETracker(0.6, track_max_second_lost=2.0, emb_max_dist=0.7, iou_max_dist1=0.8, iou_max_dist2=0.9,
+                   emb_smooth_alpha=0.9, frame_gap=8., frame_rate=30., lib=lib)
+  o = t = 0
+  for fr, (n, nt) in enumerate(zip(g["seq_n"], g["out_n"])):
+    dets = [(g["seq_tlwh"][o + i].copy(), float(g["seq_conf"][o + i]), g["seq_feat"][o + i].copy())
+            for i in range(n)]
+    o += n
+    out = trk.update(dets)
+    want = g["out"][t:t + nt]; t += nt
+    assert len(out) == nt, (fr, len(out), nt)
+    got = np.asarray([[s.track_id] + list(s.tlwh) + list(s.cur_det_tlwh) + [s.cur_det_conf, s.score,
+                      s.tracklet_len, s.start_frame] for s in out]).reshape(-1, 13)
+    assert np.array_equal(got[:, 0], want[:, 0]), fr                       # identities, order
+    assert np.array_equal(got[:, 11:], want[:, 11:]), fr                   # tracklet_len, start_frame
+    np.testing.assert_allclose(got[:, 5:11], want[:, 5:11], rtol=0, atol=0)      # detection boxes / conf
+    np.testing.assert_allclose(got[:, 1:5], want[:, 1:5], rtol=1e-7, atol=1e-5)  # Kalman boxes
+  assert len(trk.lost_stracks) == int(g["n_lost"][0])
+  assert len(trk.removed_stracks) == int(g["n_removed"][0])
+
+
+def test_tmot_reproduces_reference_track_table(backend):
+  """tests/golden/tmot_ref.npz was produced by the reference's own tmot/multitracker.py
+  (tests/golden/make_tmot_golden.py; lap / cython_bbox / numba stubbed, see there)."""
+  name, lib = backend
+  _tmot_replay(lib)
+
+
+def test_tmot_in_lockstep_with_reference(emu_lib):
+  if not os.path.isdir(os.path.join(REF, "tmot")):
+    pytest.skip("/root/reference not present (GPU box)")
+  sys.path.insert(0, G)
+  import make_tmot_golden as mg
+  mg.install_stubs()
+  from tmot.multitracker import JDETracker as RefJDE
+  from tmot.basetrack import BaseTrack as RefBase
+  from object_detection_tracking_amd.tmot import BaseTrack, JDETracker
+  seq = mg.make_sequence(seed=23, nobj=14, frames=70, D=32)
+  RefBase._count = 0; BaseTrack._count = 0
+  kw = dict(track_max_second_lost=1.5, emb_max_dist=0.6, iou_max_dist1=0.7, iou_max_dist2=0.85,
+            emb_smooth_alpha=0.8, frame_gap=8., frame_rate=30.)
+  ref = RefJDE(0.55, **kw)
+  nat = JDETracker(0.55, lib=emu_lib, **kw)
+  for fr, dets in enumerate(seq):
+    a = ref.update([(t.copy(), c, f.copy()) for t, c, f in dets])
+    b = nat.update([(t.copy(), c, f.copy()) for t, c, f in dets])
+    assert [s.track_id for s in a] == [s.track_id for s in b], fr
+    assert [s.tracklet_len for s in a] == [s.tracklet_len for s in b], fr
+    for x, y in zip(a, b):
+      np.testing.assert_allclose(y.tlwh, x.tlwh, rtol=1e-7, atol=1e-5)
+      assert np.array_equal(y.cur_det_tlwh, x.cur_det_tlwh)
+    for lst in ("tracked_stracks", "lost_stracks"):
+      assert [s.track_id for s in getattr(ref, lst)] == [s.track_id for s in getattr(nat, lst)], (fr, lst)
+    assert len(ref.removed_stracks) == len(nat.removed_stracks)
+  assert RefBase._count == BaseTrack._count and BaseTrack._count > 14
