@@ -1,0 +1,132 @@
+"""Architecture arithmetic of the EfficientNet backbones the reference's EfficientDet uses
+(reference efficientdet/backbone/efficientnet_builder.py:37-53 model table, :162-168 block strings,
+efficientnet_model.py:137-159 round_filters / round_repeats, :520-577 block expansion,
+efficientdet_wrapper.py:511-587 D0..D7 -> backbone), variable names as the TF graph creates them
+(Keras layers named 'conv2d' / 'depthwise_conv2d' / 'tpu_batch_normalization', uniquified in call
+order inside each ``blocks_N`` scope), and a seeded synthetic weight generator with those names."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+# (width_coefficient, depth_coefficient)        efficientnet_builder.py:40-51
+_PARAMS = {"efficientnet-b0": (1.0, 1.0), "efficientnet-b1": (1.0, 1.1), "efficientnet-b2": (1.1, 1.2),
+           "efficientnet-b3": (1.2, 1.4), "efficientnet-b4": (1.4, 1.8), "efficientnet-b5": (1.6, 2.2),
+           "efficientnet-b6": (1.8, 2.6), "efficientnet-b7": (2.0, 3.1)}
+# (repeat, kernel, stride, expand, in, out)     efficientnet_builder.py:162-168 (se 0.25 everywhere)
+_BLOCKS = [(1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
+           (3, 5, 1, 6, 80, 112), (4, 5, 2, 6, 112, 192), (1, 3, 1, 6, 192, 320)]
+# efficientdet_wrapper.py:511-587
+EFFICIENTDET = {
+    "efficientdet-d0": dict(backbone="efficientnet-b0", image_size=512, fpn_num_filters=64, fpn_cell_repeats=3, box_class_repeats=3),
+    "efficientdet-d1": dict(backbone="efficientnet-b1", image_size=640, fpn_num_filters=88, fpn_cell_repeats=4, box_class_repeats=3),
+    "efficientdet-d2": dict(backbone="efficientnet-b2", image_size=768, fpn_num_filters=112, fpn_cell_repeats=5, box_class_repeats=3),
+    "efficientdet-d3": dict(backbone="efficientnet-b3", image_size=896, fpn_num_filters=160, fpn_cell_repeats=6, box_class_repeats=4),
+    "efficientdet-d4": dict(backbone="efficientnet-b4", image_size=1024, fpn_num_filters=224, fpn_cell_repeats=7, box_class_repeats=4),
+    "efficientdet-d5": dict(backbone="efficientnet-b5", image_size=1280, fpn_num_filters=288, fpn_cell_repeats=7, box_class_repeats=4),
+    "efficientdet-d6": dict(backbone="efficientnet-b6", image_size=1280, fpn_num_filters=384, fpn_cell_repeats=8, box_class_repeats=5),
+    "efficientdet-d7": dict(backbone="efficientnet-b6", image_size=1536, fpn_num_filters=384, fpn_cell_repeats=8, box_class_repeats=5),
+}
+
+
+def efficientnet_params(name):
+  return _PARAMS[name]
+
+
+def round_filters(filters, width, divisor=8):
+  """efficientnet_model.py:137-151."""
+  filters *= width
+  new = max(divisor, int(filters + divisor / 2) // divisor * divisor)
+  if new < 0.9 * filters:
+    new += divisor
+  return int(new)
+
+
+def round_repeats(repeats, depth):
+  """efficientnet_model.py:154-159."""
+  return int(math.ceil(depth * repeats))
+
+
+def backbone_spec(name):
+  """-> dict(stem=filters, blocks=[dict(idx, kernel, stride, expand, cin, cout, se, reduction)]).
+  ``reduction`` is the level (1..5) whose feature map this block's output is
+  (efficientnet_model.py:617-646: the last block before a stride-2 block, and the last block)."""
+  width, depth = _PARAMS[name]
+  blocks = []
+  for (r, k, s, e, i, o) in _BLOCKS:
+    cin, cout = round_filters(i, width), round_filters(o, width)
+    for rep in range(round_repeats(r, depth)):
+      blocks.append(dict(kernel=k, stride=s if rep == 0 else 1, expand=e, cin=cin if rep == 0 else cout,
+                         cout=cout, se=max(1, int((cin if rep == 0 else cout) * 0.25)), reduction=0))
+  red = 0
+  for idx, b in enumerate(blocks):
+    b["idx"] = idx
+    if idx == len(blocks) - 1 or blocks[idx + 1]["stride"] > 1:
+      red += 1
+      b["reduction"] = red
+  return dict(name=name, stem=round_filters(32, width), blocks=blocks)
+
+
+def backbone_variable_shapes(name):
+  """{variable name: shape} in the TF layouts (conv HWIO, depthwise [k,k,C,1])."""
+  sp = backbone_spec(name)
+  pre = name + "/"
+  v = {}
+  def bn(scope, c):
+    for s in ("gamma", "beta", "moving_mean", "moving_variance"):
+      v[scope + "/" + s] = (c,)
+  v[pre + "stem/conv2d/kernel"] = (3, 3, 3, sp["stem"])
+  bn(pre + "stem/tpu_batch_normalization", sp["stem"])
+  for b in sp["blocks"]:
+    p = pre + "blocks_%d/" % b["idx"]
+    mid = b["cin"] * b["expand"]
+    nconv = nbn = 0
+    def conv_name():
+      nonlocal nconv
+      n = "conv2d" if nconv == 0 else "conv2d_%d" % nconv
+      nconv += 1
+      return n
+    def bn_name():
+      nonlocal nbn
+      n = "tpu_batch_normalization" if nbn == 0 else "tpu_batch_normalization_%d" % nbn
+      nbn += 1
+      return n
+    if b["expand"] != 1:
+      v[p + conv_name() + "/kernel"] = (1, 1, b["cin"], mid)
+      bn(p + bn_name(), mid)
+    v[p + "depthwise_conv2d/depthwise_kernel"] = (b["kernel"], b["kernel"], mid, 1)
+    bn(p + bn_name(), mid)
+    v[p + "se/conv2d/kernel"] = (1, 1, mid, b["se"]); v[p + "se/conv2d/bias"] = (b["se"],)
+    v[p + "se/conv2d_1/kernel"] = (1, 1, b["se"], mid); v[p + "se/conv2d_1/bias"] = (mid,)
+    v[p + conv_name() + "/kernel"] = (1, 1, mid, b["cout"])
+    bn(p + bn_name(), b["cout"])
+  return v
+
+
+def synthetic_backbone_weights(name, seed=0):
+  """Seeded random-init weights with the TF names / layouts (He-style convs, BN close to identity,
+  the last BN gamma of every block damped so that the residual stream stays O(1))."""
+  rng = np.random.default_rng(seed)
+  w = {}
+  for k, shp in backbone_variable_shapes(name).items():
+    base = k.rsplit("/", 1)[1]
+    if base in ("kernel", "depthwise_kernel"):
+      fan_in = shp[0] * shp[1] * (shp[2] if base == "kernel" else 1)
+      w[k] = (rng.standard_normal(shp) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+    elif base == "bias":
+      w[k] = (rng.standard_normal(shp) * 0.1).astype(np.float32)
+    elif base == "gamma":
+      w[k] = rng.uniform(0.8, 1.2, shp).astype(np.float32)
+    elif base == "beta":
+      w[k] = (rng.standard_normal(shp) * 0.05).astype(np.float32)
+    elif base == "moving_mean":
+      w[k] = (rng.standard_normal(shp) * 0.05).astype(np.float32)
+    elif base == "moving_variance":
+      w[k] = rng.uniform(0.8, 1.2, shp).astype(np.float32)
+  sp = backbone_spec(name)
+  for b in sp["blocks"]:                       # damp the projection BN of residual blocks
+    nbn = 2 if b["expand"] != 1 else 1
+    g = "%s/blocks_%d/tpu_batch_normalization%s/gamma" % (name, b["idx"], "_%d" % nbn if nbn else "")
+    w[g] = (w[g] * 0.4).astype(np.float32)
+  return w
