@@ -35,6 +35,7 @@ typedef struct odt_model* odt_handle;
 /* graph semantics: the reference ships two different inference graphs */
 #define ODT_GRAPH_SINGLE 0 /* Mask_RCNN_FPN        (models.py:488-973)   b = 1 */
 #define ODT_GRAPH_MULTI 1  /* Mask_RCNN_FPN_multi  (models.py:2058-2408) b = B */
+#define ODT_GRAPH_EFFNET 2   /* EfficientNet backbone of the EfficientDet path (work in progress: features via odt_tap) */
 
 /* Mirrors the fields of the reference's `args`/config namespace that the
  * inference graph reads (obj_detect_tracking.py:303-387). */
@@ -58,6 +59,7 @@ typedef struct odt_config {
   float head_nms_thresh;    /* fastrcnn_nms_iou_thres (0.5)                   */
   int32_t add_mask;         /* --add_mask: Mask R-CNN head on the final boxes (models.py:932-962); single-image graph */
   int32_t mask_dim;         /* mrcnn_head_dim (256)                           */
+  int32_t eff_backbone;     /* ODT_GRAPH_EFFNET: 0..7 = efficientnet-b0..b7 (efficientdet_wrapper.py:511-587) */
 } odt_config;
 
 /* Caller-owned host output buffers (capacities in elements of the row type).

@@ -22,7 +22,7 @@ c_i64_p = C.POINTER(C.c_int64)
 c_double_p = C.POINTER(C.c_double)
 
 ODT_DTYPE_U8, ODT_DTYPE_F32 = 0, 1
-ODT_GRAPH_SINGLE, ODT_GRAPH_MULTI = 0, 1
+ODT_GRAPH_SINGLE, ODT_GRAPH_MULTI, ODT_GRAPH_EFFNET = 0, 1, 2
 RPN_CH = 16
 
 
@@ -37,6 +37,7 @@ class OdtConfig(C.Structure):
       ("rpn_decode_clip", C.c_float), ("head_decode_clip", C.c_float),
       ("bbox_reg_weights", C.c_float * 4), ("result_score_thresh", C.c_float),
       ("head_nms_thresh", C.c_float), ("add_mask", C.c_int32), ("mask_dim", C.c_int32),
+      ("eff_backbone", C.c_int32),
   ]
 
 

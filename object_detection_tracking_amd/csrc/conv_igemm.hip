@@ -510,8 +510,8 @@ __global__ void __launch_bounds__(256, ST == 1 ? 3 : 2) conv_igemm_kernel(const 
     // buffer stores with out-of-range offsets for the masked chunks.  The relu flag is
     // unswitched so that the pass bodies have no control flow (the waitcnt placement stays
     // exact: one vmcnt wait for the residual tile, none between the stores).
-    auto run = [&](auto relu_c) {
-      constexpr bool RELU = decltype(relu_c)::value;
+    auto run = [&](auto act_c) {
+      constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
       for (int pass = 0; pass < PASSES; ++pass) {
         stage_pass(pass);
@@ -526,16 +526,25 @@ __global__ void __launch_bounds__(256, ST == 1 ? 3 : 2) conv_igemm_kernel(const 
           f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[(row0 + s2 * (256 / C4)) * CS + c4 * 4]);
           v += bias4;
           v += rv[pass][s2];
-          if (RELU) {
+          if (ACT == 1) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          } else if (ACT == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f / (1.0f + expf(-v[e])));
+          } else if (ACT == 3) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
           }
           __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)ooff, 0, 0);
         }
         if (pass == 0) stamp(4);
       }
     };
-    if (p.relu) run(std::true_type{}); else run(std::false_type{});
+    if (p.relu == 1) run(std::integral_constant<int, 1>{});
+    else if (p.relu == 2) run(std::integral_constant<int, 2>{});
+    else if (p.relu == 3) run(std::integral_constant<int, 3>{});
+    else run(std::integral_constant<int, 0>{});
   } else {
     // ---- generic path (Cout % 4 != 0 or unaligned pixel strides): scalar tails
     for (int pass = 0; pass < PASSES; ++pass) {
@@ -564,9 +573,11 @@ __global__ void __launch_bounds__(256, ST == 1 ? 3 : 2) conv_igemm_kernel(const 
           const float* rp = p.res + rpix * p.res_ldc + col;
           for (int e = 0; e < nv; ++e) v[e] += rp[e];
         }
-        if (p.relu) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        for (int e = 0; e < 4; ++e) {
+          if (p.relu == 1) v[e] = fmaxf(v[e], 0.f);
+          else if (p.relu == 2) v[e] = v[e] * (1.0f / (1.0f + expf(-v[e])));
+          else if (p.relu == 3) v[e] = 1.0f / (1.0f + expf(-v[e]));
         }
         float* op = p.out + opix * p.out_ldc + col;
         for (int e = 0; e < nv; ++e) op[e] = v[e];

@@ -1,0 +1,182 @@
+// EfficientNet building blocks on gfx950 (HBM-bound elementwise / stencil kernels; the 1x1 convs of
+// the MBConv blocks run on conv_igemm_kernel).  NHWC fp32, channel counts padded to a multiple of
+// 32 with zero channels (ldc) so that every tensor feeds the implicit-GEMM kernel directly.
+//
+// Restates reference efficientdet/backbone/efficientnet_model.py:162-330 (MBConvBlock: depthwise
+// kxk 'same' conv + BN + swish, squeeze-excite = spatial mean -> 1x1 reduce + swish -> 1x1 expand ->
+// sigmoid -> channel scale) and efficientdet_wrapper.py:45-60 + dataloader.normalize_image (BGR ->
+// RGB, [0,1], ImageNet mean / std).  Built with -ffp-contract=off; summation orders are fixed
+// (no atomics): bit-deterministic run to run.
+#include "odt_common.hpp"
+
+namespace odt {
+namespace {
+
+inline unsigned grid_for(long total) {
+  long g = (total + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+__device__ __forceinline__ float swishf(float x) { return x * (1.0f / (1.0f + expf(-x))); }
+
+// uint8 / float32 BGR frames -> normalised RGB, HWC4, zero padded (pad_t/pad_l = TF 'SAME' pads of
+// the stride-2 stem; the 4th channel and the padding are zero)
+template <typename T>
+__global__ void __launch_bounds__(256) preprocess_rgb_kernel(const T* __restrict__ frames, int B, int H, int W,
+                                                             int pad_t, int pad_l, int Hp, int Wp,
+                                                             float* __restrict__ out) {
+  const long total = (long)B * Hp * Wp;
+  const float mean_r = 0.485f, mean_g = 0.456f, mean_b = 0.406f;
+  const float std_r = 0.229f, std_g = 0.224f, std_b = 0.225f;
+  const float inv255 = (float)(1.0 / 255);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wp);
+    const long t = i / Wp;
+    const int y = (int)(t % Hp), b = (int)(t / Hp);
+    const int sy = y - pad_t, sx = x - pad_l;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) {
+      const T* src = frames + (((long)b * H + sy) * W + sx) * 3;       // B, G, R
+      v[0] = ((float)src[2] * inv255 - mean_r) / std_r;
+      v[1] = ((float)src[1] * inv255 - mean_g) / std_g;
+      v[2] = ((float)src[0] * inv255 - mean_b) / std_b;
+    }
+    *reinterpret_cast<f32x4*>(out + i * 4) = v;
+  }
+}
+
+// depthwise k x k conv (k = 3 or 5), TF 'SAME' padding, stride 1 or 2, folded BN, optional swish.
+// One thread = 4 channels of one output pixel (16-byte accesses, channels innermost).
+template <int K>
+__global__ void __launch_bounds__(256) dwconv_kernel(DwConvParams p) {
+  const int c4n = p.ldc >> 2;
+  const long total = (long)p.B * p.Ho * p.Wo * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    long t = i / c4n;
+    const int xo = (int)(t % p.Wo); t /= p.Wo;
+    const int yo = (int)(t % p.Ho);
+    const int b = (int)(t / p.Ho);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int y = yo * p.stride + ky - p.pad_t;
+      if ((unsigned)y >= (unsigned)p.H) continue;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const int x = xo * p.stride + kx - p.pad_l;
+        if ((unsigned)x >= (unsigned)p.W) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p.in + (((long)b * p.H + y) * p.W + x) * p.ldc + c4 * 4);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(p.wt + (long)(ky * K + kx) * p.ldc + c4 * 4);
+        acc += v * w;
+      }
+    }
+    acc += *reinterpret_cast<const f32x4*>(p.bias + c4 * 4);
+    if (p.act == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = swishf(acc[e]);
+    }
+    *reinterpret_cast<f32x4*>(p.out + (((long)b * p.Ho + yo) * p.Wo + xo) * p.ldc + c4 * 4) = acc;
+  }
+}
+
+// spatial mean per (image, channel), two deterministic stages: (1) every workgroup (image, 64-channel
+// group, pixel split) sums its pixel range with 4 phases x 64 channels and a fixed tree over the
+// phases; (2) the splits are added in index order and divided by HW.
+__global__ void __launch_bounds__(256) channel_sum_kernel(const float* __restrict__ in, int HW, int ldc, int nsplit,
+                                                          float* __restrict__ part_out) {
+  // thread = (channel quad cq of the 64-channel group, pixel phase ph of 16): 16-byte loads
+  __shared__ f32x4 part[16][16];
+  const int b = blockIdx.y, cq = threadIdx.x & 15, ph = threadIdx.x >> 4, sp = blockIdx.z;
+  const int c = blockIdx.x * 64 + cq * 4;
+  const int per = (HW + nsplit - 1) / nsplit;
+  const int lo = sp * per, hi = lo + per < HW ? lo + per : HW;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (c < ldc) {
+    const float* src = in + (long)b * HW * ldc + c;
+    for (int i = lo + ph; i < hi; i += 16) s += *reinterpret_cast<const f32x4*>(src + (long)i * ldc);
+  }
+  part[ph][cq] = s;
+  __syncthreads();
+  if (ph == 0 && c < ldc) {
+    f32x4 t = part[0][cq];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += part[q][cq];        // fixed order
+    *reinterpret_cast<f32x4*>(part_out + ((long)b * nsplit + sp) * ldc + c) = t;
+  }
+}
+
+__global__ void __launch_bounds__(256) channel_mean_final_kernel(const float* __restrict__ part, int B, int ldc,
+                                                                 int nsplit, int HW, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * ldc) return;
+  const int b = i / ldc, c = i - b * ldc;
+  float s = 0.f;
+  for (int sp = 0; sp < nsplit; ++sp) s += part[((long)b * nsplit + sp) * ldc + c];
+  out[i] = s / (float)HW;
+}
+
+// x[b, :, :, c] *= s[b, c]   (squeeze-excite gate, already passed through the sigmoid)
+__global__ void __launch_bounds__(256) channel_scale_kernel(float* __restrict__ x, const float* __restrict__ s,
+                                                            int B, int HW, int ldc) {
+  const int c4n = ldc >> 2;
+  const long total = (long)B * HW * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    const int b = (int)(i / ((long)HW * c4n));
+    f32x4* q = reinterpret_cast<f32x4*>(x + i * 4);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(s + (long)b * ldc + c4 * 4);
+    *q = *q * g;
+  }
+}
+
+}  // namespace
+
+int launch_preprocess_rgb(const void* frames, int dtype, int B, int H, int W, int pad_t, int pad_l, int Hp, int Wp,
+                          float* out, hipStream_t stream) {
+  const long total = (long)B * Hp * Wp;
+  if (dtype == 0)
+    hipLaunchKernelGGL(preprocess_rgb_kernel<unsigned char>, dim3(grid_for(total)), dim3(256), 0, stream,
+                       (const unsigned char*)frames, B, H, W, pad_t, pad_l, Hp, Wp, out);
+  else if (dtype == 1)
+    hipLaunchKernelGGL(preprocess_rgb_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream,
+                       (const float*)frames, B, H, W, pad_t, pad_l, Hp, Wp, out);
+  else { set_error("preprocess: dtype must be ODT_DTYPE_U8 or ODT_DTYPE_F32"); return 1; }
+  ODT_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_dwconv(const DwConvParams& p, hipStream_t stream) {
+  ODT_CHECK(p.ldc % 4 == 0 && (p.k == 3 || p.k == 5) && (p.stride == 1 || p.stride == 2), "dwconv: bad geometry");
+  const long total = (long)p.B * p.Ho * p.Wo * (p.ldc >> 2);
+  if (p.k == 3) hipLaunchKernelGGL(dwconv_kernel<3>, dim3(grid_for(total)), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(dwconv_kernel<5>, dim3(grid_for(total)), dim3(256), 0, stream, p);
+  ODT_HIP(hipGetLastError());
+  return 0;
+}
+
+int channel_mean_splits(int HW) {
+  int n = (HW + 511) / 512;
+  return n < 1 ? 1 : (n > 1024 ? 1024 : n);
+}
+
+// scratch: [B, channel_mean_splits(HW), ldc] floats
+int launch_channel_mean(const float* in, int B, int HW, int ldc, float* scratch, float* out, hipStream_t stream) {
+  const int ns = channel_mean_splits(HW);
+  hipLaunchKernelGGL(channel_sum_kernel, dim3((ldc + 63) / 64, B, ns), dim3(256), 0, stream, in, HW, ldc, ns, scratch);
+  hipLaunchKernelGGL(channel_mean_final_kernel, dim3((B * ldc + 255) / 256), dim3(256), 0, stream,
+                     (const float*)scratch, B, ldc, ns, HW, out);
+  ODT_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_channel_scale(float* x, const float* s, int B, int HW, int ldc, hipStream_t stream) {
+  const long total = (long)B * HW * (ldc >> 2);
+  hipLaunchKernelGGL(channel_scale_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, s, B, HW, ldc);
+  ODT_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace odt

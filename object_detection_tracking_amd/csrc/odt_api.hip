@@ -59,11 +59,15 @@ struct ConvOp {
 };
 
 enum OpKind { OP_PRE, OP_CONV, OP_POOL, OP_SUB2, OP_PROPOSALS, OP_ROI_HEAD, OP_DETECT, OP_ROI_FINAL,
-              OP_ROI_MASK, OP_MASK_SELECT };
+              OP_ROI_MASK, OP_MASK_SELECT, OP_PRE_RGB, OP_DW, OP_CMEAN, OP_CSCALE };
 struct Op {
   OpKind kind;
   int conv = -1;        // index into convs
   Tensor in, out;
+  DwConvParams dw{};    // OP_DW
+  float* aux = nullptr; // OP_CMEAN: means out [B,ldc]; OP_CSCALE: gates in [B,ldc]
+  float* aux2 = nullptr;   // OP_CMEAN: partial-sum scratch
+  int pad_t = 0, pad_l = 0;   // OP_PRE_RGB
 };
 
 }  // namespace
@@ -266,6 +270,204 @@ int add_conv(odt_model* m, const std::string& name, const Tensor& in, int cin, c
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// EfficientNet backbone plan (EfficientDet path, SURVEY.md 8f rank 3 -- detector half in progress).
+// reference efficientdet/backbone/efficientnet_builder.py:37-53,162-168, efficientnet_model.py:137-159,
+// :162-330, :520-650.  Tensors are NHWC with the channel stride padded to a multiple of 32 (zero pad
+// channels) so that every 1x1 conv feeds conv_igemm_kernel; BN (epsilon 1e-3) is folded on the host.
+int r32(int c) { return (c + 31) / 32 * 32; }
+
+int eff_round_filters(int f, double width) {
+  const double x = f * width;
+  int nf = std::max(8, (int)(x + 4) / 8 * 8);
+  if (nf < 0.9 * x) nf += 8;
+  return nf;
+}
+
+struct EffBlock { int idx, kernel, stride, expand, cin, cout, se, reduction; };
+
+std::vector<EffBlock> eff_blocks(int variant, int* stem) {
+  static const double WD[8][2] = {{1.0, 1.0}, {1.0, 1.1}, {1.1, 1.2}, {1.2, 1.4}, {1.4, 1.8}, {1.6, 2.2}, {1.8, 2.6}, {2.0, 3.1}};
+  static const int BL[7][6] = {{1, 3, 1, 1, 32, 16}, {2, 3, 2, 6, 16, 24}, {2, 5, 2, 6, 24, 40}, {3, 3, 2, 6, 40, 80},
+                               {3, 5, 1, 6, 80, 112}, {4, 5, 2, 6, 112, 192}, {1, 3, 1, 6, 192, 320}};
+  const double w = WD[variant][0], d = WD[variant][1];
+  *stem = eff_round_filters(32, w);
+  std::vector<EffBlock> v;
+  for (const auto& b : BL) {
+    const int cin = eff_round_filters(b[4], w), cout = eff_round_filters(b[5], w);
+    const int reps = (int)std::ceil(d * b[0] - 1e-9);
+    for (int r = 0; r < reps; ++r) {
+      EffBlock e;
+      e.idx = (int)v.size(); e.kernel = b[1]; e.stride = r == 0 ? b[2] : 1; e.expand = b[3];
+      e.cin = r == 0 ? cin : cout; e.cout = cout; e.se = std::max(1, (int)(e.cin * 0.25)); e.reduction = 0;
+      v.push_back(e);
+    }
+  }
+  int red = 0;
+  for (size_t i = 0; i < v.size(); ++i)
+    if (i + 1 == v.size() || v[i + 1].stride > 1) v[i].reduction = ++red;
+  return v;
+}
+
+// BN fold factors of a Keras BatchNormalization scope (gamma, beta, moving_mean, moving_variance)
+int eff_bn(odt_model* m, const std::string& scope, int c, std::vector<double>* scale, std::vector<double>* shift) {
+  const HostTensor* g = find_w(m, scope + "/gamma"); const HostTensor* b = find_w(m, scope + "/beta");
+  const HostTensor* mu = find_w(m, scope + "/moving_mean"); const HostTensor* var = find_w(m, scope + "/moving_variance");
+  ODT_CHECK(g && b && mu && var, "missing BN variables for " + scope);
+  ODT_CHECK((int)g->data.size() == c && (int)var->data.size() == c, "bad BN shape for " + scope);
+  scale->resize(c); shift->resize(c);
+  for (int o = 0; o < c; ++o) {
+    const double inv = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-3);
+    (*scale)[o] = inv; (*shift)[o] = (double)b->data[o] - (double)mu->data[o] * inv;
+  }
+  return 0;
+}
+
+// 1x1 conv weights [1,1,cin,cout] (+ BN scope or bias) -> device [cout][cin_pad] + bias[cout]
+int eff_upload_pw(odt_model* m, const std::string& conv, const std::string& bn_scope, bool has_bias, int cin,
+                  int cin_pad, int cout, const float** wt_out, const float** bias_out) {
+  const HostTensor* W = find_w(m, conv + "/kernel");
+  ODT_CHECK(W != nullptr && W->data.size() == (size_t)cin * cout, "missing / bad " + conv + "/kernel");
+  std::vector<double> scale(cout, 1.0), shift(cout, 0.0);
+  if (!bn_scope.empty() && eff_bn(m, bn_scope, cout, &scale, &shift)) return 1;
+  if (has_bias) {
+    const HostTensor* b = find_w(m, conv + "/bias");
+    ODT_CHECK(b != nullptr && (int)b->data.size() == cout, "missing / bad " + conv + "/bias");
+    for (int o = 0; o < cout; ++o) shift[o] += (double)b->data[o] * scale[o];
+  }
+  std::vector<float> wt((size_t)cout * cin_pad, 0.f), bias(cout);
+  for (int o = 0; o < cout; ++o) {
+    for (int i = 0; i < cin; ++i) wt[(size_t)o * cin_pad + i] = (float)((double)W->data[(size_t)i * cout + o] * scale[o]);
+    bias[o] = (float)shift[o];
+  }
+  if (upload_raw(m, wt, wt_out) || upload_raw(m, bias, bias_out)) return 1;
+  return 0;
+}
+
+int build_plan_effnet(odt_model* m) {
+  const odt_config& cfg = m->cfg;
+  const int B = cfg.batch, H = cfg.height, W = cfg.width;
+  ODT_CHECK(cfg.eff_backbone >= 0 && cfg.eff_backbone <= 7, "odt_create: eff_backbone must be 0..7");
+  const std::string name = "efficientnet-b" + std::to_string(cfg.eff_backbone);
+  int stemC = 0;
+  const std::vector<EffBlock> blocks = eff_blocks(cfg.eff_backbone, &stemC);
+  auto same = [](int n, int k, int s, int* out, int* before) {
+    *out = (n + s - 1) / s;
+    const int tot = std::max((*out - 1) * s + k - n, 0);
+    *before = tot / 2;
+    return tot;
+  };
+  // ---- input: normalised RGB, HWC4, physically padded with the stem's 'SAME' pads
+  int Ho, Wo, pt, pl;
+  const int ph = same(H, 3, 2, &Ho, &pt), pw = same(W, 3, 2, &Wo, &pl);
+  m->Hp = H + ph; m->Wp = std::max(W + pw, 2 * (Wo - 1) + 8);
+  if (make_tensor(m, "image_pad", B, m->Hp, m->Wp, 4, &m->image_pad, true)) return 1;
+  m->frames_bytes = (size_t)B * H * W * 3 * sizeof(float);
+  m->src_h = H; m->src_w = W;
+  { m->bufs.emplace_back(new DevBuf()); if (m->bufs.back()->alloc(m->frames_bytes)) return 1;
+    m->frames_dev.d = (float*)m->bufs.back()->p; }
+  { Op op; op.kind = OP_PRE_RGB; op.pad_t = pt; op.pad_l = pl; m->ops.push_back(op); }
+  // ---- stem: 3x3 s2 conv as a 3x1 conv over 8-pixel x 4-channel rows (K = 3 * 32), BN, swish
+  const float *wt = nullptr, *bias = nullptr;
+  {
+    const HostTensor* W0 = find_w(m, name + "/stem/conv2d/kernel");
+    ODT_CHECK(W0 && W0->data.size() == (size_t)3 * 3 * 3 * stemC, "missing / bad " + name + "/stem/conv2d/kernel");
+    std::vector<double> scale, shift;
+    if (eff_bn(m, name + "/stem/tpu_batch_normalization", stemC, &scale, &shift)) return 1;
+    std::vector<float> v((size_t)stemC * 3 * 32, 0.f), bv(stemC);
+    for (int o = 0; o < stemC; ++o) {
+      for (int y = 0; y < 3; ++y) for (int x = 0; x < 3; ++x) for (int c = 0; c < 3; ++c)
+        v[((size_t)o * 3 + y) * 32 + x * 4 + c] = (float)((double)W0->data[(((size_t)y * 3 + x) * 3 + c) * stemC + o] * scale[o]);
+      bv[o] = (float)shift[o];
+    }
+    if (upload_raw(m, v, &wt) || upload_raw(m, bv, &bias)) return 1;
+  }
+  Tensor x{};
+  if (add_conv(m, "stem", m->image_pad, 32, wt, bias, 3, 1, stemC, 2, 1, 0, 0, Ho, Wo, 0, 0, nullptr, 0, false,
+               r32(stemC), &x, "stem")) return 1;
+  m->convs.back().p.relu = 2;
+  // ---- MBConv blocks
+  for (const EffBlock& b : blocks) {
+    const std::string p = name + "/blocks_" + std::to_string(b.idx) + "/";
+    const int mid = b.cin * b.expand, lmid = r32(mid);
+    int nconv = 0, nbn = 0;
+    auto cname = [&]() { const std::string n = nconv == 0 ? "conv2d" : "conv2d_" + std::to_string(nconv); ++nconv; return p + n; };
+    auto bname = [&]() { const std::string n = nbn == 0 ? "tpu_batch_normalization" : "tpu_batch_normalization_" + std::to_string(nbn); ++nbn; return p + n; };
+    const Tensor inp = x;
+    Tensor t1 = x;
+    if (b.expand != 1) {
+      const std::string cn = cname(), bn = bname();
+      if (eff_upload_pw(m, cn, bn, false, b.cin, x.C, mid, &wt, &bias)) return 1;
+      t1 = Tensor{};
+      if (add_conv(m, cn, x, x.C, wt, bias, 1, 1, mid, 1, 1, 0, 0, x.h, x.w, 0, 0, nullptr, 0, false, lmid, &t1, "")) return 1;
+      m->convs.back().p.relu = 2;
+    }
+    // depthwise + BN + swish
+    int ho, wo, dpt, dpl;
+    same(x.h, b.kernel, b.stride, &ho, &dpt); same(x.w, b.kernel, b.stride, &wo, &dpl);
+    Tensor t2{};
+    if (make_tensor(m, "", B, ho, wo, lmid, &t2, true)) return 1;
+    {
+      const HostTensor* Wd = find_w(m, p + "depthwise_conv2d/depthwise_kernel");
+      ODT_CHECK(Wd && Wd->data.size() == (size_t)b.kernel * b.kernel * mid, "missing / bad " + p + "depthwise_conv2d/depthwise_kernel");
+      std::vector<double> scale, shift;
+      if (eff_bn(m, bname(), mid, &scale, &shift)) return 1;
+      std::vector<float> v((size_t)b.kernel * b.kernel * lmid, 0.f), bv(lmid, 0.f);
+      for (int t = 0; t < b.kernel * b.kernel; ++t)
+        for (int c = 0; c < mid; ++c) v[(size_t)t * lmid + c] = (float)((double)Wd->data[(size_t)t * mid + c] * scale[c]);
+      for (int c = 0; c < mid; ++c) bv[c] = (float)shift[c];
+      const float *dwt, *dbias;
+      if (upload_raw(m, v, &dwt) || upload_raw(m, bv, &dbias)) return 1;
+      Op op; op.kind = OP_DW;
+      op.dw.in = t1.d; op.dw.wt = dwt; op.dw.bias = dbias; op.dw.out = t2.d;
+      op.dw.B = B; op.dw.H = t1.h; op.dw.W = t1.w; op.dw.Ho = ho; op.dw.Wo = wo; op.dw.ldc = lmid;
+      op.dw.k = b.kernel; op.dw.stride = b.stride; op.dw.pad_t = dpt; op.dw.pad_l = dpl; op.dw.act = 2;
+      m->ops.push_back(op);
+    }
+    // squeeze-excite: mean -> reduce (swish) -> expand (sigmoid) -> scale
+    {
+      float* mean = m->alloc_f((size_t)B * lmid, true);
+      ODT_CHECK(mean != nullptr, "device allocation failed (SE)");
+      float* scratch = m->alloc_f((size_t)B * channel_mean_splits(ho * wo) * lmid, false);
+      ODT_CHECK(scratch != nullptr, "device allocation failed (SE scratch)");
+      { Op op; op.kind = OP_CMEAN; op.in = t2; op.aux = mean; op.aux2 = scratch; m->ops.push_back(op); }
+      Tensor ms{}; ms.d = mean; ms.B = B; ms.H = ms.h = 1; ms.W = ms.w = 1; ms.C = lmid; ms.c = mid;
+      const int lse = r32(b.se);
+      if (eff_upload_pw(m, p + "se/conv2d", "", true, mid, lmid, b.se, &wt, &bias)) return 1;
+      Tensor s1{};
+      if (add_conv(m, p + "se/conv2d", ms, lmid, wt, bias, 1, 1, b.se, 1, 1, 0, 0, 1, 1, 0, 0, nullptr, 0, false, lse, &s1, "")) return 1;
+      m->convs.back().p.relu = 2;
+      if (eff_upload_pw(m, p + "se/conv2d_1", "", true, b.se, lse, mid, &wt, &bias)) return 1;
+      Tensor s2{};
+      if (add_conv(m, p + "se/conv2d_1", s1, lse, wt, bias, 1, 1, mid, 1, 1, 0, 0, 1, 1, 0, 0, nullptr, 0, false, lmid, &s2, "")) return 1;
+      m->convs.back().p.relu = 3;
+      { Op op; op.kind = OP_CSCALE; op.in = t2; op.aux = s2.d; m->ops.push_back(op); }
+    }
+    // projection + BN (+ identity skip)
+    {
+      const std::string cn = cname(), bn = bname();
+      if (eff_upload_pw(m, cn, bn, false, mid, lmid, b.cout, &wt, &bias)) return 1;
+      const bool skip = b.stride == 1 && b.cin == b.cout;
+      Tensor y{};
+      std::string tap = "block_" + std::to_string(b.idx);
+      if (add_conv(m, cn, t2, lmid, wt, bias, 1, 1, b.cout, 1, 1, 0, 0, ho, wo, 0, 0, skip ? &inp : nullptr, 1, false,
+                   r32(b.cout), &y, tap)) return 1;
+      if (b.reduction) m->taps["reduction_" + std::to_string(b.reduction)] = y;
+      x = y;
+    }
+  }
+  {   // conv parameter records in device memory
+    std::vector<ConvParams> recs;
+    for (const ConvOp& c : m->convs) recs.push_back(c.p);
+    m->bufs.emplace_back(new DevBuf());
+    if (m->bufs.back()->alloc(recs.size() * sizeof(ConvParams))) return 1;
+    m->convs_dev = (ConvParams*)m->bufs.back()->p;
+    ODT_HIP(hipMemcpy(m->convs_dev, recs.data(), recs.size() * sizeof(ConvParams), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -281,11 +483,14 @@ int odt_device_count(int* count) {
 int odt_create(const odt_config* cfg, int device, odt_handle* out) {
   ODT_CHECK(cfg && out, "odt_create: null argument");
   ODT_CHECK(cfg->batch >= 1 && cfg->height >= 64 && cfg->width >= 64, "odt_create: bad geometry");
-  ODT_CHECK(cfg->rpn_topk >= 1 && cfg->rpn_topk <= kMaxTopK, "odt_create: rpn_topk must be in [1,1024]");
-  ODT_CHECK(cfg->fpn_channels % 32 == 0 && cfg->head_dim % 32 == 0, "odt_create: channel counts must be multiples of 32");
-  ODT_CHECK(cfg->graph == ODT_GRAPH_SINGLE || cfg->graph == ODT_GRAPH_MULTI, "odt_create: bad graph");
-  ODT_CHECK(cfg->graph == ODT_GRAPH_MULTI || cfg->batch == 1,
-            "odt_create: the Mask_RCNN_FPN graph is single-image (obj_detect_tracking.py:241-242)");
+  ODT_CHECK(cfg->graph == ODT_GRAPH_SINGLE || cfg->graph == ODT_GRAPH_MULTI || cfg->graph == ODT_GRAPH_EFFNET,
+            "odt_create: bad graph");
+  if (cfg->graph != ODT_GRAPH_EFFNET) {
+    ODT_CHECK(cfg->rpn_topk >= 1 && cfg->rpn_topk <= kMaxTopK, "odt_create: rpn_topk must be in [1,1024]");
+    ODT_CHECK(cfg->fpn_channels % 32 == 0 && cfg->head_dim % 32 == 0, "odt_create: channel counts must be multiples of 32");
+    ODT_CHECK(cfg->graph == ODT_GRAPH_MULTI || cfg->batch == 1,
+              "odt_create: the Mask_RCNN_FPN graph is single-image (obj_detect_tracking.py:241-242)");
+  }
   int n = 0;
   ODT_HIP(hipGetDeviceCount(&n));
   ODT_CHECK(device >= 0 && device < n, "odt_create: no such device");
@@ -337,6 +542,7 @@ namespace {
 // Build the whole static plan (called from odt_finalize_weights).
 int build_plan(odt_model* m) {
   const odt_config& cfg = m->cfg;
+  if (cfg.graph == ODT_GRAPH_EFFNET) return build_plan_effnet(m);
   const int B = cfg.batch, H = cfg.height, W = cfg.width;
   const int FC = cfg.fpn_channels;
   // ---- front end geometry (nn.py:860-896; tf_pad_reverse => pad [3, 2 + pad_to_32])
@@ -763,6 +969,19 @@ int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStre
       case OP_ROI_MASK:
         if (launch_roi_align(m->roi_mask, st)) return 1;
         break;
+      case OP_PRE_RGB:
+        if (launch_preprocess_rgb(src, dtype, cfg.batch, cfg.height, cfg.width, op.pad_t, op.pad_l, m->Hp, m->Wp,
+                                  m->image_pad.d, st)) return 1;
+        break;
+      case OP_DW:
+        if (launch_dwconv(op.dw, st)) return 1;
+        break;
+      case OP_CMEAN:
+        if (launch_channel_mean(op.in.d, op.in.B, op.in.h * op.in.w, op.in.C, op.aux2, op.aux, st)) return 1;
+        break;
+      case OP_CSCALE:
+        if (launch_channel_scale(op.in.d, op.aux, op.in.B, op.in.h * op.in.w, op.in.C, st)) return 1;
+        break;
       case OP_MASK_SELECT:
         if (launch_mask_select(m->mask_sel, st)) return 1;
         break;
@@ -836,6 +1055,8 @@ int odt_synchronize(odt_handle h) {
 
 int odt_forward(odt_handle h, const void* frames, int dtype, int on_device, void* stream, odt_outputs* out) {
   ODT_CHECK(h != nullptr && out != nullptr, "null argument");
+  ODT_CHECK(h->cfg.graph != ODT_GRAPH_EFFNET,
+            "odt_forward: the EfficientNet backbone graph has no detection outputs yet (odt_forward_async + odt_tap)");
   hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
   if (run_plan(h, frames, dtype, on_device, st)) return 1;
   ODT_HIP(hipStreamSynchronize(st));
@@ -918,6 +1139,7 @@ int odt_ingest_buffer(odt_handle h, int dtype, void** buffer, size_t* bytes) {
 int odt_submit(odt_handle h, const void* frames, int dtype, int* ticket) {
   ODT_CHECK(h && ticket, "odt_submit: null argument");
   ODT_CHECK(h->finalized, "odt_submit: call odt_finalize_weights first");
+  ODT_CHECK(h->cfg.graph != ODT_GRAPH_EFFNET, "odt_submit: not available for the EfficientNet backbone graph");
   ODT_CHECK(dtype == ODT_DTYPE_U8 || dtype == ODT_DTYPE_F32, "odt_submit: bad dtype");
   ODT_HIP(hipSetDevice(h->device));
   const odt_config& cfg = h->cfg;

@@ -54,7 +54,7 @@ struct ConvParams {
   int out_H, out_W, out_oy, out_ox, out_ldc;
   int res_mode;        // 0 none | 1 same shape | 2 nearest-2x upsample of [B,res_H,res_W,*]
   int res_H, res_W, res_ldc;
-  int relu;
+  int relu;            // epilogue activation: 0 none | 1 ReLU | 2 swish x*sigmoid(x) | 3 sigmoid
   // optional second A source, K-concatenated behind the first (1x1 convs only): the stage-entry
   // bottleneck computes conv3(t2) + convshortcut(x) as ONE GEMM over [t2 | x(::stride2)]
   const float* in2;    // [B,in2_Ha,in2_Wa,in2_ldc] or nullptr
@@ -76,6 +76,22 @@ int launch_preprocess_resize(const void* frames, int dtype, int B, int Hs, int W
                              int pad_l, int Hp, int Wp, float* out, hipStream_t stream);
 int launch_maxpool3x3s2(const float* in, int B, int H, int W, int C, float* out, int Ho, int Wo,
                         hipStream_t stream);
+
+// ------------------------------------------------------- EfficientNet blocks (effnet.hip)
+struct DwConvParams {
+  const float* in;     // [B,H,W,ldc]
+  const float* wt;     // [k*k][ldc]  (BN scale folded, pad channels zero)
+  const float* bias;   // [ldc]
+  float* out;          // [B,Ho,Wo,ldc]
+  int B, H, W, Ho, Wo, ldc, k, stride, pad_t, pad_l;
+  int act;             // 0 none | 2 swish
+};
+int launch_dwconv(const DwConvParams& p, hipStream_t stream);
+int launch_preprocess_rgb(const void* frames, int dtype, int B, int H, int W, int pad_t, int pad_l, int Hp, int Wp,
+                          float* out, hipStream_t stream);
+int channel_mean_splits(int HW);
+int launch_channel_mean(const float* in, int B, int HW, int ldc, float* scratch, float* out, hipStream_t stream);
+int launch_channel_scale(float* x, const float* s, int B, int HW, int ldc, hipStream_t stream);
 
 // ------------------------------------------------------- proposals (K6,K7,K8)
 struct RpnLevel {

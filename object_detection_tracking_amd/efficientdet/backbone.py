@@ -1,0 +1,73 @@
+"""EfficientNet backbone on the HIP kernels (the part of the EfficientDet path that is built):
+``EfficientNetBackbone(name, weights).features(frames)`` -> {level: [B,h,w,C] float32} for the
+reduction_1..5 endpoints (reference efficientdet/efficientdet_arch.py:396-437 ``build_backbone``:
+levels 3, 4, 5 feed the BiFPN)."""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+from .._lib import ODT_DTYPE_F32, ODT_DTYPE_U8, ODT_GRAPH_EFFNET, OdtConfig, c_i64_p, f32, fptr
+from .arch import backbone_spec
+
+
+class EfficientNetBackbone(object):
+
+  def __init__(self, name, weights, batch, height, width, device=0, lib=None):
+    self.lib = lib if lib is not None else _lib.get_lib()
+    self.name, self.batch, self.height, self.width = name, batch, height, width
+    self.spec = backbone_spec(name)
+    c = OdtConfig()
+    c.graph = ODT_GRAPH_EFFNET; c.batch = batch; c.height = height; c.width = width
+    c.eff_backbone = int(name[-1])
+    self.h = C.c_void_p()
+    self.lib.check(self.lib.dll.odt_create(C.byref(c), device, C.byref(self.h)))
+    try:
+      for k, a in weights.items():
+        a = f32(a)
+        shape = (C.c_int64 * a.ndim)(*a.shape)
+        self.lib.check(self.lib.dll.odt_load_tensor(self.h, k.encode(), fptr(a), C.cast(shape, c_i64_p), a.ndim))
+      self.lib.check(self.lib.dll.odt_finalize_weights(self.h))
+    except Exception:
+      self.lib.dll.odt_destroy(self.h); self.h = None
+      raise
+
+  def close(self):
+    if self.h is not None:
+      self.lib.dll.odt_destroy(self.h); self.h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
+  def forward_async(self, frames):
+    fr = np.ascontiguousarray(frames)
+    dt = ODT_DTYPE_U8 if fr.dtype == np.uint8 else ODT_DTYPE_F32
+    if dt == ODT_DTYPE_F32:
+      fr = np.ascontiguousarray(fr, np.float32)
+    assert fr.shape == (self.batch, self.height, self.width, 3), fr.shape
+    self._keep = fr
+    self.lib.check(self.lib.dll.odt_forward_async(self.h, fr.ctypes.data_as(C.c_void_p), dt, 0, None))
+
+  def synchronize(self):
+    self.lib.check(self.lib.dll.odt_synchronize(self.h))
+
+  def tap(self, name):
+    """Stage tensor in the device layout (NHWC, channel stride padded to 32), as numpy."""
+    shape = (C.c_int64 * 4)(); rank = C.c_int()
+    self.lib.check(self.lib.dll.odt_tap(self.h, name.encode(), None, 0, C.cast(shape, c_i64_p), C.byref(rank)))
+    out = np.zeros([int(shape[i]) for i in range(rank.value)], np.float32)
+    self.lib.check(self.lib.dll.odt_tap(self.h, name.encode(), fptr(out), out.size, C.cast(shape, c_i64_p),
+                                        C.byref(rank)))
+    return out
+
+  def features(self, frames):
+    """{level: NHWC float32 [B,h,w,C]} of reduction_1..5 (pad channels stripped)."""
+    self.forward_async(frames); self.synchronize()
+    out = {}
+    for b in self.spec["blocks"]:
+      if b["reduction"]:
+        out[b["reduction"]] = np.ascontiguousarray(self.tap("reduction_%d" % b["reduction"])[..., :b["cout"]])
+    return out

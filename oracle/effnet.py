@@ -53,7 +53,7 @@ def depthwise(x, w, name, k, s):
 def preprocess(frames_bgr_u8):
   """efficientdet_wrapper.py:45-60 + dataloader normalize_image: BGR -> RGB, [0,1], (x - mean) / std
   with the ImageNet RGB constants; NCHW float32."""
-  x = np.asarray(frames_bgr_u8)[..., ::-1].astype(F) / F(255.0)
+  x = np.asarray(frames_bgr_u8)[..., ::-1].astype(F) * F(1.0 / 255)      # tf.image.convert_image_dtype
   x = (x - np.array([0.485, 0.456, 0.406], F)) / np.array([0.229, 0.224, 0.225], F)
   return torch.from_numpy(np.ascontiguousarray(x.transpose(0, 3, 1, 2)))
 
