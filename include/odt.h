@@ -60,6 +60,9 @@ typedef struct odt_config {
   int32_t add_mask;         /* --add_mask: Mask R-CNN head on the final boxes (models.py:932-962); single-image graph */
   int32_t mask_dim;         /* mrcnn_head_dim (256)                           */
   int32_t eff_backbone;     /* ODT_GRAPH_EFFNET: 0..7 = efficientnet-b0..b7 (efficientdet_wrapper.py:511-587) */
+  int32_t eff_det;          /* -1: backbone only; 0..7: efficientdet-d0..d7 feature network + class / box nets */
+  int32_t eff_topk;         /* efficientdet_max_detection_topk (5000)         */
+  float eff_image_scale;    /* image_scale_to_original applied to the output boxes (wrapper :57) */
 } odt_config;
 
 /* Caller-owned host output buffers (capacities in elements of the row type).

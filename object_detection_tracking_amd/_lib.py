@@ -37,7 +37,8 @@ class OdtConfig(C.Structure):
       ("rpn_decode_clip", C.c_float), ("head_decode_clip", C.c_float),
       ("bbox_reg_weights", C.c_float * 4), ("result_score_thresh", C.c_float),
       ("head_nms_thresh", C.c_float), ("add_mask", C.c_int32), ("mask_dim", C.c_int32),
-      ("eff_backbone", C.c_int32),
+      ("eff_backbone", C.c_int32), ("eff_det", C.c_int32), ("eff_topk", C.c_int32),
+      ("eff_image_scale", C.c_float),
   ]
 
 

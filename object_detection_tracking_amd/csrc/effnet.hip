@@ -132,6 +132,63 @@ __global__ void __launch_bounds__(256) channel_scale_kernel(float* __restrict__ 
   }
 }
 
+// BiFPN node input combination (reference efficientdet_arch.py:105-200 resample_feature_map +
+// :615-650 build_bifpn_layer): out = act( sum_i  w_i * resample_i(in_i) ), up to three inputs, each
+// either at the node's resolution, nearest-neighbour upsampled (TF1 rule: src = min(floor(dst *
+// in/out), in-1)) or 3x3 / stride-2 / 'SAME' max-pooled on the fly.  'fastattn' weights follow the
+// graph's operand order ((x * w) / (sum_w + 1e-4)); 'sum' adds left to right.
+__global__ void __launch_bounds__(256) bifpn_fuse_kernel(FuseParams p) {
+  const int c4n = p.ldc >> 2;
+  const long total = (long)p.B * p.h * p.w * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    long t = i / c4n;
+    const int x = (int)(t % p.w); t /= p.w;
+    const int y = (int)(t % p.h);
+    const int b = (int)(t / p.h);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (k >= p.n) break;
+      const float* src = p.in[k] + (long)b * p.ih[k] * p.iw[k] * p.ldc + c4 * 4;
+      f32x4 v;
+      if (p.mode[k] == 0) {
+        v = *reinterpret_cast<const f32x4*>(src + ((long)y * p.iw[k] + x) * p.ldc);
+      } else if (p.mode[k] == 1) {
+        int sy = (int)floorf((float)y * p.sy[k]), sx = (int)floorf((float)x * p.sx[k]);
+        sy = sy < p.ih[k] - 1 ? sy : p.ih[k] - 1; sx = sx < p.iw[k] - 1 ? sx : p.iw[k] - 1;
+        v = *reinterpret_cast<const f32x4*>(src + ((long)sy * p.iw[k] + sx) * p.ldc);
+      } else {
+        const float ninf = -3.402823466e38f;
+        v = f32x4{ninf, ninf, ninf, ninf};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int yy = 2 * y + dy - p.pt[k];
+          if ((unsigned)yy >= (unsigned)p.ih[k]) continue;
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const int xx = 2 * x + dx - p.pl[k];
+            if ((unsigned)xx >= (unsigned)p.iw[k]) continue;
+            const f32x4 q = *reinterpret_cast<const f32x4*>(src + ((long)yy * p.iw[k] + xx) * p.ldc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], q[e]);
+          }
+        }
+      }
+      if (p.weighted) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * p.wgt[k] / p.denom;
+      }
+      if (k == 0) acc = v; else acc += v;
+    }
+    if (p.act == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = swishf(acc[e]);
+    }
+    *reinterpret_cast<f32x4*>(p.out + (((long)b * p.h + y) * p.w + x) * p.ldc + c4 * 4) = acc;
+  }
+}
+
 }  // namespace
 
 int launch_preprocess_rgb(const void* frames, int dtype, int B, int H, int W, int pad_t, int pad_l, int Hp, int Wp,
@@ -144,6 +201,14 @@ int launch_preprocess_rgb(const void* frames, int dtype, int B, int H, int W, in
     hipLaunchKernelGGL(preprocess_rgb_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream,
                        (const float*)frames, B, H, W, pad_t, pad_l, Hp, Wp, out);
   else { set_error("preprocess: dtype must be ODT_DTYPE_U8 or ODT_DTYPE_F32"); return 1; }
+  ODT_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_bifpn_fuse(const FuseParams& p, hipStream_t stream) {
+  ODT_CHECK(p.n >= 1 && p.n <= 3 && p.ldc % 4 == 0, "bifpn_fuse: bad arguments");
+  const long total = (long)p.B * p.h * p.w * (p.ldc >> 2);
+  hipLaunchKernelGGL(bifpn_fuse_kernel, dim3(grid_for(total)), dim3(256), 0, stream, p);
   ODT_HIP(hipGetLastError());
   return 0;
 }

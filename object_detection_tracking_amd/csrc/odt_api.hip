@@ -59,12 +59,13 @@ struct ConvOp {
 };
 
 enum OpKind { OP_PRE, OP_CONV, OP_POOL, OP_SUB2, OP_PROPOSALS, OP_ROI_HEAD, OP_DETECT, OP_ROI_FINAL,
-              OP_ROI_MASK, OP_MASK_SELECT, OP_PRE_RGB, OP_DW, OP_CMEAN, OP_CSCALE };
+              OP_ROI_MASK, OP_MASK_SELECT, OP_PRE_RGB, OP_DW, OP_CMEAN, OP_CSCALE, OP_FUSE };
 struct Op {
   OpKind kind;
   int conv = -1;        // index into convs
   Tensor in, out;
   DwConvParams dw{};    // OP_DW
+  FuseParams fuse{};    // OP_FUSE
   float* aux = nullptr; // OP_CMEAN: means out [B,ldc]; OP_CSCALE: gates in [B,ldc]
   float* aux2 = nullptr;   // OP_CMEAN: partial-sum scratch
   int pad_t = 0, pad_l = 0;   // OP_PRE_RGB
@@ -326,9 +327,10 @@ int eff_bn(odt_model* m, const std::string& scope, int c, std::vector<double>* s
 
 // 1x1 conv weights [1,1,cin,cout] (+ BN scope or bias) -> device [cout][cin_pad] + bias[cout]
 int eff_upload_pw(odt_model* m, const std::string& conv, const std::string& bn_scope, bool has_bias, int cin,
-                  int cin_pad, int cout, const float** wt_out, const float** bias_out) {
-  const HostTensor* W = find_w(m, conv + "/kernel");
-  ODT_CHECK(W != nullptr && W->data.size() == (size_t)cin * cout, "missing / bad " + conv + "/kernel");
+                  int cin_pad, int cout, const float** wt_out, const float** bias_out,
+                  const char* kernel_name = "kernel") {
+  const HostTensor* W = find_w(m, conv + "/" + kernel_name);
+  ODT_CHECK(W != nullptr && W->data.size() == (size_t)cin * cout, "missing / bad " + conv + "/" + kernel_name);
   std::vector<double> scale(cout, 1.0), shift(cout, 0.0);
   if (!bn_scope.empty() && eff_bn(m, bn_scope, cout, &scale, &shift)) return 1;
   if (has_bias) {
@@ -342,6 +344,165 @@ int eff_upload_pw(odt_model* m, const std::string& conv, const std::string& bn_s
     bias[o] = (float)shift[o];
   }
   if (upload_raw(m, wt, wt_out) || upload_raw(m, bias, bias_out)) return 1;
+  return 0;
+}
+
+
+// ---- EfficientDet feature network (BiFPN) + class / box nets
+// reference efficientdet_arch.py:105-200 (resample), :440-505 (P6/P7 + cells), :594-682 (nodes),
+// :227-393 (nets); efficientdet_wrapper.py:511-587 (D0..D7 table).
+struct EffDetCfg { int filters, cells, repeats; bool fastattn; };
+EffDetCfg effdet_cfg(int d) {
+  static const int T[8][3] = {{64, 3, 3}, {88, 4, 3}, {112, 5, 3}, {160, 6, 4}, {224, 7, 4}, {288, 7, 4}, {384, 8, 5}, {384, 8, 5}};
+  return EffDetCfg{T[d][0], T[d][1], T[d][2], d != 7};
+}
+
+int eff_same(int n, int k, int s, int* before) {
+  const int out = (n + s - 1) / s;
+  const int tot = std::max((out - 1) * s + k - n, 0);
+  *before = tot / 2;
+  return out;
+}
+
+// depthwise 3x3 'same' (no BN, no activation) + pointwise 1x1 (+bias, optional BN fold, activation)
+int eff_sepconv(odt_model* m, const std::string& scope, const std::string& bn_scope, const Tensor& in, int cin,
+                int cout, int act, const std::string& tap, Tensor* out) {
+  const int B = in.B, ldc = in.C;
+  const HostTensor* Wd = find_w(m, scope + "/depthwise_kernel");
+  ODT_CHECK(Wd && Wd->data.size() == (size_t)9 * cin, "missing / bad " + scope + "/depthwise_kernel");
+  std::vector<float> v((size_t)9 * ldc, 0.f), bv(ldc, 0.f);
+  for (int t = 0; t < 9; ++t) for (int c = 0; c < cin; ++c) v[(size_t)t * ldc + c] = Wd->data[(size_t)t * cin + c];
+  const float *dwt, *dbias;
+  if (upload_raw(m, v, &dwt) || upload_raw(m, bv, &dbias)) return 1;
+  Tensor t1{};
+  if (make_tensor(m, "", B, in.h, in.w, ldc, &t1, true)) return 1;
+  {
+    Op op; op.kind = OP_DW;
+    op.dw.in = in.d; op.dw.wt = dwt; op.dw.bias = dbias; op.dw.out = t1.d;
+    op.dw.B = B; op.dw.H = in.h; op.dw.W = in.w; op.dw.Ho = in.h; op.dw.Wo = in.w; op.dw.ldc = ldc;
+    op.dw.k = 3; op.dw.stride = 1; op.dw.pad_t = 1; op.dw.pad_l = 1; op.dw.act = 0;
+    m->ops.push_back(op);
+  }
+  const float *wt, *bias;
+  if (eff_upload_pw(m, scope, bn_scope, true, cin, ldc, cout, &wt, &bias, "pointwise_kernel")) return 1;
+  // the pointwise bias variable of separable_conv2d is "<scope>/bias"
+  if (add_conv(m, scope, t1, ldc, wt, bias, 1, 1, cout, 1, 1, 0, 0, in.h, in.w, 0, 0, nullptr, 0, false, r32(cout), out, tap)) return 1;
+  m->convs.back().p.relu = act;
+  return 0;
+}
+
+int build_effdet_heads(odt_model* m, const Tensor* red, const int* red_ch) {
+  const odt_config& cfg = m->cfg;
+  const EffDetCfg dc = effdet_cfg(cfg.eff_det);
+  const int B = cfg.batch, F = dc.filters, LF = r32(F);
+  const int ncls = cfg.num_class > 0 ? cfg.num_class : 90;
+  // node sizes: utils.get_feat_sizes
+  int fh[8], fw[8];
+  fh[0] = cfg.height; fw[0] = cfg.width;
+  for (int l = 1; l < 8; ++l) { fh[l] = (fh[l - 1] - 1) / 2 + 1; fw[l] = (fw[l - 1] - 1) / 2 + 1; }
+  struct Feat { Tensor t; int ch; };
+  std::vector<Feat> feats;
+  for (int l = 3; l <= 5; ++l) {
+    ODT_CHECK(red[l].h == fh[l] && red[l].w == fw[l], "backbone / feature-pyramid size mismatch");
+    feats.push_back(Feat{red[l], red_ch[l]});
+  }
+  const float *wt, *bias;
+  // optional 1x1 conv + BN when the channel count differs (resample_feature_map._maybe_apply_1x1)
+  auto maybe_1x1 = [&](const std::string& scope, const Feat& f, Tensor* out) {
+    if (f.ch == F) { *out = f.t; return 0; }
+    if (eff_upload_pw(m, scope + "/conv2d", scope + "/bn", true, f.ch, f.t.C, F, &wt, &bias)) return 1;
+    *out = Tensor{};
+    return add_conv(m, scope + "/conv2d", f.t, f.t.C, wt, bias, 1, 1, F, 1, 1, 0, 0, f.t.h, f.t.w, 0, 0, nullptr, 0, false, LF, out, "");
+  };
+  auto fuse_input = [&](FuseParams& fp, int k, const Tensor& t, int th, int tw) {
+    fp.in[k] = t.d; fp.ih[k] = t.h; fp.iw[k] = t.w; fp.sy[k] = fp.sx[k] = 1.f; fp.pt[k] = fp.pl[k] = 0;
+    if (t.h > th && t.w > tw) {
+      int pb; ODT_CHECK(eff_same(t.h, 3, 2, &pb) == th, "BiFPN: unsupported down-sampling ratio"); fp.pt[k] = pb;
+      ODT_CHECK(eff_same(t.w, 3, 2, &pb) == tw, "BiFPN: unsupported down-sampling ratio"); fp.pl[k] = pb;
+      fp.mode[k] = 2;
+    } else if (t.h > th || t.w > tw) {
+      ODT_CHECK(false, "BiFPN: incompatible feature map sizes (efficientdet_arch.py:196-199): every pyramid level "
+                       "must shrink in both dimensions; use a larger input");
+    } else if (t.h < th || t.w < tw) {
+      fp.mode[k] = 1; fp.sy[k] = (float)t.h / (float)th; fp.sx[k] = (float)t.w / (float)tw;
+    } else {
+      fp.mode[k] = 0;
+    }
+    return 0;
+  };
+  // P6, P7 (efficientdet_arch.py:452-475)
+  for (int l = 6; l <= 7; ++l) {
+    Tensor src{};
+    if (maybe_1x1("resample_p" + std::to_string(l), feats.back(), &src)) return 1;
+    Tensor t{};
+    if (make_tensor(m, "", B, fh[l], fw[l], LF, &t, true)) return 1;
+    Op op; op.kind = OP_FUSE; std::memset(&op.fuse, 0, sizeof(op.fuse));
+    if (fuse_input(op.fuse, 0, src, fh[l], fw[l])) return 1;
+    op.fuse.n = 1; op.fuse.B = B; op.fuse.h = fh[l]; op.fuse.w = fw[l]; op.fuse.ldc = LF; op.fuse.out = t.d;
+    m->ops.push_back(op);
+    m->taps["fpn_in_" + std::to_string(l)] = t;
+    feats.push_back(Feat{t, F});
+  }
+  static const int NODE_LVL[8] = {6, 5, 4, 3, 4, 5, 6, 7};
+  static const int NODE_IN[8][3] = {{3, 4, -1}, {2, 5, -1}, {1, 6, -1}, {0, 7, -1}, {1, 7, 8}, {2, 6, 9}, {3, 5, 10}, {4, 11, -1}};
+  for (int rep = 0; rep < dc.cells; ++rep) {
+    for (int i = 0; i < 8; ++i) {
+      const std::string p = "fpn_cells/cell_" + std::to_string(rep) + "/fnode" + std::to_string(i) + "/";
+      const int lvl = NODE_LVL[i], th = fh[lvl], tw = fw[lvl];
+      Op op; op.kind = OP_FUSE; std::memset(&op.fuse, 0, sizeof(op.fuse));
+      int n = 0;
+      double wsum = 0.0;
+      for (int k = 0; k < 3 && NODE_IN[i][k] >= 0; ++k, ++n) {
+        const int off = NODE_IN[i][k];
+        Tensor src{};
+        if (maybe_1x1(p + "resample_" + std::to_string(k) + "_" + std::to_string(off) + "_" + std::to_string(feats.size()),
+                      feats[off], &src)) return 1;
+        if (fuse_input(op.fuse, k, src, th, tw)) return 1;
+        if (dc.fastattn) {
+          const HostTensor* ws = find_w(m, p + (k == 0 ? std::string("WSM") : "WSM_" + std::to_string(k)));
+          ODT_CHECK(ws != nullptr && ws->data.size() == 1, "missing " + p + "WSM");
+          op.fuse.wgt[k] = std::max(ws->data[0], 0.f);
+        }
+      }
+      if (dc.fastattn) {      // tf.add_n of float32 scalars, left to right, + 0.0001
+        float tot = op.fuse.wgt[0];
+        for (int k = 1; k < n; ++k) tot = tot + op.fuse.wgt[k];
+        op.fuse.denom = tot + 0.0001f; op.fuse.weighted = 1;
+      }
+      (void)wsum;
+      Tensor fused{};
+      if (make_tensor(m, "", B, th, tw, LF, &fused, true)) return 1;
+      op.fuse.n = n; op.fuse.act = 2; op.fuse.B = B; op.fuse.h = th; op.fuse.w = tw; op.fuse.ldc = LF; op.fuse.out = fused.d;
+      m->ops.push_back(op);
+      const std::string q = p + "op_after_combine" + std::to_string(feats.size()) + "/";
+      Tensor node{};
+      if (eff_sepconv(m, q + "conv", q + "bn", fused, F, F, 0, "cell" + std::to_string(rep) + "_fnode" + std::to_string(i), &node)) return 1;
+      feats.push_back(Feat{node, F});
+    }
+    // next cell's inputs: the last node of every level (efficientdet_arch.py:676-682)
+    std::vector<Feat> nxt(5);
+    for (int l = 3; l <= 7; ++l)
+      for (int i = 7; i >= 0; --i)
+        if (NODE_LVL[i] == l) { nxt[l - 3] = feats[feats.size() - 8 + i]; break; }
+    feats = nxt;
+  }
+  for (int l = 3; l <= 7; ++l) m->taps["fpn_" + std::to_string(l)] = feats[l - 3].t;
+  // class / box nets: shared separable convs, per-level BN, swish (efficientdet_arch.py:227-393)
+  for (int l = 3; l <= 7; ++l) {
+    for (int net = 0; net < 2; ++net) {
+      const std::string nn = net == 0 ? "class" : "box";
+      Tensor x = feats[l - 3].t;
+      for (int r = 0; r < dc.repeats; ++r) {
+        Tensor y{};
+        if (eff_sepconv(m, nn + "_net/" + nn + "-" + std::to_string(r),
+                        nn + "_net/" + nn + "-" + std::to_string(r) + "-bn-" + std::to_string(l), x, F, F, 2, "", &y)) return 1;
+        x = y;
+      }
+      Tensor o{};
+      const int nout = net == 0 ? ncls * 9 : 36;
+      if (eff_sepconv(m, nn + "_net/" + nn + "-predict", "", x, F, nout, 0, nn + "_" + std::to_string(l), &o)) return 1;
+    }
+  }
   return 0;
 }
 
@@ -388,6 +549,7 @@ int build_plan_effnet(odt_model* m) {
                r32(stemC), &x, "stem")) return 1;
   m->convs.back().p.relu = 2;
   // ---- MBConv blocks
+  Tensor red_feats[6]; int red_ch[6] = {0, 0, 0, 0, 0, 0};
   for (const EffBlock& b : blocks) {
     const std::string p = name + "/blocks_" + std::to_string(b.idx) + "/";
     const int mid = b.cin * b.expand, lmid = r32(mid);
@@ -453,10 +615,11 @@ int build_plan_effnet(odt_model* m) {
       std::string tap = "block_" + std::to_string(b.idx);
       if (add_conv(m, cn, t2, lmid, wt, bias, 1, 1, b.cout, 1, 1, 0, 0, ho, wo, 0, 0, skip ? &inp : nullptr, 1, false,
                    r32(b.cout), &y, tap)) return 1;
-      if (b.reduction) m->taps["reduction_" + std::to_string(b.reduction)] = y;
+      if (b.reduction) { m->taps["reduction_" + std::to_string(b.reduction)] = y; red_feats[b.reduction] = y; red_ch[b.reduction] = b.cout; }
       x = y;
     }
   }
+  if (cfg.eff_det >= 0 && build_effdet_heads(m, red_feats, red_ch)) return 1;
   {   // conv parameter records in device memory
     std::vector<ConvParams> recs;
     for (const ConvOp& c : m->convs) recs.push_back(c.p);
@@ -981,6 +1144,9 @@ int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStre
         break;
       case OP_CSCALE:
         if (launch_channel_scale(op.in.d, op.aux, op.in.B, op.in.h * op.in.w, op.in.C, st)) return 1;
+        break;
+      case OP_FUSE:
+        if (launch_bifpn_fuse(op.fuse, st)) return 1;
         break;
       case OP_MASK_SELECT:
         if (launch_mask_select(m->mask_sel, st)) return 1;

@@ -87,6 +87,17 @@ struct DwConvParams {
   int act;             // 0 none | 2 swish
 };
 int launch_dwconv(const DwConvParams& p, hipStream_t stream);
+struct FuseParams {
+  const float* in[3];
+  int ih[3], iw[3], mode[3];     // mode 0 same size | 1 nearest resize | 2 max-pool 3x3 s2 'SAME'
+  float sy[3], sx[3];            // mode 1: in / out size ratios
+  int pt[3], pl[3];              // mode 2: 'SAME' pads before
+  float wgt[3], denom;           // weighted: relu(WSM_i), sum + 1e-4
+  int n, weighted, act;          // act 0 none | 2 swish
+  int B, h, w, ldc;
+  float* out;
+};
+int launch_bifpn_fuse(const FuseParams& p, hipStream_t stream);
 int launch_preprocess_rgb(const void* frames, int dtype, int B, int H, int W, int pad_t, int pad_l, int Hp, int Wp,
                           float* out, hipStream_t stream);
 int channel_mean_splits(int HW);

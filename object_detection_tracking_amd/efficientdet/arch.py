@@ -130,3 +130,95 @@ def synthetic_backbone_weights(name, seed=0):
     g = "%s/blocks_%d/tpu_batch_normalization%s/gamma" % (name, b["idx"], "_%d" % nbn if nbn else "")
     w[g] = (w[g] * 0.4).astype(np.float32)
   return w
+
+
+# ---- EfficientDet feature network + heads -------------------------------------------------------
+# bifpn node table (efficientdet_arch.py:508-522): (feat_level, inputs_offsets)
+BIFPN_NODES = [(6, [3, 4]), (5, [2, 5]), (4, [1, 6]), (3, [0, 7]), (4, [1, 7, 8]), (5, [2, 6, 9]),
+               (6, [3, 5, 10]), (7, [4, 11])]
+NUM_ANCHORS = 9              # num_scales 3 x aspect_ratios 3 (efficientdet_wrapper.py:179-181)
+NUM_CLASSES = 90
+
+
+def feat_sizes(height, width, max_level=7):
+  """utils.get_feat_sizes (efficientdet/utils.py:467-484)."""
+  out = [(height, width)]
+  for _ in range(max_level):
+    h, w = out[-1]
+    out.append(((h - 1) // 2 + 1, (w - 1) // 2 + 1))
+  return out
+
+
+def det_config(model_name):
+  c = dict(EFFICIENTDET[model_name])
+  c["name"] = model_name
+  c["weight_method"] = "sum" if model_name == "efficientdet-d7" else "fastattn"   # wrapper :585, arch :582-591
+  c["anchor_scale"] = 5.0 if model_name == "efficientdet-d7" else 4.0
+  return c
+
+
+def det_variable_shapes(model_name, num_classes=NUM_CLASSES):
+  """Variables of the feature network and the class / box nets (TF names and layouts), on top of
+  backbone_variable_shapes(backbone)."""
+  c = det_config(model_name)
+  F_ = c["fpn_num_filters"]
+  sp = backbone_spec(c["backbone"])
+  red = {b["reduction"]: b["cout"] for b in sp["blocks"] if b["reduction"]}
+  v = {}
+  def bn(scope, ch):
+    for s in ("gamma", "beta", "moving_mean", "moving_variance"):
+      v[scope + "/" + s] = (ch,)
+  def resample(scope, cin):
+    if cin != F_:
+      v[scope + "/conv2d/kernel"] = (1, 1, cin, F_); v[scope + "/conv2d/bias"] = (F_,)
+      bn(scope + "/bn", F_)
+  resample("resample_p6", red[5])                       # P6 from P5 (P7 from P6: channels equal)
+  chans = [red[3], red[4], red[5], F_, F_]              # channels of feats[0..4] entering cell 0
+  for rep in range(c["fpn_cell_repeats"]):
+    ch = list(chans) if rep == 0 else [F_] * 5
+    for i, (lvl, offs) in enumerate(BIFPN_NODES):
+      p = "fpn_cells/cell_%d/fnode%d/" % (rep, i)
+      for idx, off in enumerate(offs):
+        resample(p + "resample_%d_%d_%d" % (idx, off, len(ch)), ch[off])
+      if c["weight_method"] == "fastattn":
+        for idx in range(len(offs)):
+          v[p + ("WSM" if idx == 0 else "WSM_%d" % idx)] = ()
+      q = p + "op_after_combine%d/" % len(ch)
+      v[q + "conv/depthwise_kernel"] = (3, 3, F_, 1); v[q + "conv/pointwise_kernel"] = (1, 1, F_, F_)
+      v[q + "conv/bias"] = (F_,)
+      bn(q + "bn", F_)
+      ch.append(F_)
+  for net, nout in (("class", num_classes * NUM_ANCHORS), ("box", 4 * NUM_ANCHORS)):
+    for i in range(c["box_class_repeats"]):
+      p = "%s_net/%s-%d/" % (net, net, i)
+      v[p + "depthwise_kernel"] = (3, 3, F_, 1); v[p + "pointwise_kernel"] = (1, 1, F_, F_); v[p + "bias"] = (F_,)
+      for lvl in range(3, 8):
+        bn("%s_net/%s-%d-bn-%d" % (net, net, i, lvl), F_)
+    p = "%s_net/%s-predict/" % (net, net)
+    v[p + "depthwise_kernel"] = (3, 3, F_, 1); v[p + "pointwise_kernel"] = (1, 1, F_, nout); v[p + "bias"] = (nout,)
+  return v
+
+
+def synthetic_det_weights(model_name, seed=0, num_classes=NUM_CLASSES):
+  """Backbone + feature network + heads, seeded, TF names."""
+  c = det_config(model_name)
+  w = synthetic_backbone_weights(c["backbone"], seed)
+  rng = np.random.default_rng(seed + 1)
+  for k, shp in det_variable_shapes(model_name, num_classes).items():
+    base = k.rsplit("/", 1)[1]
+    if base.startswith("WSM"):
+      w[k] = np.asarray(rng.uniform(0.5, 1.5), np.float32)
+    elif base in ("kernel", "pointwise_kernel"):
+      w[k] = (rng.standard_normal(shp) * np.sqrt(1.5 / shp[2])).astype(np.float32)
+    elif base == "depthwise_kernel":
+      w[k] = (rng.standard_normal(shp) * np.sqrt(1.5 / 9)).astype(np.float32)
+    elif base == "bias":
+      w[k] = (rng.standard_normal(shp) * 0.05).astype(np.float32)
+    elif base == "gamma":
+      w[k] = rng.uniform(0.8, 1.2, shp).astype(np.float32)
+    elif base in ("beta", "moving_mean"):
+      w[k] = (rng.standard_normal(shp) * 0.05).astype(np.float32)
+    elif base == "moving_variance":
+      w[k] = rng.uniform(0.8, 1.2, shp).astype(np.float32)
+  w["class_net/class-predict/bias"] = (w["class_net/class-predict/bias"] - 3.0).astype(np.float32)  # sparse positives
+  return w

@@ -13,13 +13,17 @@ from .arch import backbone_spec
 
 class EfficientNetBackbone(object):
 
-  def __init__(self, name, weights, batch, height, width, device=0, lib=None):
+  def __init__(self, name, weights, batch, height, width, device=0, lib=None, det=None, num_classes=90,
+               topk=5000, score_thresh=0.0, per_im=100, image_scale=1.0):
     self.lib = lib if lib is not None else _lib.get_lib()
     self.name, self.batch, self.height, self.width = name, batch, height, width
     self.spec = backbone_spec(name)
     c = OdtConfig()
     c.graph = ODT_GRAPH_EFFNET; c.batch = batch; c.height = height; c.width = width
     c.eff_backbone = int(name[-1])
+    c.eff_det = -1 if det is None else int(det[-1])      # "efficientdet-dN"
+    c.num_class = num_classes; c.eff_topk = topk; c.result_score_thresh = score_thresh
+    c.result_per_im = per_im; c.eff_image_scale = image_scale; c.head_nms_thresh = 0.5
     self.h = C.c_void_p()
     self.lib.check(self.lib.dll.odt_create(C.byref(c), device, C.byref(self.h)))
     try:

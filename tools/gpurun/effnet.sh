@@ -3,13 +3,13 @@ timeout 600 python -m pytest tests/test_efficientnet.py -m gpu -q -p no:cachepro
 cat > /tmp/effbench.py <<'PY'
 import sys, time, numpy as np
 sys.path.insert(0, "/root/repo")
-from object_detection_tracking_amd.efficientdet import EfficientNetBackbone, synthetic_backbone_weights
+from object_detection_tracking_amd.efficientdet import EfficientNetBackbone, arch
 from object_detection_tracking_amd.weights import synthetic_frames
-cases = [("efficientnet-b6", 1536, 1536, 1), ("efficientnet-b6", 1536, 1536, 4), ("efficientnet-b0", 512, 512, 8)]
+cases = [("efficientdet-d7", 1536, 1536, 1), ("efficientdet-d7", 1536, 1536, 2), ("efficientdet-d0", 512, 512, 8)]
 if len(sys.argv) > 1: cases = cases[:1]
 for name, H, W, B in cases:
-  w = synthetic_backbone_weights(name, 0)
-  net = EfficientNetBackbone(name, w, B, H, W)
+  w = arch.synthetic_det_weights(name, 0)
+  net = EfficientNetBackbone(arch.det_config(name)["backbone"], w, B, H, W, det=name)
   fr = synthetic_frames(B, H, W)
   for _ in range(2): net.forward_async(fr)
   net.synchronize()
