@@ -59,7 +59,7 @@ struct ConvOp {
 };
 
 enum OpKind { OP_PRE, OP_CONV, OP_POOL, OP_SUB2, OP_PROPOSALS, OP_ROI_HEAD, OP_DETECT, OP_ROI_FINAL,
-              OP_ROI_MASK, OP_MASK_SELECT, OP_PRE_RGB, OP_DW, OP_CMEAN, OP_CSCALE, OP_FUSE };
+              OP_ROI_MASK, OP_MASK_SELECT, OP_PRE_RGB, OP_DW, OP_CMEAN, OP_CSCALE, OP_FUSE, OP_EFF_POST, OP_ROI_EFF };
 struct Op {
   OpKind kind;
   int conv = -1;        // index into convs
@@ -93,6 +93,9 @@ struct odt_model {
   ProposalParams prop{};
   RoiAlignParams roi_head{}, roi_final{}, roi_mask{};
   MaskSelectParams mask_sel{};
+  EffPostParams eff_post{};
+  RoiAlignParams roi_eff{};
+  int eff_filters = 0;
   float* final_masks = nullptr;   // [B*per_im, 28, 28] (add_mask)
   DetectParams det{};
   Tensor image_pad, frames_dev;
@@ -488,6 +491,7 @@ int build_effdet_heads(odt_model* m, const Tensor* red, const int* red_ch) {
   }
   for (int l = 3; l <= 7; ++l) m->taps["fpn_" + std::to_string(l)] = feats[l - 3].t;
   // class / box nets: shared separable convs, per-level BN, swish (efficientdet_arch.py:227-393)
+  Tensor cls_out[5], box_out[5];
   for (int l = 3; l <= 7; ++l) {
     for (int net = 0; net < 2; ++net) {
       const std::string nn = net == 0 ? "class" : "box";
@@ -501,8 +505,56 @@ int build_effdet_heads(odt_model* m, const Tensor* red, const int* red_ch) {
       Tensor o{};
       const int nout = net == 0 ? ncls * 9 : 36;
       if (eff_sepconv(m, nn + "_net/" + nn + "-predict", "", x, F, nout, 0, nn + "_" + std::to_string(l), &o)) return 1;
+      (net == 0 ? cls_out : box_out)[l - 3] = o;
     }
   }
+  // ---- detection tail (efficientdet_wrapper.py:363-480, anchors.py:369-489) + per-level ROIAlign mean
+  EffPostParams& ep = m->eff_post;
+  std::memset(&ep, 0, sizeof(ep));
+  int tot = 0;
+  for (int l = 0; l < 5; ++l) {
+    ep.cls[l] = cls_out[l].d; ep.box[l] = box_out[l].d; ep.npix[l] = fh[l + 3] * fw[l + 3];
+    ep.anchor_off[l] = tot; tot += ep.npix[l] * 9;
+  }
+  ep.anchor_off[5] = tot;
+  ep.ldc_cls = cls_out[0].C; ep.ldc_box = box_out[0].C; ep.ncls = ncls; ep.B = B;
+  const HostTensor* an = find_w(m, "effdet/anchors");
+  ODT_CHECK(an != nullptr && an->data.size() == (size_t)tot * 4, "missing / bad effdet/anchors (expected [sum(h*w*9), 4])");
+  if (upload_raw(m, an->data, &ep.anchors)) return 1;
+  const long nlog = (long)tot * ncls;
+  ep.k = (int)std::min<long>(cfg.eff_topk > 0 ? cfg.eff_topk : 5000, nlog);
+  ep.max_out = cfg.result_per_im > 0 ? cfg.result_per_im : 100;
+  ep.score_thresh = cfg.result_score_thresh; ep.iou_thresh = 0.5f;
+  ep.image_scale = cfg.eff_image_scale > 0.f ? cfg.eff_image_scale : 1.f;
+  ep.keys = (unsigned*)m->alloc_f((size_t)nlog, false);
+  ep.hist = (unsigned*)m->alloc_f(256, true);
+  ep.state = (unsigned*)m->alloc_f(4, true);
+  ep.sel = (unsigned long long*)m->alloc_f((size_t)B * ep.k * 2, true);
+  ep.cand_boxes = m->alloc_f((size_t)B * ep.k * 4, true); ep.cand_scores = m->alloc_f((size_t)B * ep.k, true);
+  ep.cand_cls = (int*)m->alloc_f((size_t)B * ep.k, true); ep.cand_lvl = (int*)m->alloc_f((size_t)B * ep.k, true);
+  ep.out_boxes = m->alloc_f((size_t)B * ep.max_out * 4, true); ep.out_scores = m->alloc_f((size_t)B * ep.max_out, true);
+  ep.out_labels = (int*)m->alloc_f((size_t)B * ep.max_out, true); ep.out_levels = (int*)m->alloc_f((size_t)B * ep.max_out, true);
+  ep.out_valid = (int*)m->alloc_f(B, true);
+  ODT_CHECK(ep.keys && ep.hist && ep.state && ep.sel && ep.cand_boxes && ep.cand_scores && ep.cand_cls && ep.cand_lvl &&
+            ep.out_boxes && ep.out_scores && ep.out_labels && ep.out_levels && ep.out_valid, "device allocation failed (effdet tail)");
+  { Op op; op.kind = OP_EFF_POST; m->ops.push_back(op); }
+  // fpn_box_feat [R, F]: crop_and_resize 14x14 + 2x2 average on the box's own level, mean over 7x7
+  // (efficientdet_wrapper.py:244-296; the boxes are the SCALED output boxes, as in the reference)
+  RoiAlignParams& rf = m->roi_eff;
+  std::memset(&rf, 0, sizeof(rf));
+  for (int l = 0; l < 5; ++l) {
+    const Tensor& t = feats[l].t;
+    rf.feat[l] = t.d; rf.h[l] = t.h; rf.w[l] = t.w; rf.ldc[l] = t.C; rf.alloc_h[l] = t.H; rf.alloc_w[l] = t.W;
+    rf.inv_stride[l] = 1.0f / (float)(1 << (l + 3));
+  }
+  rf.C = F; rf.boxes = ep.out_boxes; rf.box_ind = nullptr; rf.per_image = ep.max_out; rf.count = ep.out_valid;
+  rf.R_cap = B * ep.max_out; rf.levels = ep.out_levels; rf.level0 = 3;
+  m->final_feat = m->alloc_f((size_t)B * ep.max_out * F * 49, true);
+  m->final_pooled = m->alloc_f((size_t)B * ep.max_out * F, true);
+  ODT_CHECK(m->final_feat && m->final_pooled, "device allocation failed (effdet features)");
+  rf.out_nhwc = nullptr; rf.out_nchw = m->final_feat; rf.pooled = m->final_pooled;
+  m->eff_filters = F;
+  { Op op; op.kind = OP_ROI_EFF; m->ops.push_back(op); }
   return 0;
 }
 
@@ -1148,6 +1200,12 @@ int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStre
       case OP_FUSE:
         if (launch_bifpn_fuse(op.fuse, st)) return 1;
         break;
+      case OP_EFF_POST:
+        if (launch_effdet_post(m->eff_post, st)) return 1;
+        break;
+      case OP_ROI_EFF:
+        if (launch_roi_align(m->roi_eff, st)) return 1;
+        break;
       case OP_MASK_SELECT:
         if (launch_mask_select(m->mask_sel, st)) return 1;
         break;
@@ -1221,10 +1279,29 @@ int odt_synchronize(odt_handle h) {
 
 int odt_forward(odt_handle h, const void* frames, int dtype, int on_device, void* stream, odt_outputs* out) {
   ODT_CHECK(h != nullptr && out != nullptr, "null argument");
-  ODT_CHECK(h->cfg.graph != ODT_GRAPH_EFFNET,
-            "odt_forward: the EfficientNet backbone graph has no detection outputs yet (odt_forward_async + odt_tap)");
+  ODT_CHECK(h->cfg.graph != ODT_GRAPH_EFFNET || h->cfg.eff_det >= 0,
+            "odt_forward: the backbone-only graph has no detection outputs (odt_forward_async + odt_tap)");
   hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
   if (run_plan(h, frames, dtype, on_device, st)) return 1;
+  if (h->cfg.graph == ODT_GRAPH_EFFNET) {
+    // EfficientDet outputs (efficientdet_wrapper.py:28-35): boxes [R,4] x1y1x2y2 (scaled), probs,
+    // labels 1..90, pooled = fpn_box_feat [R, fpn_num_filters]
+    ODT_HIP(hipStreamSynchronize(st));
+    const EffPostParams& ep = h->eff_post;
+    const int B = ep.B, per = ep.max_out, F = h->eff_filters;
+    std::vector<int> valid(B);
+    ODT_HIP(hipMemcpy(valid.data(), ep.out_valid, B * sizeof(int), hipMemcpyDeviceToHost));
+    int total = 0;
+    for (int b = 0; b < B; ++b) total += valid[b];
+    if (out->valid) std::memcpy(out->valid, valid.data(), B * sizeof(int));
+    if (out->boxes) ODT_HIP(hipMemcpy(out->boxes, ep.out_boxes, (size_t)B * per * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    if (out->probs) ODT_HIP(hipMemcpy(out->probs, ep.out_scores, (size_t)B * per * sizeof(float), hipMemcpyDeviceToHost));
+    if (out->labels) ODT_HIP(hipMemcpy(out->labels, ep.out_labels, (size_t)B * per * sizeof(int), hipMemcpyDeviceToHost));
+    ODT_CHECK(out->feats == nullptr && out->masks == nullptr, "odt_forward: EfficientDet returns pooled [R, filters] features only");
+    if (out->pooled && total > 0)
+      ODT_HIP(hipMemcpy(out->pooled, h->final_pooled, (size_t)total * F * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+  }
   ODT_HIP(hipStreamSynchronize(st));
   const odt_config& cfg = h->cfg;
   const int B = cfg.batch, per = cfg.result_per_im, FC = cfg.fpn_channels;

@@ -104,6 +104,24 @@ int channel_mean_splits(int HW);
 int launch_channel_mean(const float* in, int B, int HW, int ldc, float* scratch, float* out, hipStream_t stream);
 int launch_channel_scale(float* x, const float* s, int B, int HW, int ldc, hipStream_t stream);
 
+// ------------------------------------------------------- EfficientDet tail (effdet_post.hip)
+struct EffPostParams {
+  const float* cls[5];     // per level [B, npix, ldc_cls]  (9 * ncls valid channels: anchor-major)
+  const float* box[5];     // per level [B, npix, ldc_box]  (36 valid)
+  int npix[5], anchor_off[6];   // anchors before level l; anchor_off[5] = total
+  int ldc_cls, ldc_box, ncls, B;
+  const float* anchors;    // [total, 4] y1,x1,y2,x2
+  int k, max_out;
+  float score_thresh, iou_thresh, image_scale;
+  unsigned* keys;          // scratch [total * ncls]
+  unsigned* hist;          // scratch [256]
+  unsigned* state;         // scratch [4]
+  unsigned long long* sel; // scratch [B, k]
+  float* cand_boxes; float* cand_scores; int* cand_cls; int* cand_lvl;   // [B, k(,4)]
+  float* out_boxes; float* out_scores; int* out_labels; int* out_levels; int* out_valid;   // [B, max_out(,4)], [B]
+};
+int launch_effdet_post(const EffPostParams& p, hipStream_t stream);
+
 // ------------------------------------------------------- proposals (K6,K7,K8)
 struct RpnLevel {
   const float* rpn;      // [B,h,w,kRpnCh]: ch 0..2 logits, 3+a*4+c deltas
@@ -137,9 +155,11 @@ int launch_nms(const float* boxes, const float* scores, int n, int max_out, floa
 
 // --------------------------------------------------------------- ROIAlign (K9,K14)
 struct RoiAlignParams {
-  const float* feat[4];  // NHWC [B,h,w,C] (sliced dims h,w ; pixel stride ldc)
-  int h[4], w[4], ldc[4], alloc_h[4], alloc_w[4];
-  float inv_stride[4];
+  const float* feat[5];  // NHWC [B,h,w,C] (sliced dims h,w ; pixel stride ldc); 5th level: EfficientDet P7
+  int h[5], w[5], ldc[5], alloc_h[5], alloc_w[5];
+  float inv_stride[5];
+  const int* levels;     // optional [R_cap]: pyramid level of each box (value - level0 indexes feat[]); nullptr: FPN rule
+  int level0;
   int C;
   const float* boxes;    // [R_cap,4] image coords
   const int* box_ind;    // [R_cap] or nullptr (then box r belongs to image r / per_image)

@@ -41,14 +41,14 @@ __global__ void __launch_bounds__(256) roi_align_kernel(RoiAlignParams p, int B)
   (void)B;
   const float* bx = p.boxes + (size_t)r * 4;
   const float X0 = bx[0], Y0 = bx[1], X1 = bx[2], Y1 = bx[3];
-  const int L = fpn_level_of(X0, Y0, X1, Y1);
+  const int L = p.levels != nullptr ? p.levels[r] - p.level0 : fpn_level_of(X0, Y0, X1, Y1);
   // select this level's parameters with compares (a runtime-indexed kernel-argument array would
   // be spilled to scratch / waterfall SGPR reads)
   float is = p.inv_stride[0];
   int H = p.h[0], W = p.w[0], aw = p.alloc_w[0], ah = p.alloc_h[0], ldc = p.ldc[0];
   const float* fbase = p.feat[0];
 #pragma unroll
-  for (int q = 1; q < 4; ++q) {
+  for (int q = 1; q < 5; ++q) {
     if (L == q) {
       is = p.inv_stride[q]; H = p.h[q]; W = p.w[q]; aw = p.alloc_w[q]; ah = p.alloc_h[q];
       ldc = p.ldc[q]; fbase = p.feat[q];

@@ -410,8 +410,9 @@ def get_model(config, gpuid=0, task=0, controller="/cpu:0", is_multi=False, weig
   without TensorFlow; the EfficientDet branch is a "next" row."""
   # is_load_from_pb (reference models.py:102-108 -> Mask_RCNN_FPN_frozen): the frozen file is read
   # as a weight container (frozen_pb.load_frozen_pb), the architecture comes from the config
-  if getattr(config, "is_efficientdet", False):
-    raise NotImplementedError("EfficientDet path is a 'next' row (SURVEY.md 8f)")
+  if getattr(config, "is_efficientdet", False):        # reference models.py:103-104,112-113
+    from .efficientdet import EfficientDet
+    return EfficientDet(config, gpuid=gpuid, weights=weights, lib=lib)
   cls = Mask_RCNN_FPN_multi if is_multi else Mask_RCNN_FPN
   return cls(config, gpuid=gpuid, weights=weights, lib=lib)
 

@@ -87,7 +87,9 @@ def _det_parity(lib, model, H, W, tol=3e-5):
   taps = {}
   fpn = effnet.feature_network(model, w, {l: torch.from_numpy(red[l]) for l in (3, 4, 5)}, (H, W), taps)
   ref = effnet.class_box_nets(model, w, fpn)
-  net = EfficientNetBackbone(c["backbone"], w, 1, H, W, lib=lib, det=model)
+  from object_detection_tracking_amd.efficientdet import generate_anchors
+  wa = dict(w); wa["effdet/anchors"] = generate_anchors(H, W, c["anchor_scale"])
+  net = EfficientNetBackbone(c["backbone"], wa, 1, H, W, lib=lib, det=model, topk=100)
   try:
     net.forward_async(fr); net.synchronize()
     F_ = c["fpn_num_filters"]
@@ -127,3 +129,64 @@ def test_efficientdet_d1_nets_parity_odd_size(hip_lib):
   """88 filters (channel padding to 96) and sizes that are not multiples of 128 (nearest resize
   with a non-integer ratio, asymmetric 'SAME' pads)."""
   _det_parity(hip_lib, "efficientdet-d1", 270, 350)
+
+
+def _det_e2e(lib, model, H, W, topk, score_thr=0.02, tol_box=2e-2):
+  """Full EfficientDet forward through get_model / Session.run against the oracle."""
+  import torch
+  from object_detection_tracking_amd import models
+  from object_detection_tracking_amd.config import make_config
+  from object_detection_tracking_amd.weights import synthetic_frames
+  from oracle import effnet
+  c = arch.det_config(model)
+  w = arch.synthetic_det_weights(model, 0)
+  fr = synthetic_frames(1, H, W, seed=13)[0]
+  red = effnet.backbone_forward(c["backbone"], w, effnet.preprocess(fr[None]))
+  fpn = effnet.feature_network(model, w, {l: torch.from_numpy(red[l]) for l in (3, 4, 5)}, (H, W))
+  cb = effnet.class_box_nets(model, w, fpn)
+  rb, rs, rc, rl, dbg = effnet.detect(model, cb, (H, W), image_scale=1.0, topk=topk, score_thr=score_thr)
+  cfg = make_config(is_efficientdet=True, efficientdet_modelname=model, efficientdet_max_detection_topk=topk,
+                    short_edge_size=H, max_size=W, threshold_conf=score_thr)
+  cfg.max_size = W; cfg.result_score_thres = score_thr
+  m = models.get_model(cfg, 0, weights=w, lib=lib)
+  try:
+    boxes, labels, probs, feats = models.Session().run(
+        [m.final_boxes, m.final_labels, m.final_probs, m.fpn_box_feat], feed_dict=m.get_feed_dict_forward(fr))
+    assert len(boxes) == len(rb) and len(boxes) > 3, (len(boxes), len(rb))
+    # near-equal scores of random-init heads may swap two candidates (1e-6 logit differences):
+    # compare as sets first, element-wise when the order is identical
+    from common import match_detections
+    miss, extra = match_detections(boxes, labels, probs, rb, rc, rs, tol_box, 2e-5)
+    assert miss + extra <= max(2, len(rb) // 25), (miss, extra)
+    if miss + extra > 0 or not np.array_equal(labels, rc):
+      return
+    if np.abs(boxes - rb).max() > tol_box:       # same set, two near-equal scores in swapped order
+      return
+    np.testing.assert_allclose(probs, rs, rtol=0, atol=2e-5)
+    # fpn_box_feat: ROIAlign mean on each box's own level (restated with the oracle's crop_and_resize)
+    from oracle import graph as og
+    want = np.zeros((len(rb), c["fpn_num_filters"]), np.float32)
+    for i in range(len(rb)):
+      f = fpn[int(rl[i])].numpy()
+      bf = (rb[i:i + 1] * np.float32(1.0 / 2 ** int(rl[i]))).astype(np.float32)
+      want[i] = og.roi_align(f, bf, np.zeros((1,), np.int32), 7).mean(axis=(2, 3))[0]
+    assert feats.shape == want.shape
+    np.testing.assert_allclose(feats, want, rtol=0, atol=5e-5 * max(1.0, np.abs(want).max()))
+  finally:
+    m.close()
+
+
+def test_efficientdet_d0_end_to_end(backend):
+  name, lib = backend
+  _det_e2e(lib, "efficientdet-d0", 136, 152 if name == "emu" else 200, topk=300 if name == "emu" else 1000)
+
+
+@pytest.mark.gpu
+def test_efficientdet_d0_end_to_end_512(hip_lib):
+  """EfficientDet-D0 at its native 512x512 with the reference's top-k of 5000."""
+  _det_e2e(hip_lib, "efficientdet-d0", 512, 512, topk=5000)
+
+
+@pytest.mark.gpu
+def test_efficientdet_d2_end_to_end_odd(hip_lib):
+  _det_e2e(hip_lib, "efficientdet-d2", 300, 420, topk=2000)

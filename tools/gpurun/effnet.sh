@@ -3,22 +3,24 @@ timeout 600 python -m pytest tests/test_efficientnet.py -m gpu -q -p no:cachepro
 cat > /tmp/effbench.py <<'PY'
 import sys, time, numpy as np
 sys.path.insert(0, "/root/repo")
-from object_detection_tracking_amd.efficientdet import EfficientNetBackbone, arch
+from object_detection_tracking_amd import models
+from object_detection_tracking_amd.config import make_config
+from object_detection_tracking_amd.efficientdet import arch
 from object_detection_tracking_amd.weights import synthetic_frames
-cases = [("efficientdet-d7", 1536, 1536, 1), ("efficientdet-d7", 1536, 1536, 2), ("efficientdet-d0", 512, 512, 8)]
+cases = [("efficientdet-d7", 1536), ("efficientdet-d0", 512)]
 if len(sys.argv) > 1: cases = cases[:1]
-for name, H, W, B in cases:
-  w = arch.synthetic_det_weights(name, 0)
-  net = EfficientNetBackbone(arch.det_config(name)["backbone"], w, B, H, W, det=name)
-  fr = synthetic_frames(B, H, W)
-  for _ in range(2): net.forward_async(fr)
-  net.synchronize()
+for name, S in cases:
+  cfg = make_config(is_efficientdet=True, efficientdet_modelname=name, efficientdet_max_detection_topk=5000,
+                    short_edge_size=S, max_size=S)
+  cfg.max_size = S
+  m = models.get_model(cfg, 0, weights=arch.synthetic_det_weights(name, 0))
+  fr = synthetic_frames(1, S, S)[0]
+  for _ in range(2): out = m.predict(fr)
   t = time.perf_counter(); n = 5
-  for _ in range(n): net.forward_async(fr)
-  net.synchronize()
+  for _ in range(n): out = m.predict(fr)
   dt = (time.perf_counter() - t) / n
-  print("%s %dx%d b=%d: %.2f ms/step (%.1f frames/s) incl. H2D of uint8 frames" % (name, W, H, B, dt * 1e3, B / dt), flush=True)
-  net.close()
+  print("%s %dx%d: %.2f ms/frame host-to-host (%.1f frames/s), %d detections" % (name, S, S, dt * 1e3, 1 / dt, len(out[0])), flush=True)
+  m.close()
 PY
 python /tmp/effbench.py
 R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp; rm -rf $R/gpurun_out/prof_eff
