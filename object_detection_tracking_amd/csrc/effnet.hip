@@ -47,6 +47,48 @@ __global__ void __launch_bounds__(256) preprocess_rgb_kernel(const T* __restrict
   }
 }
 
+// Same with the reference's input resize (dataloader.py:100-123 set_scale_factors_to_output_size +
+// resize_and_crop_image on the NORMALISED image): the source [Hs,Ws] is scaled to [Hr,Wr] with
+// TF-1.x tf.image.resize_images(BILINEAR) -- legacy coordinates in = out * (in_size / out_size),
+// lower = floor, upper = min(lower + 1, size - 1), value = top + (bottom - top) * y_lerp with
+// top = tl + (tr - tl) * x_lerp -- and zero padded to [H,W] at the bottom / right.
+template <typename T>
+__global__ void __launch_bounds__(256) preprocess_rgb_resize_kernel(const T* __restrict__ frames, int B, int Hs, int Ws,
+                                                                    int Hr, int Wr, int pad_t, int pad_l, int Hp,
+                                                                    int Wp, float* __restrict__ out) {
+  const long total = (long)B * Hp * Wp;
+  const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+  const float inv255 = (float)(1.0 / 255);
+  const float sy = (float)Hs / (float)Hr, sx = (float)Ws / (float)Wr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wp);
+    const long t = i / Wp;
+    const int y = (int)(t % Hp), b = (int)(t / Hp);
+    const int dy = y - pad_t, dx = x - pad_l;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)dy < (unsigned)Hr && (unsigned)dx < (unsigned)Wr) {
+      const float fy = (float)dy * sy, fx = (float)dx * sx;
+      const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+      const int y1 = y0 + 1 < Hs ? y0 + 1 : Hs - 1, x1 = x0 + 1 < Ws ? x0 + 1 : Ws - 1;
+      const float ly = fy - (float)y0, lx = fx - (float)x0;
+      const T* r0 = frames + ((long)b * Hs + y0) * Ws * 3;
+      const T* r1 = frames + ((long)b * Hs + y1) * Ws * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {          // output channel c = R,G,B <- source channel 2 - c
+        const int sc = 2 - c;
+        const float tl = ((float)r0[x0 * 3 + sc] * inv255 - mean[c]) / stdv[c];
+        const float tr = ((float)r0[x1 * 3 + sc] * inv255 - mean[c]) / stdv[c];
+        const float bl = ((float)r1[x0 * 3 + sc] * inv255 - mean[c]) / stdv[c];
+        const float br = ((float)r1[x1 * 3 + sc] * inv255 - mean[c]) / stdv[c];
+        const float top = tl + (tr - tl) * lx;
+        const float bot = bl + (br - bl) * lx;
+        v[c] = top + (bot - top) * ly;
+      }
+    }
+    *reinterpret_cast<f32x4*>(out + i * 4) = v;
+  }
+}
+
 // depthwise k x k conv (k = 3 or 5), TF 'SAME' padding, stride 1 or 2, folded BN, optional swish.
 // One thread = 4 channels of one output pixel (16-byte accesses, channels innermost).
 template <int K>
@@ -209,6 +251,20 @@ int launch_bifpn_fuse(const FuseParams& p, hipStream_t stream) {
   ODT_CHECK(p.n >= 1 && p.n <= 3 && p.ldc % 4 == 0, "bifpn_fuse: bad arguments");
   const long total = (long)p.B * p.h * p.w * (p.ldc >> 2);
   hipLaunchKernelGGL(bifpn_fuse_kernel, dim3(grid_for(total)), dim3(256), 0, stream, p);
+  ODT_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_preprocess_rgb_resize(const void* frames, int dtype, int B, int Hs, int Ws, int Hr, int Wr, int pad_t,
+                                 int pad_l, int Hp, int Wp, float* out, hipStream_t stream) {
+  const long total = (long)B * Hp * Wp;
+  if (dtype == 0)
+    hipLaunchKernelGGL(preprocess_rgb_resize_kernel<unsigned char>, dim3(grid_for(total)), dim3(256), 0, stream,
+                       (const unsigned char*)frames, B, Hs, Ws, Hr, Wr, pad_t, pad_l, Hp, Wp, out);
+  else if (dtype == 1)
+    hipLaunchKernelGGL(preprocess_rgb_resize_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream,
+                       (const float*)frames, B, Hs, Ws, Hr, Wr, pad_t, pad_l, Hp, Wp, out);
+  else { set_error("preprocess: dtype must be ODT_DTYPE_U8 or ODT_DTYPE_F32"); return 1; }
   ODT_HIP(hipGetLastError());
   return 0;
 }

@@ -96,6 +96,7 @@ struct odt_model {
   EffPostParams eff_post{};
   RoiAlignParams roi_eff{};
   int eff_filters = 0;
+  int eff_scaled_h = 0, eff_scaled_w = 0;   // EfficientDet: size of the resized frame inside the padded input
   float* final_masks = nullptr;   // [B*per_im, 28, 28] (add_mask)
   DetectParams det{};
   Tensor image_pad, frames_dev;
@@ -1185,8 +1186,13 @@ int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStre
         if (launch_roi_align(m->roi_mask, st)) return 1;
         break;
       case OP_PRE_RGB:
-        if (launch_preprocess_rgb(src, dtype, cfg.batch, cfg.height, cfg.width, op.pad_t, op.pad_l, m->Hp, m->Wp,
-                                  m->image_pad.d, st)) return 1;
+        if (m->src_h == cfg.height && m->src_w == cfg.width) {
+          if (launch_preprocess_rgb(src, dtype, cfg.batch, cfg.height, cfg.width, op.pad_t, op.pad_l, m->Hp, m->Wp,
+                                    m->image_pad.d, st)) return 1;
+        } else if (launch_preprocess_rgb_resize(src, dtype, cfg.batch, m->src_h, m->src_w, m->eff_scaled_h,
+                                                m->eff_scaled_w, op.pad_t, op.pad_l, m->Hp, m->Wp, m->image_pad.d, st)) {
+          return 1;
+        }
         break;
       case OP_DW:
         if (launch_dwconv(op.dw, st)) return 1;
@@ -1364,6 +1370,16 @@ int odt_set_source_size(odt_handle h, int src_height, int src_width) {
     if (h->frames_src.alloc(need)) return 1;
   }
   h->src_h = src_height; h->src_w = src_width;
+  if (h->cfg.graph == ODT_GRAPH_EFFNET) {
+    // dataloader.py:100-112: image_scale = min(out_w / w, out_h / h) in float32, scaled size by truncation;
+    // image_scale_to_original = 1 / image_scale multiplies the output boxes (efficientdet_wrapper.py:57)
+    const float sy = (float)h->cfg.height / (float)src_height, sx = (float)h->cfg.width / (float)src_width;
+    const float sc = sx < sy ? sx : sy;
+    h->eff_scaled_h = (int)((float)src_height * sc); h->eff_scaled_w = (int)((float)src_width * sc);
+    ODT_CHECK(h->eff_scaled_h >= 1 && h->eff_scaled_w >= 1 && h->eff_scaled_h <= h->cfg.height &&
+              h->eff_scaled_w <= h->cfg.width, "odt_set_source_size: scaled frame does not fit the network input");
+    h->eff_post.image_scale = 1.0f / sc;
+  }
   return 0;
 }
 

@@ -101,6 +101,8 @@ int launch_bifpn_fuse(const FuseParams& p, hipStream_t stream);
 int launch_preprocess_rgb(const void* frames, int dtype, int B, int H, int W, int pad_t, int pad_l, int Hp, int Wp,
                           float* out, hipStream_t stream);
 int channel_mean_splits(int HW);
+int launch_preprocess_rgb_resize(const void* frames, int dtype, int B, int Hs, int Ws, int Hr, int Wr, int pad_t,
+                                 int pad_l, int Hp, int Wp, float* out, hipStream_t stream);
 int launch_channel_mean(const float* in, int B, int HW, int ldc, float* scratch, float* out, hipStream_t stream);
 int launch_channel_scale(float* x, const float* s, int B, int HW, int ldc, hipStream_t stream);
 

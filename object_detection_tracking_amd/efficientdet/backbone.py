@@ -17,6 +17,7 @@ class EfficientNetBackbone(object):
                topk=5000, score_thresh=0.0, per_im=100, image_scale=1.0):
     self.lib = lib if lib is not None else _lib.get_lib()
     self.name, self.batch, self.height, self.width = name, batch, height, width
+    self.src_height, self.src_width = height, width
     self.spec = backbone_spec(name)
     c = OdtConfig()
     c.graph = ODT_GRAPH_EFFNET; c.batch = batch; c.height = height; c.width = width
@@ -36,6 +37,12 @@ class EfficientNetBackbone(object):
       self.lib.dll.odt_destroy(self.h); self.h = None
       raise
 
+  def set_source_size(self, src_height, src_width):
+    """Frames of [B, src_height, src_width, 3]; the reference's input scaling (dataloader.py:100-123)
+    runs on the device and the output boxes are multiplied by image_scale_to_original."""
+    self.lib.check(self.lib.dll.odt_set_source_size(self.h, int(src_height), int(src_width)))
+    self.src_height, self.src_width = int(src_height), int(src_width)
+
   def close(self):
     if self.h is not None:
       self.lib.dll.odt_destroy(self.h); self.h = None
@@ -51,7 +58,7 @@ class EfficientNetBackbone(object):
     dt = ODT_DTYPE_U8 if fr.dtype == np.uint8 else ODT_DTYPE_F32
     if dt == ODT_DTYPE_F32:
       fr = np.ascontiguousarray(fr, np.float32)
-    assert fr.shape == (self.batch, self.height, self.width, 3), fr.shape
+    assert fr.shape == (self.batch, self.src_height, self.src_width, 3), fr.shape
     self._keep = fr
     self.lib.check(self.lib.dll.odt_forward_async(self.h, fr.ctypes.data_as(C.c_void_p), dt, 0, None))
 

@@ -8,10 +8,10 @@ Config fields read (reference obj_detect_tracking*.py argument names): ``efficie
 efficientdet_wrapper.py:237), ``result_score_thres``, ``result_per_im``, ``use_partial_classes`` /
 ``partial_classes``.
 
-Input: frames that already have the network's input size in at least one dimension and do not
-exceed it in the other (scale factor 1: the reference's resize is then the identity and only the
-zero padding to (short_edge_size, max_size) remains).  Other sizes need the TF bilinear resize of
-dataloader.DetectionInputProcessor, which is not built yet -> NotImplementedError.
+Input: frames of any size; the reference's input processor (dataloader.py:100-123: scale by
+min(out_w / w, out_h / h), TF-1.x bilinear resize of the normalised image, zero padding to
+(short_edge_size, max_size)) runs on the device, and the boxes come back multiplied by
+image_scale_to_original like the reference's.
 """
 import numpy as np
 
@@ -81,17 +81,20 @@ class EfficientDet(object):
     self.final_probs = TensorHandle(self, "final_probs")
     self.fpn_box_feat = TensorHandle(self, "fpn_box_feat")
 
-  def engine(self, image_scale=1.0):
-    key = float(image_scale)
+  def engine(self, src_hw=None):
+    key = tuple(src_hw) if src_hw is not None else (self.height, self.width)
     if key not in self._engines:
       w = dict(self.weights)
       w["effdet/anchors"] = generate_anchors(self.height, self.width, self.cfg["anchor_scale"])
-      self._engines[key] = EfficientNetBackbone(
+      e = EfficientNetBackbone(
           self.cfg["backbone"], w, 1, self.height, self.width, device=self.gpuid, lib=self.lib,
           det=self.model_name, num_classes=self.num_classes,
           topk=int(getattr(self.config, "efficientdet_max_detection_topk", 5000)),
           score_thresh=float(getattr(self.config, "result_score_thres", 0.0)),
-          per_im=int(getattr(self.config, "result_per_im", 100)), image_scale=image_scale)
+          per_im=int(getattr(self.config, "result_per_im", 100)))
+      if key != (self.height, self.width):
+        e.set_source_size(*key)
+      self._engines[key] = e
     return self._engines[key]
 
   def get_feed_dict_forward(self, imgdata):      # efficientdet_wrapper.py:99-105
@@ -101,19 +104,7 @@ class EfficientDet(object):
     """uint8 (or float32) BGR frame [H0,W0,3] -> (boxes [R,4], labels [R] int32, probs [R],
     fpn_box_feat [R, filters])."""
     frame = np.asarray(frame)
-    h0, w0 = frame.shape[:2]
-    scale = min(self.height / float(h0), self.width / float(w0))     # dataloader set_scale_factors_to_output_size
-    if int(h0 * scale) != h0 or int(w0 * scale) != w0:
-      raise NotImplementedError("EfficientDet: frame %dx%d needs the TF bilinear resize to the %dx%d input "
-                                "(not built yet); feed frames with scale factor 1" % (w0, h0, self.width, self.height))
-    if (h0, w0) != (self.height, self.width):
-      pad = np.zeros((self.height, self.width, 3), frame.dtype)
-      # zero padding happens AFTER normalisation in the reference (pad_to_bounding_box of the
-      # normalised image): feed the value that normalises to exactly 0 is impossible for uint8, so
-      # padded inputs go through float32 with the per-channel means
-      raise NotImplementedError("EfficientDet: padded inputs are not built yet; feed %dx%d frames"
-                                % (self.width, self.height))
-    e = self.engine(1.0 / scale)
+    e = self.engine(frame.shape[:2])
     per = int(getattr(self.config, "result_per_im", 100))
     F_ = self.cfg["fpn_num_filters"]
     boxes = np.zeros((1, per, 4), np.float32); probs = np.zeros((1, per), np.float32)

@@ -58,6 +58,28 @@ def preprocess(frames_bgr_u8):
   return torch.from_numpy(np.ascontiguousarray(x.transpose(0, 3, 1, 2)))
 
 
+def preprocess_resized(frame_bgr, out_hw):
+  """efficientdet_wrapper.py:45-60 for one frame of any size: normalise, scale by min(out_w / w,
+  out_h / h) (float32, sizes by truncation), tf.image.resize_images BILINEAR with the TF-1.x legacy
+  coordinates (in = out * in_size / out_size, lower = floor, upper = min(lower + 1, size - 1)),
+  zero pad to out_hw.  Returns (NCHW float32 [1,3,H,W], image_scale_to_original)."""
+  x = preprocess(np.asarray(frame_bgr)[None])[0].numpy().transpose(1, 2, 0)          # [h,w,3] RGB normalised
+  h, w = x.shape[:2]
+  sc = min(F(out_hw[1]) / F(w), F(out_hw[0]) / F(h))
+  sh, sw = int(F(h) * sc), int(F(w) * sc)
+  if (sh, sw) != (h, w):
+    fy = np.arange(sh, dtype=F) * (F(h) / F(sh)); fx = np.arange(sw, dtype=F) * (F(w) / F(sw))
+    y0 = np.floor(fy).astype(np.int64); x0 = np.floor(fx).astype(np.int64)
+    y1 = np.minimum(y0 + 1, h - 1); x1 = np.minimum(x0 + 1, w - 1)
+    ly = (fy - y0.astype(F))[:, None, None]; lx = (fx - x0.astype(F))[None, :, None]
+    top = x[y0][:, x0] + (x[y0][:, x1] - x[y0][:, x0]) * lx
+    bot = x[y1][:, x0] + (x[y1][:, x1] - x[y1][:, x0]) * lx
+    x = (top + (bot - top) * ly).astype(F)
+  out = np.zeros((out_hw[0], out_hw[1], 3), F)
+  out[:sh, :sw] = x
+  return torch.from_numpy(np.ascontiguousarray(out.transpose(2, 0, 1)[None])), F(1.0) / sc
+
+
 def backbone_forward(name, weights, x, taps=None):
   """x: NCHW float32 (already normalised).  Returns {level: NCHW numpy} for reduction_1..5."""
   sp = backbone_spec(name)

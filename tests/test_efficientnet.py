@@ -131,7 +131,7 @@ def test_efficientdet_d1_nets_parity_odd_size(hip_lib):
   _det_parity(hip_lib, "efficientdet-d1", 270, 350)
 
 
-def _det_e2e(lib, model, H, W, topk, score_thr=0.02, tol_box=2e-2):
+def _det_e2e(lib, model, H, W, topk, score_thr=0.02, tol_box=2e-2, src_hw=None):
   """Full EfficientDet forward through get_model / Session.run against the oracle."""
   import torch
   from object_detection_tracking_amd import models
@@ -140,11 +140,16 @@ def _det_e2e(lib, model, H, W, topk, score_thr=0.02, tol_box=2e-2):
   from oracle import effnet
   c = arch.det_config(model)
   w = arch.synthetic_det_weights(model, 0)
-  fr = synthetic_frames(1, H, W, seed=13)[0]
-  red = effnet.backbone_forward(c["backbone"], w, effnet.preprocess(fr[None]))
+  if src_hw is None:
+    fr = synthetic_frames(1, H, W, seed=13)[0]
+    x, scale = effnet.preprocess(fr[None]), 1.0
+  else:                                         # frame of another size: device-side resize + pad
+    fr = synthetic_frames(1, src_hw[0], src_hw[1], seed=13)[0]
+    x, scale = effnet.preprocess_resized(fr, (H, W))
+  red = effnet.backbone_forward(c["backbone"], w, x)
   fpn = effnet.feature_network(model, w, {l: torch.from_numpy(red[l]) for l in (3, 4, 5)}, (H, W))
   cb = effnet.class_box_nets(model, w, fpn)
-  rb, rs, rc, rl, dbg = effnet.detect(model, cb, (H, W), image_scale=1.0, topk=topk, score_thr=score_thr)
+  rb, rs, rc, rl, dbg = effnet.detect(model, cb, (H, W), image_scale=scale, topk=topk, score_thr=score_thr)
   cfg = make_config(is_efficientdet=True, efficientdet_modelname=model, efficientdet_max_detection_topk=topk,
                     short_edge_size=H, max_size=W, threshold_conf=score_thr)
   cfg.max_size = W; cfg.result_score_thres = score_thr
@@ -179,6 +184,15 @@ def _det_e2e(lib, model, H, W, topk, score_thr=0.02, tol_box=2e-2):
 def test_efficientdet_d0_end_to_end(backend):
   name, lib = backend
   _det_e2e(lib, "efficientdet-d0", 136, 152 if name == "emu" else 200, topk=300 if name == "emu" else 1000)
+
+
+def test_efficientdet_d0_resized_input(backend):
+  """A 16:9 frame into a square network input: scale 0.8 down / 1.25 up, zero padding at the bottom,
+  boxes multiplied by image_scale_to_original (efficientdet_wrapper.py:45-60)."""
+  name, lib = backend
+  _det_e2e(lib, "efficientdet-d0", 144, 144, topk=300, src_hw=(108, 180), tol_box=4e-2)
+  if name == "hip":
+    _det_e2e(lib, "efficientdet-d0", 256, 256, topk=1000, src_hw=(135, 200), tol_box=4e-2)   # upscaling
 
 
 @pytest.mark.gpu
