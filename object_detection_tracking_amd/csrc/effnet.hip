@@ -7,6 +7,8 @@
 // sigmoid -> channel scale) and efficientdet_wrapper.py:45-60 + dataloader.normalize_image (BGR ->
 // RGB, [0,1], ImageNet mean / std).  Built with -ffp-contract=off; summation orders are fixed
 // (no atomics): bit-deterministic run to run.
+#include <algorithm>
+
 #include "odt_common.hpp"
 
 namespace odt {
@@ -160,6 +162,59 @@ __global__ void __launch_bounds__(256) channel_mean_final_kernel(const float* __
   out[i] = s / (float)HW;
 }
 
+// Squeeze-excite gate in two small launches per block: mean (sum of the pixel-split partials / HW) -> 1x1
+// reduce + bias + swish -> 1x1 expand + bias + sigmoid.  One workgroup per image; fixed summation
+// orders (splits in index order, 64-lane strided partial sums + a fixed shuffle tree, reduced
+// channels in index order).
+constexpr int kSeMaxC = 4096, kSeMaxR = 256;     // EfficientNet-B7: 3840 expanded channels, 160 reduced
+// stage A, grid (ceil(se / 4), B): mean of the pixel-split partials (recomputed per workgroup, cheap)
+// and one reduced channel per wave: r[j] = swish(b1[j] + <mean, w1[j]>)
+__global__ void __launch_bounds__(256) se_reduce_kernel(SeGateParams p) {
+  __shared__ float mean[kSeMaxC];
+  __shared__ float ph4[4][64];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {
+    const int cl = tid & 63, q = tid >> 6;
+    for (int cb = 0; cb < p.ldc; cb += 64) {
+      const int c = cb + cl;
+      float s = 0.f;
+      if (c < p.ldc) {
+        const float* src = p.part + (long)b * p.nsplit * p.ldc + c;
+#pragma unroll 8
+        for (int sp = q; sp < p.nsplit; sp += 4) s += src[(long)sp * p.ldc];
+      }
+      ph4[q][cl] = s;
+      __syncthreads();
+      if (q == 0 && c < p.ldc) mean[c] = ((ph4[0][cl] + ph4[1][cl]) + (ph4[2][cl] + ph4[3][cl])) / (float)p.HW;
+      __syncthreads();
+    }
+  }
+  const int j = blockIdx.x * 4 + wave;
+  if (j < p.se) {
+    const float* w = p.w1 + (long)j * p.ldc;
+    float s = 0.f;
+#pragma unroll 4
+    for (int c = lane; c < p.ldc; c += 64) s += mean[c] * w[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) { const float v = s + p.b1[j]; p.r[(long)b * kSeMaxR + j] = v * (1.0f / (1.0f + expf(-v))); }
+  }
+}
+
+// stage B, grid (ceil(mid / 256), B): gate[c] = sigmoid(b2[c] + sum_j r[j] * w2t[j][c]), j in index order
+__global__ void __launch_bounds__(256) se_expand_kernel(SeGateParams p) {
+  __shared__ float r[kSeMaxR];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  for (int j = tid; j < p.se; j += blockDim.x) r[j] = p.r[(long)b * kSeMaxR + j];
+  __syncthreads();
+  const int c = blockIdx.x * 256 + tid;
+  if (c >= p.mid) return;
+  float s = p.b2[c];
+#pragma unroll 8
+  for (int j = 0; j < p.se; ++j) s += r[j] * p.w2t[(long)j * p.ldc + c];
+  p.gate[(long)b * p.ldc + c] = 1.0f / (1.0f + expf(-s));
+}
+
 // x[b, :, :, c] *= s[b, c]   (squeeze-excite gate, already passed through the sigmoid)
 __global__ void __launch_bounds__(256) channel_scale_kernel(float* __restrict__ x, const float* __restrict__ s,
                                                             int B, int HW, int ldc) {
@@ -278,17 +333,33 @@ int launch_dwconv(const DwConvParams& p, hipStream_t stream) {
   return 0;
 }
 
-int channel_mean_splits(int HW) {
-  int n = (HW + 511) / 512;
-  return n < 1 ? 1 : (n > 1024 ? 1024 : n);
+// pixel splits so that (channel groups x images x splits) is about 512 workgroups, >= 64 pixels each
+int channel_mean_splits(int HW, int ldc, int B) {
+  const int groups = std::max(1, (ldc + 63) / 64 * B);
+  int n = (512 + groups - 1) / groups;
+  n = std::min(n, std::max(1, HW / 64));
+  return std::max(1, std::min(n, 512));
 }
 
 // scratch: [B, channel_mean_splits(HW), ldc] floats
 int launch_channel_mean(const float* in, int B, int HW, int ldc, float* scratch, float* out, hipStream_t stream) {
-  const int ns = channel_mean_splits(HW);
+  const int ns = channel_mean_splits(HW, ldc, B);
   hipLaunchKernelGGL(channel_sum_kernel, dim3((ldc + 63) / 64, B, ns), dim3(256), 0, stream, in, HW, ldc, ns, scratch);
   hipLaunchKernelGGL(channel_mean_final_kernel, dim3((B * ldc + 255) / 256), dim3(256), 0, stream,
                      (const float*)scratch, B, ldc, ns, HW, out);
+  ODT_HIP(hipGetLastError());
+  return 0;
+}
+
+// channel_sum_kernel partials (scratch) + the gate, replacing channel_mean_final + two tiny GEMMs
+int launch_se_gate(const float* in, const SeGateParams& p0, int B, float* scratch, hipStream_t stream) {
+  SeGateParams p = p0;
+  p.nsplit = channel_mean_splits(p.HW, p.ldc, B); p.part = scratch;
+  hipLaunchKernelGGL(channel_sum_kernel, dim3((p.ldc + 63) / 64, B, p.nsplit), dim3(256), 0, stream, in, p.HW, p.ldc,
+                     p.nsplit, scratch);
+  ODT_CHECK(p.ldc <= kSeMaxC && p.se <= kSeMaxR, "se_gate: channel count too large for the LDS staging");
+  hipLaunchKernelGGL(se_reduce_kernel, dim3((p.se + 3) / 4, B), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(se_expand_kernel, dim3((p.mid + 255) / 256, B), dim3(256), 0, stream, p);
   ODT_HIP(hipGetLastError());
   return 0;
 }

@@ -59,13 +59,14 @@ struct ConvOp {
 };
 
 enum OpKind { OP_PRE, OP_CONV, OP_POOL, OP_SUB2, OP_PROPOSALS, OP_ROI_HEAD, OP_DETECT, OP_ROI_FINAL,
-              OP_ROI_MASK, OP_MASK_SELECT, OP_PRE_RGB, OP_DW, OP_CMEAN, OP_CSCALE, OP_FUSE, OP_EFF_POST, OP_ROI_EFF };
+              OP_ROI_MASK, OP_MASK_SELECT, OP_PRE_RGB, OP_DW, OP_CMEAN, OP_CSCALE, OP_FUSE, OP_EFF_POST, OP_ROI_EFF, OP_SE_GATE };
 struct Op {
   OpKind kind;
   int conv = -1;        // index into convs
   Tensor in, out;
   DwConvParams dw{};    // OP_DW
   FuseParams fuse{};    // OP_FUSE
+  SeGateParams se{};    // OP_SE_GATE (aux2 = partial-sum scratch)
   float* aux = nullptr; // OP_CMEAN: means out [B,ldc]; OP_CSCALE: gates in [B,ldc]
   float* aux2 = nullptr;   // OP_CMEAN: partial-sum scratch
   int pad_t = 0, pad_l = 0;   // OP_PRE_RGB
@@ -640,24 +641,30 @@ int build_plan_effnet(odt_model* m) {
       op.dw.k = b.kernel; op.dw.stride = b.stride; op.dw.pad_t = dpt; op.dw.pad_l = dpl; op.dw.act = 2;
       m->ops.push_back(op);
     }
-    // squeeze-excite: mean -> reduce (swish) -> expand (sigmoid) -> scale
+    // squeeze-excite: one gate kernel (mean -> reduce + swish -> expand + sigmoid), then the scale
     {
-      float* mean = m->alloc_f((size_t)B * lmid, true);
-      ODT_CHECK(mean != nullptr, "device allocation failed (SE)");
-      float* scratch = m->alloc_f((size_t)B * channel_mean_splits(ho * wo) * lmid, false);
-      ODT_CHECK(scratch != nullptr, "device allocation failed (SE scratch)");
-      { Op op; op.kind = OP_CMEAN; op.in = t2; op.aux = mean; op.aux2 = scratch; m->ops.push_back(op); }
-      Tensor ms{}; ms.d = mean; ms.B = B; ms.H = ms.h = 1; ms.W = ms.w = 1; ms.C = lmid; ms.c = mid;
-      const int lse = r32(b.se);
-      if (eff_upload_pw(m, p + "se/conv2d", "", true, mid, lmid, b.se, &wt, &bias)) return 1;
-      Tensor s1{};
-      if (add_conv(m, p + "se/conv2d", ms, lmid, wt, bias, 1, 1, b.se, 1, 1, 0, 0, 1, 1, 0, 0, nullptr, 0, false, lse, &s1, "")) return 1;
-      m->convs.back().p.relu = 2;
-      if (eff_upload_pw(m, p + "se/conv2d_1", "", true, b.se, lse, mid, &wt, &bias)) return 1;
-      Tensor s2{};
-      if (add_conv(m, p + "se/conv2d_1", s1, lse, wt, bias, 1, 1, mid, 1, 1, 0, 0, 1, 1, 0, 0, nullptr, 0, false, lmid, &s2, "")) return 1;
-      m->convs.back().p.relu = 3;
-      { Op op; op.kind = OP_CSCALE; op.in = t2; op.aux = s2.d; m->ops.push_back(op); }
+      float* gate = m->alloc_f((size_t)B * lmid, true);
+      float* scratch = m->alloc_f((size_t)B * channel_mean_splits(ho * wo, lmid, B) * lmid, false);
+      ODT_CHECK(gate && scratch, "device allocation failed (SE)");
+      const HostTensor* W1 = find_w(m, p + "se/conv2d/kernel"); const HostTensor* B1 = find_w(m, p + "se/conv2d/bias");
+      const HostTensor* W2 = find_w(m, p + "se/conv2d_1/kernel"); const HostTensor* B2 = find_w(m, p + "se/conv2d_1/bias");
+      ODT_CHECK(W1 && B1 && W2 && B2, "missing squeeze-excite variables of " + p);
+      ODT_CHECK(W1->data.size() == (size_t)mid * b.se && W2->data.size() == (size_t)b.se * mid &&
+                (int)B1->data.size() == b.se && (int)B2->data.size() == mid, "bad squeeze-excite shapes in " + p);
+      std::vector<float> w1((size_t)b.se * lmid, 0.f), w2t((size_t)b.se * lmid, 0.f);
+      for (int j = 0; j < b.se; ++j)
+        for (int c = 0; c < mid; ++c) {
+          w1[(size_t)j * lmid + c] = W1->data[(size_t)c * b.se + j];      // kernel [1,1,mid,se]
+          w2t[(size_t)j * lmid + c] = W2->data[(size_t)j * mid + c];      // kernel [1,1,se,mid]
+        }
+      Op op; op.kind = OP_SE_GATE; op.in = t2; op.aux2 = scratch;
+      op.se.HW = ho * wo; op.se.ldc = lmid; op.se.mid = mid; op.se.se = b.se; op.se.gate = gate;
+      op.se.r = m->alloc_f((size_t)B * 256, true);
+      ODT_CHECK(op.se.r != nullptr, "device allocation failed (SE)");
+      if (upload_raw(m, w1, &op.se.w1) || upload_raw(m, B1->data, &op.se.b1) || upload_raw(m, w2t, &op.se.w2t) ||
+          upload_raw(m, B2->data, &op.se.b2)) return 1;
+      m->ops.push_back(op);
+      { Op sc; sc.kind = OP_CSCALE; sc.in = t2; sc.aux = gate; m->ops.push_back(sc); }
     }
     // projection + BN (+ identity skip)
     {
@@ -1208,6 +1215,9 @@ int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStre
         break;
       case OP_EFF_POST:
         if (launch_effdet_post(m->eff_post, st)) return 1;
+        break;
+      case OP_SE_GATE:
+        if (launch_se_gate(op.in.d, op.se, op.in.B, op.aux2, st)) return 1;
         break;
       case OP_ROI_EFF:
         if (launch_roi_align(m->roi_eff, st)) return 1;

@@ -100,11 +100,22 @@ struct FuseParams {
 int launch_bifpn_fuse(const FuseParams& p, hipStream_t stream);
 int launch_preprocess_rgb(const void* frames, int dtype, int B, int H, int W, int pad_t, int pad_l, int Hp, int Wp,
                           float* out, hipStream_t stream);
-int channel_mean_splits(int HW);
+int channel_mean_splits(int HW, int ldc, int B);
 int launch_preprocess_rgb_resize(const void* frames, int dtype, int B, int Hs, int Ws, int Hr, int Wr, int pad_t,
                                  int pad_l, int Hp, int Wp, float* out, hipStream_t stream);
 int launch_channel_mean(const float* in, int B, int HW, int ldc, float* scratch, float* out, hipStream_t stream);
 int launch_channel_scale(float* x, const float* s, int B, int HW, int ldc, hipStream_t stream);
+struct SeGateParams {
+  const float* part; int nsplit;      // filled by launch_se_gate
+  int HW, ldc, mid, se;
+  const float* w1;   // [se][ldc]   reduce weights (pad channels zero)
+  const float* b1;   // [se]
+  const float* w2t;  // [se][ldc]   expand weights, transposed
+  const float* b2;   // [mid]
+  float* gate;       // [B][ldc]    (pad channels stay 0)
+  float* r;          // [B][256]    reduced vector (scratch)
+};
+int launch_se_gate(const float* in, const SeGateParams& p, int B, float* scratch, hipStream_t stream);
 
 // ------------------------------------------------------- EfficientDet tail (effdet_post.hip)
 struct EffPostParams {
