@@ -66,8 +66,17 @@ class EfficientDet(object):
     self.model_name = config.efficientdet_modelname
     self.cfg = det_config(self.model_name)
     if weights is None:
-      raise ValueError("EfficientDet: pass weights={name: array} (TF variable names); checkpoint "
-                       "directories: tf_checkpoint.load_checkpoint(config.model_path)")
+      # --model_path efficientdet-d0/ (reference COMMANDS.md:27-33): a TF checkpoint directory with
+      # the automl variable names, read without TensorFlow; .npz with the same names also works
+      path = getattr(config, "model_path", None)
+      if not path:
+        raise ValueError("EfficientDet: pass weights={name: array} or set config.model_path")
+      if str(path).endswith(".npz"):
+        from ..weights import load_npz
+        weights = load_npz(path)
+      else:
+        from ..tf_checkpoint import load_checkpoint
+        weights = load_checkpoint(str(path))
     self.num_classes = NUM_CLASSES
     if getattr(config, "use_partial_classes", False) and getattr(config, "partial_class_idxs", None):
       weights = select_partial_classes(weights, config.partial_class_idxs)

@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""BASELINE config #5: EfficientDet forward on one MI355X (random-init weights of the real
+architecture, synthetic frames).  python tools/bench_efficientdet.py [--model efficientdet-d7]
+[--size 1536] [--frame 1080x1920] [--steps 20]  -> one JSON line."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--model", default="efficientdet-d7")
+  ap.add_argument("--size", type=int, default=0, help="network input (square); 0 = the model's native size")
+  ap.add_argument("--frame", default="", help="HxW of the source frames (default: the network input size)")
+  ap.add_argument("--steps", type=int, default=20)
+  ap.add_argument("--warmup", type=int, default=3)
+  a = ap.parse_args()
+  import torch
+  from object_detection_tracking_amd import models
+  from object_detection_tracking_amd._lib import ODT_DTYPE_U8
+  from object_detection_tracking_amd.config import make_config
+  from object_detection_tracking_amd.efficientdet import arch
+  from object_detection_tracking_amd.weights import synthetic_frames
+  S = a.size or arch.det_config(a.model)["image_size"]
+  fh, fw = (int(v) for v in a.frame.split("x")) if a.frame else (S, S)
+  cfg = make_config(is_efficientdet=True, efficientdet_modelname=a.model, efficientdet_max_detection_topk=5000,
+                    short_edge_size=S, max_size=S)
+  cfg.max_size = S
+  m = models.get_model(cfg, 0, weights=arch.synthetic_det_weights(a.model, 0))
+  fr = synthetic_frames(1, fh, fw)[0]
+  e = m.engine((fh, fw))
+  dev = torch.from_numpy(fr[None].copy()).cuda(0)              # HBM-resident uint8 frame
+  step = lambda: e.lib.check(e.lib.dll.odt_forward_async(e.h, dev.data_ptr(), ODT_DTYPE_U8, 1, None))
+  for _ in range(a.warmup):
+    step()
+  e.synchronize(); torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(a.steps):
+    step()
+  e.synchronize(); torch.cuda.synchronize()
+  dt = (time.perf_counter() - t0) / a.steps
+  t1 = time.perf_counter()
+  for _ in range(5):
+    out = m.predict(fr)
+  host = (time.perf_counter() - t1) / 5
+  print(json.dumps({"metric": "%s FPS @%dx%d input per MI355X" % (a.model, S, S), "value": 1.0 / dt, "unit": "frames/s",
+                    "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3, "dtype": "f32",
+                    "data": "synthetic", "config": {"workload": "%s (EfficientNet backbone + BiFPN + class/box nets + top-5000 / NMS / "
+                    "per-level ROI features), frame %dx%d scaled on the device, batch 1, 90 classes, random-init weights, frame "
+                    "resident in HBM (uint8)" % (a.model, fw, fh)},
+                    "extra": {"host_to_host_ms": host * 1e3, "detections": int(len(out[0]))}}), flush=True)
+  m.close()
+
+
+if __name__ == "__main__":
+  main()
