@@ -269,7 +269,8 @@ def nms_with_scores(boxes, scores, max_out, iou_thr, score_thr):
   return keep[idx]
 
 
-def detect(model_name, cls_box, image_hw, image_scale=1.0, topk=5000, score_thr=0.0, per_im=100, iou_thr=0.5):
+def detect(model_name, cls_box, image_hw, image_scale=1.0, topk=5000, score_thr=0.0, per_im=100, iou_thr=0.5,
+           partial_class_idxs=None):
   """add_metric_fn_inputs (efficientdet_wrapper.py:363-480) + anchors._generate_detections_tf
   (anchors.py:399-489) for ONE image: top-k over all (anchor, class) logits, gather, decode,
   sigmoid, NMS -> boxes [R,4] x1y1x2y2 * scale, scores, classes (1-based), level index."""
@@ -278,7 +279,10 @@ def detect(model_name, cls_box, image_hw, image_scale=1.0, topk=5000, score_thr=
   for lvl in range(3, 8):
     cl, bx = cls_box[lvl]
     ncls = cl.shape[-1] // NUM_ANCHORS
-    cls_all.append(cl[0].reshape(-1, ncls)); box_all.append(bx[0].reshape(-1, 4))
+    cl = cl[0].reshape(-1, ncls)
+    if partial_class_idxs:          # efficientdet_wrapper.py:402-410: gather of the class logits
+      cl = np.ascontiguousarray(cl[:, list(partial_class_idxs)])
+    cls_all.append(cl); box_all.append(bx[0].reshape(-1, 4))
     lvl_all.append(np.full((cls_all[-1].shape[0],), lvl, np.int32))
   cls_all = np.concatenate(cls_all, 0); box_all = np.concatenate(box_all, 0); lvl_all = np.concatenate(lvl_all, 0)
   ncls = cls_all.shape[1]

@@ -131,7 +131,7 @@ def test_efficientdet_d1_nets_parity_odd_size(hip_lib):
   _det_parity(hip_lib, "efficientdet-d1", 270, 350)
 
 
-def _det_e2e(lib, model, H, W, topk, score_thr=0.02, tol_box=2e-2, src_hw=None):
+def _det_e2e(lib, model, H, W, topk, score_thr=0.02, tol_box=2e-2, src_hw=None, partial=None):
   """Full EfficientDet forward through get_model / Session.run against the oracle."""
   import torch
   from object_detection_tracking_amd import models
@@ -149,10 +149,13 @@ def _det_e2e(lib, model, H, W, topk, score_thr=0.02, tol_box=2e-2, src_hw=None):
   red = effnet.backbone_forward(c["backbone"], w, x)
   fpn = effnet.feature_network(model, w, {l: torch.from_numpy(red[l]) for l in (3, 4, 5)}, (H, W))
   cb = effnet.class_box_nets(model, w, fpn)
-  rb, rs, rc, rl, dbg = effnet.detect(model, cb, (H, W), image_scale=scale, topk=topk, score_thr=score_thr)
+  rb, rs, rc, rl, dbg = effnet.detect(model, cb, (H, W), image_scale=scale, topk=topk, score_thr=score_thr,
+                                      partial_class_idxs=partial)
   cfg = make_config(is_efficientdet=True, efficientdet_modelname=model, efficientdet_max_detection_topk=topk,
                     short_edge_size=H, max_size=W, threshold_conf=score_thr)
   cfg.max_size = W; cfg.result_score_thres = score_thr
+  if partial:
+    cfg.use_partial_classes = True; cfg.partial_class_idxs = list(partial)
   m = models.get_model(cfg, 0, weights=w, lib=lib)
   try:
     boxes, labels, probs, feats = models.Session().run(
@@ -184,6 +187,12 @@ def _det_e2e(lib, model, H, W, topk, score_thr=0.02, tol_box=2e-2, src_hw=None):
 def test_efficientdet_d0_end_to_end(backend):
   name, lib = backend
   _det_e2e(lib, "efficientdet-d0", 136, 152 if name == "emu" else 200, topk=300 if name == "emu" else 1000)
+
+
+def test_efficientdet_d0_partial_classes(emu_lib):
+  """--use_partial_classes on the EfficientDet path (efficientdet_wrapper.py:243-250, 402-410):
+  labels are 1..len(partial) in the order of partial_class_idxs."""
+  _det_e2e(emu_lib, "efficientdet-d0", 136, 152, topk=200, partial=[0, 2, 7, 44, 89])
 
 
 def test_efficientdet_d0_resized_input(backend):
