@@ -61,7 +61,8 @@ def test_session_shim_single(backend):
   cfg = small_config(resnet_num_block=[1, 1, 1, 1])
   m = models.get_model(cfg, 0, controller="/cpu:0", weights=weights_for(cfg), lib=lib)
   try:
-    img = synthetic_frames(1, 96, 128)[0].astype("float32")     # the reference feeds float32
+    hw = (64, 96) if name == "emu" else (96, 128)
+    img = synthetic_frames(1, *hw)[0].astype("float32")         # the reference feeds float32
     with models.Session() as sess:
       models.initialize(cfg, sess)
       feed = m.get_feed_dict_forward(img)
@@ -74,9 +75,9 @@ def test_session_shim_single(backend):
     assert feats.shape == (len(boxes), 256, 7, 7) and len(feats) == len(boxes)
     assert np.array_equal(only, probs)
     boxes[:, 2] -= boxes[:, 0]                                   # caller mutates in place
-    u8 = m.predict(synthetic_frames(1, 96, 128)[0])              # uint8 feed is bit-identical
+    u8 = m.predict(synthetic_frames(1, *hw)[0])                  # uint8 feed is bit-identical
     assert np.array_equal(u8[2], probs)
-    pooled = m.predict(synthetic_frames(1, 96, 128)[0], pooled=True)[3]
+    pooled = m.predict(synthetic_frames(1, *hw)[0], pooled=True)[3]
     np.testing.assert_allclose(pooled, feats.mean(axis=(2, 3)), atol=2e-6)
   finally:
     m.close()
@@ -222,26 +223,27 @@ def test_frozen_pb_reader_roundtrip(tmp_path):
     load_frozen_pb(path)
 
 
-def test_get_model_from_frozen_pb(emu_lib, tmp_path):
-  """obj_detect_tracking.py --is_load_from_pb --model_path x.pb: same detections as the same
-  weights passed directly."""
+def test_get_model_from_frozen_pb_and_checkpoint_dir(emu_lib, tmp_path):
+  """obj_detect_tracking.py --is_load_from_pb --model_path x.pb and --model_path <checkpoint dir>:
+  same detections as the same weights passed directly."""
   from object_detection_tracking_amd.frozen_pb import write_frozen_pb
+  from object_detection_tracking_amd.tf_checkpoint import write_checkpoint
   cfg = small_config(resnet_num_block=[1, 1, 1, 1])
   w = weights_for(cfg)
-  path = str(tmp_path / "obj_v3.pb")
-  write_frozen_pb(path, w)
+  pb = str(tmp_path / "obj_v3.pb")
+  write_frozen_pb(pb, w)
+  ck = tmp_path / "obj_v3_model"; ck.mkdir()
+  write_checkpoint(str(ck / "model-77"), w)
   fr = synthetic_frames(1, 64, 96)[0]
   m0 = models.get_model(cfg, 0, weights=w, lib=emu_lib)
   want = m0.predict(fr); m0.close()
-  cfg2 = small_config(resnet_num_block=[1, 1, 1, 1], is_load_from_pb=True, model_path=path,
-                      load_from=path)
-  m1 = models.get_model(cfg2, 0, lib=emu_lib)
-  try:
-    got = m1.predict(fr)
-    for a, b in zip(want, got):
-      assert np.array_equal(a, b)
-  finally:
-    m1.close()
+  for kw in (dict(is_load_from_pb=True, model_path=pb, load_from=pb), dict(model_path=str(ck))):
+    m1 = models.get_model(small_config(resnet_num_block=[1, 1, 1, 1], **kw), 0, lib=emu_lib)
+    try:
+      for a_, b_ in zip(want, m1.predict(fr)):
+        assert np.array_equal(a_, b_)
+    finally:
+      m1.close()
 
 
 # ---- TF checkpoint route (reference obj_detect_tracking.py:404-416; obj_v3_model.tgz is one) ----
@@ -265,20 +267,3 @@ def test_tf_checkpoint_reader_roundtrip(tmp_path):
   open(prefix + ".index", "ab").write(b"x")
   with pytest.raises(ValueError):
     load_checkpoint(prefix)
-
-
-def test_get_model_from_tf_checkpoint_dir(emu_lib, tmp_path):
-  from object_detection_tracking_amd.tf_checkpoint import write_checkpoint
-  cfg = small_config(resnet_num_block=[1, 1, 1, 1])
-  w = weights_for(cfg)
-  write_checkpoint(str(tmp_path / "model-77"), w)
-  fr = synthetic_frames(1, 64, 96)[0]
-  m0 = models.get_model(cfg, 0, weights=w, lib=emu_lib)
-  want = m0.predict(fr); m0.close()
-  m1 = models.get_model(small_config(resnet_num_block=[1, 1, 1, 1], model_path=str(tmp_path)), 0,
-                        lib=emu_lib)
-  try:
-    for a, b in zip(want, m1.predict(fr)):
-      assert np.array_equal(a, b)
-  finally:
-    m1.close()
