@@ -92,37 +92,57 @@ __global__ void __launch_bounds__(256) preprocess_rgb_resize_kernel(const T* __r
 }
 
 // depthwise k x k conv (k = 3 or 5), TF 'SAME' padding, stride 1 or 2, folded BN, optional swish.
-// One thread = 4 channels of one output pixel (16-byte accesses, channels innermost).
-template <int K>
+// One thread = 4 channels (16-byte accesses, channels innermost) of PX horizontally adjacent
+// output pixels: the (PX-1)*S+K input columns of a kernel row are loaded once and reused by all PX
+// outputs, the K*K weights once per thread.  Taps outside the image contribute 0 * w; the sum runs
+// ky-major, kx inner for every output.
+template <int K, int S, int PX>
 __global__ void __launch_bounds__(256) dwconv_kernel(DwConvParams p) {
+  constexpr int NC = (PX - 1) * S + K;
   const int c4n = p.ldc >> 2;
-  const long total = (long)p.B * p.Ho * p.Wo * c4n;
+  const int wob = (p.Wo + PX - 1) / PX;
+  const long total = (long)p.B * p.Ho * wob * c4n;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % c4n);
     long t = i / c4n;
-    const int xo = (int)(t % p.Wo); t /= p.Wo;
+    const int xb = (int)(t % wob); t /= wob;
     const int yo = (int)(t % p.Ho);
     const int b = (int)(t / p.Ho);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int xo0 = xb * PX, x0 = xo0 * S - p.pad_l;
+    f32x4 acc[PX];
+#pragma unroll
+    for (int q = 0; q < PX; ++q) acc[q] = zero;
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
-      const int y = yo * p.stride + ky - p.pad_t;
+      const int y = yo * S + ky - p.pad_t;
       if ((unsigned)y >= (unsigned)p.H) continue;
+      const float* row = p.in + (((long)b * p.H + y) * p.W) * p.ldc + c4 * 4;
+      f32x4 col[NC];
+#pragma unroll
+      for (int cidx = 0; cidx < NC; ++cidx) {
+        const int x = x0 + cidx;
+        col[cidx] = (unsigned)x < (unsigned)p.W ? *reinterpret_cast<const f32x4*>(row + (long)x * p.ldc) : zero;
+      }
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
-        const int x = xo * p.stride + kx - p.pad_l;
-        if ((unsigned)x >= (unsigned)p.W) continue;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(p.in + (((long)b * p.H + y) * p.W + x) * p.ldc + c4 * 4);
         const f32x4 w = *reinterpret_cast<const f32x4*>(p.wt + (long)(ky * K + kx) * p.ldc + c4 * 4);
-        acc += v * w;
+#pragma unroll
+        for (int q = 0; q < PX; ++q) acc[q] += col[q * S + kx] * w;
       }
     }
-    acc += *reinterpret_cast<const f32x4*>(p.bias + c4 * 4);
-    if (p.act == 2) {
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + c4 * 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] = swishf(acc[e]);
+    for (int q = 0; q < PX; ++q) {
+      const int xo = xo0 + q;
+      if (xo >= p.Wo) break;
+      f32x4 v = acc[q] + bias;
+      if (p.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = swishf(v[e]);
+      }
+      *reinterpret_cast<f32x4*>(p.out + (((long)b * p.Ho + yo) * p.Wo + xo) * p.ldc + c4 * 4) = v;
     }
-    *reinterpret_cast<f32x4*>(p.out + (((long)b * p.Ho + yo) * p.Wo + xo) * p.ldc + c4 * 4) = acc;
   }
 }
 
@@ -326,9 +346,14 @@ int launch_preprocess_rgb_resize(const void* frames, int dtype, int B, int Hs, i
 
 int launch_dwconv(const DwConvParams& p, hipStream_t stream) {
   ODT_CHECK(p.ldc % 4 == 0 && (p.k == 3 || p.k == 5) && (p.stride == 1 || p.stride == 2), "dwconv: bad geometry");
-  const long total = (long)p.B * p.Ho * p.Wo * (p.ldc >> 2);
-  if (p.k == 3) hipLaunchKernelGGL(dwconv_kernel<3>, dim3(grid_for(total)), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL(dwconv_kernel<5>, dim3(grid_for(total)), dim3(256), 0, stream, p);
+  constexpr int PX1 = 4, PX2 = 2;
+  const int px = p.stride == 1 ? PX1 : PX2;
+  const long total = (long)p.B * p.Ho * ((p.Wo + px - 1) / px) * (p.ldc >> 2);
+  const dim3 g(grid_for(total)), t(256);
+  if (p.k == 3 && p.stride == 1) hipLaunchKernelGGL((dwconv_kernel<3, 1, PX1>), g, t, 0, stream, p);
+  else if (p.k == 3) hipLaunchKernelGGL((dwconv_kernel<3, 2, PX2>), g, t, 0, stream, p);
+  else if (p.stride == 1) hipLaunchKernelGGL((dwconv_kernel<5, 1, PX1>), g, t, 0, stream, p);
+  else hipLaunchKernelGGL((dwconv_kernel<5, 2, PX2>), g, t, 0, stream, p);
   ODT_HIP(hipGetLastError());
   return 0;
 }
