@@ -222,3 +222,62 @@ def synthetic_det_weights(model_name, seed=0, num_classes=NUM_CLASSES):
       w[k] = rng.uniform(0.8, 1.2, shp).astype(np.float32)
   w["class_net/class-predict/bias"] = (w["class_net/class-predict/bias"] - 3.0).astype(np.float32)  # sparse positives
   return w
+
+
+def algorithmic_traffic_and_flops(model_name, height, width, num_classes=NUM_CLASSES):
+  """(bytes, flops) of one forward with every operator reading its inputs and writing its output
+  exactly once in fp32 (unpadded channel counts, weights read once) -- the unfused HBM floor the
+  kernels are measured against -- and 2*MAC flops.  Walks the same graph as the plan builder."""
+  c = det_config(model_name)
+  sp = backbone_spec(c["backbone"])
+  F_ = c["fpn_num_filters"]
+  by = fl = 0
+  def t(h, w, ch):
+    return 4 * h * w * ch
+  h, w = -(-height // 2), -(-width // 2)
+  by += height * width * 3 + t(h, w, sp["stem"]); fl += 2 * h * w * 27 * sp["stem"]
+  red = {}
+  for b in sp["blocks"]:
+    mid = b["cin"] * b["expand"]
+    if b["expand"] != 1:
+      by += t(h, w, b["cin"]) + t(h, w, mid) + 4 * b["cin"] * mid; fl += 2 * h * w * b["cin"] * mid
+    ho, wo = (-(-h // 2), -(-w // 2)) if b["stride"] == 2 else (h, w)
+    k2 = b["kernel"] ** 2
+    by += t(h, w, mid) + t(ho, wo, mid); fl += 2 * ho * wo * mid * k2            # depthwise
+    by += t(ho, wo, mid)                                                          # SE mean
+    by += 2 * t(ho, wo, mid) + 8 * mid * b["se"]; fl += 4 * mid * b["se"] + ho * wo * mid   # gate FCs + scale
+    by += t(ho, wo, mid) + t(ho, wo, b["cout"]) + 4 * mid * b["cout"]; fl += 2 * ho * wo * mid * b["cout"]
+    if b["stride"] == 1 and b["cin"] == b["cout"]:
+      by += t(ho, wo, b["cout"])
+    h, w = ho, wo
+    if b["reduction"]:
+      red[b["reduction"]] = (h, w, b["cout"])
+  sizes = feat_sizes(height, width)
+  def sep(hh, ww, cin, cout):
+    return (2 * t(hh, ww, cin) + t(hh, ww, cin) + t(hh, ww, cout) + 4 * cin * (9 + cout),
+            2 * hh * ww * cin * (9 + cout))
+  chans = [red[3][2], red[4][2], red[5][2], F_, F_]
+  by += t(*red[5]) + 2 * t(sizes[6][0], sizes[6][1], F_) + t(sizes[7][0], sizes[7][1], F_)     # P6, P7
+  fl += 2 * red[5][0] * red[5][1] * red[5][2] * F_
+  for rep in range(c["fpn_cell_repeats"]):
+    ch = list(chans) if rep == 0 else [F_] * 5
+    lv = [3, 4, 5, 6, 7]
+    for lvl, offs in BIFPN_NODES:
+      hh, ww = sizes[lvl]
+      for off in offs:
+        hs, ws = sizes[lv[off]]
+        if ch[off] != F_:
+          by += t(hs, ws, ch[off]) + t(hs, ws, F_); fl += 2 * hs * ws * ch[off] * F_
+        by += t(hs, ws, F_)
+      by += t(hh, ww, F_)
+      b2, f2 = sep(hh, ww, F_, F_); by += b2; fl += f2
+      ch.append(F_); lv.append(lvl)
+  for lvl in range(3, 8):
+    hh, ww = sizes[lvl]
+    for nout in (num_classes * NUM_ANCHORS, 4 * NUM_ANCHORS):
+      for _ in range(c["box_class_repeats"]):
+        b2, f2 = sep(hh, ww, F_, F_); by += b2; fl += f2
+      b2, f2 = sep(hh, ww, F_, nout); by += b2; fl += f2
+  nlog = sum(sizes[l][0] * sizes[l][1] for l in range(3, 8)) * NUM_ANCHORS * num_classes
+  by += 4 * nlog * 10                                   # pack + 8 radix passes + compaction over the logits
+  return by, fl

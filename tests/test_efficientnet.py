@@ -213,3 +213,11 @@ def test_efficientdet_d0_end_to_end_512(hip_lib):
 @pytest.mark.gpu
 def test_efficientdet_d2_end_to_end_odd(hip_lib):
   _det_e2e(hip_lib, "efficientdet-d2", 300, 420, topk=2000)
+
+
+def test_efficientdet_flops_match_published():
+  """Tan et al. 2020, table 1: EfficientDet-D0 2.5 B, D7 325 B multiply-adds at 512 / 1536 pixels --
+  pins the spatial sizes and operator list of the traffic / FLOP model used by the bench."""
+  _, f0 = arch.algorithmic_traffic_and_flops("efficientdet-d0", 512, 512)
+  _, f7 = arch.algorithmic_traffic_and_flops("efficientdet-d7", 1536, 1536)
+  assert abs(f0 / 2e9 - 2.5) < 0.1 and abs(f7 / 2e9 - 325) < 5

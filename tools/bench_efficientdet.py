@@ -14,6 +14,7 @@ def main():
   ap.add_argument("--frame", default="", help="HxW of the source frames (default: the network input size)")
   ap.add_argument("--steps", type=int, default=20)
   ap.add_argument("--warmup", type=int, default=3)
+  ap.add_argument("--no-cpu-baseline", action="store_true")
   a = ap.parse_args()
   import torch
   from object_detection_tracking_amd import models
@@ -43,12 +44,34 @@ def main():
   for _ in range(5):
     out = m.predict(fr)
   host = (time.perf_counter() - t1) / 5
-  print(json.dumps({"metric": "%s FPS @%dx%d input per MI355X" % (a.model, S, S), "value": 1.0 / dt, "unit": "frames/s",
+  algo_bytes, algo_flops = arch.algorithmic_traffic_and_flops(a.model, S, S)
+  res_extra = {"host_to_host_ms": host * 1e3, "detections": int(len(out[0])),
+               "algorithmic_gflop_per_frame": algo_flops / 1e9, "effective_tflops": algo_flops / dt / 1e12}
+  cpu = None
+  if not a.no_cpu_baseline:
+    # the oracle (torch-CPU fp32 restatement of the TF graph; NOT TensorFlow) on the same frame
+    import torch as _t
+    from oracle import effnet
+    w = m.weights
+    t2 = time.perf_counter()
+    x, sc = effnet.preprocess_resized(fr, (S, S))
+    redf = effnet.backbone_forward(m.cfg["backbone"], w, x)
+    fpn = effnet.feature_network(a.model, w, {l: _t.from_numpy(redf[l]) for l in (3, 4, 5)}, (S, S))
+    cb = effnet.class_box_nets(a.model, w, fpn)
+    effnet.detect(a.model, cb, (S, S), image_scale=sc)
+    cdt = time.perf_counter() - t2
+    cpu = {"value": 1.0 / cdt, "unit": "frames/s", "cores": int(_t.get_num_threads()), "kind": "port",
+           "sample": "one frame through oracle.effnet (torch-CPU fp32 + numpy tail), one pass, %.1f s" % cdt}
+  print(json.dumps({"roofline": {"bound": "hbm", "kernel": "whole network (depthwise / SE / fusion kernels are HBM-bound, "
+                    "the 1x1 convs small-K MFMA)", "achieved": algo_bytes / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
+                    "frac": algo_bytes / dt / 1e9 / 8000.0, "traffic": None,
+                    "algorithmic_bytes_per_frame": algo_bytes},
+                    "cpu_baseline": cpu, "metric": "%s FPS @%dx%d input per MI355X" % (a.model, S, S), "value": 1.0 / dt, "unit": "frames/s",
                     "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3, "dtype": "f32",
                     "data": "synthetic", "config": {"workload": "%s (EfficientNet backbone + BiFPN + class/box nets + top-5000 / NMS / "
                     "per-level ROI features), frame %dx%d scaled on the device, batch 1, 90 classes, random-init weights, frame "
                     "resident in HBM (uint8)" % (a.model, fw, fh)},
-                    "extra": {"host_to_host_ms": host * 1e3, "detections": int(len(out[0]))}}), flush=True)
+                    "extra": res_extra}), flush=True)
   m.close()
 
 
