@@ -97,6 +97,11 @@ struct odt_model {
   EffPostParams eff_post{};
   RoiAlignParams roi_eff{};
   int eff_filters = 0;
+  // hipGraph of the whole op list (one cached instance per input pointer / dtype / source size / stream):
+  // the EfficientDet plan is ~700 small launches, replaying them as a graph removes the dispatch gaps
+  struct GraphCache { const void* src = nullptr; int dtype = -1, sh = 0, sw = 0; hipStream_t st = nullptr;
+                      hipGraphExec_t exec = nullptr; } graph;
+  int graph_mode = -1;               // -1 undecided, 0 off, 1 on (ODT_GRAPH=0 disables)
   int eff_scaled_h = 0, eff_scaled_w = 0;   // EfficientDet: size of the resized frame inside the padded input
   float* final_masks = nullptr;   // [B*per_im, 28, 28] (add_mask)
   DetectParams det{};
@@ -730,6 +735,7 @@ int odt_destroy(odt_handle h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
+  if (h->graph.exec) { (void)hipGraphExecDestroy(h->graph.exec); h->graph.exec = nullptr; }
   for (auto e : h->ev) (void)hipEventDestroy(e);
   for (auto e : h->ev_total) if (e) (void)hipEventDestroy(e);
   for (auto& sl : h->slot) {
@@ -1127,29 +1133,10 @@ int build_plan(odt_model* m) {
   return 0;
 }
 
-static size_t input_bytes(const odt_model* m, int dtype) {
-  return (size_t)m->cfg.batch * m->src_h * m->src_w * 3 * (dtype == ODT_DTYPE_U8 ? 1 : 4);
-}
-
-int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStream_t st) {
+// the op list of the static plan, launched on `st` (directly, or while the stream is being captured)
+static int run_ops(odt_model* m, const void* src, int dtype, hipStream_t st, size_t* ev_io) {
   const odt_config& cfg = m->cfg;
-  ODT_CHECK(m->finalized, "odt_forward: call odt_finalize_weights first");
-  ODT_CHECK(frames != nullptr, "odt_forward: null frames");
-  ODT_CHECK(dtype == ODT_DTYPE_U8 || dtype == ODT_DTYPE_F32, "odt_forward: bad dtype");
-  ODT_HIP(hipSetDevice(m->device));
-  const void* src = frames;
-  if (!on_device) {
-    const size_t n = input_bytes(m, dtype);
-    void* stage = n <= m->frames_bytes ? (void*)m->frames_dev.d : m->frames_src.p;
-    ODT_HIP(hipMemcpyAsync(stage, frames, n, hipMemcpyHostToDevice, st));
-    src = stage;
-  }
-  size_t ev_i = 0;
-  if (m->profile) {
-    while (m->ev.size() < 2 * m->convs.size()) { hipEvent_t e; ODT_HIP(hipEventCreate(&e)); m->ev.push_back(e); }
-    for (int i = 0; i < 2; ++i) if (!m->ev_total[i]) ODT_HIP(hipEventCreate(&m->ev_total[i]));
-    ODT_HIP(hipEventRecord(m->ev_total[0], st));
-  }
+  size_t ev_i = *ev_io;
   for (const Op& op : m->ops) {
     switch (op.kind) {
       case OP_PRE:
@@ -1227,6 +1214,62 @@ int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStre
         break;
     }
   }
+  *ev_io = ev_i;
+  return 0;
+}
+
+static size_t input_bytes(const odt_model* m, int dtype) {
+  return (size_t)m->cfg.batch * m->src_h * m->src_w * 3 * (dtype == ODT_DTYPE_U8 ? 1 : 4);
+}
+
+int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStream_t st) {
+  const odt_config& cfg = m->cfg;
+  ODT_CHECK(m->finalized, "odt_forward: call odt_finalize_weights first");
+  ODT_CHECK(frames != nullptr, "odt_forward: null frames");
+  ODT_CHECK(dtype == ODT_DTYPE_U8 || dtype == ODT_DTYPE_F32, "odt_forward: bad dtype");
+  ODT_HIP(hipSetDevice(m->device));
+  const void* src = frames;
+  if (!on_device) {
+    const size_t n = input_bytes(m, dtype);
+    void* stage = n <= m->frames_bytes ? (void*)m->frames_dev.d : m->frames_src.p;
+    ODT_HIP(hipMemcpyAsync(stage, frames, n, hipMemcpyHostToDevice, st));
+    src = stage;
+  }
+  size_t ev_i = 0;
+  if (m->profile) {
+    while (m->ev.size() < 2 * m->convs.size()) { hipEvent_t e; ODT_HIP(hipEventCreate(&e)); m->ev.push_back(e); }
+    for (int i = 0; i < 2; ++i) if (!m->ev_total[i]) ODT_HIP(hipEventCreate(&m->ev_total[i]));
+    ODT_HIP(hipEventRecord(m->ev_total[0], st));
+  }
+  // ---- graph replay (not while profiling, not when the pipelined ingest needs an event wait)
+  if (m->graph_mode < 0) { const char* e = getenv("ODT_GRAPH"); m->graph_mode = (e && e[0] == '0') ? 0 : 1; }
+  if (m->graph_mode == 1 && !m->profile && m->wait_before_detect == nullptr) {
+    odt_model::GraphCache& g = m->graph;
+    if (g.exec != nullptr && g.src == src && g.dtype == dtype && g.sh == m->src_h && g.sw == m->src_w && g.st == st) {
+      ODT_HIP(hipGraphLaunch(g.exec, st));
+      return 0;
+    }
+    if (g.exec != nullptr) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      size_t dummy = 0;
+      const int rc = run_ops(m, src, dtype, st, &dummy);
+      const hipError_t ec = hipStreamEndCapture(st, &graph);
+      if (rc == 0 && ec == hipSuccess && graph != nullptr &&
+          hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        g.src = src; g.dtype = dtype; g.sh = m->src_h; g.sw = m->src_w; g.st = st;
+        ODT_HIP(hipGraphLaunch(g.exec, st));
+        return 0;
+      }
+      if (graph != nullptr) (void)hipGraphDestroy(graph);
+      g.exec = nullptr;
+      if (rc != 0) return 1;
+    }
+    (void)hipGetLastError();
+    m->graph_mode = 0;               // capture not available (simulator) or failed: direct launches from now on
+  }
+  if (run_ops(m, src, dtype, st, &ev_i)) return 1;
   if (m->profile) {
     ODT_HIP(hipEventRecord(m->ev_total[1], st));
     ODT_HIP(hipStreamSynchronize(st));

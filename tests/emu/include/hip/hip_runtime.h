@@ -65,7 +65,7 @@ typedef int hipError_t;
 typedef void* hipStream_t;
 struct hipEvent_s { double t; };
 typedef hipEvent_s* hipEvent_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorUnknown = 999 };
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost,
                      hipMemcpyDeviceToDevice, hipMemcpyDefault };
 struct hipDeviceProp_t { char name[256]; int multiProcessorCount; char gcnArchName[256]; };
@@ -320,6 +320,17 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = 0) { me
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+// ---- graphs: not emulated; capture reports failure and the library falls back to direct launches
+typedef struct hipGraph_s* hipGraph_t;
+typedef struct hipGraphExec_s* hipGraphExec_t;
+typedef void* hipGraphNode_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1 };
+inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorUnknown; }
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return hipErrorUnknown; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, hipGraphNode_t*, char*, size_t) { return hipErrorUnknown; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorUnknown; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipEvent_s{0}; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = 0) { e->t = hipemu::now_ms(); return hipSuccess; }
