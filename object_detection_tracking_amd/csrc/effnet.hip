@@ -187,28 +187,29 @@ __global__ void __launch_bounds__(256) channel_mean_final_kernel(const float* __
 // orders (splits in index order, 64-lane strided partial sums + a fixed shuffle tree, reduced
 // channels in index order).
 constexpr int kSeMaxC = 4096, kSeMaxR = 256;     // EfficientNet-B7: 3840 expanded channels, 160 reduced
-// stage A, grid (ceil(se / 4), B): mean of the pixel-split partials (recomputed per workgroup, cheap)
-// and one reduced channel per wave: r[j] = swish(b1[j] + <mean, w1[j]>)
+// stage A, grid (ceil(se / 4), B): one reduced channel per wave: r[j] = swish(b1[j] + <mean, w1[j]>)
+// fold: mean[b][c] = (sum of the pixel-split partials, 4 phases in fixed order) / HW; grid (ldc/64, B)
+__global__ void __launch_bounds__(256) channel_mean_fold_kernel(SeGateParams p) {
+  __shared__ float ph4[4][64];
+  const int b = blockIdx.y, cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s = 0.f;
+  if (c < p.ldc) {
+    const float* src = p.part + (long)b * p.nsplit * p.ldc + c;
+#pragma unroll 8
+    for (int sp = q; sp < p.nsplit; sp += 4) s += src[(long)sp * p.ldc];
+  }
+  ph4[q][cl] = s;
+  __syncthreads();
+  if (q == 0 && c < p.ldc)
+    p.mean[(long)b * p.ldc + c] = ((ph4[0][cl] + ph4[1][cl]) + (ph4[2][cl] + ph4[3][cl])) / (float)p.HW;
+}
+
 __global__ void __launch_bounds__(256) se_reduce_kernel(SeGateParams p) {
   __shared__ float mean[kSeMaxC];
-  __shared__ float ph4[4][64];
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  {
-    const int cl = tid & 63, q = tid >> 6;
-    for (int cb = 0; cb < p.ldc; cb += 64) {
-      const int c = cb + cl;
-      float s = 0.f;
-      if (c < p.ldc) {
-        const float* src = p.part + (long)b * p.nsplit * p.ldc + c;
-#pragma unroll 8
-        for (int sp = q; sp < p.nsplit; sp += 4) s += src[(long)sp * p.ldc];
-      }
-      ph4[q][cl] = s;
-      __syncthreads();
-      if (q == 0 && c < p.ldc) mean[c] = ((ph4[0][cl] + ph4[1][cl]) + (ph4[2][cl] + ph4[3][cl])) / (float)p.HW;
-      __syncthreads();
-    }
-  }
+  for (int c = tid; c < p.ldc; c += blockDim.x) mean[c] = p.mean[(long)b * p.ldc + c];
+  __syncthreads();
   const int j = blockIdx.x * 4 + wave;
   if (j < p.se) {
     const float* w = p.w1 + (long)j * p.ldc;
@@ -383,6 +384,7 @@ int launch_se_gate(const float* in, const SeGateParams& p0, int B, float* scratc
   hipLaunchKernelGGL(channel_sum_kernel, dim3((p.ldc + 63) / 64, B, p.nsplit), dim3(256), 0, stream, in, p.HW, p.ldc,
                      p.nsplit, scratch);
   ODT_CHECK(p.ldc <= kSeMaxC && p.se <= kSeMaxR, "se_gate: channel count too large for the LDS staging");
+  hipLaunchKernelGGL(channel_mean_fold_kernel, dim3((p.ldc + 63) / 64, B), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(se_reduce_kernel, dim3((p.se + 3) / 4, B), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(se_expand_kernel, dim3((p.mid + 255) / 256, B), dim3(256), 0, stream, p);
   ODT_HIP(hipGetLastError());

@@ -665,7 +665,8 @@ int build_plan_effnet(odt_model* m) {
       Op op; op.kind = OP_SE_GATE; op.in = t2; op.aux2 = scratch;
       op.se.HW = ho * wo; op.se.ldc = lmid; op.se.mid = mid; op.se.se = b.se; op.se.gate = gate;
       op.se.r = m->alloc_f((size_t)B * 256, true);
-      ODT_CHECK(op.se.r != nullptr, "device allocation failed (SE)");
+      op.se.mean = m->alloc_f((size_t)B * lmid, true);
+      ODT_CHECK(op.se.r != nullptr && op.se.mean != nullptr, "device allocation failed (SE)");
       if (upload_raw(m, w1, &op.se.w1) || upload_raw(m, B1->data, &op.se.b1) || upload_raw(m, w2t, &op.se.w2t) ||
           upload_raw(m, B2->data, &op.se.b2)) return 1;
       m->ops.push_back(op);

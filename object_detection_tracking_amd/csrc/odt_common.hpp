@@ -114,6 +114,7 @@ struct SeGateParams {
   const float* b2;   // [mid]
   float* gate;       // [B][ldc]    (pad channels stay 0)
   float* r;          // [B][256]    reduced vector (scratch)
+  float* mean;       // [B][ldc]    spatial mean (scratch)
 };
 int launch_se_gate(const float* in, const SeGateParams& p, int B, float* scratch, hipStream_t stream);
 
