@@ -221,3 +221,16 @@ def test_efficientdet_flops_match_published():
   _, f0 = arch.algorithmic_traffic_and_flops("efficientdet-d0", 512, 512)
   _, f7 = arch.algorithmic_traffic_and_flops("efficientdet-d7", 1536, 1536)
   assert abs(f0 / 2e9 - 2.5) < 0.1 and abs(f7 / 2e9 - 325) < 5
+
+
+def test_anchor_known_answers():
+  """EfficientDet-D0 @512: 49 104 anchors (the count every port of the model quotes); the first
+  anchor is the 32-pixel square centred on the first stride-8 cell; product generator == oracle."""
+  from object_detection_tracking_amd.efficientdet import generate_anchors
+  from oracle import effnet
+  a = generate_anchors(512, 512, 4.0)
+  assert a.shape == (49104, 4) and a.dtype == np.float32
+  assert np.array_equal(a[0], np.array([-12, -12, 20, 20], np.float32))
+  np.testing.assert_allclose(a[1], [4 - 32 * 0.7 / 2, 4 - 32 * 1.4 / 2, 4 + 32 * 0.7 / 2, 4 + 32 * 1.4 / 2], rtol=1e-6)
+  assert np.array_equal(a, effnet.generate_anchors((512, 512), 4.0))
+  assert generate_anchors(1536, 1536, 5.0).shape == (441936, 4)          # D7
