@@ -648,7 +648,12 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
     ODT_HIP(hipMemcpy(tmp, &q, sizeof(ConvParams), hipMemcpyHostToDevice));
     dev_params = tmp;
   }
-  if (tile == 0) tile = p.Cout <= 64 ? 1 : (tiles128 < 384 ? 2 : 3);
+  // short reductions (K <= 384: EfficientNet / BiFPN 1x1 convs, the res2 / res3 1x1 layers): the
+  // 64x64 tile wins -- more workgroups per CU hide the per-tile prologue / epilogue that a two-to-
+  // twelve-slice main loop cannot amortise (measured per layer; ODT_CONV_SMALLK=0 for the A/B)
+  static const bool smallk = !(getenv("ODT_CONV_SMALLK") && getenv("ODT_CONV_SMALLK")[0] == '0');
+  const int Kfull = p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0);
+  if (tile == 0) tile = p.Cout <= 64 ? 1 : ((tiles128 < 384 || (smallk && Kfull <= 384)) ? 2 : 3);
   // LDS stages: the single-stage / 3-workgroups-per-CU variant wins everywhere (measured per
   // layer, profiles/) except the long 1x1 reductions on the 128x128 tile (res4 conv1, K = 1024:
   // every slice is fresh HBM data, the two-slice register+LDS prefetch of ST = 2 hides it better).
