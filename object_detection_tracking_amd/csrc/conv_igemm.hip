@@ -616,6 +616,21 @@ double conv_flops(const ConvParams& p) {
          (double)(p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0));
 }
 
+int conv_split_mode() {
+  const char* e = getenv("ODT_CONV_SPLIT");      // read per call: tests and A/B runs flip it
+  return e != nullptr ? atoi(e) : 0;
+}
+
+bool conv_split_wanted(const ConvParams& p) {
+  if (conv_split_mode() == 0 || !conv_split_supported(p)) return false;
+  // 128 x 256 tiles, two workgroups per CU: below one full round the exact-f32 kernel's smaller
+  // tiles fill the chip better (b=1 res4: 64 tiles)
+  const char* e = getenv("ODT_CONV_SPLIT_MINTILES");
+  const long min_tiles = e != nullptr ? atol(e) : 384L;
+  const long M = (long)p.B * p.Ho * p.Wo;
+  return ((M + 127) / 128) * (p.Cout / 256) >= min_tiles;
+}
+
 int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_params) {
   ODT_CHECK(p.Cin % 32 == 0, "conv: Cin must be a multiple of 32");
   ODT_CHECK(p.in_ldc % 4 == 0, "conv: input pixel stride must be a multiple of 4 floats");
@@ -641,12 +656,31 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
   if (const char* e = getenv("ODT_CONV_DEBUG")) {
     if (atoi(e) != 0) { q.debug = atoi(e); modified = true; }
   }
+  // bf16x3 split path: plan convs carry their weight image; stand-alone calls (tests, tuning)
+  // build a temporary one
+  void* tmp_img = nullptr;
+  const bool split = q.wt_split != nullptr ? conv_split_mode() != 0 : conv_split_wanted(q);
+  if (split && q.wt_split == nullptr) {
+    const int Ksp = q.kh * q.kw * q.Cin;
+    ODT_HIP(hipMalloc(&tmp_img, conv_split_weight_bytes(q.Cout, Ksp)));
+    if (conv_make_split_weights(q.wt, q.Cout, Ksp, tmp_img, stream)) { (void)hipFree(tmp_img); return 1; }
+    q.wt_split = tmp_img; modified = true;
+  }
   // stand-alone calls (tests, tuning) and debug overrides: stage the record in a temporary
   ConvParams* tmp = nullptr;
   if (dev_params == nullptr || modified) {
     ODT_HIP(hipMalloc((void**)&tmp, sizeof(ConvParams)));
     ODT_HIP(hipMemcpy(tmp, &q, sizeof(ConvParams), hipMemcpyHostToDevice));
     dev_params = tmp;
+  }
+  if (split) {
+    if (launch_conv_split(q, dev_params, stream)) return 1;
+    if (tmp != nullptr || tmp_img != nullptr) {
+      ODT_HIP(hipStreamSynchronize(stream));
+      if (tmp != nullptr) ODT_HIP(hipFree(tmp));
+      if (tmp_img != nullptr) ODT_HIP(hipFree(tmp_img));
+    }
+    return 0;
   }
   // short reductions (K <= 384: EfficientNet / BiFPN 1x1 convs, the res2 / res3 1x1 layers): the
   // 64x64 tile wins -- more workgroups per CU hide the per-tile prologue / epilogue that a two-to-

@@ -1,0 +1,324 @@
+// f32 implicit-GEMM convolution on the bf16 matrix pipe of gfx950 ("bf16x3 split"), for the
+// Cout % 256 == 0 layers that dominate the ResNet-101-FPN frame (res4 3x3 / 1x1 convs, FPN
+// post-hoc 3x3, RPN 3x3: ~60 % of the conv time; same reference ops as conv_igemm.hip:
+// nn.py:337-381 conv2d + :1771-1774 folded BN + ReLU).
+//
+// Arithmetic.  Every f32 operand is cut into three bf16 pieces by round-to-nearest,
+//     x = hi + mid + lo   exactly   (3 x 8 significand bits = the 24 bits of an f32),
+// |mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|, so a*b is the sum of nine piece products.  The six largest
+// are evaluated on v_mfma_f32_32x32x16_bf16 (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid); the
+// three dropped ones (mid*lo, lo*mid, lo*lo) are bounded by (2^-23 + 2^-32) |a||b|: two f32
+// roundings of the product, unbiased (the pieces carry either sign).  Each piece product is exact
+// in f32 (8 x 8 bits) and the accumulation is f32 inside the MFMA unit: the result carries the
+// error of an f32 dot product with a different summation order (measured ~1e-7 of sum|a||b| on
+// K = 2304, the same as a sequential f32 loop; tools/experiments/split_gemm.hip; the bound is
+// asserted in tests/test_ops.py).  |x| above 3.39e38 (bf16 rounds to inf) is outside the domain.  bf16 MFMA runs at 16x the f32 MFMA rate, so six products
+// cost 6/16 of the f32 instruction time: the ceiling is 2.67x the f32 MFMA peak.
+//
+// Tiling.  128 x 256 block tile (the whole Cout of a 256-channel layer: A is fetched from HBM
+// and split once), 4 waves as 2 x 2, wave tile 64 x 128 (acc = 128 VGPRs), BK = 32, one LDS stage
+// (72 KB: 3 A planes + 3 B planes) + register prefetch of the next slice, 2 workgroups per CU.
+// A: f32 NHWC activations, gathered per tap exactly as in conv_igemm.hip, split on the way into
+// LDS.  B: weights split ONCE at plan-build time (conv_make_split_weights) into the per-stage LDS
+// image [n-tile][k-slice][piece][k-group][256 n][8 k] so that a stage is one linear 48 KB copy.
+// LDS planes are [k-group][row][8 bf16]: a wave's ds_read_b128 of an MFMA operand is one
+// contiguous 512-byte run per 32 lanes.
+//
+// Scope: res_mode == 0, no second A source, Cout % 256 == 0, Cin % 32 == 0, 16-byte-aligned
+// output rows; everything else stays on the exact-f32 MFMA kernel (launch_conv decides).
+#include <cstdlib>
+#include <type_traits>
+
+#include "odt_common.hpp"
+
+namespace odt {
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((vector_size(16)));
+typedef unsigned int u32x2 __attribute__((vector_size(8)));
+typedef short bf16x8 __attribute__((vector_size(16)));
+
+constexpr unsigned kOOB = 0x80000000u;
+constexpr int SBM = 128, SBN = 256;
+constexpr int AKG = SBM * 16 + 32, APL = 4 * AKG;     // bytes: one k-group / one piece plane of A
+constexpr int BKG = SBN * 16 + 32, BPL = 4 * BKG;
+constexpr int LDS_SPLIT = 3 * APL + 3 * BPL;          // 74,496 B
+constexpr int STAGE_B_BYTES = 3 * 4 * SBN * 16;       // 49,152 B of pre-imaged weights per stage
+
+__device__ __forceinline__ int sfast_div(int n, unsigned mul, unsigned sh) {
+  return mul ? (int)(__umulhi((unsigned)n, mul) >> sh) : n;
+}
+// Two f32 -> two bf16 (round to nearest even) in one dword: v_cvt_pk_bf16_f32.  (The CPU simulator
+// of the test suite supplies its own ODT_CVT_PK_BF16.)
+#ifndef ODT_CVT_PK_BF16
+typedef __bf16 odt_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float odt_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a0, float a1) {
+  const odt_f32x2 v = {a0, a1};
+  const odt_bf16x2 r = __builtin_convertvector(v, odt_bf16x2);
+  return *reinterpret_cast<const unsigned*>(&r);
+}
+#define ODT_CVT_PK_BF16(a0, a1) cvt_pk_bf16(a0, a1)
+#endif
+// x = hi + mid + lo exactly: hi = RN8(x); x - hi has <= 16 significant bits and is exact in f32;
+// mid = RN8(x - hi); the rest has <= 8 bits, so lo is exact.  |mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|.
+__device__ __forceinline__ void split2(float a0, float a1, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = ODT_CVT_PK_BF16(a0, a1);
+  const float r0 = a0 - __uint_as_float(hi << 16);
+  const float r1 = a1 - __uint_as_float(hi & 0xffff0000u);
+  mid = ODT_CVT_PK_BF16(r0, r1);
+  const float s0 = r0 - __uint_as_float(mid << 16);
+  const float s1 = r1 - __uint_as_float(mid & 0xffff0000u);
+  lo = ODT_CVT_PK_BF16(s0, s1);
+}
+
+__global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __restrict__ pp) {
+  const ConvParams p = *pp;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_SPLIT];
+  unsigned char* const ldsB = lds + 3 * APL;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = p.Cout / SBN;
+  // XCD-aware tile order (see conv_igemm.hip): one contiguous run of tiles per XCD
+  int wg = (int)blockIdx.x;
+  {
+    const int nwg = (int)gridDim.x, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  const int mt = wg / ntn, nt = wg - mt * ntn;
+  const int m0 = mt * SBM, n0 = nt * SBN;
+  const int HoWo = p.Ho * p.Wo;
+  const int M = p.B * HoWo;
+  const int cpt = p.Cin >> 5;
+  const int nslices = p.kh * p.kw * cpt;
+
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.in, 0, (int)((unsigned)p.B * p.in_Ha * p.in_Wa * p.in_ldc * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.wt_split, 0, (int)((unsigned)ntn * nslices * (unsigned)STAGE_B_BYTES), 0x00020000);
+
+  // ---- A loader: thread -> (row lr + 32*j, 16-byte column lc), as in conv_igemm.hip
+  const int lc = tid & 7, lr = tid >> 3;
+  int a_hw0[4];
+  unsigned a_img[4];
+  const bool dense_in = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 &&
+                        p.H == p.in_Ha && p.W == p.in_Wa && p.Ho == p.H && p.Wo == p.W;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + lr + 32 * j;
+    const bool ok = m < M;
+    if (dense_in) {
+      a_hw0[j] = 0;
+      a_img[j] = ok ? (unsigned)m * p.in_ldc * 4u + lc * 16u : kOOB;
+    } else {
+      const int mm = ok ? m : 0;
+      const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), r = mm - n * HoWo;
+      const int ho = sfast_div(r, p.div_wo_mul, p.div_wo_sh), wo = r - ho * p.Wo;
+      a_hw0[j] = (int)(((unsigned)(ho * p.stride - p.pad_t) << 16) | ((unsigned)(wo * p.stride - p.pad_l) & 0xffffu));
+      a_img[j] = ok ? (unsigned)n * p.in_Ha * p.in_Wa * p.in_ldc * 4u + lc * 16u : kOOB;
+    }
+  }
+  const unsigned pix_bytes = (unsigned)p.in_ldc * 4u;
+  int l_cc = 0, l_kh = 0, l_kw = 0;
+  unsigned a_row[4];
+  auto set_tap = [&](int khh, int kww) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int hi = (a_hw0[j] >> 16) + khh * p.dil, wi = (int)(short)(a_hw0[j] & 0xffff) + kww * p.dil;
+      const bool v = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W && a_img[j] != kOOB;
+      a_row[j] = v ? a_img[j] + (unsigned)(hi * p.in_Wa + wi) * pix_bytes : kOOB;
+    }
+  };
+  set_tap(0, 0);
+  unsigned l_b = (unsigned)nt * (unsigned)nslices * (unsigned)STAGE_B_BYTES;   // weight-image offset of the load stream
+
+  f32x4 ga[4];
+  u32x4 gb[12];
+  auto load_slice = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      ga[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)a_row[j], l_cc * 128, 0);
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+      gb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, tid * 16 + i * 4096, (int)l_b, 0);
+    l_b += (unsigned)STAGE_B_BYTES;
+    if (++l_cc == cpt) {
+      l_cc = 0;
+      if (++l_kw == p.kw) { l_kw = 0; ++l_kh; }
+      set_tap(l_kh, l_kw);        // harmless past the last tap (never loaded)
+    }
+  };
+  auto store_slice = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned h0, m0_, l0, h1, m1, l1;
+      split2(ga[j][0], ga[j][1], h0, m0_, l0);
+      split2(ga[j][2], ga[j][3], h1, m1, l1);
+      const int off = (lc >> 1) * AKG + (lr + 32 * j) * 16 + (lc & 1) * 8;
+      *reinterpret_cast<u32x2*>(lds + 0 * APL + off) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(lds + 1 * APL + off) = u32x2{m0_, m1};
+      *reinterpret_cast<u32x2*>(lds + 2 * APL + off) = u32x2{l0, l1};
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+      *reinterpret_cast<u32x4*>(ldsB + (i >> 2) * BPL + (i & 3) * BKG + tid * 16) = gb[i];
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fr = lane & 31, fg = lane >> 5;
+  load_slice();
+  for (int c = 0; c < nslices; ++c) {
+    store_slice();
+    __syncthreads();
+    if (c + 1 < nslices) load_slice();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {                  // two k16 steps per slice
+      const int kg = ks * 2 + fg;
+      bf16x8 fa[3][2];
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          fa[q][t] = *reinterpret_cast<const bf16x8*>(lds + q * APL + kg * AKG + (wm * 64 + t * 32 + fr) * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bf16x8 fb[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          fb[q] = *reinterpret_cast<const bf16x8*>(ldsB + q * BPL + kg * BKG + (wn * 128 + j * 32 + fr) * 16);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                 // smallest terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue (the fast path of conv_igemm.hip without a residual): stage the tile through
+  // LDS in two 64-row passes (pass == wm), bias + activation, whole 16-byte-per-lane row segments.
+  constexpr int CS = SBN + 4;
+  constexpr int RP = 64, NCH = RP * (SBN / 4) / 256;       // 16 chunks per thread and pass
+  static_assert(RP * CS * 4 <= LDS_SPLIT, "C tile pass must fit");
+  float* Ct = reinterpret_cast<float*>(lds);
+  const bool dense_io = p.out_oy == 0 && p.out_ox == 0 && p.out_H == p.Ho && p.out_W == p.Wo;
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.out, 0, (int)((unsigned)p.B * p.out_H * p.out_W * p.out_ldc * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_bias =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (int)((unsigned)p.Cout * 4u), 0x00020000);
+  const int c4 = tid & 63, row0 = tid >> 6;
+  const int col = n0 + c4 * 4;
+  const f32x4 bias4 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, col * 4, 0, 0);
+  auto run = [&](auto act_c) {
+    constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass > 0) __syncthreads();
+      if (wm == pass) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              Ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * CS + wn * 128 + j * 32 + fr] = acc[i][j][r];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int s2 = 0; s2 < NCH; ++s2) {
+        const int rl = row0 + s2 * 4;
+        const int m = m0 + pass * RP + rl;
+        const bool ok = m < M;
+        unsigned opix;
+        if (dense_io) {
+          opix = (unsigned)m;
+        } else {
+          const int mm = ok ? m : 0;
+          const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), rr = mm - n * HoWo;
+          const int ho = sfast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
+          opix = ((unsigned)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
+        }
+        const unsigned ooff = ok ? (opix * p.out_ldc + col) * 4u : kOOB;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[rl * CS + c4 * 4]);
+        v += bias4;
+        if (ACT == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (ACT == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f / (1.0f + expf(-v[e])));
+        } else if (ACT == 3) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
+        }
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)ooff, 0, 0);
+      }
+    }
+  };
+  if (p.relu == 1) run(std::integral_constant<int, 1>{});
+  else if (p.relu == 2) run(std::integral_constant<int, 2>{});
+  else if (p.relu == 3) run(std::integral_constant<int, 3>{});
+  else run(std::integral_constant<int, 0>{});
+}
+
+// f32 weights [Cout][K] -> per-stage image of bf16 pieces (one thread per 8 consecutive k of a row)
+__global__ void split_weights_kernel(const float* __restrict__ wt, int Cout, int K, unsigned short* __restrict__ img) {
+  const int nsl = K >> 5;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;       // (n, k8)
+  const long total = (long)Cout * (K >> 3);
+  if (idx >= total) return;
+  const int n = (int)(idx / (K >> 3)), k8 = (int)(idx - (long)n * (K >> 3));
+  const int tn = n / SBN, nn = n - tn * SBN, sl = k8 >> 2, kg = k8 & 3;
+  for (int e = 0; e < 8; e += 2) {
+    unsigned piece[3];
+    split2(wt[(size_t)n * K + k8 * 8 + e], wt[(size_t)n * K + k8 * 8 + e + 1], piece[0], piece[1], piece[2]);
+    for (int q = 0; q < 3; ++q) {
+      const size_t at = ((((size_t)(tn * nsl + sl) * 3 + q) * 4 + kg) * SBN + nn) * 8 + e;
+      img[at] = (unsigned short)(piece[q] & 0xffffu);
+      img[at + 1] = (unsigned short)(piece[q] >> 16);
+    }
+  }
+}
+
+}  // namespace
+
+size_t conv_split_weight_bytes(int Cout, int K) { return (size_t)Cout * K * 6; }
+
+bool conv_split_supported(const ConvParams& p) {
+  const double wbytes = (double)p.Cout * p.kh * p.kw * p.Cin * 6.0;
+  return p.Cout % SBN == 0 && p.Cin % 32 == 0 && p.in2 == nullptr && p.res_mode == 0 && p.out_ldc % 4 == 0 &&
+         p.in_ldc % 4 == 0 && wbytes < 2147483648.0 && p.trace == nullptr;
+}
+
+int conv_make_split_weights(const float* wt_dev, int Cout, int K, void* img_dev, hipStream_t stream) {
+  ODT_CHECK(Cout % SBN == 0 && K % 32 == 0, "conv_make_split_weights: Cout % 256 == 0 and K % 32 == 0 required");
+  const long total = (long)Cout * (K >> 3);
+  hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, wt_dev, Cout, K,
+                     (unsigned short*)img_dev);
+  ODT_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t stream) {
+  const long M = (long)p.B * p.Ho * p.Wo;
+  const unsigned grid = (unsigned)(((M + SBM - 1) / SBM) * (p.Cout / SBN));
+  hipLaunchKernelGGL(conv_split_kernel, dim3(grid), dim3(256), 0, stream, dev);
+  ODT_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace odt

@@ -710,6 +710,22 @@ int build_plan(odt_model* m) {
     ms.per_image = per_im; ms.masks = m->final_masks;
     { Op op; op.kind = OP_MASK_SELECT; m->ops.push_back(op); }
   }
+  if (conv_split_mode() != 0) {   // bf16-piece weight images for the layers the split kernel takes
+    std::map<const float*, const void*> made;      // the RPN conv is shared by the five levels
+    for (ConvOp& c : m->convs) {
+      if (!conv_split_wanted(c.p)) continue;
+      auto it = made.find(c.p.wt);
+      if (it == made.end()) {
+        const int K = c.p.kh * c.p.kw * c.p.Cin;
+        float* img = m->alloc_f((conv_split_weight_bytes(c.p.Cout, K) + 3) / 4, false);
+        ODT_CHECK(img != nullptr, "device allocation failed (split weights of " + c.name + ")");
+        if (conv_make_split_weights(c.p.wt, c.p.Cout, K, img, 0)) return 1;
+        it = made.emplace(c.p.wt, img).first;
+      }
+      c.p.wt_split = it->second;
+    }
+    ODT_HIP(hipDeviceSynchronize());
+  }
   {   // conv parameter records in device memory
     std::vector<ConvParams> recs;
     for (const ConvOp& c : m->convs) recs.push_back(c.p);

@@ -62,12 +62,23 @@ struct ConvParams {
   unsigned div_howo_mul, div_howo_sh, div_wo_mul, div_wo_sh;   // exact m / (Ho*Wo), r / Wo by multiply-shift (conv_prepare)
   int debug;           // ablation bits for kernel tuning (0 in production; ODT_CONV_DEBUG)
   unsigned long long* trace;   // optional [grid][8] wall-clock phase stamps (tuning only)
+  // optional bf16-piece image of `wt` (conv_make_split_weights): the layer runs on the bf16x3
+  // split kernel (conv_split.hip: f32 result through six exact bf16 MFMA products per MAC)
+  const void* wt_split;
 };
 // fills the derived fields (multiply-shift divisors); call before copying a record to the device
 void conv_prepare(ConvParams& p);
 // dev_params: device copy of `p` (plan-owned); nullptr = stage a temporary (stand-alone calls)
 int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_params = nullptr);
 double conv_flops(const ConvParams& p);   // algorithmic 2*M*N*K
+// bf16x3 split path (conv_split.hip).  conv_split_mode(): ODT_CONV_SPLIT (0 off | 1 on).
+// conv_split_wanted(): the layer is supported AND large enough to fill the chip with 128x256 tiles.
+int conv_split_mode();
+bool conv_split_supported(const ConvParams& p);
+bool conv_split_wanted(const ConvParams& p);
+size_t conv_split_weight_bytes(int Cout, int K);
+int conv_make_split_weights(const float* wt_dev, int Cout, int K, void* img_dev, hipStream_t stream);
+int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t stream);
 
 // ------------------------------------------------------------ elementwise (K1,K4)
 int launch_preprocess(const void* frames, int dtype, int B, int H, int W, int pad_t, int pad_l,

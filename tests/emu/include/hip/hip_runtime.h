@@ -78,6 +78,7 @@ constexpr size_t kStack = 96 * 1024;
 struct WaveX {           // per-wave exchange area (double buffered)
   uint64_t u[2][kWave];
   float a[2][kWave], b[2][kWave];
+  unsigned short wa[2][kWave][8], wb[2][kWave][8];   // bf16x8 MFMA operands
   int src[2][kWave];
   unsigned long long seq[kWave];
 };
@@ -231,6 +232,46 @@ inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipem
     c[r] = acc;
   }
   return c;
+}
+// v_mfma_f32_32x32x16_bf16: lane l holds A[i=l&31][k=8*(l>>5)+e], B[k=8*(l>>5)+e][j=l&31], e=0..7;
+// C/D as the f32 32x32 form.  bf16 x bf16 products are exact in f32; the sum over k is modelled
+// in double and rounded once (the hardware's internal order is not specified).
+typedef short hipemu_bf16x8 __attribute__((vector_size(16)));
+inline float hipemu_bf16_to_f32(unsigned short h) {
+  unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f;
+}
+inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x16 c,
+                                                             int, int, int) {
+  int s = hipemu::wave_sync_begin();
+  hipemu::WaveX& x = hipemu::wavex();
+  int l = hipemu::lane_id();
+  for (int e = 0; e < 8; ++e) { x.wa[s][l][e] = (unsigned short)a[e]; x.wb[s][l][e] = (unsigned short)b[e]; }
+  hipemu::wave_sync_end();
+  int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    double acc = c[r];
+    for (int g = 0; g < 2; ++g)
+      for (int e = 0; e < 8; ++e)
+        acc += (double)hipemu_bf16_to_f32(x.wa[s][row + 32 * g][e]) * (double)hipemu_bf16_to_f32(x.wb[s][col + 32 * g][e]);
+    c[r] = (float)acc;
+  }
+  return c;
+}
+// v_cvt_pk_bf16_f32 (round to nearest even); conv_split.hip takes this instead of the clang
+// __bf16 vector conversion
+inline unsigned hipemu_bf16_rne(float f) {
+  unsigned u; memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN stays NaN
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+#define ODT_CVT_PK_BF16(a0, a1) (hipemu_bf16_rne(a0) | (hipemu_bf16_rne(a1) << 16))
+// v_perm_b32: byte select from {s0 (bytes 4..7), s1 (bytes 0..3)}; selectors 0..7 only
+inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned sel) {
+  const unsigned long long v = ((unsigned long long)s0 << 32) | s1;
+  unsigned r = 0;
+  for (int i = 0; i < 4; ++i) r |= (unsigned)((v >> (8 * ((sel >> (8 * i)) & 7))) & 0xff) << (8 * i);
+  return r;
 }
 // ---- raw buffer loads (SRSRC descriptor; out-of-range dwords read as 0) ------------------------
 struct __amdgpu_buffer_rsrc_t { const char* base; unsigned num_records; };

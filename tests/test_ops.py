@@ -466,3 +466,73 @@ def test_conv_two_sources(backend, monkeypatch):
       want = a @ wa + b2[:, ::stride_b, ::stride_b][:, :Ho, :Wo] @ wb + bias
       got = ops.conv2d_cat(a, b2, wa, wb, bias, stride_b=stride_b, relu=True, lib=lib)
       np.testing.assert_allclose(got, np.maximum(want, 0), rtol=2e-4, atol=2e-4)
+
+
+# ---- bf16x3 split path (csrc/conv_split.hip): f32 results through six exact bf16 products ----
+SPLIT_CASES = [
+    # B, H, W, Cin, Cout, k, stride, dil, pad_t, pad_l, Ho, Wo, relu
+    (1, 9, 11, 64, 256, 3, 1, 1, 1, 1, 9, 11, True),         # 3x3 SAME, M = 99 (ragged tile)
+    (2, 10, 13, 32, 512, 1, 1, 1, 0, 0, 10, 13, False),      # dense 1x1, two N tiles, M = 260
+    (1, 12, 14, 32, 256, 3, 2, 1, 1, 1, 6, 7, True),         # pad T/L 1 + 3x3 s2 VALID (res4 block0 conv2)
+    (1, 13, 15, 32, 256, 3, 2, 2, 1, 1, 5, 6, False),        # dilated + strided
+    (1, 11, 13, 96, 256, 1, 2, 1, 0, 0, 5, 6, False),        # 1x1 s2 over a cropped input, 3 slices per tap
+]
+
+
+def _split_env(monkeypatch):
+  monkeypatch.setenv("ODT_CONV_SPLIT", "1")
+  monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1")
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_conv2d_split(backend, case, monkeypatch):
+  name, lib = backend
+  _split_env(monkeypatch)
+  _run_conv(lib, case, np.random.default_rng(11))
+
+
+def test_conv2d_split_matches_f32_kernel_at_f32_rounding(backend, monkeypatch):
+  """The split result must sit as close to the f64 truth as the exact-f32 MFMA kernel does
+  (error of an f32 dot product, not of a bf16 one), incl. operands spanning many binades."""
+  name, lib = backend
+  rng = np.random.default_rng(12)
+  B, H, W, Cin, Cout = 1, 8, 9, 128, 256
+  x = (rng.standard_normal((B, H, W, Cin)) * np.exp2(rng.integers(-12, 12, (B, H, W, Cin)))).astype(F)
+  w = (rng.standard_normal((3, 3, Cin, Cout)) * np.exp2(rng.integers(-8, 8, (3, 3, Cin, Cout)))).astype(F)
+  b = rng.standard_normal(Cout).astype(F)
+  xp = np.pad(x.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
+  ref = np.zeros((B, H, W, Cout)); mag = np.zeros((B, H, W, Cout))
+  for dy in range(3):
+    for dx in range(3):
+      patch = xp[:, dy:dy + H, dx:dx + W]
+      ref += patch @ w[dy, dx].astype(np.float64)
+      mag += np.abs(patch) @ np.abs(w[dy, dx].astype(np.float64))
+  ref += b
+  y32 = ops.conv2d(x, w, b, 1, 1, 1, 1, (H, W), lib=lib)
+  _split_env(monkeypatch)
+  ysp = ops.conv2d(x, w, b, 1, 1, 1, 1, (H, W), lib=lib)
+  e32 = np.max(np.abs(y32 - ref) / mag)
+  esp = np.max(np.abs(ysp - ref) / mag)
+  # both carry the f32 accumulation error of a K = 1152 dot product (~1e-6 of sum|a||b| on this
+  # data); the split adds at most 2^-23 for its dropped piece products.  A single bf16 product
+  # would be at ~4e-3.
+  assert esp <= 1.5 * e32 + 1.2e-7, (esp, e32)
+  assert esp < 4e-6, esp
+
+
+def test_conv2d_split_output_offset_and_fallback(backend, monkeypatch):
+  name, lib = backend
+  _split_env(monkeypatch)
+  rng = np.random.default_rng(13)
+  x = rng.standard_normal((1, 10, 12, 64)).astype(F)
+  w = (rng.standard_normal((3, 3, 64, 256)) * 0.05).astype(F)
+  b = rng.standard_normal(256).astype(F)
+  got = ops.conv2d(x, w, b, 1, 1, 1, 1, (10, 12), out_off=(1, 1), relu=True, lib=lib)
+  want = np.maximum(torch_conv_nhwc(x, w, b, 1, 1, 1, 1, 10, 12), 0)
+  assert np.all(got[:, :1] == 0) and np.all(got[:, :, :1] == 0)
+  np.testing.assert_allclose(got[:, 1:, 1:], want, rtol=1e-4, atol=1e-4)
+  # a residual layer is outside the split kernel's scope: it must run on the exact-f32 kernel
+  res = rng.standard_normal((1, 10, 12, 256)).astype(F)
+  got = ops.conv2d(x, w, b, 1, 1, 1, 1, (10, 12), res=res, res_mode=1, relu=True, lib=lib)
+  np.testing.assert_allclose(got, np.maximum(torch_conv_nhwc(x, w, b, 1, 1, 1, 1, 10, 12) + res, 0),
+                             rtol=1e-4, atol=1e-4)

@@ -1,0 +1,378 @@
+// Feasibility probe (NOT part of the product path): f32 GEMM through bf16 MFMA with exact 3-way
+// operand splitting ("bf16x3").  x = hi + mid + lo exactly (three truncated 8-bit mantissa pieces
+// of the 24-bit f32 significand), so  a*b = sum of 9 piece products; the 6 largest are kept
+// (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid), the 3 dropped ones are <= 2^-24 |a||b| -- the
+// size of one f32 rounding.  Every kept piece product is exact in f32; accumulation is f32 in the
+// MFMA unit.  Question answered here: what does this reach on gfx950 against the 157 TF f32 MFMA
+// peak (130 TF measured by the product's conv kernel), and what is its error against f64?
+//
+//   C[M,N] = A[M,K] (f32, k contiguous -- an NHWC activation)  x  B (weights, pre-split at load
+//   time into 3 bf16 planes [N][K]).  128x128 tile, 256 threads (2x2 waves of 64x64), BK=32,
+//   one LDS stage + register prefetch.  M,N multiples of 128, K of 32.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/experiments/build/split_gemm tools/experiments/split_gemm.hip
+// Run:   split_gemm [M N K products(6|3)]
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+  fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+// one operand plane in LDS: [kgroup 0..3][row 0..127][8 bf16] (+pad per kgroup) -> a wave's
+// ds_read_b128 of one k-group is one contiguous 512 B run per 32 lanes.
+constexpr int KG_STRIDE = 128 * 16 + 32;          // bytes
+constexpr int PLANE = 4 * KG_STRIDE;              // bytes
+constexpr int LDS_BYTES = 6 * PLANE;              // A hi/mid/lo, B hi/mid/lo
+
+__device__ __forceinline__ unsigned pack_top(unsigned x0, unsigned x1) {
+  // (x1 & 0xffff0000) | (x0 >> 16): two truncated bf16 in one dword
+  return __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+}
+
+__device__ __forceinline__ void split2(float a0, float a1, unsigned& hi, unsigned& mid, unsigned& lo) {
+  unsigned u0 = __float_as_uint(a0), u1 = __float_as_uint(a1);
+  hi = pack_top(u0, u1);
+  float r0 = a0 - __uint_as_float(u0 & 0xffff0000u);
+  float r1 = a1 - __uint_as_float(u1 & 0xffff0000u);
+  unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+  mid = pack_top(v0, v1);
+  float s0 = r0 - __uint_as_float(v0 & 0xffff0000u);
+  float s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+  lo = pack_top(__float_as_uint(s0), __float_as_uint(s1));
+}
+
+// FLAGS: 1 = XCD-aware tile order, 2 = no split arithmetic (hi piece in all planes; timing only),
+//        4 = no global loads after the first stage (timing only)
+template <int NPROD, int FLAGS, int OCC>
+__global__ __launch_bounds__(256, OCC) void split_gemm_kernel(const float* __restrict__ A,
+                                                           const uint16_t* __restrict__ Bs,  // [3][N][K]
+                                                           float* __restrict__ C, int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = N / BN;
+  int tile = blockIdx.x;
+  if (FLAGS & 1) {                      // blocks b, b+8, ... share an XCD: give each XCD one contiguous run
+    const int per = gridDim.x >> 3;     // grid is a multiple of 8 here
+    tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  }
+  const int tile_m = tile / ntn, tile_n = tile % ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // global A: 128 rows x 32 k f32 = 1024 float4, 4 per thread: row = tid/8 + 32*i, k4 = tid%8
+  const int a_row = tid >> 3, a_k4 = tid & 7;
+  const float* a_ptr = A + (size_t)(m0 + a_row) * K + a_k4 * 4;
+  // global B plane p: 128 n x 32 k bf16 = 512 x 16 B, 2 per thread per plane: n = tid/4 + 64*i, k8 = tid%4
+  const int b_n = tid >> 2, b_k8 = tid & 3;
+  const uint16_t* b_ptr = Bs + (size_t)(n0 + b_n) * K + b_k8 * 8;
+  const size_t b_plane = (size_t)N * K;
+
+  f32x4 ga[4];
+  u32x4 gb[3][2];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      ga[i] = *reinterpret_cast<const f32x4*>(a_ptr + (size_t)(32 * i) * K + k0);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        gb[p][i] = *reinterpret_cast<const u32x4*>(b_ptr + p * b_plane + (size_t)(64 * i) * K + k0);
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned h0, m0_, l0, h1, m1, l1;
+      if (FLAGS & 2) {
+        h0 = m0_ = l0 = pack_top(__float_as_uint(ga[i].x), __float_as_uint(ga[i].y));
+        h1 = m1 = l1 = pack_top(__float_as_uint(ga[i].z), __float_as_uint(ga[i].w));
+      } else {
+        split2(ga[i].x, ga[i].y, h0, m0_, l0);
+        split2(ga[i].z, ga[i].w, h1, m1, l1);
+      }
+      const int row = a_row + 32 * i;
+      const int off = (a_k4 >> 1) * KG_STRIDE + row * 16 + (a_k4 & 1) * 8;
+      *reinterpret_cast<u32x2*>(lds + 0 * PLANE + off) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(lds + 1 * PLANE + off) = u32x2{m0_, m1};
+      *reinterpret_cast<u32x2*>(lds + 2 * PLANE + off) = u32x2{l0, l1};
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int n = b_n + 64 * i;
+        *reinterpret_cast<u32x4*>(lds + (3 + p) * PLANE + b_k8 * KG_STRIDE + n * 16) = gb[p][i];
+      }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fr = lane & 31, fg = lane >> 5;
+  gload(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    lstore();
+    __syncthreads();
+    if (!(FLAGS & 4) && k0 + BK < K) gload(k0 + BK);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {               // two k16 steps per stage
+      bf16x8 fa[3][2], fb[3][2];
+      const int kg = ks * 2 + fg;
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          fa[p][t] = *reinterpret_cast<const bf16x8*>(lds + p * PLANE + kg * KG_STRIDE + (wm * 64 + t * 32 + fr) * 16);
+          fb[p][t] = *reinterpret_cast<const bf16x8*>(lds + (3 + p) * PLANE + kg * KG_STRIDE + (wn * 64 + t * 32 + fr) * 16);
+        }
+      // smallest terms first
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (NPROD == 6) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
+          }
+          if (NPROD >= 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  // C/D layout of the 32x32 MFMA: col = lane&31, row = (r/4)*8 + (lane>>5)*4 + r%4
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r >> 2) * 8 + fg * 4 + (r & 3);
+        const int col = n0 + wn * 64 + j * 32 + fr;
+        C[(size_t)row * N + col] = acc[i][j][r];
+      }
+}
+
+
+// ---- variant 2: 128 x 256 tile (whole N of the 256-channel layers: A is fetched and split once),
+// wave tile 64 x 128, B pre-imaged at weight-upload time as [ntile][kslice][plane][kgroup][256 n][8 k]
+// so a stage's B tile is one contiguous 48 KB block (linear 16-B/lane copies into LDS).
+constexpr int AKG = 128 * 16 + 32, APL = 4 * AKG;
+constexpr int BKG = 256 * 16 + 32, BPL = 4 * BKG;
+constexpr int LDS2 = 3 * APL + 3 * BPL;
+
+template <int NPROD, int FLAGS>
+__global__ __launch_bounds__(256, 2) void split_gemm2_kernel(const float* __restrict__ A,
+                                                            const u32x4* __restrict__ Bimg,
+                                                            float* __restrict__ C, int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = N / 256;
+  int tile = blockIdx.x;
+  if (FLAGS & 1) { const int per = gridDim.x >> 3; tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3); }
+  const int tile_m = tile / ntn, tile_n = tile % ntn;
+  const int m0 = tile_m * 128, n0 = tile_n * 256;
+  const int nsl = K / 32;
+  const int a_row = tid >> 3, a_k4 = tid & 7;
+  const float* a_ptr = A + (size_t)(m0 + a_row) * K + a_k4 * 4;
+  const u32x4* b_ptr = Bimg + (size_t)tile_n * nsl * 3072 + tid;     // 3072 chunks of 16 B per stage
+  unsigned char* const ldsB = lds + 3 * APL;
+
+  f32x4 ga[4];
+  u32x4 gb[12];
+  auto gload = [&](int sl) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ga[i] = *reinterpret_cast<const f32x4*>(a_ptr + (size_t)(32 * i) * K + sl * 32);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) gb[i] = b_ptr[(size_t)sl * 3072 + i * 256];
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned h0, m0_, l0, h1, m1, l1;
+      if (FLAGS & 2) {
+        h0 = m0_ = l0 = pack_top(__float_as_uint(ga[i].x), __float_as_uint(ga[i].y));
+        h1 = m1 = l1 = pack_top(__float_as_uint(ga[i].z), __float_as_uint(ga[i].w));
+      } else {
+        split2(ga[i].x, ga[i].y, h0, m0_, l0);
+        split2(ga[i].z, ga[i].w, h1, m1, l1);
+      }
+      const int off = (a_k4 >> 1) * AKG + (a_row + 32 * i) * 16 + (a_k4 & 1) * 8;
+      *reinterpret_cast<u32x2*>(lds + 0 * APL + off) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(lds + 1 * APL + off) = u32x2{m0_, m1};
+      *reinterpret_cast<u32x2*>(lds + 2 * APL + off) = u32x2{l0, l1};
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+      *reinterpret_cast<u32x4*>(ldsB + (i >> 2) * BPL + (i & 3) * BKG + tid * 16) = gb[i];
+  };
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int fr = lane & 31, fg = lane >> 5;
+  gload(0);
+  for (int sl = 0; sl < nsl; ++sl) {
+    lstore();
+    __syncthreads();
+    if (!(FLAGS & 4) && sl + 1 < nsl) gload(sl + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kg = ks * 2 + fg;
+      bf16x8 fa[3][2];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          fa[p][t] = *reinterpret_cast<const bf16x8*>(lds + p * APL + kg * AKG + (wm * 64 + t * 32 + fr) * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bf16x8 fb[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          fb[p] = *reinterpret_cast<const bf16x8*>(ldsB + p * BPL + kg * BKG + (wn * 128 + j * 32 + fr) * 16);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if (NPROD == 6) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1], acc[i][j], 0, 0, 0);
+          }
+          if (NPROD >= 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r >> 2) * 8 + fg * 4 + (r & 3);
+        const int col = n0 + wn * 128 + j * 32 + fr;
+        C[(size_t)row * N + col] = acc[i][j][r];
+      }
+}
+
+void host_split(float x, uint16_t& h, uint16_t& m, uint16_t& l) {
+  uint32_t u; memcpy(&u, &x, 4);
+  h = u >> 16; uint32_t hu = u & 0xffff0000u; float hf; memcpy(&hf, &hu, 4);
+  float r = x - hf; memcpy(&u, &r, 4);
+  m = u >> 16; hu = u & 0xffff0000u; memcpy(&hf, &hu, 4);
+  float s = r - hf; memcpy(&u, &s, 4);
+  l = u >> 16;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  int M = argc > 1 ? atoi(argv[1]) : 65280, N = argc > 2 ? atoi(argv[2]) : 256, K = argc > 3 ? atoi(argv[3]) : 2304;
+  int nprod = argc > 4 ? atoi(argv[4]) : 6;
+  int flags = argc > 5 ? atoi(argv[5]) : 0, occ = argc > 6 ? atoi(argv[6]) : 2;
+  M = (M + 127) / 128 * 128; N = (N + 127) / 128 * 128; K = (K + 31) / 32 * 32;
+  std::vector<float> a((size_t)M * K), b((size_t)K * N);   // b[k][n] logical
+  uint64_t s = 88172645463325252ull;
+  auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (float)((s >> 40) / 16777216.0 * 2.0 - 1.0); };
+  for (auto& v : a) v = rnd();
+  for (auto& v : b) v = rnd() * 0.05f;
+  std::vector<uint16_t> bs((size_t)3 * N * K);
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < K; ++k)
+      host_split(b[(size_t)k * N + n], bs[(size_t)n * K + k], bs[(size_t)N * K + (size_t)n * K + k],
+                 bs[(size_t)2 * N * K + (size_t)n * K + k]);
+  const int variant = argc > 7 ? atoi(argv[7]) : 1;
+  std::vector<uint16_t> bimg;
+  if (variant == 2) {
+    if (N % 256) { fprintf(stderr, "variant 2 needs N %% 256 == 0\n"); return 2; }
+    const int nsl = K / 32;
+    bimg.resize((size_t)3 * N * K);
+    for (int tn = 0; tn < N / 256; ++tn)
+      for (int sl = 0; sl < nsl; ++sl)
+        for (int p = 0; p < 3; ++p)
+          for (int kg = 0; kg < 4; ++kg)
+            for (int n = 0; n < 256; ++n)
+              for (int e = 0; e < 8; ++e)
+                bimg[((((size_t)(tn * nsl + sl) * 3 + p) * 4 + kg) * 256 + n) * 8 + e] =
+                    bs[(size_t)p * N * K + (size_t)(tn * 256 + n) * K + sl * 32 + kg * 8 + e];
+    bs.swap(bimg);
+  }
+  float *dA, *dC; uint16_t* dB;
+  CHECK(hipMalloc(&dA, a.size() * 4)); CHECK(hipMalloc(&dC, (size_t)M * N * 4)); CHECK(hipMalloc(&dB, bs.size() * 2));
+  CHECK(hipMemcpy(dA, a.data(), a.size() * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(dB, bs.data(), bs.size() * 2, hipMemcpyHostToDevice));
+  dim3 grid(variant == 2 ? (M / 128) * (N / 256) : (M / BM) * (N / BN)), block(256);
+  auto launch = [&]() {
+#define L2(P, F) if (variant == 2 && nprod == P && flags == F) { \
+      hipLaunchKernelGGL((split_gemm2_kernel<P, F>), grid, block, 0, 0, dA, (const u32x4*)dB, dC, M, N, K); return; }
+    L2(6, 1) L2(6, 3) L2(6, 5) L2(6, 7) L2(1, 1) L2(1, 5)
+#undef L2
+#define L(P, F, O) if (variant == 1 && nprod == P && flags == F && occ == O) { \
+      hipLaunchKernelGGL((split_gemm_kernel<P, F, O>), grid, block, 0, 0, dA, dB, dC, M, N, K); return; }
+    L(6, 0, 2) L(6, 1, 2) L(6, 3, 2) L(6, 5, 2) L(6, 7, 2) L(6, 1, 3) L(3, 1, 2) L(1, 1, 2) L(1, 5, 2) L(1, 7, 2)
+#undef L
+    fprintf(stderr, "variant not built\n"); exit(2);
+  };
+  for (int i = 0; i < 3; ++i) launch();
+  CHECK(hipDeviceSynchronize());
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  const int reps = 20;
+  CHECK(hipEventRecord(e0));
+  for (int i = 0; i < reps; ++i) launch();
+  CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+  float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+  std::vector<float> c((size_t)M * N);
+  CHECK(hipMemcpy(c.data(), dC, c.size() * 4, hipMemcpyDeviceToHost));
+  // error against f64 on a sample of rows; a sequential f32 host GEMM beside it for scale
+  double worst = 0, worst32 = 0;
+  for (int t = 0; t < 48; ++t) {
+    int row = (int)(((uint64_t)t * 2654435761ull) % (uint64_t)M);
+    for (int n = 0; n < N; n += 7) {
+      double ref = 0, mag = 0; float f = 0.f;
+      for (int k = 0; k < K; ++k) {
+        double p = (double)a[(size_t)row * K + k] * (double)b[(size_t)k * N + n];
+        ref += p; mag += fabs(p);
+        f += a[(size_t)row * K + k] * b[(size_t)k * N + n];
+      }
+      worst = fmax(worst, fabs(c[(size_t)row * N + n] - ref) / mag);
+      worst32 = fmax(worst32, fabs((double)f - ref) / mag);
+    }
+  }
+  double tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12;
+  printf("{\"M\": %d, \"N\": %d, \"K\": %d, \"products\": %d, \"flags\": %d, \"occ\": %d, \"variant\": %d, \"ms\": %.4f, \"effective_f32_TFLOPs\": %.1f, "
+         "\"bf16_mfma_TFLOPs\": %.1f, \"max_err_over_sum_abs\": %.3e, \"host_f32_sequential_err\": %.3e}\n",
+         M, N, K, nprod, flags, occ, variant, ms, tf, tf * nprod, worst, worst32);
+  return 0;
+}
