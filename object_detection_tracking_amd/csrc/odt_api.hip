@@ -1156,7 +1156,10 @@ int odt_profile_layer(odt_handle h, int index, char* name, int name_cap, double*
   if (count) *count = (int)h->convs.size();
   if (index < 0 || index >= (int)h->convs.size()) return 0;
   const ConvOp& c = h->convs[index];
-  if (name && name_cap > 0) { std::strncpy(name, c.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (name && name_cap > 0) {    // layers on the bf16x3 split kernel are tagged (bench.py / profile_layers.py group by it)
+    const std::string nm = c.name + (c.p.wt_split != nullptr && conv_split_mode() != 0 ? "[bf16x3]" : "");
+    std::strncpy(name, nm.c_str(), name_cap - 1); name[name_cap - 1] = 0;
+  }
   if (flops) *flops = conv_flops(c.p);
   if (ms) *ms = index < (int)h->prof_layer_ms.size() ? h->prof_layer_ms[index] : 0.0;
   if (mnk) { mnk[0] = (int64_t)c.p.B * c.p.Ho * c.p.Wo; mnk[1] = c.p.Cout; mnk[2] = (int64_t)c.p.kh * c.p.kw * c.p.Cin; }

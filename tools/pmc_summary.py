@@ -13,7 +13,7 @@ def agg(rows, pred):
     if pred(r["Kernel_Name"]):
       tot[r["Counter_Name"]] += float(r["Counter_Value"]); disp.add(r["Dispatch_Id"])
   return tot, len(disp)
-is_conv = lambda k: "conv_igemm_kernel" in k
+is_conv = lambda k: "conv_igemm_kernel" in k or "conv_split_kernel" in k
 is_pre = lambda k: "preprocess_kernel" in k
 f, nconv = agg(load("FETCH_SIZE"), is_conv)
 w, _ = agg(load("WRITE_SIZE"), is_conv)
