@@ -629,6 +629,9 @@ bool conv_split_wanted(const ConvParams& p) {
   // tiles fill the chip better (b=1 res4: 64 tiles)
   const char* e = getenv("ODT_CONV_SPLIT_MINTILES");
   const long min_tiles = e != nullptr ? atol(e) : 384L;
+  // short reductions (K < 256: res2 / res3 conv3) are prologue / epilogue bound: the 64x64 tile of the
+  // exact-f32 kernel wins there
+  if (p.kh * p.kw * p.Cin < 256) return false;
   const long M = (long)p.B * p.Ho * p.Wo;
   return ((M + 127) / 128) * (p.Cout / 256) >= min_tiles;
 }

@@ -24,7 +24,7 @@
 // LDS planes are [k-group][row][8 bf16]: a wave's ds_read_b128 of an MFMA operand is one
 // contiguous 512-byte run per 32 lanes.
 //
-// Scope: res_mode == 0, no second A source, Cout % 256 == 0, Cin % 32 == 0, 16-byte-aligned
+// Scope: no residual or a same-shape residual (accumulator start value), no second A source, Cout % 256 == 0, Cin % 32 == 0, 16-byte-aligned
 // output rows; everything else stays on the exact-f32 MFMA kernel (launch_conv decides).
 #include <cstdlib>
 #include <type_traits>
@@ -176,35 +176,73 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
 
   const int fr = lane & 31, fg = lane >> 5;
   load_slice();
+  if (p.res_mode == 1) {
+    // residual of the same shape (bottleneck conv3): the accumulators START at the residual, read
+    // in the MFMA C layout (a 32-lane group covers one 128-byte row segment) while the first slice
+    // is in flight -- no residual traffic in the epilogue.
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.res, 0, (int)((unsigned)p.B * p.res_H * p.res_W * p.res_ldc * 4u), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
+        const unsigned roff = row < M ? (unsigned)row * (unsigned)p.res_ldc * 4u + (unsigned)(n0 + wn * 128 + fr) * 4u : kOOB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, (int)roff, j * 128, 0));
+      }
+  }
   for (int c = 0; c < nslices; ++c) {
     store_slice();
     __syncthreads();
     if (c + 1 < nslices) load_slice();
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {                  // two k16 steps per slice
-      const int kg = ks * 2 + fg;
-      bf16x8 fa[3][2];
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
+    {
+      // Two k16 steps x four 32-column groups.  Within a group the b0 (hi) products run first,
+      // then b1, then b2; each piece's fragment of the NEXT group is re-read right after its last
+      // use, behind the remaining MFMAs of this group (sched_barrier fences pin the order: left
+      // alone the scheduler issues a group's three reads and waits for them in front of its MFMAs).
+      bf16x8 fa[3][2], fb[3];
+      auto rdA = [&](int q, int ks) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-          fa[q][t] = *reinterpret_cast<const bf16x8*>(lds + q * APL + kg * AKG + (wm * 64 + t * 32 + fr) * 16);
+          fa[q][t] = *reinterpret_cast<const bf16x8*>(lds + q * APL + (ks * 2 + fg) * AKG + (wm * 64 + t * 32 + fr) * 16);
+      };
+      auto rdB = [&](int q, int ks, int j) {
+        fb[q] = *reinterpret_cast<const bf16x8*>(ldsB + q * BPL + (ks * 2 + fg) * BKG + (wn * 128 + j * 32 + fr) * 16);
+      };
+#define ODT_MF(qa, qb, j) { acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][0], fb[qb], acc[0][j], 0, 0, 0); \
+                            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][1], fb[qb], acc[1][j], 0, 0, 0); }
+#define ODT_FENCE() __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        bf16x8 fb[3];
+      for (int q = 0; q < 3; ++q) rdA(q, 0);
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
-          fb[q] = *reinterpret_cast<const bf16x8*>(ldsB + q * BPL + kg * BKG + (wn * 128 + j * 32 + fr) * 16);
+      for (int q = 0; q < 3; ++q) rdB(q, 0, 0);
+      ODT_FENCE();
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {                 // smallest terms first
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0], acc[i][j], 0, 0, 0);
-        }
+      for (int g = 0; g < 8; ++g) {
+        const int j = g & 3;
+        const int nks = (g + 1) >> 2, nj = (g + 1) & 3;
+        const bool has_next = g < 7, a_next = has_next && nj == 0;
+        ODT_MF(2, 0, j); ODT_FENCE();          // lo * hi
+        if (a_next) rdA(2, nks);
+        ODT_FENCE();
+        ODT_MF(1, 0, j); ODT_MF(0, 0, j); ODT_FENCE();   // mid * hi, hi * hi
+        if (has_next) rdB(0, nks, nj);
+        ODT_FENCE();
+        ODT_MF(1, 1, j); ODT_FENCE();          // mid * mid
+        if (a_next) rdA(1, nks);
+        ODT_FENCE();
+        ODT_MF(0, 1, j); ODT_FENCE();          // hi * mid
+        if (has_next) rdB(1, nks, nj);
+        ODT_FENCE();
+        ODT_MF(0, 2, j); ODT_FENCE();          // hi * lo
+        if (a_next) rdA(0, nks);
+        if (has_next) rdB(2, nks, nj);
+        ODT_FENCE();
       }
+#undef ODT_MF
+#undef ODT_FENCE
     }
     __syncthreads();
   }
@@ -300,7 +338,8 @@ size_t conv_split_weight_bytes(int Cout, int K) { return (size_t)Cout * K * 6; }
 
 bool conv_split_supported(const ConvParams& p) {
   const double wbytes = (double)p.Cout * p.kh * p.kw * p.Cin * 6.0;
-  return p.Cout % SBN == 0 && p.Cin % 32 == 0 && p.in2 == nullptr && p.res_mode == 0 && p.out_ldc % 4 == 0 &&
+  const bool res_ok = p.res_mode == 0 || (p.res_mode == 1 && p.res_H == p.Ho && p.res_W == p.Wo);
+  return p.Cout % SBN == 0 && p.Cin % 32 == 0 && p.in2 == nullptr && res_ok && p.out_ldc % 4 == 0 &&
          p.in_ldc % 4 == 0 && wbytes < 2147483648.0 && p.trace == nullptr;
 }
 

@@ -520,7 +520,7 @@ def test_conv2d_split_matches_f32_kernel_at_f32_rounding(backend, monkeypatch):
   assert esp < 4e-6, esp
 
 
-def test_conv2d_split_output_offset_and_fallback(backend, monkeypatch):
+def test_conv2d_split_output_offset_and_residual(backend, monkeypatch):
   name, lib = backend
   _split_env(monkeypatch)
   rng = np.random.default_rng(13)
@@ -531,8 +531,27 @@ def test_conv2d_split_output_offset_and_fallback(backend, monkeypatch):
   want = np.maximum(torch_conv_nhwc(x, w, b, 1, 1, 1, 1, 10, 12), 0)
   assert np.all(got[:, :1] == 0) and np.all(got[:, :, :1] == 0)
   np.testing.assert_allclose(got[:, 1:, 1:], want, rtol=1e-4, atol=1e-4)
-  # a residual layer is outside the split kernel's scope: it must run on the exact-f32 kernel
+  # same-shape residual: the split kernel starts its accumulators at the residual
   res = rng.standard_normal((1, 10, 12, 256)).astype(F)
   got = ops.conv2d(x, w, b, 1, 1, 1, 1, (10, 12), res=res, res_mode=1, relu=True, lib=lib)
   np.testing.assert_allclose(got, np.maximum(torch_conv_nhwc(x, w, b, 1, 1, 1, 1, 10, 12) + res, 0),
                              rtol=1e-4, atol=1e-4)
+
+
+def test_conv2d_split_residual_bottleneck_conv3(backend, monkeypatch):
+  """1x1 conv + same-shape residual + ReLU over two N tiles and a ragged M (res4 conv3 shape class);
+  a nearest-2x residual (FPN lateral) is outside the split kernel's scope and must still be right."""
+  name, lib = backend
+  _split_env(monkeypatch)
+  rng = np.random.default_rng(14)
+  x = rng.standard_normal((2, 9, 11, 256)).astype(F)
+  w = (rng.standard_normal((1, 1, 256, 512)) / 16).astype(F)
+  b = rng.standard_normal(512).astype(F)
+  res = rng.standard_normal((2, 9, 11, 512)).astype(F)
+  got = ops.conv2d(x, w, b, res=res, res_mode=1, relu=True, lib=lib)
+  want = np.maximum(torch_conv_nhwc(x, w, b, 1, 1, 0, 0, 9, 11) + res, 0)
+  np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+  up = rng.standard_normal((2, 5, 6, 512)).astype(F)
+  got = ops.conv2d(x, w, b, res=up, res_mode=2, lib=lib)
+  want = torch_conv_nhwc(x, w, b, 1, 1, 0, 0, 9, 11) + np.repeat(np.repeat(up, 2, 1), 2, 2)[:, :9, :11]
+  np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)

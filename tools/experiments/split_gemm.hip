@@ -243,6 +243,51 @@ __global__ __launch_bounds__(256, 2) void split_gemm2_kernel(const float* __rest
     lstore();
     __syncthreads();
     if (!(FLAGS & 4) && sl + 1 < nsl) gload(sl + 1);
+    if constexpr (FLAGS & 8) {
+      // pinned schedule: within a (ks, j) group the b0 products run first, then b1, then b2; each
+      // piece's next-group fragment is re-read right after its last use, behind the remaining MFMAs
+      bf16x8 fa[3][2], fb[3];
+      auto rdA = [&](int q, int ks) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          fa[q][t] = *reinterpret_cast<const bf16x8*>(lds + q * APL + (ks * 2 + fg) * AKG + (wm * 64 + t * 32 + fr) * 16);
+      };
+      auto rdB = [&](int q, int ks, int j) {
+        fb[q] = *reinterpret_cast<const bf16x8*>(ldsB + q * BPL + (ks * 2 + fg) * BKG + (wn * 128 + j * 32 + fr) * 16);
+      };
+#define MF(qa, qb, j) { acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][0], fb[qb], acc[0][j], 0, 0, 0); \
+                        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][1], fb[qb], acc[1][j], 0, 0, 0); }
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) rdA(q, 0);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) rdB(q, 0, 0);
+      FENCE();
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int j = g & 3;
+        const int nks = (g + 1) >> 2, nj = (g + 1) & 3;
+        const bool has_next = g < 7, a_next = has_next && nj == 0;
+        MF(2, 0, j); FENCE();
+        if (a_next) rdA(2, nks);
+        FENCE();
+        MF(1, 0, j); MF(0, 0, j); FENCE();
+        if (has_next) rdB(0, nks, nj);
+        FENCE();
+        MF(1, 1, j); FENCE();
+        if (a_next) rdA(1, nks);
+        FENCE();
+        MF(0, 1, j); FENCE();
+        if (has_next) rdB(1, nks, nj);
+        FENCE();
+        MF(0, 2, j); FENCE();
+        if (a_next) rdA(0, nks);
+        if (has_next) rdB(2, nks, nj);
+        FENCE();
+      }
+#undef MF
+#undef FENCE
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int kg = ks * 2 + fg;
@@ -272,6 +317,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm2_kernel(const float* __rest
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0], acc[i][j], 0, 0, 0);
         }
       }
+    }
     }
     __syncthreads();
   }
@@ -337,7 +383,7 @@ int main(int argc, char** argv) {
   auto launch = [&]() {
 #define L2(P, F) if (variant == 2 && nprod == P && flags == F) { \
       hipLaunchKernelGGL((split_gemm2_kernel<P, F>), grid, block, 0, 0, dA, (const u32x4*)dB, dC, M, N, K); return; }
-    L2(6, 1) L2(6, 3) L2(6, 5) L2(6, 7) L2(1, 1) L2(1, 5)
+    L2(6, 1) L2(6, 9) L2(6, 5) L2(6, 13)
 #undef L2
 #define L(P, F, O) if (variant == 1 && nprod == P && flags == F && occ == O) { \
       hipLaunchKernelGGL((split_gemm_kernel<P, F, O>), grid, block, 0, 0, dA, dB, dC, M, N, K); return; }

@@ -3,12 +3,20 @@
 mkdir -p gpurun_out
 B=tools/experiments/build/split_gemm
 {
-timeout 120 $B 65280 256 2304 6 1 2 1
-for v in "6 1" "6 3" "6 5" "6 7" "1 1" "1 5"; do
+for rep in 1 2; do
+for v in "6 1" "6 9" "6 5" "6 13"; do
   timeout 120 $B 65280 256 2304 $v 2 2
 done
-timeout 120 $B 65280 256 1024 6 1 2 2
-timeout 120 $B 1044480 256 2304 6 1 2 2
-timeout 120 $B 65280 1024 256 6 1 2 2
+for v in "6 1" "6 9"; do
+  timeout 120 $B 1044480 256 2304 $v 2 2
+  timeout 120 $B 65280 256 1024 $v 2 2
+done
+done
 } > gpurun_out/split_gemm.log 2>&1
-cat gpurun_out/split_gemm.log
+python - <<'PY'
+import json
+for l in open("gpurun_out/split_gemm.log"):
+  try: d = json.loads(l)
+  except Exception: print(l.strip()); continue
+  print(d["M"], d["N"], d["K"], "flags", d["flags"], "ms %.4f" % d["ms"], "TF %.1f" % d["effective_f32_TFLOPs"], "err %.2e" % d["max_err_over_sum_abs"])
+PY
