@@ -40,6 +40,7 @@ def main():
   ap.add_argument("--width", type=int, default=1920)
   ap.add_argument("--topk", type=int, default=300, help="rpn_test_post_nms_topk (BASELINE: 300)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-extras", action="store_true", help="skip the `extra` measurements (A/B runs)")
   ap.add_argument("--cpu-frames", type=int, default=2, help="frames in the bounded CPU sample")
   ap.add_argument("--profile-steps", type=int, default=2)
   ap.add_argument("--dist-backend", default="nccl",
@@ -145,7 +146,7 @@ def main():
   # odt_forward -> host outputs incl. [M,256,7,7] features): PCIe-inclusive rate; (b) the DeepSORT
   # appearance matching kernel at BASELINE config #3 size (T=64 tracks x budget 5, N=100 dets).
   extra = {}
-  if rank == 0:
+  if rank == 0 and not args.no_extras:
     from object_detection_tracking_amd import ops
     t1 = time.perf_counter()
     for _ in range(3):

@@ -625,15 +625,18 @@ int conv_split_mode() {
 
 bool conv_split_wanted(const ConvParams& p) {
   if (conv_split_mode() == 0 || !conv_split_supported(p)) return false;
-  // 128 x 256 tiles, two workgroups per CU: below one full round the exact-f32 kernel's smaller
-  // tiles fill the chip better (b=1 res4: 64 tiles)
+  // 128 x 256 / 256 x 128 / 256 x 64 tiles, two workgroups per CU: below one workgroup per CU the
+  // exact-f32 kernel's smaller tiles fill the chip better (b=1 res4: 64 tiles)
   const char* e = getenv("ODT_CONV_SPLIT_MINTILES");
-  const long min_tiles = e != nullptr ? atol(e) : 384L;
+  const long min_tiles = e != nullptr ? atol(e) : 256L;   // A/B at b=8 and b=1: 256 > 384 > 128 >> 64
   // short reductions (K < 256: res2 / res3 conv3) are prologue / epilogue bound: the 64x64 tile of the
   // exact-f32 kernel wins there
   if (p.kh * p.kw * p.Cin < 256) return false;
   const long M = (long)p.B * p.Ho * p.Wo;
-  return ((M + 127) / 128) * (p.Cout / 256) >= min_tiles;
+  const int bm = conv_split_bm(p.Cout), bn = conv_split_bn(p.Cout);
+  const char* eb = getenv("ODT_CONV_SPLIT_MINBN");      // tuning knob: 256 = only the 128 x 256 tile
+  if (eb != nullptr && bn < atoi(eb)) return false;
+  return ((M + bm - 1) / bm) * (p.Cout / bn) >= min_tiles;
 }
 
 int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_params) {
@@ -664,7 +667,8 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
   // bf16x3 split path: plan convs carry their weight image; stand-alone calls (tests, tuning)
   // build a temporary one
   void* tmp_img = nullptr;
-  const bool split = q.wt_split != nullptr ? conv_split_mode() != 0 : conv_split_wanted(q);
+  // (a plan conv without an image stays on the exact-f32 kernel: no allocation on the hot path)
+  const bool split = q.wt_split != nullptr ? conv_split_mode() != 0 : (dev_params == nullptr && conv_split_wanted(q));
   if (split && q.wt_split == nullptr) {
     const int Ksp = q.kh * q.kw * q.Cin;
     ODT_HIP(hipMalloc(&tmp_img, conv_split_weight_bytes(q.Cout, Ksp)));

@@ -40,11 +40,19 @@ typedef unsigned int u32x2 __attribute__((vector_size(8)));
 typedef short bf16x8 __attribute__((vector_size(16)));
 
 constexpr unsigned kOOB = 0x80000000u;
-constexpr int SBM = 128, SBN = 256;
-constexpr int AKG = SBM * 16 + 32, APL = 4 * AKG;     // bytes: one k-group / one piece plane of A
-constexpr int BKG = SBN * 16 + 32, BPL = 4 * BKG;
-constexpr int LDS_SPLIT = 3 * APL + 3 * BPL;          // 74,496 B
-constexpr int STAGE_B_BYTES = 3 * 4 * SBN * 16;       // 49,152 B of pre-imaged weights per stage
+// Tile configurations <WM, WN, TN>: 4 waves as WM x WN, wave tile 64 x (32*TN):
+//   <2,2,4> 128 x 256  (Cout % 256 == 0)     <4,1,4> 256 x 128  (Cout % 128 == 0: res3)
+//   <4,1,2> 256 x 64   (Cout % 64 == 0: res2)
+template <int WM, int WN, int TN>
+struct SplitCfg {
+  static constexpr int BM = WM * 64, BN = WN * TN * 32;
+  static constexpr int AKG = BM * 16 + 32, APL = 4 * AKG;     // bytes: one k-group / one piece plane of A
+  static constexpr int BKG = BN * 16 + 32, BPL = 4 * BKG;
+  static constexpr int LDS = 3 * APL + 3 * BPL;               // 74,496 B (62,208 for 256 x 64)
+  static constexpr int STAGE_B = 3 * 4 * BN * 16;             // bytes of pre-imaged weights per stage
+  static constexpr int RA = BM / 32;                          // A rows (16-B loads) per thread and slice
+  static constexpr int NB = STAGE_B / 4096;                   // B 16-B chunks per thread and slice
+};
 
 __device__ __forceinline__ int sfast_div(int n, unsigned mul, unsigned sh) {
   return mul ? (int)(__umulhi((unsigned)n, mul) >> sh) : n;
@@ -73,13 +81,18 @@ __device__ __forceinline__ void split2(float a0, float a1, unsigned& hi, unsigne
   lo = ODT_CVT_PK_BF16(s0, s1);
 }
 
+template <int WM, int WN, int TN>
 __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __restrict__ pp) {
+  using Cfg = SplitCfg<WM, WN, TN>;
+  constexpr int SBM = Cfg::BM, SBN = Cfg::BN, AKG = Cfg::AKG, APL = Cfg::APL, BKG = Cfg::BKG, BPL = Cfg::BPL;
+  constexpr int LDS_SPLIT = Cfg::LDS, STAGE_B_BYTES = Cfg::STAGE_B, RA = Cfg::RA, NB = Cfg::NB;
+  static_assert(WM * WN == 4, "4 waves");
   const ConvParams p = *pp;
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_SPLIT];
   unsigned char* const ldsB = lds + 3 * APL;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int ntn = p.Cout / SBN;
   // XCD-aware tile order (see conv_igemm.hip): one contiguous run of tiles per XCD
   int wg = (int)blockIdx.x;
@@ -101,12 +114,12 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
 
   // ---- A loader: thread -> (row lr + 32*j, 16-byte column lc), as in conv_igemm.hip
   const int lc = tid & 7, lr = tid >> 3;
-  int a_hw0[4];
-  unsigned a_img[4];
+  int a_hw0[RA];
+  unsigned a_img[RA];
   const bool dense_in = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 &&
                         p.H == p.in_Ha && p.W == p.in_Wa && p.Ho == p.H && p.Wo == p.W;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < RA; ++j) {
     const int m = m0 + lr + 32 * j;
     const bool ok = m < M;
     if (dense_in) {
@@ -122,10 +135,10 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
   }
   const unsigned pix_bytes = (unsigned)p.in_ldc * 4u;
   int l_cc = 0, l_kh = 0, l_kw = 0;
-  unsigned a_row[4];
+  unsigned a_row[RA];
   auto set_tap = [&](int khh, int kww) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < RA; ++j) {
       const int hi = (a_hw0[j] >> 16) + khh * p.dil, wi = (int)(short)(a_hw0[j] & 0xffff) + kww * p.dil;
       const bool v = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W && a_img[j] != kOOB;
       a_row[j] = v ? a_img[j] + (unsigned)(hi * p.in_Wa + wi) * pix_bytes : kOOB;
@@ -134,14 +147,15 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
   set_tap(0, 0);
   unsigned l_b = (unsigned)nt * (unsigned)nslices * (unsigned)STAGE_B_BYTES;   // weight-image offset of the load stream
 
-  f32x4 ga[4];
-  u32x4 gb[12];
+  f32x4 ga[RA];
+  u32x4 gb[NB];
+  const int b_st = (tid / SBN) * BKG + (tid % SBN) * 16;   // this thread's place inside a 256-chunk run
   auto load_slice = [&]() {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < RA; ++j)
       ga[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)a_row[j], l_cc * 128, 0);
 #pragma unroll
-    for (int i = 0; i < 12; ++i)
+    for (int i = 0; i < NB; ++i)
       gb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, tid * 16 + i * 4096, (int)l_b, 0);
     l_b += (unsigned)STAGE_B_BYTES;
     if (++l_cc == cpt) {
@@ -152,7 +166,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
   };
   auto store_slice = [&]() {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < RA; ++j) {
       unsigned h0, m0_, l0, h1, m1, l1;
       split2(ga[j][0], ga[j][1], h0, m0_, l0);
       split2(ga[j][2], ga[j][3], h1, m1, l1);
@@ -162,15 +176,17 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
       *reinterpret_cast<u32x2*>(lds + 2 * APL + off) = u32x2{l0, l1};
     }
 #pragma unroll
-    for (int i = 0; i < 12; ++i)
-      *reinterpret_cast<u32x4*>(ldsB + (i >> 2) * BPL + (i & 3) * BKG + tid * 16) = gb[i];
+    for (int i = 0; i < NB; ++i) {        // chunk tid + 256 i of the stage image [piece][k-group][n]
+      constexpr int per = 4 * SBN / 256;  // chunks-of-256 per piece
+      *reinterpret_cast<u32x4*>(ldsB + (i / per) * BPL + (((i % per) * 256) / SBN) * BKG + b_st) = gb[i];
+    }
   };
 
-  f32x16 acc[2][4];
+  f32x16 acc[2][TN];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -187,9 +203,9 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
-        const unsigned roff = row < M ? (unsigned)row * (unsigned)p.res_ldc * 4u + (unsigned)(n0 + wn * 128 + fr) * 4u : kOOB;
+        const unsigned roff = row < M ? (unsigned)row * (unsigned)p.res_ldc * 4u + (unsigned)(n0 + wn * TN * 32 + fr) * 4u : kOOB;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TN; ++j)
           acc[i][j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, (int)roff, j * 128, 0));
       }
   }
@@ -198,7 +214,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
     __syncthreads();
     if (c + 1 < nslices) load_slice();
     {
-      // Two k16 steps x four 32-column groups.  Within a group the b0 (hi) products run first,
+      // Two k16 steps x TN 32-column groups.  Within a group the b0 (hi) products run first,
       // then b1, then b2; each piece's fragment of the NEXT group is re-read right after its last
       // use, behind the remaining MFMAs of this group (sched_barrier fences pin the order: left
       // alone the scheduler issues a group's three reads and waits for them in front of its MFMAs).
@@ -209,7 +225,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
           fa[q][t] = *reinterpret_cast<const bf16x8*>(lds + q * APL + (ks * 2 + fg) * AKG + (wm * 64 + t * 32 + fr) * 16);
       };
       auto rdB = [&](int q, int ks, int j) {
-        fb[q] = *reinterpret_cast<const bf16x8*>(ldsB + q * BPL + (ks * 2 + fg) * BKG + (wn * 128 + j * 32 + fr) * 16);
+        fb[q] = *reinterpret_cast<const bf16x8*>(ldsB + q * BPL + (ks * 2 + fg) * BKG + (wn * TN * 32 + j * 32 + fr) * 16);
       };
 #define ODT_MF(qa, qb, j) { acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][0], fb[qb], acc[0][j], 0, 0, 0); \
                             acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][1], fb[qb], acc[1][j], 0, 0, 0); }
@@ -220,10 +236,10 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
       for (int q = 0; q < 3; ++q) rdB(q, 0, 0);
       ODT_FENCE();
 #pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        const int j = g & 3;
-        const int nks = (g + 1) >> 2, nj = (g + 1) & 3;
-        const bool has_next = g < 7, a_next = has_next && nj == 0;
+      for (int g = 0; g < 2 * TN; ++g) {
+        const int j = g % TN;
+        const int nks = (g + 1) / TN, nj = (g + 1) % TN;
+        const bool has_next = g < 2 * TN - 1, a_next = has_next && nj == 0;
         ODT_MF(2, 0, j); ODT_FENCE();          // lo * hi
         if (a_next) rdA(2, nks);
         ODT_FENCE();
@@ -248,9 +264,11 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
   }
 
   // ---- epilogue (the fast path of conv_igemm.hip without a residual): stage the tile through
-  // LDS in two 64-row passes (pass == wm), bias + activation, whole 16-byte-per-lane row segments.
+  // LDS in two passes of RP rows, bias + activation, whole 16-byte-per-lane row segments.
   constexpr int CS = SBN + 4;
-  constexpr int RP = 64, NCH = RP * (SBN / 4) / 256;       // 16 chunks per thread and pass
+  constexpr int RP = SBM / 2, WPP = RP / 64;               // rows / wave-rows per pass
+  constexpr int C4 = SBN / 4, RSTEP = 256 / C4;            // 16-byte chunks per row; rows per sweep of the block
+  constexpr int NCH = RP / RSTEP;                          // chunks per thread and pass
   static_assert(RP * CS * 4 <= LDS_SPLIT, "C tile pass must fit");
   float* Ct = reinterpret_cast<float*>(lds);
   const bool dense_io = p.out_oy == 0 && p.out_ox == 0 && p.out_H == p.Ho && p.out_W == p.Wo;
@@ -258,7 +276,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
       (void*)p.out, 0, (int)((unsigned)p.B * p.out_H * p.out_W * p.out_ldc * 4u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_bias =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (int)((unsigned)p.Cout * 4u), 0x00020000);
-  const int c4 = tid & 63, row0 = tid >> 6;
+  const int c4 = tid % C4, row0 = tid / C4;
   const int col = n0 + c4 * 4;
   const f32x4 bias4 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, col * 4, 0, 0);
   auto run = [&](auto act_c) {
@@ -266,19 +284,19 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       if (pass > 0) __syncthreads();
-      if (wm == pass) {
+      if (wm / WPP == pass) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+          for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-              Ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * CS + wn * 128 + j * 32 + fr] = acc[i][j][r];
+              Ct[((wm % WPP) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * CS + wn * TN * 32 + j * 32 + fr] = acc[i][j][r];
       }
       __syncthreads();
 #pragma unroll
       for (int s2 = 0; s2 < NCH; ++s2) {
-        const int rl = row0 + s2 * 4;
+        const int rl = row0 + s2 * RSTEP;
         const int m = m0 + pass * RP + rl;
         const bool ok = m < M;
         unsigned opix;
@@ -314,7 +332,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
 }
 
 // f32 weights [Cout][K] -> per-stage image of bf16 pieces (one thread per 8 consecutive k of a row)
-__global__ void split_weights_kernel(const float* __restrict__ wt, int Cout, int K, unsigned short* __restrict__ img) {
+__global__ void split_weights_kernel(const float* __restrict__ wt, int Cout, int K, int SBN, unsigned short* __restrict__ img) {
   const int nsl = K >> 5;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;       // (n, k8)
   const long total = (long)Cout * (K >> 3);
@@ -336,26 +354,34 @@ __global__ void split_weights_kernel(const float* __restrict__ wt, int Cout, int
 
 size_t conv_split_weight_bytes(int Cout, int K) { return (size_t)Cout * K * 6; }
 
+// n-tile width of the configuration that takes a layer with this Cout (0: none)
+int conv_split_bn(int Cout) { return Cout % 256 == 0 ? 256 : (Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 0)); }
+int conv_split_bm(int Cout) { return Cout % 256 == 0 ? 128 : 256; }
+
 bool conv_split_supported(const ConvParams& p) {
   const double wbytes = (double)p.Cout * p.kh * p.kw * p.Cin * 6.0;
   const bool res_ok = p.res_mode == 0 || (p.res_mode == 1 && p.res_H == p.Ho && p.res_W == p.Wo);
-  return p.Cout % SBN == 0 && p.Cin % 32 == 0 && p.in2 == nullptr && res_ok && p.out_ldc % 4 == 0 &&
+  return conv_split_bn(p.Cout) != 0 && p.Cin % 32 == 0 && p.in2 == nullptr && res_ok && p.out_ldc % 4 == 0 &&
          p.in_ldc % 4 == 0 && wbytes < 2147483648.0 && p.trace == nullptr;
 }
 
 int conv_make_split_weights(const float* wt_dev, int Cout, int K, void* img_dev, hipStream_t stream) {
-  ODT_CHECK(Cout % SBN == 0 && K % 32 == 0, "conv_make_split_weights: Cout % 256 == 0 and K % 32 == 0 required");
+  const int bn = conv_split_bn(Cout);
+  ODT_CHECK(bn != 0 && K % 32 == 0, "conv_make_split_weights: Cout % 64 == 0 and K % 32 == 0 required");
   const long total = (long)Cout * (K >> 3);
   hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, wt_dev, Cout, K,
-                     (unsigned short*)img_dev);
+                     bn, (unsigned short*)img_dev);
   ODT_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t stream) {
   const long M = (long)p.B * p.Ho * p.Wo;
-  const unsigned grid = (unsigned)(((M + SBM - 1) / SBM) * (p.Cout / SBN));
-  hipLaunchKernelGGL(conv_split_kernel, dim3(grid), dim3(256), 0, stream, dev);
+  const int bn = conv_split_bn(p.Cout), bm = conv_split_bm(p.Cout);
+  const unsigned grid = (unsigned)(((M + bm - 1) / bm) * (p.Cout / bn));
+  if (bn == 256) hipLaunchKernelGGL((conv_split_kernel<2, 2, 4>), dim3(grid), dim3(256), 0, stream, dev);
+  else if (bn == 128) hipLaunchKernelGGL((conv_split_kernel<4, 1, 4>), dim3(grid), dim3(256), 0, stream, dev);
+  else hipLaunchKernelGGL((conv_split_kernel<4, 1, 2>), dim3(grid), dim3(256), 0, stream, dev);
   ODT_HIP(hipGetLastError());
   return 0;
 }

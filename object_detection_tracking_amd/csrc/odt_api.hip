@@ -282,6 +282,27 @@ int add_conv(odt_model* m, const std::string& name, const Tensor& in, int cin, c
 }
 
 
+// bf16-piece weight images (conv_split.hip) for the plan's convs that the split kernel takes
+int attach_split_weights(odt_model* m) {
+  if (conv_split_mode() == 0) return 0;
+  std::map<const float*, const void*> made;      // the RPN conv is shared by the five levels
+  for (ConvOp& c : m->convs) {
+    if (!conv_split_wanted(c.p)) continue;
+    auto it = made.find(c.p.wt);
+    if (it == made.end()) {
+      const int K = c.p.kh * c.p.kw * c.p.Cin;
+      float* img = m->alloc_f((conv_split_weight_bytes(c.p.Cout, K) + 3) / 4, false);
+      ODT_CHECK(img != nullptr, "device allocation failed (split weights of " + c.name + ")");
+      if (conv_make_split_weights(c.p.wt, c.p.Cout, K, img, 0)) return 1;
+      it = made.emplace(c.p.wt, img).first;
+    }
+    c.p.wt_split = it->second;
+  }
+  ODT_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
+
 #include "effdet_plan.inc"
 
 }  // namespace
@@ -710,22 +731,7 @@ int build_plan(odt_model* m) {
     ms.per_image = per_im; ms.masks = m->final_masks;
     { Op op; op.kind = OP_MASK_SELECT; m->ops.push_back(op); }
   }
-  if (conv_split_mode() != 0) {   // bf16-piece weight images for the layers the split kernel takes
-    std::map<const float*, const void*> made;      // the RPN conv is shared by the five levels
-    for (ConvOp& c : m->convs) {
-      if (!conv_split_wanted(c.p)) continue;
-      auto it = made.find(c.p.wt);
-      if (it == made.end()) {
-        const int K = c.p.kh * c.p.kw * c.p.Cin;
-        float* img = m->alloc_f((conv_split_weight_bytes(c.p.Cout, K) + 3) / 4, false);
-        ODT_CHECK(img != nullptr, "device allocation failed (split weights of " + c.name + ")");
-        if (conv_make_split_weights(c.p.wt, c.p.Cout, K, img, 0)) return 1;
-        it = made.emplace(c.p.wt, img).first;
-      }
-      c.p.wt_split = it->second;
-    }
-    ODT_HIP(hipDeviceSynchronize());
-  }
+  if (attach_split_weights(m)) return 1;
   {   // conv parameter records in device memory
     std::vector<ConvParams> recs;
     for (const ConvOp& c : m->convs) recs.push_back(c.p);

@@ -77,6 +77,8 @@ int conv_split_mode();
 bool conv_split_supported(const ConvParams& p);
 bool conv_split_wanted(const ConvParams& p);
 size_t conv_split_weight_bytes(int Cout, int K);
+int conv_split_bn(int Cout);   // n-tile width of the split configuration for this Cout (0: none)
+int conv_split_bm(int Cout);
 int conv_make_split_weights(const float* wt_dev, int Cout, int K, void* img_dev, hipStream_t stream);
 int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t stream);
 

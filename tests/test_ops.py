@@ -476,6 +476,10 @@ SPLIT_CASES = [
     (1, 12, 14, 32, 256, 3, 2, 1, 1, 1, 6, 7, True),         # pad T/L 1 + 3x3 s2 VALID (res4 block0 conv2)
     (1, 13, 15, 32, 256, 3, 2, 2, 1, 1, 5, 6, False),        # dilated + strided
     (1, 11, 13, 96, 256, 1, 2, 1, 0, 0, 5, 6, False),        # 1x1 s2 over a cropped input, 3 slices per tap
+    (2, 12, 13, 64, 128, 3, 1, 1, 1, 1, 12, 13, True),       # 256 x 128 tile (res3 conv2), M = 312
+    (1, 18, 17, 32, 384, 3, 1, 1, 1, 1, 18, 17, False),      # 256 x 128 tile, three N tiles, M = 306
+    (1, 17, 19, 64, 64, 3, 1, 1, 1, 1, 17, 19, True),        # 256 x 64 tile (res2 conv2), M = 323
+    (1, 9, 30, 256, 64, 1, 1, 1, 0, 0, 9, 30, True),         # 256 x 64 tile, dense 1x1 (res2 conv1), M = 270
 ]
 
 
@@ -551,6 +555,12 @@ def test_conv2d_split_residual_bottleneck_conv3(backend, monkeypatch):
   got = ops.conv2d(x, w, b, res=res, res_mode=1, relu=True, lib=lib)
   want = np.maximum(torch_conv_nhwc(x, w, b, 1, 1, 0, 0, 9, 11) + res, 0)
   np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+  for cout in (128, 64):               # the 256 x 128 and 256 x 64 tiles
+    w2 = (rng.standard_normal((1, 1, 256, cout)) / 16).astype(F)
+    r2 = rng.standard_normal((2, 9, 11, cout)).astype(F)
+    got = ops.conv2d(x, w2, b[:cout], res=r2, res_mode=1, relu=True, lib=lib)
+    want = np.maximum(torch_conv_nhwc(x, w2, b[:cout], 1, 1, 0, 0, 9, 11) + r2, 0)
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
   up = rng.standard_normal((2, 5, 6, 512)).astype(F)
   got = ops.conv2d(x, w, b, res=up, res_mode=2, lib=lib)
   want = torch_conv_nhwc(x, w, b, 1, 1, 0, 0, 9, 11) + np.repeat(np.repeat(up, 2, 1), 2, 2)[:, :9, :11]
