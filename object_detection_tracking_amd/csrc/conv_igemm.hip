@@ -629,9 +629,12 @@ bool conv_split_wanted(const ConvParams& p) {
   // exact-f32 kernel's smaller tiles fill the chip better (b=1 res4: 64 tiles)
   const char* e = getenv("ODT_CONV_SPLIT_MINTILES");
   const long min_tiles = e != nullptr ? atol(e) : 256L;   // A/B at b=8 and b=1: 256 > 384 > 128 >> 64
-  // short reductions (K < 256: res2 / res3 conv3) are prologue / epilogue bound: the 64x64 tile of the
-  // exact-f32 kernel wins there
-  if (p.kh * p.kw * p.Cin < 256) return false;
+  // (A/B at b=8: the split tile also wins on the short reductions -- K >= 256: 155.0, >= 128: 156.2,
+  // >= 64: 156.6 FPS; ODT_CONV_SPLIT_MINK is the tuning knob)
+  const char* ek = getenv("ODT_CONV_SPLIT_MINK");
+  if (p.kh * p.kw * p.Cin < (ek != nullptr ? atoi(ek) : 64)) return false;
+  const char* er = getenv("ODT_CONV_SPLIT_RES2");        // tuning knob: 0 keeps the FPN laterals on the f32 kernel
+  if (p.res_mode == 2 && er != nullptr && er[0] == '0') return false;
   const long M = (long)p.B * p.Ho * p.Wo;
   const int bm = conv_split_bm(p.Cout), bn = conv_split_bn(p.Cout);
   const char* eb = getenv("ODT_CONV_SPLIT_MINBN");      // tuning knob: 256 = only the 128 x 256 tile

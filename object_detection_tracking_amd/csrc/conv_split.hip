@@ -24,7 +24,7 @@
 // LDS planes are [k-group][row][8 bf16]: a wave's ds_read_b128 of an MFMA operand is one
 // contiguous 512-byte run per 32 lanes.
 //
-// Scope: no residual or a same-shape residual (accumulator start value), no second A source, Cout % 256 == 0, Cin % 32 == 0, 16-byte-aligned
+// Scope: no residual, a same-shape residual or a nearest-2x upsampled one (accumulator start value), no second A source, Cout % 256 == 0, Cin % 32 == 0, 16-byte-aligned
 // output rows; everything else stays on the exact-f32 MFMA kernel (launch_conv decides).
 #include <cstdlib>
 #include <type_traits>
@@ -192,10 +192,11 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
 
   const int fr = lane & 31, fg = lane >> 5;
   load_slice();
-  if (p.res_mode == 1) {
-    // residual of the same shape (bottleneck conv3): the accumulators START at the residual, read
-    // in the MFMA C layout (a 32-lane group covers one 128-byte row segment) while the first slice
-    // is in flight -- no residual traffic in the epilogue.
+  if (p.res_mode != 0) {
+    // residual of the same shape (bottleneck conv3) or the nearest-2x upsampled coarser level (FPN
+    // lateral, res_mode 2): the accumulators START at the residual, read in the MFMA C layout (a
+    // 32-lane group covers one 128-byte row segment) while the first slice is in flight -- no
+    // residual traffic in the epilogue.
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.res, 0, (int)((unsigned)p.B * p.res_H * p.res_W * p.res_ldc * 4u), 0x00020000);
 #pragma unroll
@@ -203,7 +204,14 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
-        const unsigned roff = row < M ? (unsigned)row * (unsigned)p.res_ldc * 4u + (unsigned)(n0 + wn * TN * 32 + fr) * 4u : kOOB;
+        unsigned rpix = (unsigned)row;
+        if (p.res_mode == 2) {
+          const int mm = row < M ? row : 0;
+          const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), rr = mm - n * HoWo;
+          const int ho = sfast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
+          rpix = ((unsigned)n * p.res_H + (unsigned)(ho >> 1)) * p.res_W + (unsigned)(wo >> 1);
+        }
+        const unsigned roff = row < M ? rpix * (unsigned)p.res_ldc * 4u + (unsigned)(n0 + wn * TN * 32 + fr) * 4u : kOOB;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, (int)roff, j * 128, 0));
@@ -360,7 +368,8 @@ int conv_split_bm(int Cout) { return Cout % 256 == 0 ? 128 : 256; }
 
 bool conv_split_supported(const ConvParams& p) {
   const double wbytes = (double)p.Cout * p.kh * p.kw * p.Cin * 6.0;
-  const bool res_ok = p.res_mode == 0 || (p.res_mode == 1 && p.res_H == p.Ho && p.res_W == p.Wo);
+  const bool res_ok = p.res_mode == 0 || (p.res_mode == 1 && p.res_H == p.Ho && p.res_W == p.Wo) ||
+                      (p.res_mode == 2 && 2 * p.res_H >= p.Ho && 2 * p.res_W >= p.Wo);
   return conv_split_bn(p.Cout) != 0 && p.Cin % 32 == 0 && p.in2 == nullptr && res_ok && p.out_ldc % 4 == 0 &&
          p.in_ldc % 4 == 0 && wbytes < 2147483648.0 && p.trace == nullptr;
 }

@@ -544,7 +544,7 @@ def test_conv2d_split_output_offset_and_residual(backend, monkeypatch):
 
 def test_conv2d_split_residual_bottleneck_conv3(backend, monkeypatch):
   """1x1 conv + same-shape residual + ReLU over two N tiles and a ragged M (res4 conv3 shape class);
-  a nearest-2x residual (FPN lateral) is outside the split kernel's scope and must still be right."""
+  then the nearest-2x upsampled residual of an FPN lateral (odd sizes: the coarse level is ceil(n/2))."""
   name, lib = backend
   _split_env(monkeypatch)
   rng = np.random.default_rng(14)
