@@ -255,7 +255,8 @@ def pmc_traffic(mode):
   path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json" if mode == "f32" else "r01_pmc_summary_split.json")
   try:
     with open(path) as fh:
-      return float(json.load(fh)["conv_hbm_bytes_per_launch_fetch_x2"])
+      return float(json.load(fh)["conv_hbm_bytes_per_launch_fetch_x2" if mode == "f32" else
+                                 "split_hbm_bytes_per_launch_fetch_x2"])
   except Exception:
     return None
 
