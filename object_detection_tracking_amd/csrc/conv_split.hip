@@ -1,7 +1,7 @@
 // f32 implicit-GEMM convolution on the bf16 matrix pipe of gfx950 ("bf16x3 split"), for the
-// Cout % 256 == 0 layers that dominate the ResNet-101-FPN frame (res4 3x3 / 1x1 convs, FPN
-// post-hoc 3x3, RPN 3x3: ~60 % of the conv time; same reference ops as conv_igemm.hip:
-// nn.py:337-381 conv2d + :1771-1774 folded BN + ReLU).
+// Cout % 64 == 0 layers of the ResNet-101-FPN frame with at least one tile per CU (97 of the 121
+// conv launches at b=8, 87 % of the conv time; same reference ops as conv_igemm.hip:
+// nn.py:337-381 conv2d + :1771-1774 folded BN + ReLU, :503-521 residual, :949-1014 FPN lateral).
 //
 // Arithmetic.  Every f32 operand is cut into three bf16 pieces by round-to-nearest,
 //     x = hi + mid + lo   exactly   (3 x 8 significand bits = the 24 bits of an f32),
@@ -12,19 +12,22 @@
 // in f32 (8 x 8 bits) and the accumulation is f32 inside the MFMA unit: the result carries the
 // error of an f32 dot product with a different summation order (measured ~1e-7 of sum|a||b| on
 // K = 2304, the same as a sequential f32 loop; tools/experiments/split_gemm.hip; the bound is
-// asserted in tests/test_ops.py).  |x| above 3.39e38 (bf16 rounds to inf) is outside the domain.  bf16 MFMA runs at 16x the f32 MFMA rate, so six products
-// cost 6/16 of the f32 instruction time: the ceiling is 2.67x the f32 MFMA peak.
+// asserted in tests/test_ops.py).  |x| above 3.39e38 (bf16 rounds to inf) is outside the domain.
+// bf16 MFMA runs at 16x the f32 MFMA rate, so six products cost 6/16 of the f32 instruction time:
+// the ceiling is 2.67x the f32 MFMA peak.
 //
-// Tiling.  128 x 256 block tile (the whole Cout of a 256-channel layer: A is fetched from HBM
-// and split once), 4 waves as 2 x 2, wave tile 64 x 128 (acc = 128 VGPRs), BK = 32, one LDS stage
-// (72 KB: 3 A planes + 3 B planes) + register prefetch of the next slice, 2 workgroups per CU.
+// Tiling.  128 x 256 block tile for the Cout % 256 layers (the whole Cout of a 256-channel layer:
+// A is fetched from HBM and split once), 256 x 128 / 256 x 64 for Cout % 128 / % 64; 4 waves, wave
+// tile 64 x 128 (64 x 64), BK = 32, one LDS stage (72 KB: 3 A planes + 3 B planes) + register
+// prefetch of the next slice, 2 workgroups per CU.
 // A: f32 NHWC activations, gathered per tap exactly as in conv_igemm.hip, split on the way into
 // LDS.  B: weights split ONCE at plan-build time (conv_make_split_weights) into the per-stage LDS
-// image [n-tile][k-slice][piece][k-group][256 n][8 k] so that a stage is one linear 48 KB copy.
+// image [n-tile][k-slice][piece][k-group][BN n][8 k] so that a stage is one linear copy.
 // LDS planes are [k-group][row][8 bf16]: a wave's ds_read_b128 of an MFMA operand is one
 // contiguous 512-byte run per 32 lanes.
 //
-// Scope: no residual, a same-shape residual or a nearest-2x upsampled one (accumulator start value), no second A source, Cout % 256 == 0, Cin % 32 == 0, 16-byte-aligned
+// Scope: no residual, a same-shape residual or a nearest-2x upsampled one (both become the
+// accumulators' start value), no second A source, Cout % 64 == 0, Cin % 32 == 0, 16-byte-aligned
 // output rows; everything else stays on the exact-f32 MFMA kernel (launch_conv decides).
 #include <cstdlib>
 #include <type_traits>
