@@ -632,7 +632,9 @@ bool conv_split_wanted(const ConvParams& p) {
   // (A/B at b=8: the split tile also wins on the short reductions -- K >= 256: 155.0, >= 128: 156.2,
   // >= 64: 156.6 FPS; ODT_CONV_SPLIT_MINK is the tuning knob)
   const char* ek = getenv("ODT_CONV_SPLIT_MINK");
-  if (p.kh * p.kw * p.Cin < (ek != nullptr ? atoi(ek) : 64)) return false;
+  if (p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0) < (ek != nullptr ? atoi(ek) : 64)) return false;
+  const char* e2 = getenv("ODT_CONV_SPLIT_SRC2");        // tuning knob: 0 keeps the fused stage-entry convs on the f32 kernel
+  if (p.in2 != nullptr && e2 != nullptr && e2[0] == '0') return false;
   const char* er = getenv("ODT_CONV_SPLIT_RES2");        // tuning knob: 0 keeps the FPN laterals on the f32 kernel
   if (p.res_mode == 2 && er != nullptr && er[0] == '0') return false;
   const long M = (long)p.B * p.Ho * p.Wo;
@@ -673,7 +675,7 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
   // (a plan conv without an image stays on the exact-f32 kernel: no allocation on the hot path)
   const bool split = q.wt_split != nullptr ? conv_split_mode() != 0 : (dev_params == nullptr && conv_split_wanted(q));
   if (split && q.wt_split == nullptr) {
-    const int Ksp = q.kh * q.kw * q.Cin;
+    const int Ksp = q.kh * q.kw * q.Cin + (q.in2 != nullptr ? q.Cin2 : 0);
     ODT_HIP(hipMalloc(&tmp_img, conv_split_weight_bytes(q.Cout, Ksp)));
     if (conv_make_split_weights(q.wt, q.Cout, Ksp, tmp_img, stream)) { (void)hipFree(tmp_img); return 1; }
     q.wt_split = tmp_img; modified = true;

@@ -27,7 +27,7 @@
 // contiguous 512-byte run per 32 lanes.
 //
 // Scope: no residual, a same-shape residual or a nearest-2x upsampled one (both become the
-// accumulators' start value), no second A source, Cout % 64 == 0, Cin % 32 == 0, 16-byte-aligned
+// accumulators' start value), an optional K-concatenated second A source (1x1), Cout % 64 == 0, Cin % 32 == 0, 16-byte-aligned
 // output rows; everything else stays on the exact-f32 MFMA kernel (launch_conv decides).
 #include <cstdlib>
 #include <type_traits>
@@ -108,10 +108,14 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
   const int HoWo = p.Ho * p.Wo;
   const int M = p.B * HoWo;
   const int cpt = p.Cin >> 5;
-  const int nslices = p.kh * p.kw * cpt;
+  const int cpt2 = p.in2 != nullptr ? p.Cin2 >> 5 : 0;    // slices of the second A source (1x1 only)
+  const int nslices = p.kh * p.kw * cpt + cpt2;
 
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.in, 0, (int)((unsigned)p.B * p.in_Ha * p.in_Wa * p.in_ldc * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.in2 != nullptr ? p.in2 : p.in), 0,
+      (int)(p.in2 != nullptr ? (unsigned)p.B * p.in2_Ha * p.in2_Wa * p.in2_ldc * 4u : 0u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.wt_split, 0, (int)((unsigned)ntn * nslices * (unsigned)STAGE_B_BYTES), 0x00020000);
 
@@ -148,6 +152,22 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
     }
   };
   set_tap(0, 0);
+  // second source (stage-entry bottleneck: conv3(t2) + convshortcut(x) as one K-concatenated GEMM):
+  // output row m reads pixel (n, ho * in2_stride, wo * in2_stride) of in2
+  bool l_src2 = false;
+  int l_cpt = cpt;
+  auto set_src2 = [&]() {
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+      const int m = m0 + lr + 32 * j;
+      const bool ok = m < M;
+      const int mm = ok ? m : 0;
+      const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), r = mm - n * HoWo;
+      const int ho = sfast_div(r, p.div_wo_mul, p.div_wo_sh), wo = r - ho * p.Wo;
+      const unsigned pix = ((unsigned)n * p.in2_Ha + (unsigned)(ho * p.in2_stride)) * p.in2_Wa + (unsigned)(wo * p.in2_stride);
+      a_row[j] = ok ? pix * (unsigned)p.in2_ldc * 4u + lc * 16u : kOOB;
+    }
+  };
   unsigned l_b = (unsigned)nt * (unsigned)nslices * (unsigned)STAGE_B_BYTES;   // weight-image offset of the load stream
 
   f32x4 ga[RA];
@@ -156,15 +176,22 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
   auto load_slice = [&]() {
 #pragma unroll
     for (int j = 0; j < RA; ++j)
-      ga[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)a_row[j], l_cc * 128, 0);
+      ga[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(l_src2 ? rs_in2 : rs_in, (int)a_row[j], l_cc * 128, 0);
 #pragma unroll
     for (int i = 0; i < NB; ++i)
       gb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, tid * 16 + i * 4096, (int)l_b, 0);
     l_b += (unsigned)STAGE_B_BYTES;
-    if (++l_cc == cpt) {
+    if (++l_cc == l_cpt) {
       l_cc = 0;
-      if (++l_kw == p.kw) { l_kw = 0; ++l_kh; }
-      set_tap(l_kh, l_kw);        // harmless past the last tap (never loaded)
+      if (!l_src2) {
+        if (++l_kw == p.kw) { l_kw = 0; ++l_kh; }
+        if (l_kh == p.kh && cpt2 > 0) {
+          l_src2 = true; l_cpt = cpt2;
+          set_src2();
+        } else {
+          set_tap(l_kh, l_kw);      // harmless past the last tap (never loaded)
+        }
+      }
     }
   };
   auto store_slice = [&]() {
@@ -370,10 +397,11 @@ int conv_split_bn(int Cout) { return Cout % 256 == 0 ? 256 : (Cout % 128 == 0 ? 
 int conv_split_bm(int Cout) { return Cout % 256 == 0 ? 128 : 256; }
 
 bool conv_split_supported(const ConvParams& p) {
-  const double wbytes = (double)p.Cout * p.kh * p.kw * p.Cin * 6.0;
+  const double wbytes = (double)p.Cout * (p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0)) * 6.0;
   const bool res_ok = p.res_mode == 0 || (p.res_mode == 1 && p.res_H == p.Ho && p.res_W == p.Wo) ||
                       (p.res_mode == 2 && 2 * p.res_H >= p.Ho && 2 * p.res_W >= p.Wo);
-  return conv_split_bn(p.Cout) != 0 && p.Cin % 32 == 0 && p.in2 == nullptr && res_ok && p.out_ldc % 4 == 0 &&
+  const bool src2_ok = p.in2 == nullptr || (p.kh == 1 && p.kw == 1 && p.Cin2 % 32 == 0 && p.in2_ldc % 4 == 0);
+  return conv_split_bn(p.Cout) != 0 && p.Cin % 32 == 0 && src2_ok && res_ok && p.out_ldc % 4 == 0 &&
          p.in_ldc % 4 == 0 && wbytes < 2147483648.0 && p.trace == nullptr;
 }
 

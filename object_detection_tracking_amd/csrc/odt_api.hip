@@ -290,7 +290,7 @@ int attach_split_weights(odt_model* m) {
     if (!conv_split_wanted(c.p)) continue;
     auto it = made.find(c.p.wt);
     if (it == made.end()) {
-      const int K = c.p.kh * c.p.kw * c.p.Cin;
+      const int K = c.p.kh * c.p.kw * c.p.Cin + (c.p.in2 != nullptr ? c.p.Cin2 : 0);
       float* img = m->alloc_f((conv_split_weight_bytes(c.p.Cout, K) + 3) / 4, false);
       ODT_CHECK(img != nullptr, "device allocation failed (split weights of " + c.name + ")");
       if (conv_make_split_weights(c.p.wt, c.p.Cout, K, img, 0)) return 1;

@@ -565,3 +565,22 @@ def test_conv2d_split_residual_bottleneck_conv3(backend, monkeypatch):
   got = ops.conv2d(x, w, b, res=up, res_mode=2, lib=lib)
   want = torch_conv_nhwc(x, w, b, 1, 1, 0, 0, 9, 11) + np.repeat(np.repeat(up, 2, 1), 2, 2)[:, :9, :11]
   np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+
+
+def test_conv2d_split_two_sources(backend, monkeypatch):
+  """Stage-entry fusion on the split kernel: conv3(t2) + convshortcut(x[::s]) as one K-concatenated
+  GEMM, second source at stride 1 and 2, all three tile configurations."""
+  name, lib = backend
+  _split_env(monkeypatch)
+  rng = np.random.default_rng(15)
+  for stride_b, Ca, Cb, Cout in ((1, 64, 64, 256), (2, 128, 256, 512), (2, 32, 96, 128), (1, 64, 32, 64)):
+    B, Ho, Wo = 2, 9, 11
+    Hb, Wb = (Ho, Wo) if stride_b == 1 else (2 * Ho, 2 * Wo - 1)
+    a = rng.standard_normal((B, Ho, Wo, Ca)).astype(F)
+    b2 = rng.standard_normal((B, Hb, Wb, Cb)).astype(F)
+    wa = (rng.standard_normal((Ca, Cout)) / np.sqrt(Ca)).astype(F)
+    wb = (rng.standard_normal((Cb, Cout)) / np.sqrt(Cb)).astype(F)
+    bias = rng.standard_normal((Cout,)).astype(F)
+    want = a @ wa + b2[:, ::stride_b, ::stride_b][:, :Ho, :Wo] @ wb + bias
+    got = ops.conv2d_cat(a, b2, wa, wb, bias, stride_b=stride_b, relu=True, lib=lib)
+    np.testing.assert_allclose(got, np.maximum(want, 0), rtol=2e-4, atol=2e-4)
