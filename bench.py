@@ -9,8 +9,9 @@ A "step" is one pass of the hot path (preprocess -> ResNet-101-dilated+FPN -> RP
 batch of 8 synthetic 1920x1080 frames that are already resident in HBM (uint8).  One process
 per GPU, one video stream per GPU, weights replicated, no data-path collective (streams are
 independent: "weak" scaling; RCCL only carries the barrier and the max-over-ranks timing).
-Rank 0 prints ONE JSON line with the contract fields plus `roofline` (conv implicit-GEMM kernel
-family, HIP-event timed on its launch stream) and, at N=1, `cpu_baseline` (the oracle -- a CPU
+Rank 0 prints ONE JSON line with the contract fields plus `roofline` (the conv implicit-GEMM
+launches, HIP-event timed on their launch stream, split by kernel family: `conv_split_kernel` --
+f32 convolution through six exact bf16 MFMA products per MAC -- and the exact-f32 `conv_igemm_kernel`) and, at N=1, `cpu_baseline` (the oracle -- a CPU
 restatement of the reference's TF graph, kind "port" -- timed on the host cores over a bounded
 sample of the same workload).
 """
@@ -229,7 +230,12 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if fam["split"][0] == 0 else "f32 (in/out/accumulate; products of the Cout%256 layers via exact bf16x3 split)",
+        "dtype": "f32",
+        "arithmetic": ("f32 tensors, f32 accumulation; exact-f32 MFMA products" if fam["split"][0] == 0 else
+                       "f32 tensors, f32 accumulation; the products of %d of the %d conv launches are evaluated as six "
+                       "exact bf16 x bf16 MFMA products of a 3-way bf16 split of both f32 operands (error at the "
+                       "exact-f32 kernel's level, DESIGN.md section 3; ODT_CONV_SPLIT=0: exact-f32 MFMA everywhere)"
+                       % (fam["split"][0], fam["split"][0] + fam["f32"][0])),
         "data": "synthetic",
         "config": {"workload": "ResNet-101-dilated+FPN detector + RoI appearance features, "
                                "%dx%d, batch %d per GPU, rpn_post_nms_topk %d, 15 classes, "

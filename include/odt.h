@@ -16,6 +16,13 @@
  * Layouts: frames are HWC BGR (uint8 or float32 0..255) exactly as the
  * reference feeds them; outputs use the reference's layouts (boxes x1,y1,x2,y2
  * in resized-image coordinates, features NCHW [R,256,7,7]).
+ *
+ * Arithmetic: all tensors and accumulations are float32.  Environment knob read
+ * by the library: ODT_CONV_SPLIT=1 (default) evaluates the products of the large
+ * convolutions as six exact bf16 x bf16 matrix-core products of a 3-way bf16 split
+ * of both float32 operands (error at the level of an f32 dot product in another
+ * summation order); ODT_CONV_SPLIT=0 uses the exact-f32 matrix instruction for
+ * every layer.  ODT_GRAPH=0 disables hipGraph replay of the launch sequence.
  */
 #ifndef ODT_H_
 #define ODT_H_
@@ -35,7 +42,7 @@ typedef struct odt_model* odt_handle;
 /* graph semantics: the reference ships two different inference graphs */
 #define ODT_GRAPH_SINGLE 0 /* Mask_RCNN_FPN        (models.py:488-973)   b = 1 */
 #define ODT_GRAPH_MULTI 1  /* Mask_RCNN_FPN_multi  (models.py:2058-2408) b = B */
-#define ODT_GRAPH_EFFNET 2   /* EfficientNet backbone of the EfficientDet path (work in progress: features via odt_tap) */
+#define ODT_GRAPH_EFFNET 2 /* EfficientDet (efficientdet_wrapper.py:12-106): EfficientNet backbone + BiFPN + class / box nets + top-k / NMS */
 
 /* Mirrors the fields of the reference's `args`/config namespace that the
  * inference graph reads (obj_detect_tracking.py:303-387). */
