@@ -616,34 +616,6 @@ double conv_flops(const ConvParams& p) {
          (double)(p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0));
 }
 
-int conv_split_mode() {
-  // default ON (same-box A/B at b=8 1080p: 116.2 -> 143.1 FPS, parity suite green); ODT_CONV_SPLIT=0
-  // keeps every layer on the exact-f32 MFMA kernel.  Read per call: tests and A/B runs flip it.
-  const char* e = getenv("ODT_CONV_SPLIT");
-  return e != nullptr ? atoi(e) : 1;
-}
-
-bool conv_split_wanted(const ConvParams& p) {
-  if (conv_split_mode() == 0 || !conv_split_supported(p)) return false;
-  // 128 x 256 / 256 x 128 / 256 x 64 tiles, two workgroups per CU: below one workgroup per CU the
-  // exact-f32 kernel's smaller tiles fill the chip better (b=1 res4: 64 tiles)
-  const char* e = getenv("ODT_CONV_SPLIT_MINTILES");
-  const long min_tiles = e != nullptr ? atol(e) : 256L;   // A/B at b=8 and b=1: 256 > 384 > 128 >> 64
-  // (A/B at b=8: the split tile also wins on the short reductions -- K >= 256: 155.0, >= 128: 156.2,
-  // >= 64: 156.6 FPS; ODT_CONV_SPLIT_MINK is the tuning knob)
-  const char* ek = getenv("ODT_CONV_SPLIT_MINK");
-  if (p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0) < (ek != nullptr ? atoi(ek) : 64)) return false;
-  const char* e2 = getenv("ODT_CONV_SPLIT_SRC2");        // tuning knob: 0 keeps the fused stage-entry convs on the f32 kernel
-  if (p.in2 != nullptr && e2 != nullptr && e2[0] == '0') return false;
-  const char* er = getenv("ODT_CONV_SPLIT_RES2");        // tuning knob: 0 keeps the FPN laterals on the f32 kernel
-  if (p.res_mode == 2 && er != nullptr && er[0] == '0') return false;
-  const long M = (long)p.B * p.Ho * p.Wo;
-  const int bm = conv_split_bm(p.Cout), bn = conv_split_bn(p.Cout);
-  const char* eb = getenv("ODT_CONV_SPLIT_MINBN");      // tuning knob: 256 = only the 128 x 256 tile
-  if (eb != nullptr && bn < atoi(eb)) return false;
-  return ((M + bm - 1) / bm) * (p.Cout / bn) >= min_tiles;
-}
-
 int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_params) {
   ODT_CHECK(p.Cin % 32 == 0, "conv: Cin must be a multiple of 32");
   ODT_CHECK(p.in_ldc % 4 == 0, "conv: input pixel stride must be a multiple of 4 floats");

@@ -12,7 +12,8 @@
 // in f32 (8 x 8 bits) and the accumulation is f32 inside the MFMA unit: the result carries the
 // error of an f32 dot product with a different summation order (measured ~1e-7 of sum|a||b| on
 // K = 2304, the same as a sequential f32 loop; tools/experiments/split_gemm.hip; the bound is
-// asserted in tests/test_ops.py).  |x| above 3.39e38 (bf16 rounds to inf) is outside the domain.
+// asserted in tests/test_ops.py).  |x| above 3.39e38 (bf16 rounds to inf) is outside the domain;
+// below ~1e-33 the lo piece is a bf16 subnormal (absolute effect < 1e-38 per product).
 // bf16 MFMA runs at 16x the f32 MFMA rate, so six products cost 6/16 of the f32 instruction time:
 // the ceiling is 2.67x the f32 MFMA peak.
 //
@@ -403,6 +404,35 @@ bool conv_split_supported(const ConvParams& p) {
   const bool src2_ok = p.in2 == nullptr || (p.kh == 1 && p.kw == 1 && p.Cin2 % 32 == 0 && p.in2_ldc % 4 == 0);
   return conv_split_bn(p.Cout) != 0 && p.Cin % 32 == 0 && src2_ok && res_ok && p.out_ldc % 4 == 0 &&
          p.in_ldc % 4 == 0 && wbytes < 2147483648.0 && p.trace == nullptr;
+}
+
+// ---- policy: which convs take the split kernel (launch_conv and the plan builder ask)
+int conv_split_mode() {
+  // default ON (same-box A/B at b=8 1080p: 116.2 -> 143.1 FPS, parity suite green); ODT_CONV_SPLIT=0
+  // keeps every layer on the exact-f32 MFMA kernel.  Read per call: tests and A/B runs flip it.
+  const char* e = getenv("ODT_CONV_SPLIT");
+  return e != nullptr ? atoi(e) : 1;
+}
+
+bool conv_split_wanted(const ConvParams& p) {
+  if (conv_split_mode() == 0 || !conv_split_supported(p)) return false;
+  // 128 x 256 / 256 x 128 / 256 x 64 tiles, two workgroups per CU: below one workgroup per CU the
+  // exact-f32 kernel's smaller tiles fill the chip better (b=1 res4: 64 tiles)
+  const char* e = getenv("ODT_CONV_SPLIT_MINTILES");
+  const long min_tiles = e != nullptr ? atol(e) : 256L;   // A/B at b=8 and b=1: 256 > 384 > 128 >> 64
+  // (A/B at b=8: the split tile also wins on the short reductions -- K >= 256: 155.0, >= 128: 156.2,
+  // >= 64: 156.6 FPS; ODT_CONV_SPLIT_MINK is the tuning knob)
+  const char* ek = getenv("ODT_CONV_SPLIT_MINK");
+  if (p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0) < (ek != nullptr ? atoi(ek) : 64)) return false;
+  const char* e2 = getenv("ODT_CONV_SPLIT_SRC2");        // tuning knob: 0 keeps the fused stage-entry convs on the f32 kernel
+  if (p.in2 != nullptr && e2 != nullptr && e2[0] == '0') return false;
+  const char* er = getenv("ODT_CONV_SPLIT_RES2");        // tuning knob: 0 keeps the FPN laterals on the f32 kernel
+  if (p.res_mode == 2 && er != nullptr && er[0] == '0') return false;
+  const long M = (long)p.B * p.Ho * p.Wo;
+  const int bm = conv_split_bm(p.Cout), bn = conv_split_bn(p.Cout);
+  const char* eb = getenv("ODT_CONV_SPLIT_MINBN");      // tuning knob: 256 = only the 128 x 256 tile
+  if (eb != nullptr && bn < atoi(eb)) return false;
+  return ((M + bm - 1) / bm) * (p.Cout / bn) >= min_tiles;
 }
 
 int conv_make_split_weights(const float* wt_dev, int Cout, int K, void* img_dev, hipStream_t stream) {
