@@ -174,6 +174,27 @@ def main():
       eng.synchronize(); e2.synchronize()
       extra["two_streams_per_gpu_fps"] = 2 * 6 * B / (time.perf_counter() - t1)
       m2.close()
+      # (d) the same step with every conv on the exact-f32 MFMA kernel (ODT_CONV_SPLIT=0): the
+      # other arithmetic mode of the library, measured in the same process on the same box
+      prev = os.environ.get("ODT_CONV_SPLIT")
+      try:
+        os.environ["ODT_CONV_SPLIT"] = "0"
+        m3 = models.get_model(cfg, local_rank, weights=weights, is_multi=True)
+        e3 = m3.engine(B, H, W)
+        for k in range(1 + 5):
+          if k == 1:
+            e3.synchronize(); t1 = time.perf_counter()
+          e3.forward_device_async(dev_frames.data_ptr(), ODT_DTYPE_U8)
+        e3.synchronize()
+        extra["exact_f32_mfma_only_fps"] = 5 * B / (time.perf_counter() - t1)
+        m3.close()
+      except Exception as ex:     # never fatal: `value` above is already measured
+        extra["exact_f32_mfma_only_fps"] = "failed: %r" % (ex,)
+      finally:
+        if prev is None:
+          os.environ.pop("ODT_CONV_SPLIT", None)
+        else:
+          os.environ["ODT_CONV_SPLIT"] = prev
     rng = np.random.default_rng(0)
     gal = rng.standard_normal((320, 256)).astype(np.float32)
     seg = (np.arange(65) * 5).astype(np.int32)
