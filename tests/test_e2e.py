@@ -242,3 +242,33 @@ def test_forward_single_with_mask_head(backend):
     m.close()
   with pytest.raises(NotImplementedError):
     models.get_model(small_config(add_mask=True, im_batch_size=2), 0, weights=w, lib=lib, is_multi=True)
+
+
+def test_arithmetic_modes_agree(backend, monkeypatch):
+  """The two arithmetic modes of the conv path on the same frame: exact-f32 MFMA everywhere
+  (ODT_CONV_SPLIT=0) against every eligible layer on the bf16x3 split kernel (forced with
+  MINTILES=1; at 1080p the library picks it by itself).  Stage tensors agree at f32 rounding
+  level, detections as matched sets; both are separately checked against the oracle elsewhere."""
+  name, lib = backend
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1] if name == "emu" else [1, 1, 2, 3])
+  w = weights_for(cfg)
+  H, W = (64, 96) if name == "emu" else (96, 128)
+  fr = synthetic_frames(1, H, W, seed=5)
+  out = {}
+  for mode in ("0", "1"):
+    monkeypatch.setenv("ODT_CONV_SPLIT", mode)
+    monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1")
+    m = models.get_model(cfg, 0, weights=w, lib=lib)
+    try:
+      boxes, labels, probs, feats = m.predict(fr[0])
+      e = m.engine(1, H, W)
+      nsplit = sum(1 for nm, _, _, _ in e.profile_layers() if nm.endswith("[bf16x3]"))
+      out[mode] = (boxes, labels, probs, {k: e.tap(k) for k in ("c2", "c3", "c4", "c5", "p2", "p5", "rpn2")}, nsplit)
+    finally:
+      m.close()
+  assert out["0"][4] == 0 and out["1"][4] > 20, (out["0"][4], out["1"][4])
+  for k, t in out["0"][3].items():
+    assert _rel(out["1"][3][k], t) < 2e-5, k
+  miss, extra = match_detections(out["1"][0], out["1"][1], out["1"][2], out["0"][0], out["0"][1], out["0"][2],
+                                 1e-3, 1e-4)
+  assert miss + extra <= 2, (miss, extra)
