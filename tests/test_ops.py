@@ -398,13 +398,15 @@ def test_nn_cosine(backend):
 
 
 # ---- randomized conv coverage: every kernel instantiation (tile x stages x loop style) ----------
-def _fuzz_case(rng, lib, big):
+def _fuzz_case(rng, lib, big, couts=None):
   B = int(rng.integers(1, 3)); k = int(rng.choice([1, 1, 3])); stride = int(rng.choice([1, 1, 2]))
   dil = int(rng.choice([1, 1, 2])) if k == 3 else 1
   lo, hi = (6, 20) if not big else (9, 70)
   H, W = int(rng.integers(lo, hi)), int(rng.integers(lo, hi))
   Cin = int(rng.choice([32, 64, 96] if not big else [32, 64, 96, 256]))
   Cout = int(rng.choice([4, 8, 15, 32, 64, 72, 128, 200] if big else [4, 15, 32, 72]))
+  if couts is not None:
+    Cout = int(rng.choice(couts))
   pad_t, pad_l = int(rng.integers(0, k)) * dil, int(rng.integers(0, k)) * dil
   ke = (k - 1) * dil + 1
   Ho = (H + pad_t + int(rng.integers(0, ke)) - ke) // stride + 1
@@ -584,3 +586,13 @@ def test_conv2d_split_two_sources(backend, monkeypatch):
     want = a @ wa + b2[:, ::stride_b, ::stride_b][:, :Ho, :Wo] @ wb + bias
     got = ops.conv2d_cat(a, b2, wa, wb, bias, stride_b=stride_b, relu=True, lib=lib)
     np.testing.assert_allclose(got, np.maximum(want, 0), rtol=2e-4, atol=2e-4)
+
+
+def test_conv_fuzz_split(backend, monkeypatch):
+  """Randomized shapes / strides / dilations / pads / output offsets / residual modes through the
+  three tile configurations of the split kernel."""
+  name, lib = backend
+  _split_env(monkeypatch)
+  rng = np.random.default_rng(2025)
+  for _ in range(6 if name == "emu" else 40):
+    _fuzz_case(rng, lib, big=name == "hip", couts=[64, 128, 192, 256, 384])
