@@ -293,10 +293,11 @@ int attach_split_weights(odt_model* m) {
       const int K = c.p.kh * c.p.kw * c.p.Cin + (c.p.in2 != nullptr ? c.p.Cin2 : 0);
       float* img = m->alloc_f((conv_split_weight_bytes(c.p.Cout, K) + 3) / 4, false);
       ODT_CHECK(img != nullptr, "device allocation failed (split weights of " + c.name + ")");
-      if (conv_make_split_weights(c.p.wt, c.p.Cout, K, img, 0)) return 1;
+      if (conv_make_split_weights(c.p.wt, c.p.Cout, K, conv_split_bk(c.p), img, 0)) return 1;
       it = made.emplace(c.p.wt, img).first;
     }
     c.p.wt_split = it->second;
+    c.p.wt_split_bk = conv_split_bk(c.p);
   }
   ODT_HIP(hipDeviceSynchronize());
   return 0;

@@ -65,6 +65,7 @@ struct ConvParams {
   // optional bf16-piece image of `wt` (conv_make_split_weights): the layer runs on the bf16x3
   // split kernel (conv_split.hip: f32 result through six exact bf16 MFMA products per MAC)
   const void* wt_split;
+  int wt_split_bk;     // K extent of one stage of that image: 32 (default kernel) or 16 (conv_split2_kernel)
 };
 // fills the derived fields (multiply-shift divisors); call before copying a record to the device
 void conv_prepare(ConvParams& p);
@@ -79,7 +80,8 @@ bool conv_split_wanted(const ConvParams& p);
 size_t conv_split_weight_bytes(int Cout, int K);
 int conv_split_bn(int Cout);   // n-tile width of the split configuration for this Cout (0: none)
 int conv_split_bm(int Cout);
-int conv_make_split_weights(const float* wt_dev, int Cout, int K, void* img_dev, hipStream_t stream);
+int conv_split_bk(const ConvParams& p);   // stage width of the kernel that will take this conv (32, or 16 with ODT_CONV_SPLIT_PIPE=2)
+int conv_make_split_weights(const float* wt_dev, int Cout, int K, int bk, void* img_dev, hipStream_t stream);
 int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t stream);
 
 // ------------------------------------------------------------ elementwise (K1,K4)
