@@ -596,3 +596,31 @@ def test_conv_fuzz_split(backend, monkeypatch):
   rng = np.random.default_rng(2025)
   for _ in range(6 if name == "emu" else 40):
     _fuzz_case(rng, lib, big=name == "hip", couts=[64, 128, 192, 256, 384])
+
+
+def test_conv2d_split_pipe2_experimental(emu_lib, monkeypatch):
+  """ODT_CONV_SPLIT_PIPE=2: the experimental two-stage (BK = 16) loop of the 128 x 256 tile.
+  Simulator only for now: it has not been on the GPU yet (written after the round's GPU budget
+  was spent); the default kernel is unaffected."""
+  _split_env(monkeypatch)
+  monkeypatch.setenv("ODT_CONV_SPLIT_PIPE", "2")
+  rng = np.random.default_rng(16)
+  for case in SPLIT_CASES:
+    if case[4] % 256 == 0:
+      _run_conv(emu_lib, case, rng)
+  for _ in range(4):
+    _fuzz_case(rng, emu_lib, big=False, couts=[256, 512])
+  # residual (same shape, 2x upsampled) and the K-concatenated second source
+  x = rng.standard_normal((2, 9, 11, 96)).astype(F)
+  w = (rng.standard_normal((1, 1, 96, 256)) / 10).astype(F)
+  b = rng.standard_normal(256).astype(F)
+  res = rng.standard_normal((2, 9, 11, 256)).astype(F)
+  got = ops.conv2d(x, w, b, res=res, res_mode=1, relu=True, lib=emu_lib)
+  np.testing.assert_allclose(got, np.maximum(torch_conv_nhwc(x, w, b, 1, 1, 0, 0, 9, 11) + res, 0), rtol=1e-4, atol=1e-4)
+  a = rng.standard_normal((2, 9, 11, 64)).astype(F)
+  b2 = rng.standard_normal((2, 18, 21, 160)).astype(F)
+  wa = (rng.standard_normal((64, 256)) / 8).astype(F)
+  wb = (rng.standard_normal((160, 256)) / 12).astype(F)
+  want = a @ wa + b2[:, ::2, ::2][:, :9, :11] @ wb + b
+  got = ops.conv2d_cat(a, b2, wa, wb, b, stride_b=2, relu=False, lib=emu_lib)
+  np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4)
