@@ -371,7 +371,8 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
 }
 
 // ---- experimental second loop structure (ODT_CONV_SPLIT_PIPE=2, 128 x 256 tile only; not the default:
-// written at the end of round 1 without GPU time left to measure it).  BK = 16 per stage, TWO LDS
+// written at the end of round 1: simulator-verified and bit-identical to the default kernel on the
+// GPU for two shapes, but not timed yet).  BK = 16 per stage, TWO LDS
 // stages (2 x 36.4 KB), one barrier per slice, no MFMA-free phase: the registers -> LDS move of
 // slice c+1 (split arithmetic + stores) rides behind the MFMAs of groups 1-2 of slice c, the global
 // prefetch of slice c+2 is issued right after it, and the first fragments of slice c+1 are read

@@ -600,8 +600,9 @@ def test_conv_fuzz_split(backend, monkeypatch):
 
 def test_conv2d_split_pipe2_experimental(emu_lib, monkeypatch):
   """ODT_CONV_SPLIT_PIPE=2: the experimental two-stage (BK = 16) loop of the 128 x 256 tile.
-  Simulator only for now: it has not been on the GPU yet (written after the round's GPU budget
-  was spent); the default kernel is unaffected."""
+  Simulator only for now: on the GPU it has only run tools/gpurun/pipe2_check.py (bit-identical to the
+  default kernel on two shapes; written after the round's GPU budget was spent, not timed yet); the
+  default kernel is unaffected."""
   _split_env(monkeypatch)
   monkeypatch.setenv("ODT_CONV_SPLIT_PIPE", "2")
   rng = np.random.default_rng(16)
