@@ -5,6 +5,35 @@
 #include <chrono>
 #include <mutex>
 
+#if !defined(__x86_64__)
+#error "the HIP-on-CPU simulator's context switch is written for x86-64"
+#endif
+// void hipemu_switch(void** save_sp, void* const* load_sp): push the callee-saved registers, park the
+// stack pointer in *save_sp, continue on the stack *load_sp (whose top holds the same six registers
+// and a return address).
+asm(R"(
+.text
+.globl hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq (%rsi), %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size hipemu_switch, .-hipemu_switch
+)");
+
 namespace hipemu {
 
 thread_local Worker* tl_worker = nullptr;
@@ -19,7 +48,8 @@ static void fiber_entry() {
   (*w.body)();
   w.cur->state = 2;
   w.live--;
-  swapcontext(&w.cur->ctx, &w.sched);
+  hipemu_switch(&w.cur->sp, &w.sched_sp);    // never resumed
+  abort();
 }
 
 static void run_block(Worker& w, unsigned bx, unsigned by, unsigned bz, dim3 grid, dim3 block) {
@@ -43,11 +73,14 @@ static void run_block(Worker& w, unsigned bx, unsigned by, unsigned bz, dim3 gri
     f.tid.z = i / (block.x * block.y);
     f.state = 0;
     f.wseq = 0;
-    getcontext(&f.ctx);
-    f.ctx.uc_stack.ss_sp = f.stack;
-    f.ctx.uc_stack.ss_size = kStack;
-    f.ctx.uc_link = nullptr;
-    makecontext(&f.ctx, fiber_entry, 0);
+    // initial frame: six zeroed callee-saved registers, fiber_entry as the return address of the first
+    // switch, a null return address above it (fiber_entry never returns); rsp % 16 == 8 at its entry
+    uintptr_t top = ((uintptr_t)f.stack + kStack) & ~(uintptr_t)15;
+    void** sp = (void**)(top - 8 * sizeof(void*));
+    for (int k = 0; k < 6; ++k) sp[k] = nullptr;
+    sp[6] = (void*)&fiber_entry;
+    sp[7] = nullptr;
+    f.sp = (void*)sp;
   }
   while (w.live > 0) {
     bool progressed = false;
@@ -55,7 +88,7 @@ static void run_block(Worker& w, unsigned bx, unsigned by, unsigned bz, dim3 gri
       Fiber& f = w.fibers[i];
       if (f.state != 0) continue;
       w.cur = &f;
-      swapcontext(&w.sched, &f.ctx);
+      hipemu_switch(&w.sched_sp, &f.sp);
       progressed = true;
     }
     if (w.live > 0 && w.at_barrier == w.live) {

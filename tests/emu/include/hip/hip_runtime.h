@@ -11,7 +11,7 @@
 // no performance number is ever taken from it.
 //
 // Model: one workgroup at a time per host worker thread; every HIP thread is a
-// ucontext fiber.  __syncthreads() and the wave-level primitives (shuffles,
+// fiber (own stack, hand-written context switch).  __syncthreads() and the wave-level primitives (shuffles,
 // ballots, MFMA) are fiber switch points.  Wave = 64 lanes.  Wave-level ops
 // must be reached by all 64 lanes of a wave in the same order (true of the
 // real hardware too).  MFMA fragment maps follow the gfx950 layout:
@@ -20,7 +20,6 @@
 //   v_mfma_f32_16x16x4_f32 : A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
 //                            D reg r -> row 4*(l>>4)+r, col l&15
 #pragma once
-#include <ucontext.h>
 
 #include <atomic>
 #include <cmath>
@@ -84,7 +83,7 @@ struct WaveX {           // per-wave exchange area (double buffered)
 };
 
 struct Fiber {
-  ucontext_t ctx;
+  void* sp;              // saved stack pointer while the fiber is not running (hipemu_switch)
   uint3_emu tid;
   int linear;            // linear thread id in block
   int state;             // 0 runnable, 1 at barrier, 2 done
@@ -93,7 +92,7 @@ struct Fiber {
 };
 
 struct Worker {
-  ucontext_t sched;
+  void* sched_sp;        // the scheduler's saved stack pointer while a fiber runs
   std::vector<Fiber> fibers;
   std::vector<WaveX> waves;
   Fiber* cur = nullptr;
@@ -105,7 +104,12 @@ struct Worker {
 extern thread_local Worker* tl_worker;
 
 inline Worker& W() { return *tl_worker; }
-inline void yield_to_sched() { Worker& w = W(); swapcontext(&w.cur->ctx, &w.sched); }
+}  // namespace hipemu
+// minimal x86-64 context switch (callee-saved registers + stack pointer): glibc's swapcontext
+// makes a sigprocmask system call per switch, which dominated the simulator's run time
+extern "C" void hipemu_switch(void** save_sp, void* const* load_sp);
+namespace hipemu {
+inline void yield_to_sched() { Worker& w = W(); hipemu_switch(&w.cur->sp, &w.sched_sp); }
 
 void launch(const std::function<void()>& body, dim3 grid, dim3 block);
 double now_ms();
