@@ -468,8 +468,8 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvParams* _
   auto load_b = [&](int i) {
     gb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, tid * 16 + i * 4096, (int)l_b, 0);
   };
-  auto advance_stream = [&]() {
-    l_b += (unsigned)STAGE_B_BYTES;
+  auto advance_b = [&]() { l_b += (unsigned)STAGE_B_BYTES; };
+  auto advance_a = [&]() {
     if (++l_cc == l_cpt) {
       l_cc = 0;
       if (!l_src2) {
@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvParams* _
   for (int j = 0; j < 2; ++j) load_a(j);
 #pragma unroll
   for (int i = 0; i < NB; ++i) load_b(i);
-  advance_stream();
+  advance_a(); advance_b();
   if (p.res_mode != 0) {
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.res, 0, (int)((unsigned)p.B * p.res_H * p.res_W * p.res_ldc * 4u), 0x00020000);
@@ -542,7 +542,7 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvParams* _
     for (int j = 0; j < 2; ++j) load_a(j);
 #pragma unroll
     for (int i = 0; i < NB; ++i) load_b(i);
-    advance_stream();
+    advance_a(); advance_b();
   }
   __syncthreads();
 
@@ -587,10 +587,14 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvParams* _
     if constexpr (next) store_a(nxt, 1);
     ODT_FENCE();
     ODT_MF(0, 1, 1); ODT_FENCE();
-    rdB(cur, 1, 2); ODT_FENCE();
+    rdB(cur, 1, 2);
+    // the A registers are free again: fetch the activations of slice c+2 right away (they come from
+    // HBM; the lead over their use in group 1 of the next slice is what covers the round trip)
+    if constexpr (pre) { load_a(0); load_a(1); advance_a(); }
+    ODT_FENCE();
     ODT_MF(0, 2, 1); ODT_FENCE();
     rdB(cur, 2, 2); ODT_FENCE();
-    // group 2: weights of slice c+1 -> LDS, then the global prefetch of slice c+2
+    // group 2: weights of slice c+1 -> LDS, then the weight prefetch of slice c+2 (L2 hits)
     ODT_MF(2, 0, 2); ODT_FENCE();
     if constexpr (next) { store_b(nxt, 0); store_b(nxt, 1); }
     ODT_FENCE();
@@ -602,7 +606,7 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvParams* _
     if constexpr (next) { store_b(nxt, 4); store_b(nxt, 5); }
     ODT_FENCE();
     ODT_MF(1, 1, 2); ODT_FENCE();
-    if constexpr (pre) { load_a(0); load_a(1); load_b(0); load_b(1); }
+    if constexpr (pre) { load_b(0); load_b(1); }
     ODT_FENCE();
     ODT_MF(0, 1, 2); ODT_FENCE();
     rdB(cur, 1, 3);
@@ -610,7 +614,7 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvParams* _
     ODT_FENCE();
     ODT_MF(0, 2, 2); ODT_FENCE();
     rdB(cur, 2, 3);
-    if constexpr (pre) { load_b(4); load_b(5); advance_stream(); }
+    if constexpr (pre) { load_b(4); load_b(5); advance_b(); }
     ODT_FENCE();
     __syncthreads();          // stage nxt is complete; nobody reads stage cur any more
     ODT_FENCE();
