@@ -85,7 +85,10 @@ __device__ __forceinline__ void split2(float a0, float a1, unsigned& hi, unsigne
   lo = ODT_CVT_PK_BF16(s0, s1);
 }
 
-template <int WM, int WN, int TN>
+// TRACE: tuning builds only (ODT_CONV_TRACE through odt_op_conv2d): wall-clock stamps per workgroup in
+// the slots of conv_igemm.hip (0 start, 6 first loads issued, 7 first stage stored, 1 main loop, 2 epilogue,
+// 3/4 first pass staged / stored, 5 end; 8/9 HW_ID / XCC_ID).  Compiled out of the production kernels.
+template <int WM, int WN, int TN, bool TRACE = false>
 __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __restrict__ pp) {
   using Cfg = SplitCfg<WM, WN, TN>;
   constexpr int SBM = Cfg::BM, SBN = Cfg::BN, AKG = Cfg::AKG, APL = Cfg::APL, BKG = Cfg::BKG, BPL = Cfg::BPL;
@@ -97,6 +100,18 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
+  auto stamp = [&](int i) {
+    if constexpr (TRACE) {
+      if (tid == 0) p.trace[(size_t)blockIdx.x * 16 + i] = wall_clock64();
+    }
+  };
+  stamp(0);
+  if constexpr (TRACE) {
+    if (tid == 0) {
+      p.trace[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+      p.trace[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+  }
   const int ntn = p.Cout / SBN;
   // XCD-aware tile order (see conv_igemm.hip): one contiguous run of tiles per XCD
   int wg = (int)blockIdx.x;
@@ -223,6 +238,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
 
   const int fr = lane & 31, fg = lane >> 5;
   load_slice();
+  stamp(6);
   if (p.res_mode != 0) {
     // residual of the same shape (bottleneck conv3) or the nearest-2x upsampled coarser level (FPN
     // lateral, res_mode 2): the accumulators START at the residual, read in the MFMA C layout (a
@@ -251,6 +267,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
   for (int c = 0; c < nslices; ++c) {
     store_slice();
     __syncthreads();
+    if constexpr (TRACE) { if (c == 0) { stamp(7); stamp(1); } }
     if (c + 1 < nslices) load_slice();
     {
       // Two k16 steps x TN 32-column groups.  Within a group the b0 (hi) products run first,
@@ -302,6 +319,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
     __syncthreads();
   }
 
+  stamp(2);
   // ---- epilogue (the fast path of conv_igemm.hip without a residual): stage the tile through
   // LDS in two passes of RP rows, bias + activation, whole 16-byte-per-lane row segments.
   constexpr int CS = SBN + 4;
@@ -333,6 +351,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
               Ct[((wm % WPP) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * CS + wn * TN * 32 + j * 32 + fr] = acc[i][j][r];
       }
       __syncthreads();
+      if (pass == 0) stamp(3);
 #pragma unroll
       for (int s2 = 0; s2 < NCH; ++s2) {
         const int rl = row0 + s2 * RSTEP;
@@ -362,12 +381,14 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
         }
         __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)ooff, 0, 0);
       }
+      if (pass == 0) stamp(4);
     }
   };
   if (p.relu == 1) run(std::integral_constant<int, 1>{});
   else if (p.relu == 2) run(std::integral_constant<int, 2>{});
   else if (p.relu == 3) run(std::integral_constant<int, 3>{});
   else run(std::integral_constant<int, 0>{});
+  stamp(5);
 }
 
 // ---- experimental second loop structure (ODT_CONV_SPLIT_PIPE=2, 128 x 256 tile only; not the default:
@@ -742,7 +763,7 @@ bool conv_split_supported(const ConvParams& p) {
                       (p.res_mode == 2 && 2 * p.res_H >= p.Ho && 2 * p.res_W >= p.Wo);
   const bool src2_ok = p.in2 == nullptr || (p.kh == 1 && p.kw == 1 && p.Cin2 % 32 == 0 && p.in2_ldc % 4 == 0);
   return conv_split_bn(p.Cout) != 0 && p.Cin % 32 == 0 && src2_ok && res_ok && p.out_ldc % 4 == 0 &&
-         p.in_ldc % 4 == 0 && wbytes < 2147483648.0 && p.trace == nullptr;
+         p.in_ldc % 4 == 0 && wbytes < 2147483648.0;
 }
 
 // ---- policy: which convs take the split kernel (launch_conv and the plan builder ask)
@@ -799,6 +820,10 @@ int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t st
   if (p.wt_split_bk == 16) {
     ODT_CHECK(bn == 256, "conv split: the 16-wide stage image belongs to the 128 x 256 tile");
     hipLaunchKernelGGL(conv_split2_kernel, dim3(grid), dim3(256), 0, stream, dev);
+  } else if (p.trace != nullptr) {        // tuning: the stamped instantiations
+    if (bn == 256) hipLaunchKernelGGL((conv_split_kernel<2, 2, 4, true>), dim3(grid), dim3(256), 0, stream, dev);
+    else if (bn == 128) hipLaunchKernelGGL((conv_split_kernel<4, 1, 4, true>), dim3(grid), dim3(256), 0, stream, dev);
+    else hipLaunchKernelGGL((conv_split_kernel<4, 1, 2, true>), dim3(grid), dim3(256), 0, stream, dev);
   } else if (bn == 256) hipLaunchKernelGGL((conv_split_kernel<2, 2, 4>), dim3(grid), dim3(256), 0, stream, dev);
   else if (bn == 128) hipLaunchKernelGGL((conv_split_kernel<4, 1, 4>), dim3(grid), dim3(256), 0, stream, dev);
   else hipLaunchKernelGGL((conv_split_kernel<4, 1, 2>), dim3(grid), dim3(256), 0, stream, dev);
