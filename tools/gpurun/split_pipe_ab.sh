@@ -9,3 +9,9 @@ for v in "ODT_CONV_SPLIT_PIPE=0" "ODT_CONV_SPLIT_PIPE=2" "ODT_CONV_SPLIT_PIPE=0"
 done | tee gpurun_out/split_pipe_ab.txt
 BATCH=8 bash tools/gpurun/ab_layers_env.sh "ODT_CONV_SPLIT_PIPE=0" "ODT_CONV_SPLIT_PIPE=2" > gpurun_out/split_pipe_layers_b8.txt 2>&1
 head -30 gpurun_out/split_pipe_layers_b8.txt
+# where does a short-K tile spend its time?  in-kernel stamps of the split kernel (TRACE instantiation)
+# next to the exact-f32 kernel on the res4 shapes
+for v in 1 0; do
+  echo "--- ODT_CONV_SPLIT=$v"; ODT_CONV_SPLIT=$v timeout 120 python tools/conv_trace.py conv3 conv3nores conv2 conv1 2>&1 | grep -E "^==|conv trace"
+done > gpurun_out/split_trace.txt 2>&1
+head -40 gpurun_out/split_trace.txt
