@@ -672,6 +672,7 @@ int build_plan(odt_model* m) {
   RoiAlignParams& rf = m->roi_final;
   rf.boxes = dp.out_boxes; rf.per_image = per_im; rf.count = dp.out_valid; rf.R_cap = B * per_im;
   rf.out_nhwc = nullptr; rf.out_nchw = m->final_feat; rf.pooled = m->final_pooled;
+  rf.pack_rows = 1;                      // fpn_box_feat is [M,...] over the valid detections of all images
   { Op op; op.kind = OP_ROI_FINAL; m->ops.push_back(op); }
 
   // ---- Mask R-CNN head on the final boxes (--add_mask; models.py:932-962, 1173-1199): 14x14

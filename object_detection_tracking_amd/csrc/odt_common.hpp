@@ -199,6 +199,8 @@ struct RoiAlignParams {
   float* out_nchw;       // [R_cap,C,7,7] or nullptr   (fpn_box_feat)
   float* pooled;         // [R_cap,C] or nullptr
   int out_size;          // 0 / 7: box head + features; 14: mask head (models.py:935-936)
+  int pack_rows;         // with count: 1 = output rows packed over the valid rows of all images (final features, masks);
+                         // 0 = row r stays row r, rows past count[b] untouched (box head: its consumers index b * per_image + j)
 };
 int launch_roi_align(const RoiAlignParams& p, hipStream_t stream);
 

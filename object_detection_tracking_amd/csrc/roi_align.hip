@@ -33,9 +33,11 @@ __global__ void __launch_bounds__(256) roi_align_kernel(RoiAlignParams p, int B)
     const int j = r - b * p.per_image;
     if (p.count != nullptr) {
       if (j >= p.count[b]) return;
-      int base = 0;
-      for (int q = 0; q < b; ++q) base += p.count[q];
-      out_row = base + j;          // outputs are packed over valid rows (reference [M,...])
+      if (p.pack_rows) {           // outputs packed over the valid rows (reference [M,...]: fpn_box_feat, masks)
+        int base = 0;
+        for (int q = 0; q < b; ++q) base += p.count[q];
+        out_row = base + j;
+      }                            // else row r stays row r: the box head's consumers index b * per_image + j
     }
   }
   (void)B;

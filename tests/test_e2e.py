@@ -69,8 +69,8 @@ def test_forward_single_small(backend):
   assert miss == 0 and extra == 0
 
 
-def _run_multi(lib, cfg, B, H, W, tol=2e-5):
-  w = weights_for(cfg)
+def _run_multi(lib, cfg, B, H, W, tol=2e-5, w=None, info=None):
+  w = weights_for(cfg) if w is None else w
   fr = synthetic_frames(B, H, W)
   ref = OracleModel(cfg, w).forward_multi(fr)
   m = models.get_model(cfg, 0, weights=w, lib=lib, is_multi=True)
@@ -82,6 +82,8 @@ def _run_multi(lib, cfg, B, H, W, tol=2e-5):
     assert boxes.shape == (B, cfg.result_per_im, 4)
     assert np.array_equal(valid, ref["final_valid_indices"])
     assert feats.shape[0] == valid.sum()
+    if info is not None:
+      info["nproposals"] = e.tap("nproposals").reshape(-1).copy()
     box_tol = 1e-3 * max(H, W) / 128
     tot = 0
     for b in range(B):
@@ -102,6 +104,21 @@ def test_forward_multi_small(backend):
   name, lib = backend
   cfg = small_config(resnet_num_block=[1, 1, 1, 1], im_batch_size=2, rpn_test_post_nms_topk=48)
   assert _run_multi(lib, cfg, 2, 96, 128) == 0
+
+
+def test_forward_multi_fewer_proposals_than_k(backend):
+  """Trained RPNs score most anchors negative, so an image keeps fewer than K proposals (the
+  zero-padded NMS slots outrank negative logits and are dropped by the area > 0 filter,
+  models.py:2487-2520).  The box head's rows must stay at b * K + j for the images behind such an
+  image (a packed ROIAlign output shifted them: ADVICE round 1)."""
+  name, lib = backend
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1], im_batch_size=2, rpn_test_post_nms_topk=48)
+  w = dict(weights_for(cfg))
+  w["rpn/class/b"] = (w["rpn/class/b"] - 3.0).astype(np.float32)
+  info = {}
+  assert _run_multi(lib, cfg, 2, 96, 128, w=w, info=info) == 0
+  n = info["nproposals"]
+  assert 0 < n[0] < 48 and 0 < n[1], n     # the case under test: a short first image, a live second one
 
 
 @pytest.mark.gpu
