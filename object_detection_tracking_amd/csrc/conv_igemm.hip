@@ -649,8 +649,8 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
   if (split && q.wt_split == nullptr) {
     const int Ksp = q.kh * q.kw * q.Cin + (q.in2 != nullptr ? q.Cin2 : 0);
     ODT_HIP(hipMalloc(&tmp_img, conv_split_weight_bytes(q.Cout, Ksp)));
-    q.wt_split_bk = conv_split_bk(q);
-    if (conv_make_split_weights(q.wt, q.Cout, Ksp, q.wt_split_bk, tmp_img, stream)) { (void)hipFree(tmp_img); return 1; }
+    conv_split_choose(q);
+    if (conv_make_split_weights(q, tmp_img, stream)) { (void)hipFree(tmp_img); return 1; }
     q.wt_split = tmp_img; modified = true;
   }
   // stand-alone calls (tests, tuning) and debug overrides: stage the record in a temporary

@@ -730,6 +730,391 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvParams* _
   else run(std::integral_constant<int, 0>{});
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// conv_split3_kernel: the round-2 loop structure.  Same arithmetic (bf16x3, six piece products), but
+//   * 8 waves / 512 threads, ONE workgroup per CU, 256-row tiles: a weight stage is fetched once per 256
+//     output rows (half the L2 -> LDS weight traffic of the 128-row tiles);
+//   * BK = 16 per LDS stage, a ring of THREE stages, ONE barrier per stage;
+//   * weights: the pre-split image goes global -> LDS by LDS-DMA (buffer_load ... lds), two stages ahead --
+//     no prefetch registers, no ds_write; the pipeline never drains (counted vmcnt, raw s_barrier);
+//   * activations: f32 -> registers (one stage ahead) -> split -> LDS behind the MFMAs of the first
+//     column group; the last column group's operands are read before the barrier and its MFMAs cover
+//     the first fragment reads of the next stage;
+//   * K order = (16-channel slice, kh, kw): the nine taps of a channel slice are consecutive stages, so
+//     a 3x3 conv re-reads its activation lines from L1 / L2 instead of the fabric (tap-major order
+//     streamed the whole tile's input through L2 once per tap);
+//   * residual (same shape / nearest-2x) added in the epilogue from 16-byte row chunks that are fetched
+//     while the C tile is staged through LDS (the MFMA-layout accumulator preload of the one-stage
+//     kernel cost 128 four-byte loads per lane: 9 us of a 63 us res4 conv3 tile).
+// Tile configurations <WM, WN, TN> (WM x WN = 8 waves, wave tile 64 x 32 TN):
+//   <4,2,4> 256 x 256 (Cout % 256 == 0)   <4,2,2> 256 x 128 (Cout % 128 == 0)   <4,2,1> 256 x 64 (Cout % 64 == 0)
+#ifdef ODT_HIP_EMULATOR
+#define ODT_WAIT_VM_LGKM0(n) do { } while (0)
+#define ODT_BARRIER_LDS() __syncthreads()
+#define ODT_LDS_PTR(p) ((void*)(p))
+#else
+// counted wait: at most n vector-memory operations (A fetches / DMA of younger stages) stay in flight; all LDS done
+#define ODT_WAIT_VM_LGKM0(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(n) : "memory")
+// workgroup barrier that orders LDS traffic only (__syncthreads() would also drain the global stores in flight)
+#define ODT_BARRIER_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+#define ODT_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#endif
+
+template <int WM, int WN, int TN>
+struct Split3Cfg {
+  static constexpr int BM = 64 * WM, BN = 32 * TN * WN;
+  static constexpr int AKG = BM * 16 + 64, APL = 2 * AKG;   // A piece plane: [k-group 2][row][8 bf16], 64-B pad per k-group
+  static constexpr int BKG = BN * 16, BPL = 2 * BKG;        // B: the linear image the DMA writes
+  static constexpr int STAGE_B = 3 * BPL;                   // bytes of weight image per stage
+  static constexpr int STAGE = 3 * APL + STAGE_B;
+  static constexpr int LDS = 3 * STAGE;
+  static constexpr int NCHUNK = STAGE_B / 1024;             // 1-KB DMA pieces (one wave instruction each) per stage
+  static constexpr int RA = BM / 128;                       // A rows (16-byte loads) per thread and stage
+  static_assert(LDS <= 160 * 1024, "LDS ring");
+};
+
+template <int WM, int WN, int TN, bool TRACE = false>
+__global__ void __launch_bounds__(512, 2) conv_split3_kernel(const ConvParams* __restrict__ pp) {
+  using G = Split3Cfg<WM, WN, TN>;
+  constexpr int BM = G::BM, BN = G::BN, AKG = G::AKG, APL = G::APL, BKG = G::BKG, BPL = G::BPL;
+  constexpr int STAGE = G::STAGE, STAGE_B = G::STAGE_B, NCHUNK = G::NCHUNK, RA = G::RA;
+  static_assert(WM * WN == 8, "8 waves");
+  const ConvParams p = *pp;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  auto stamp = [&](int i) {
+    if constexpr (TRACE) {
+      if (tid == 0) p.trace[(size_t)blockIdx.x * 16 + i] = wall_clock64();
+    }
+  };
+  stamp(0);
+  if constexpr (TRACE) {
+    if (tid == 0) {
+      p.trace[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+      p.trace[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+  }
+  const int ntn = p.Cout / BN;
+  int wg = (int)blockIdx.x;
+  {
+    const int nwg = (int)gridDim.x, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  const int mt = wg / ntn, nt = wg - mt * ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int HoWo = p.Ho * p.Wo;
+  const int M = p.B * HoWo;
+  const int ntaps = p.kh * p.kw;
+  const int cpt = p.Cin >> 4;                                // 16-channel slices of the first source
+  const int cpt2 = p.in2 != nullptr ? p.Cin2 >> 4 : 0;       // ... of the K-concatenated second source (1x1 only)
+  const int nsteps1 = ntaps * cpt, nsteps = nsteps1 + cpt2;
+
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.in, 0, (int)((unsigned)p.B * p.in_Ha * p.in_Wa * p.in_ldc * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.in2 != nullptr ? p.in2 : p.in), 0,
+      (int)(p.in2 != nullptr ? (unsigned)p.B * p.in2_Ha * p.in2_Wa * p.in2_ldc * 4u : 0u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.wt_split, 0, (int)((unsigned)ntn * nsteps * (unsigned)STAGE_B), 0x00020000);
+
+  // ---- weights: wave w, instruction i copies the 1-KB piece i * 8 + w of the stage image
+  unsigned l_b = (unsigned)nt * (unsigned)nsteps * (unsigned)STAGE_B;
+  auto dma_b = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < (NCHUNK + 7) / 8; ++i) {
+      if ((i + 1) * 8 <= NCHUNK || i * 8 + wave < NCHUNK)    // wave-uniform
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, ODT_LDS_PTR(lds + st + 3 * APL + (i * 8 + wave) * 1024), 16,
+                                                 lane * 16 + (i * 8 + wave) * 1024, (int)l_b, 0, 0);
+    }
+    l_b += (unsigned)STAGE_B;
+  };
+  // this wave's DMA instructions per stage: NW or NW - 1 (the counted wait in front of a barrier needs the exact
+  // number).  wait_stage: this wave's share of the stage that the barrier publishes has landed -- its DMA (issued
+  // one stage earlier) and its LDS stores; YOUNGER: one stage's worth of A fetches + DMA was issued behind that
+  // DMA and may stay in flight.
+  constexpr int NW = (NCHUNK + 7) / 8;
+  const bool dma_full = (NCHUNK % 8) == 0 || wave < (NCHUNK % 8);
+  auto wait_stage = [&](auto YOUNGER) {
+    if constexpr (decltype(YOUNGER)::value) {
+      if (dma_full) ODT_WAIT_VM_LGKM0(RA + NW); else ODT_WAIT_VM_LGKM0(RA + NW - 1);
+    } else {
+      ODT_WAIT_VM_LGKM0(0);
+    }
+  };
+  dma_b(0);
+  if (nsteps > 1) dma_b(STAGE);
+
+  // ---- activations: thread -> (row (t >> 2) + 128 j, 16-byte column t & 3): four lanes cover the 64 contiguous
+  // bytes (16 channels) of a row's stage.  Per row: the byte offset of the tap-(0,0) input pixel and a bit per tap
+  // (inside the image and m < M); a stage's offset is base + tap offset, or out of range (the load returns zeros).
+  const int a_c = tid & 3, a_r = tid >> 2;
+  const unsigned pix_bytes = (unsigned)p.in_ldc * 4u;
+  int a_base[RA];
+  unsigned a_mask[RA];
+  const bool dense_in = ntaps == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 &&
+                        p.H == p.in_Ha && p.W == p.in_Wa && p.Ho == p.H && p.Wo == p.W;
+#pragma unroll
+  for (int j = 0; j < RA; ++j) {
+    const int m = m0 + a_r + 128 * j;
+    const bool ok = m < M;
+    if (dense_in) {
+      a_base[j] = (int)((unsigned)m * pix_bytes + a_c * 16u);
+      a_mask[j] = ok ? 1u : 0u;
+    } else {
+      const int mm = ok ? m : 0;
+      const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), r = mm - n * HoWo;
+      const int ho = sfast_div(r, p.div_wo_mul, p.div_wo_sh), wo = r - ho * p.Wo;
+      const int hi0 = ho * p.stride - p.pad_t, wi0 = wo * p.stride - p.pad_l;
+      a_base[j] = (int)(((unsigned)n * p.in_Ha * p.in_Wa + (unsigned)(hi0 * p.in_Wa + wi0)) * pix_bytes + a_c * 16u);
+      unsigned mk = 0;
+      for (int t = 0, khh = 0, kww = 0; t < ntaps; ++t) {
+        const int hi = hi0 + khh * p.dil, wi = wi0 + kww * p.dil;
+        if (ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) mk |= 1u << t;
+        if (++kww == p.kw) { kww = 0; ++khh; }
+      }
+      a_mask[j] = mk;
+    }
+  }
+  // load stream position: (16-channel slice, tap) with the tap innermost; then the second source's slices
+  int l_cs = 0, l_tap = 0, l_kh = 0, l_kw = 0;
+  bool l_src2 = false;
+  unsigned a_row[RA];
+  auto set_rows = [&]() {
+    const unsigned tapoff = (unsigned)(l_kh * p.dil * p.in_Wa + l_kw * p.dil) * pix_bytes;
+#pragma unroll
+    for (int j = 0; j < RA; ++j) a_row[j] = ((a_mask[j] >> l_tap) & 1u) ? (unsigned)a_base[j] + tapoff : kOOB;
+  };
+  auto set_src2 = [&]() {
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+      const int m = m0 + a_r + 128 * j;
+      const bool ok = m < M;
+      const int mm = ok ? m : 0;
+      const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), r = mm - n * HoWo;
+      const int ho = sfast_div(r, p.div_wo_mul, p.div_wo_sh), wo = r - ho * p.Wo;
+      const unsigned pix = ((unsigned)n * p.in2_Ha + (unsigned)(ho * p.in2_stride)) * p.in2_Wa + (unsigned)(wo * p.in2_stride);
+      a_row[j] = ok ? pix * (unsigned)p.in2_ldc * 4u + a_c * 16u : kOOB;
+    }
+  };
+  set_rows();
+  f32x4 ga[RA];
+  auto load_a = [&]() {
+#pragma unroll
+    for (int j = 0; j < RA; ++j)
+      ga[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(l_src2 ? rs_in2 : rs_in, (int)a_row[j], l_cs * 64, 0);
+    // advance
+    if (l_src2) {
+      ++l_cs;
+    } else if (ntaps == 1) {
+      if (++l_cs == cpt && cpt2 > 0) { l_cs = 0; l_src2 = true; set_src2(); }
+    } else {
+      ++l_tap;
+      if (++l_kw == p.kw) { l_kw = 0; ++l_kh; }
+      if (l_tap == ntaps) { l_tap = 0; l_kh = 0; l_kw = 0; ++l_cs; }
+      set_rows();            // (harmless past the last stage: never loaded)
+    }
+  };
+  auto store_a = [&](int st) {
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+      unsigned h0, m0_, l0, h1, m1, l1;
+      split2(ga[j][0], ga[j][1], h0, m0_, l0);
+      split2(ga[j][2], ga[j][3], h1, m1, l1);
+      unsigned char* d = lds + st + (a_c >> 1) * AKG + (a_r + 128 * j) * 16 + (a_c & 1) * 8;
+      *reinterpret_cast<u32x2*>(d + 0 * APL) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(d + 1 * APL) = u32x2{m0_, m1};
+      *reinterpret_cast<u32x2*>(d + 2 * APL) = u32x2{l0, l1};
+    }
+  };
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fr = lane & 31, fg = lane >> 5;
+  // ---- prologue: stage 0 complete, stage 1's weights in flight, A of stage 1 in registers
+  load_a();
+  stamp(6);
+  store_a(0);
+  if (nsteps > 1) load_a();
+  if (nsteps > 1) wait_stage(std::true_type{}); else wait_stage(std::false_type{});
+  __builtin_amdgcn_s_barrier();
+  stamp(7); stamp(1);
+
+  bf16x8 fa[3][2], fb[3];
+  const int a_rd = fg * AKG + (wm * 64 + fr) * 16;
+  const int b_rd = 3 * APL + fg * BKG + (wn * TN * 32 + fr) * 16;
+  auto rdA = [&](int st, int q) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) fa[q][t] = *reinterpret_cast<const bf16x8*>(lds + st + q * APL + a_rd + t * 512);
+  };
+  auto rdB = [&](int st, int q, int j) {
+    fb[q] = *reinterpret_cast<const bf16x8*>(lds + st + q * BPL + b_rd + j * 512);
+  };
+#pragma unroll
+  for (int q = 0; q < 3; ++q) rdA(0, q);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) rdB(0, q, 0);
+
+#define ODT_MF(qa, qb, j) { acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][0], fb[qb], acc[0][j], 0, 0, 0); \
+                            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][1], fb[qb], acc[1][j], 0, 0, 0); }
+#define ODT_FENCE() __builtin_amdgcn_sched_barrier(0)
+  int st_cur = 0, st_nxt = STAGE, st_nn = 2 * STAGE;
+  // One stage.  NEXT: stage c+1 exists (its A: registers -> LDS; read its first fragments behind the last column
+  // group); PRE: stage c+2 exists (fetch its A, start its weight DMA).  The K loop is peeled so that no MFMA sits
+  // in a conditional arm.
+  auto step = [&](auto NEXT, auto PRE) {
+    constexpr bool next = decltype(NEXT)::value, pre = decltype(PRE)::value;
+    ODT_FENCE();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const bool last = j == TN - 1, first = j == 0;
+      // where the side work of a stage rides: A store behind the first product of the first group, the A fetch
+      // behind its fourth, the DMA issue behind the fifth product of the second group (TN = 1: all in the one
+      // group, in front of the barrier)
+      if (last) {
+        if (TN == 1) {
+          // single column group: the side work precedes the barrier
+          if constexpr (next) store_a(st_nxt);
+          if constexpr (pre) { load_a(); dma_b(st_nn); }
+        }
+        // stage nxt must be complete before its first fragment reads below: own LDS stores, own DMA of stage c+1
+        // (issued one stage ago; this stage's A fetch and DMA may stay in flight), then the barrier
+        wait_stage(std::integral_constant<bool, pre>{});
+        __builtin_amdgcn_s_barrier();
+        ODT_FENCE();
+      }
+      ODT_MF(2, 0, j); ODT_FENCE();
+      if (last) { if constexpr (next) rdA(st_nxt, 2); }
+      else if (first) { if constexpr (next) store_a(st_nxt); }
+      ODT_FENCE();
+      ODT_MF(1, 0, j); ODT_MF(0, 0, j); ODT_FENCE();
+      if (!last) rdB(st_cur, 0, j + 1); else if constexpr (next) rdB(st_nxt, 0, 0);
+      ODT_FENCE();
+      ODT_MF(1, 1, j); ODT_FENCE();
+      if (last) { if constexpr (next) rdA(st_nxt, 1); }
+      else if (first) { if constexpr (pre) load_a(); }
+      ODT_FENCE();
+      ODT_MF(0, 1, j); ODT_FENCE();
+      if (!last) rdB(st_cur, 1, j + 1); else if constexpr (next) rdB(st_nxt, 1, 0);
+      if (!last && j == (TN > 2 ? 1 : 0)) { if constexpr (pre) dma_b(st_nn); }
+      ODT_FENCE();
+      ODT_MF(0, 2, j); ODT_FENCE();
+      if (!last) rdB(st_cur, 2, j + 1); else if constexpr (next) { rdA(st_nxt, 0); rdB(st_nxt, 2, 0); }
+      ODT_FENCE();
+    }
+    const int t = st_cur; st_cur = st_nxt; st_nxt = st_nn; st_nn = t;
+  };
+  {
+    int c = 0;
+    for (; c + 2 < nsteps; ++c) step(std::true_type{}, std::true_type{});
+    if (c + 1 < nsteps) { step(std::true_type{}, std::false_type{}); ++c; }
+    step(std::false_type{}, std::false_type{});
+  }
+#undef ODT_MF
+#undef ODT_FENCE
+  stamp(2);
+
+  // ---- epilogue: the C tile goes through LDS in passes of RP rows; per 16-byte row chunk: bias (+ residual)
+  // + activation, 16-byte stores (a wave writes whole row segments).  The residual chunks of a pass are fetched
+  // before the pass is staged, so their latency hides behind the LDS round trip.
+  constexpr int CS = BN + 4;
+  constexpr int FIT = G::LDS / (CS * 4);                    // rows of the C tile the ring's LDS holds
+  constexpr int RP = FIT >= BM ? BM : (FIT >= BM / 2 ? BM / 2 : (FIT >= BM / 4 ? BM / 4 : 64));   // rows per pass
+  constexpr int NPASS = BM / RP, WPP = RP / 64;
+  constexpr int C4 = BN / 4, RSTEP = 512 / C4, NCH = RP / RSTEP;
+  static_assert(RP >= 64 && BM % RP == 0 && RP % RSTEP == 0, "epilogue passes");
+  float* Ct = reinterpret_cast<float*>(lds);
+  const bool dense_io = p.out_oy == 0 && p.out_ox == 0 && p.out_H == p.Ho && p.out_W == p.Wo &&
+                        (p.res_mode == 0 || (p.res_mode == 1 && p.res_H == p.Ho && p.res_W == p.Wo));
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.out, 0, (int)((unsigned)p.B * p.out_H * p.out_W * p.out_ldc * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_bias =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (int)((unsigned)p.Cout * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.res_mode != 0 ? p.res : p.bias), 0,
+      (int)(p.res_mode != 0 ? (unsigned)p.B * p.res_H * p.res_W * p.res_ldc * 4u : 0u), 0x00020000);
+  const int c4 = tid % C4, row0 = tid / C4;
+  const int col = n0 + c4 * 4;
+  const f32x4 bias4 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, col * 4, 0, 0);
+  // (no barrier needed here: the last stage's barrier sits behind every fragment read of the ring)
+  auto run = [&](auto act_c, auto res_c) {
+    constexpr int ACT = decltype(act_c)::value;
+    constexpr bool RES = decltype(res_c)::value;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      unsigned ooff[NCH];
+      f32x4 rres[RES ? NCH : 1];
+#pragma unroll
+      for (int s2 = 0; s2 < NCH; ++s2) {
+        const int m = m0 + pass * RP + row0 + s2 * RSTEP;
+        const bool ok = m < M;
+        unsigned opix = (unsigned)m, rpix = (unsigned)m;
+        if (!dense_io) {
+          const int mm = ok ? m : 0;
+          const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), rr = mm - n * HoWo;
+          const int ho = sfast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
+          opix = ((unsigned)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
+          rpix = p.res_mode == 2 ? ((unsigned)n * p.res_H + (unsigned)(ho >> 1)) * p.res_W + (unsigned)(wo >> 1)
+                                 : ((unsigned)n * p.res_H + (unsigned)ho) * p.res_W + (unsigned)wo;
+        }
+        ooff[s2] = ok ? (opix * p.out_ldc + col) * 4u : kOOB;
+        if constexpr (RES)
+          rres[s2] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_res, ok ? (int)((rpix * p.res_ldc + col) * 4u) : (int)kOOB, 0, 0);
+      }
+      if (pass > 0) ODT_BARRIER_LDS();        // the previous pass has been read
+      if (wm / WPP == pass) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              Ct[((wm % WPP) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * CS + wn * TN * 32 + j * 32 + fr] = acc[i][j][r];
+      }
+      ODT_BARRIER_LDS();
+      if (pass == 0) stamp(3);
+#pragma unroll
+      for (int s2 = 0; s2 < NCH; ++s2) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[(row0 + s2 * RSTEP) * CS + c4 * 4]);
+        v += bias4;
+        if constexpr (RES) v += rres[s2];
+        if (ACT == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (ACT == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f / (1.0f + expf(-v[e])));
+        } else if (ACT == 3) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
+        }
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)ooff[s2], 0, 0);
+      }
+      if (pass == 0) stamp(4);
+    }
+  };
+  if (p.res_mode != 0) {
+    if (p.relu == 1) run(std::integral_constant<int, 1>{}, std::true_type{});
+    else if (p.relu == 0) run(std::integral_constant<int, 0>{}, std::true_type{});
+    else if (p.relu == 2) run(std::integral_constant<int, 2>{}, std::true_type{});
+    else run(std::integral_constant<int, 3>{}, std::true_type{});
+  } else {
+    if (p.relu == 1) run(std::integral_constant<int, 1>{}, std::false_type{});
+    else if (p.relu == 0) run(std::integral_constant<int, 0>{}, std::false_type{});
+    else if (p.relu == 2) run(std::integral_constant<int, 2>{}, std::false_type{});
+    else run(std::integral_constant<int, 3>{}, std::false_type{});
+  }
+  stamp(5);
+}
+
 // f32 weights [Cout][K] -> per-stage image of bf16 pieces (one thread per 8 consecutive k of a row)
 __global__ void split_weights_kernel(const float* __restrict__ wt, int Cout, int K, int SBN, int bk, unsigned short* __restrict__ img) {
   const int nsl = K / bk, kgs = bk >> 3;     // stages along K, k-groups of 8 per stage
@@ -743,6 +1128,31 @@ __global__ void split_weights_kernel(const float* __restrict__ wt, int Cout, int
     split2(wt[(size_t)n * K + k8 * 8 + e], wt[(size_t)n * K + k8 * 8 + e + 1], piece[0], piece[1], piece[2]);
     for (int q = 0; q < 3; ++q) {
       const size_t at = ((((size_t)(tn * nsl + sl) * 3 + q) * kgs + kg) * SBN + nn) * 8 + e;
+      img[at] = (unsigned short)(piece[q] & 0xffffu);
+      img[at + 1] = (unsigned short)(piece[q] >> 16);
+    }
+  }
+}
+
+// conv_split3_kernel's image: [n-tile][stage][piece][k-group 2][BN n][8 k], stage order = (16-channel slice, tap)
+// for the first source, then the second source's slices; wt is [Cout][tap][Cin] (+ [Cin2] behind it)
+__global__ void split_weights3_kernel(const float* __restrict__ wt, int Cout, int K, int SBN, int ntaps, int Cin,
+                                      unsigned short* __restrict__ img) {
+  const int nst = K >> 4, nst1 = ntaps * (Cin >> 4);
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;       // (n, stage, k-group)
+  const long total = (long)Cout * nst * 2;
+  if (idx >= total) return;
+  const int n = (int)(idx / (nst * 2)), rem = (int)(idx - (long)n * (nst * 2)), st = rem >> 1, kg = rem & 1;
+  int k0;
+  if (st < nst1) { const int cs = st / ntaps, tap = st - cs * ntaps; k0 = tap * Cin + cs * 16; }
+  else k0 = ntaps * Cin + (st - nst1) * 16;
+  k0 += kg * 8;
+  const int tn = n / SBN, nn = n - tn * SBN;
+  for (int e = 0; e < 8; e += 2) {
+    unsigned piece[3];
+    split2(wt[(size_t)n * K + k0 + e], wt[(size_t)n * K + k0 + e + 1], piece[0], piece[1], piece[2]);
+    for (int q = 0; q < 3; ++q) {
+      const size_t at = ((((size_t)(tn * nst + st) * 3 + q) * 2 + kg) * SBN + nn) * 8 + e;
       img[at] = (unsigned short)(piece[q] & 0xffffu);
       img[at + 1] = (unsigned short)(piece[q] >> 16);
     }
@@ -795,29 +1205,81 @@ bool conv_split_wanted(const ConvParams& p) {
   return ((M + bm - 1) / bm) * (p.Cout / bn) >= min_tiles;
 }
 
-// K extent of one LDS stage of the kernel that will run this conv: 32, or 16 for the experimental
-// two-stage loop (ODT_CONV_SPLIT_PIPE=2, 128 x 256 tile only)
-int conv_split_bk(const ConvParams& p) {
+// ---- which kernel family takes a conv that conv_split_wanted() accepted
+// ODT_CONV_SPLIT_PIPE (tuning / A-B knob): 1 = one-stage BK = 32 kernel everywhere, 2 = two-stage 128 x 256 kernel
+// where it exists, 3 (default) = conv_split3_kernel where its tiles fill the chip.
+static int split_pipe_mode() {
   const char* e = getenv("ODT_CONV_SPLIT_PIPE");
-  return (e != nullptr && atoi(e) == 2 && conv_split_bn(p.Cout) == 256) ? 16 : 32;
+  return e != nullptr ? atoi(e) : 3;
 }
 
-int conv_make_split_weights(const float* wt_dev, int Cout, int K, int bk, void* img_dev, hipStream_t stream) {
-  const int bn = conv_split_bn(Cout);
-  ODT_CHECK(bn != 0 && K % 32 == 0 && (bk == 16 || bk == 32),
-            "conv_make_split_weights: Cout % 64 == 0, K % 32 == 0 and a 16- or 32-wide stage required");
-  const long total = (long)Cout * (K >> 3);
-  hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, wt_dev, Cout, K,
-                     bn, bk, (unsigned short*)img_dev);
+void conv_split_choose(ConvParams& p) {
+  const int bn = conv_split_bn(p.Cout), mode = split_pipe_mode();
+  const long M = (long)p.B * p.Ho * p.Wo;
+  p.wt_split_kind = 1; p.wt_split_bm = conv_split_bm(p.Cout);
+  const int K = p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0);
+  // (64-wide layers stay on the one-stage 256 x 64 tile: a 64 x 32 wave tile reads too many fragments per MFMA --
+  // same-box A/B at b=8: res2 conv2 132 vs 118 TF, conv0 136 vs 112; ODT_CONV_SPLIT3_BM forces split3 anyway)
+  if (mode >= 3 && p.kh * p.kw <= 32 && K >= 32 && (bn >= 128 || getenv("ODT_CONV_SPLIT3_BM") != nullptr)) {
+    // 256-row tiles when they give every CU work for most of a round; 128-row tiles (N >= 128) below that
+    const char* e = getenv("ODT_CONV_SPLIT3_MINTILES");
+    const long min_tiles = e != nullptr ? atol(e) : 200L;
+    const long t256 = ((M + 255) / 256) * (p.Cout / bn), t128 = ((M + 127) / 128) * (p.Cout / bn);
+    if (const char* eb = getenv("ODT_CONV_SPLIT3_BM")) {     // test / tuning knob: force the tile height
+      const int fb = atoi(eb);
+      if (fb == 256 || (fb == 128 && bn >= 128)) { p.wt_split_kind = 3; p.wt_split_bm = fb; return; }
+    }
+    if (t256 >= min_tiles) { p.wt_split_kind = 3; p.wt_split_bm = 256; return; }
+    if (bn >= 128 && t128 >= min_tiles) { p.wt_split_kind = 3; p.wt_split_bm = 128; return; }
+  }
+  if (mode >= 2 && bn == 256) { p.wt_split_kind = 2; p.wt_split_bm = 128; }
+}
+
+int conv_make_split_weights(const ConvParams& p, void* img_dev, hipStream_t stream) {
+  const int bn = conv_split_bn(p.Cout);
+  const int K = p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0);
+  ODT_CHECK(bn != 0 && K % 32 == 0 && p.wt_split_kind >= 1 && p.wt_split_kind <= 3,
+            "conv_make_split_weights: Cout % 64 == 0, K % 32 == 0 and a chosen kernel family required");
+  if (p.wt_split_kind == 3) {
+    const long total = (long)p.Cout * (K >> 4) * 2;
+    hipLaunchKernelGGL(split_weights3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p.wt, p.Cout, K,
+                       bn, p.kh * p.kw, p.Cin, (unsigned short*)img_dev);
+  } else {
+    const long total = (long)p.Cout * (K >> 3);
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p.wt, p.Cout, K,
+                       bn, p.wt_split_kind == 2 ? 16 : 32, (unsigned short*)img_dev);
+  }
   ODT_HIP(hipGetLastError());
   return 0;
 }
 
+template <int WM, int WN, int TN>
+static void launch_split3(const ConvParams& p, const ConvParams* dev, unsigned grid, hipStream_t stream) {
+  if (p.trace != nullptr) hipLaunchKernelGGL((conv_split3_kernel<WM, WN, TN, true>), dim3(grid), dim3(512), 0, stream, dev);
+  else hipLaunchKernelGGL((conv_split3_kernel<WM, WN, TN, false>), dim3(grid), dim3(512), 0, stream, dev);
+}
+
 int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t stream) {
   const long M = (long)p.B * p.Ho * p.Wo;
-  const int bn = conv_split_bn(p.Cout), bm = conv_split_bm(p.Cout);
+  const int bn = conv_split_bn(p.Cout);
+  if (p.wt_split_kind == 3) {
+    const int bm = p.wt_split_bm;
+    ODT_CHECK((bm == 256 || (bm == 128 && bn >= 128)) && p.Cin % 16 == 0 && p.kh * p.kw <= 32, "conv split3: unsupported tile / shape");
+    const unsigned grid = (unsigned)(((M + bm - 1) / bm) * (p.Cout / bn));
+    if (bm == 256) {
+      if (bn == 256) launch_split3<4, 2, 4>(p, dev, grid, stream);
+      else if (bn == 128) launch_split3<4, 2, 2>(p, dev, grid, stream);
+      else launch_split3<4, 2, 1>(p, dev, grid, stream);
+    } else {
+      if (bn == 256) launch_split3<2, 4, 2>(p, dev, grid, stream);
+      else launch_split3<2, 4, 1>(p, dev, grid, stream);
+    }
+    ODT_HIP(hipGetLastError());
+    return 0;
+  }
+  const int bm = conv_split_bm(p.Cout);
   const unsigned grid = (unsigned)(((M + bm - 1) / bm) * (p.Cout / bn));
-  if (p.wt_split_bk == 16) {
+  if (p.wt_split_kind == 2) {
     ODT_CHECK(bn == 256, "conv split: the 16-wide stage image belongs to the 128 x 256 tile");
     hipLaunchKernelGGL(conv_split2_kernel, dim3(grid), dim3(256), 0, stream, dev);
   } else if (p.trace != nullptr) {        // tuning: the stamped instantiations

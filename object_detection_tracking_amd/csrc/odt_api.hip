@@ -286,6 +286,7 @@ int add_conv(odt_model* m, const std::string& name, const Tensor& in, int cin, c
 int attach_split_weights(odt_model* m) {
   if (conv_split_mode() == 0) return 0;
   std::map<const float*, const void*> made;      // the RPN conv is shared by the five levels
+  std::map<const float*, int> made_kind;
   for (ConvOp& c : m->convs) {
     if (!conv_split_wanted(c.p)) continue;
     auto it = made.find(c.p.wt);
@@ -293,11 +294,19 @@ int attach_split_weights(odt_model* m) {
       const int K = c.p.kh * c.p.kw * c.p.Cin + (c.p.in2 != nullptr ? c.p.Cin2 : 0);
       float* img = m->alloc_f((conv_split_weight_bytes(c.p.Cout, K) + 3) / 4, false);
       ODT_CHECK(img != nullptr, "device allocation failed (split weights of " + c.name + ")");
-      if (conv_make_split_weights(c.p.wt, c.p.Cout, K, conv_split_bk(c.p), img, 0)) return 1;
+      conv_split_choose(c.p);
+      if (conv_make_split_weights(c.p, img, 0)) return 1;
       it = made.emplace(c.p.wt, img).first;
+      made_kind[c.p.wt] = c.p.wt_split_kind;
+    }
+    conv_split_choose(c.p);
+    // shared weights (the RPN conv over five levels): one image, so one kernel family -- the first (largest) level's
+    if (c.p.wt_split_kind != made_kind[c.p.wt]) {
+      ODT_CHECK(made_kind[c.p.wt] != 3 || c.p.Cin % 16 == 0, "split weights: shared image of an unsupported layout");
+      c.p.wt_split_kind = made_kind[c.p.wt];
+      if (c.p.wt_split_kind == 3 && c.p.wt_split_bm == 0) c.p.wt_split_bm = 128;
     }
     c.p.wt_split = it->second;
-    c.p.wt_split_bk = conv_split_bk(c.p);
   }
   ODT_HIP(hipDeviceSynchronize());
   return 0;

@@ -65,7 +65,9 @@ struct ConvParams {
   // optional bf16-piece image of `wt` (conv_make_split_weights): the layer runs on the bf16x3
   // split kernel (conv_split.hip: f32 result through six exact bf16 MFMA products per MAC)
   const void* wt_split;
-  int wt_split_bk;     // K extent of one stage of that image: 32 (default kernel) or 16 (conv_split2_kernel)
+  int wt_split_kind;   // which kernel family the image was laid out for: 1 one-stage BK = 32 (conv_split_kernel) |
+                       // 2 two-stage BK = 16, 128 x 256 (conv_split2_kernel) | 3 conv_split3_kernel (8 waves, LDS-DMA)
+  int wt_split_bm;     // kind 3: rows of the block tile (256, or 128 when 256-row tiles would not fill the chip)
 };
 // fills the derived fields (multiply-shift divisors); call before copying a record to the device
 void conv_prepare(ConvParams& p);
@@ -80,8 +82,10 @@ bool conv_split_wanted(const ConvParams& p);
 size_t conv_split_weight_bytes(int Cout, int K);
 int conv_split_bn(int Cout);   // n-tile width of the split configuration for this Cout (0: none)
 int conv_split_bm(int Cout);
-int conv_split_bk(const ConvParams& p);   // stage width of the kernel that will take this conv (32, or 16 with ODT_CONV_SPLIT_PIPE=2)
-int conv_make_split_weights(const float* wt_dev, int Cout, int K, int bk, void* img_dev, hipStream_t stream);
+// picks the split kernel family / tile for a conv that conv_split_wanted() accepted (fills wt_split_kind / wt_split_bm)
+void conv_split_choose(ConvParams& p);
+// builds the bf16-piece image of p.wt for p.wt_split_kind (conv_split_choose first)
+int conv_make_split_weights(const ConvParams& p, void* img_dev, hipStream_t stream);
 int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t stream);
 
 // ------------------------------------------------------------ elementwise (K1,K4)

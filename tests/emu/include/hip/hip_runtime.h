@@ -309,6 +309,22 @@ inline void __builtin_amdgcn_raw_buffer_store_b128(hipemu_u32x4 v, __amdgpu_buff
     if (o + 4 <= r.num_records) { unsigned t = v[d]; memcpy(const_cast<char*>(r.base) + o, &t, 4); }
   }
 }
+// LDS-DMA (buffer_load ... lds): every lane's `size` bytes land at lds_base + lane * size (wave-uniform base; the per-lane
+// part is the SOURCE offset); out-of-range lanes write zeros.  Synchronous here: the simulator checks addressing, not
+// the vmcnt / barrier protocol.
+inline void __builtin_amdgcn_raw_ptr_buffer_load_lds(__amdgpu_buffer_rsrc_t r, void* lds_base, int size, int voffset,
+                                                     int soffset, int /*offset*/, int /*aux*/) {
+  const int l = hipemu::lane_id();
+  const unsigned long long off = (unsigned long long)(unsigned)voffset + (unsigned)soffset;
+  for (int d = 0; d < size / 4; ++d) {
+    const unsigned long long o = off + 4ull * d;
+    unsigned t = 0;
+    if (o + 4 <= r.num_records) memcpy(&t, r.base + o, 4);
+    memcpy((char*)lds_base + (size_t)l * size + 4 * d, &t, 4);
+  }
+}
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }    // callers pass wave-uniform values
+inline void __builtin_amdgcn_s_barrier() { __syncthreads(); }
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline unsigned __builtin_amdgcn_s_getreg(int) { return 0; }
 inline void __builtin_amdgcn_sched_barrier(int) {}

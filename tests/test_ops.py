@@ -485,19 +485,33 @@ SPLIT_CASES = [
 ]
 
 
-def _split_env(monkeypatch):
+# kernel families of the split path (conv_split_choose): "3/256", "3/128": conv_split3_kernel (8 waves, LDS-DMA weight
+# stages, three-stage ring; the default) with 256- / 128-row tiles; "2": the two-stage 128 x 256 loop; "1": the
+# one-stage BK = 32 loop of round 1
+SPLIT_PIPES = ["3/256", "3/128", "2", "1"]
+
+
+def _split_env(monkeypatch, pipe="3/256"):
   monkeypatch.setenv("ODT_CONV_SPLIT", "1")
   monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1")
+  monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "1")
+  monkeypatch.setenv("ODT_CONV_SPLIT_PIPE", pipe[0])
+  if "/" in pipe:
+    monkeypatch.setenv("ODT_CONV_SPLIT3_BM", pipe.split("/")[1])
+  else:
+    monkeypatch.delenv("ODT_CONV_SPLIT3_BM", raising=False)
 
 
+@pytest.mark.parametrize("pipe", SPLIT_PIPES)
 @pytest.mark.parametrize("case", SPLIT_CASES)
-def test_conv2d_split(backend, case, monkeypatch):
+def test_conv2d_split(backend, case, pipe, monkeypatch):
   name, lib = backend
-  _split_env(monkeypatch)
+  _split_env(monkeypatch, pipe)
   _run_conv(lib, case, np.random.default_rng(11))
 
 
-def test_conv2d_split_matches_f32_kernel_at_f32_rounding(backend, monkeypatch):
+@pytest.mark.parametrize("pipe", ["3/256", "1"])
+def test_conv2d_split_matches_f32_kernel_at_f32_rounding(backend, pipe, monkeypatch):
   """The split result must sit as close to the f64 truth as the exact-f32 MFMA kernel does
   (error of an f32 dot product, not of a bf16 one), incl. operands spanning many binades."""
   name, lib = backend
@@ -514,8 +528,9 @@ def test_conv2d_split_matches_f32_kernel_at_f32_rounding(backend, monkeypatch):
       ref += patch @ w[dy, dx].astype(np.float64)
       mag += np.abs(patch) @ np.abs(w[dy, dx].astype(np.float64))
   ref += b
+  monkeypatch.setenv("ODT_CONV_SPLIT", "0")
   y32 = ops.conv2d(x, w, b, 1, 1, 1, 1, (H, W), lib=lib)
-  _split_env(monkeypatch)
+  _split_env(monkeypatch, pipe)
   ysp = ops.conv2d(x, w, b, 1, 1, 1, 1, (H, W), lib=lib)
   e32 = np.max(np.abs(y32 - ref) / mag)
   esp = np.max(np.abs(ysp - ref) / mag)
@@ -526,9 +541,10 @@ def test_conv2d_split_matches_f32_kernel_at_f32_rounding(backend, monkeypatch):
   assert esp < 4e-6, esp
 
 
-def test_conv2d_split_output_offset_and_residual(backend, monkeypatch):
+@pytest.mark.parametrize("pipe", SPLIT_PIPES)
+def test_conv2d_split_output_offset_and_residual(backend, pipe, monkeypatch):
   name, lib = backend
-  _split_env(monkeypatch)
+  _split_env(monkeypatch, pipe)
   rng = np.random.default_rng(13)
   x = rng.standard_normal((1, 10, 12, 64)).astype(F)
   w = (rng.standard_normal((3, 3, 64, 256)) * 0.05).astype(F)
@@ -537,18 +553,19 @@ def test_conv2d_split_output_offset_and_residual(backend, monkeypatch):
   want = np.maximum(torch_conv_nhwc(x, w, b, 1, 1, 1, 1, 10, 12), 0)
   assert np.all(got[:, :1] == 0) and np.all(got[:, :, :1] == 0)
   np.testing.assert_allclose(got[:, 1:, 1:], want, rtol=1e-4, atol=1e-4)
-  # same-shape residual: the split kernel starts its accumulators at the residual
+  # same-shape residual (added in the epilogue by conv_split3_kernel, accumulator start value in the older loops)
   res = rng.standard_normal((1, 10, 12, 256)).astype(F)
   got = ops.conv2d(x, w, b, 1, 1, 1, 1, (10, 12), res=res, res_mode=1, relu=True, lib=lib)
   np.testing.assert_allclose(got, np.maximum(torch_conv_nhwc(x, w, b, 1, 1, 1, 1, 10, 12) + res, 0),
                              rtol=1e-4, atol=1e-4)
 
 
-def test_conv2d_split_residual_bottleneck_conv3(backend, monkeypatch):
+@pytest.mark.parametrize("pipe", SPLIT_PIPES)
+def test_conv2d_split_residual_bottleneck_conv3(backend, pipe, monkeypatch):
   """1x1 conv + same-shape residual + ReLU over two N tiles and a ragged M (res4 conv3 shape class);
   then the nearest-2x upsampled residual of an FPN lateral (odd sizes: the coarse level is ceil(n/2))."""
   name, lib = backend
-  _split_env(monkeypatch)
+  _split_env(monkeypatch, pipe)
   rng = np.random.default_rng(14)
   x = rng.standard_normal((2, 9, 11, 256)).astype(F)
   w = (rng.standard_normal((1, 1, 256, 512)) / 16).astype(F)
@@ -569,11 +586,12 @@ def test_conv2d_split_residual_bottleneck_conv3(backend, monkeypatch):
   np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
 
 
-def test_conv2d_split_two_sources(backend, monkeypatch):
+@pytest.mark.parametrize("pipe", SPLIT_PIPES)
+def test_conv2d_split_two_sources(backend, pipe, monkeypatch):
   """Stage-entry fusion on the split kernel: conv3(t2) + convshortcut(x[::s]) as one K-concatenated
   GEMM, second source at stride 1 and 2, all three tile configurations."""
   name, lib = backend
-  _split_env(monkeypatch)
+  _split_env(monkeypatch, pipe)
   rng = np.random.default_rng(15)
   for stride_b, Ca, Cb, Cout in ((1, 64, 64, 256), (2, 128, 256, 512), (2, 32, 96, 128), (1, 64, 32, 64)):
     B, Ho, Wo = 2, 9, 11
@@ -588,29 +606,24 @@ def test_conv2d_split_two_sources(backend, monkeypatch):
     np.testing.assert_allclose(got, np.maximum(want, 0), rtol=2e-4, atol=2e-4)
 
 
-def test_conv_fuzz_split(backend, monkeypatch):
+@pytest.mark.parametrize("pipe", SPLIT_PIPES)
+def test_conv_fuzz_split(backend, pipe, monkeypatch):
   """Randomized shapes / strides / dilations / pads / output offsets / residual modes through the
-  three tile configurations of the split kernel."""
+  tile configurations of each split kernel family."""
   name, lib = backend
-  _split_env(monkeypatch)
+  _split_env(monkeypatch, pipe)
   rng = np.random.default_rng(2025)
-  for _ in range(6 if name == "emu" else 40):
+  for _ in range(5 if name == "emu" else 40):
     _fuzz_case(rng, lib, big=name == "hip", couts=[64, 128, 192, 256, 384])
 
 
-def test_conv2d_split_pipe2_experimental(emu_lib, monkeypatch):
-  """ODT_CONV_SPLIT_PIPE=2: the experimental two-stage (BK = 16) loop of the 128 x 256 tile.
-  Simulator only for now: on the GPU it has only run tools/gpurun/pipe2_check.py (bit-identical to the
-  default kernel on two shapes; written after the round's GPU budget was spent, not timed yet); the
-  default kernel is unaffected."""
-  _split_env(monkeypatch)
-  monkeypatch.setenv("ODT_CONV_SPLIT_PIPE", "2")
+@pytest.mark.parametrize("pipe", ["3/256", "3/128", "2"])
+def test_conv2d_split_16wide_stage_extras(backend, pipe, monkeypatch):
+  """BK = 16 stage kernels: 96- and 160-channel sources (odd numbers of 16-channel slices), residual, second
+  source at stride 2."""
+  name, emu_lib = backend
+  _split_env(monkeypatch, pipe)
   rng = np.random.default_rng(16)
-  for case in SPLIT_CASES:
-    if case[4] % 256 == 0:
-      _run_conv(emu_lib, case, rng)
-  for _ in range(4):
-    _fuzz_case(rng, emu_lib, big=False, couts=[256, 512])
   # residual (same shape, 2x upsampled) and the K-concatenated second source
   x = rng.standard_normal((2, 9, 11, 96)).astype(F)
   w = (rng.standard_normal((1, 1, 96, 256)) / 10).astype(F)

@@ -1,0 +1,10 @@
+#!/bin/bash
+# conv_split3_kernel: GPU parity subset, then same-box per-layer A/B against the two-stage 128x256 loop
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_ops.py -q -m gpu -k "split" -x 2>&1 | tail -3
+BATCH=8 bash tools/gpurun/ab_layers_env.sh "ODT_CONV_SPLIT_PIPE=2" "ODT_CONV_SPLIT_PIPE=3" > gpurun_out/split3_layers_b8.txt 2>&1
+head -34 gpurun_out/split3_layers_b8.txt
+for v in "ODT_CONV_SPLIT_PIPE=2" "ODT_CONV_SPLIT_PIPE=3"; do
+  r8=$(env $v timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.2f FPS all-conv %.1f TF split %.1f TF' % (d['value'], d['roofline']['all_conv_launches']['achieved'], d['roofline']['achieved']))")
+  echo "$v  b8: $r8"
+done | tee gpurun_out/split3_ab.txt
