@@ -42,7 +42,7 @@ def main():
   ap.add_argument("--topk", type=int, default=300, help="rpn_test_post_nms_topk (BASELINE: 300)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-extras", action="store_true", help="skip the `extra` measurements (A/B runs)")
-  ap.add_argument("--cpu-frames", type=int, default=2, help="frames in the bounded CPU sample")
+  ap.add_argument("--cpu-frames", type=int, default=1, help="frames in the bounded CPU sample (7 passes: 2 warm-up + 5 timed)")
   ap.add_argument("--profile-steps", type=int, default=2)
   ap.add_argument("--dist-backend", default="nccl",
                   help="nccl (= RCCL, the default) | gloo (debug: lets N ranks share one GPU)")
@@ -51,7 +51,16 @@ def main():
                        "one batch on every stream")
   ap.add_argument("--device", type=int, default=None,
                   help="debug: force every rank onto this GPU (with --dist-backend gloo)")
+  ap.add_argument("--launcher-selftest", action="store_true",
+                  help="no GPU work: start the N ranks exactly as a real run does (self-launch, rendezvous, the "
+                       "barrier / all-gather / max-over-ranks reduction of the timed region) over gloo and print the "
+                       "contract line's launch fields -- what the CPU suite runs")
   args = ap.parse_args()
+
+  if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    # `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, the same launcher
+    # line the driver uses) and relay rank 0's JSON line
+    sys.exit(self_launch(args.gpus))
 
   import torch
   import torch.distributed as dist
@@ -59,10 +68,18 @@ def main():
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
   world = int(os.environ.get("WORLD_SIZE", "1"))
+  if world != args.gpus:
+    raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+  if args.launcher_selftest:
+    return launcher_selftest(args, rank, world)
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs a GPU: the product path is the HIP library only")
   if args.device is not None:
     local_rank = args.device
+  elif torch.cuda.device_count() < world:
+    raise SystemExit("bench.py: --gpus %d needs %d visible GPUs, found %d (one process per GPU; "
+                     "--dist-backend gloo --device 0 shares one GPU for debugging)"
+                     % (world, world, torch.cuda.device_count()))
   torch.cuda.set_device(local_rank)
   if world > 1:
     if args.dist_backend == "nccl":
@@ -116,11 +133,8 @@ def main():
   torch.cuda.synchronize()
   barrier()
   dt = time.perf_counter() - t0
-  if world > 1:
-    t = torch.tensor([dt], dtype=torch.float64,
-                     device="cuda" if args.dist_backend == "nccl" else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+  dt, ranks_seen, rank_dts = reduce_timing(dt, rank, world, "cuda" if args.dist_backend == "nccl" else "cpu")
+  rank_fps = [S * B * args.steps / t for t in rank_dts]
 
   # roofline of the dominant kernel family (implicit-GEMM conv, ~99% of the FLOPs): HIP events
   # around every launch on the launch stream, outside the timed region.
@@ -245,12 +259,16 @@ def main():
         "value": fps,
         "unit": "frames/s",
         "n_gpus": world,
+        "ranks_seen": ranks_seen,
+        "per_rank_fps": rank_fps,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
+        "value_scope": "device-resident: uint8 frames already in HBM when the timed region starts, outputs left in HBM "
+                       "(the PCIe-inclusive pipelined rate and the detect+track rate are under `extra`)",
         "dtype": "f32",
         "arithmetic": ("f32 tensors, f32 accumulation; exact-f32 MFMA products" if fam["split"][0] == 0 else
                        "f32 tensors, f32 accumulation; the products of %d of the %d conv launches are evaluated as six "
@@ -279,7 +297,7 @@ def main():
 def pmc_traffic(mode):
   """HBM bytes per conv launch from the separate rocprofv3 --pmc passes of this same command
   (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; tools/pmc_summary.py), or None."""
-  path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json" if mode == "f32" else "r01_pmc_summary_split.json")
+  path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json" if mode == "f32" else "r02_pmc_summary_split.json")
   try:
     with open(path) as fh:
       return float(json.load(fh)["conv_hbm_bytes_per_launch_fetch_x2" if mode == "f32" else
@@ -288,20 +306,91 @@ def pmc_traffic(mode):
     return None
 
 
+def cpu_model_name():
+  try:
+    with open("/proc/cpuinfo") as fh:
+      for line in fh:
+        if line.startswith("model name"):
+          return line.split(":", 1)[1].strip()
+  except OSError:
+    pass
+  return "unknown"
+
+
 def cpu_baseline(cfg, weights, frames, nframes):
-  """Oracle (CPU restatement of the TF graph; NOT TensorFlow) on a bounded sample."""
+  """Oracle (CPU restatement of the TF graph; NOT TensorFlow) on a bounded sample, by the protocol of
+  BASELINE.md section 3: all host cores, 2 warm-up passes, median of 5 timed passes."""
   import torch
   from oracle.graph import OracleModel
   n = max(1, min(nframes, frames.shape[0]))
+  nproc = os.cpu_count() or 1
+  torch.set_num_threads(nproc)
   om = OracleModel(cfg, weights)
-  t0 = time.perf_counter()
-  om.forward_multi(frames[:n])
-  dt = time.perf_counter() - t0
-  return {"value": n / dt, "unit": "frames/s", "cores": int(torch.get_num_threads()),
+  times = []
+  for i in range(2 + 5):
+    t0 = time.perf_counter()
+    om.forward_multi(frames[:n])
+    if i >= 2:
+      times.append(time.perf_counter() - t0)
+  med = float(np.median(times))
+  return {"value": n / med, "unit": "frames/s", "cores": int(torch.get_num_threads()), "nproc": nproc,
+          "cpu_model": cpu_model_name(), "torch": torch.__version__,
           "kind": "port",
+          "protocol": "2 warm-up + median of 5 timed passes", "pass_seconds": [round(t, 3) for t in times],
           "sample": "%d of the step's %d frames through oracle.graph.OracleModel.forward_multi "
-                    "(torch-CPU fp32 conv/matmul + numpy selection ops), one pass, %.1f s"
-                    % (n, frames.shape[0], dt)}
+                    "(torch-CPU fp32 conv/matmul + numpy selection ops: a CPU restatement of the TF graph, not TensorFlow)"
+                    % (n, frames.shape[0])}
+
+
+def reduce_timing(dt, rank, world, cdev):
+  """Max over ranks of the timed region + who took part (all-gather of (rank, own clock))."""
+  if world == 1:
+    return dt, [0], [dt]
+  import torch
+  import torch.distributed as dist
+  mine = torch.tensor([float(rank), dt], dtype=torch.float64, device=cdev)
+  allr = [torch.zeros(2, dtype=torch.float64, device=cdev) for _ in range(world)]
+  dist.all_gather(allr, mine)
+  allr = sorted(allr, key=lambda t: t[0].item())
+  t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+  dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  return float(t.item()), [int(t[0].item()) for t in allr], [float(t[1].item()) for t in allr]
+
+
+def launcher_selftest(args, rank, world):
+  """The launch / rendezvous / reduction path of a real run without a GPU (gloo)."""
+  import torch.distributed as dist
+  if world > 1:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()
+  t0 = time.perf_counter()
+  time.sleep(0.01 * (1 + rank))            # ranks finish at different times: the max must win
+  if world > 1:
+    dist.barrier()
+  dt = time.perf_counter() - t0
+  dt, seen, dts = reduce_timing(dt, rank, world, "cpu")
+  if rank == 0:
+    print(json.dumps({"launcher_selftest": True, "n_gpus": world, "ranks_seen": seen,
+                      "max_over_ranks_ok": bool(dt >= max(dts) - 1e-12), "steps": args.steps, "warmup": args.warmup}),
+          flush=True)
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+  return 0
+
+
+def self_launch(n):
+  """python bench.py --gpus N (no launcher in front): run torch.distributed.run ourselves."""
+  import socket
+  import subprocess
+  with socket.socket() as sk:
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  env = dict(os.environ)
+  env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+  return subprocess.call(cmd, env=env)
 
 
 if __name__ == "__main__":

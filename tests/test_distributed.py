@@ -58,3 +58,28 @@ def test_allgather_is_identity_without_process_group():
   f = torch.ones(2, 256); b = torch.zeros(2, 4)
   gf, gb = all_gather_reid_features(f, b)
   assert len(gf) == 1 and gf[0] is f and gb[0] is b
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+  """`python bench.py --gpus 2` (no launcher in front, as the driver calls it) must start two ranks itself,
+  rendezvous on 127.0.0.1 and report n_gpus == world == 2 with both ranks seen (--gpus was parsed
+  and never used).  --launcher-selftest swaps the GPU work for a sleep and RCCL for gloo; the launch path is the
+  real one."""
+  import json
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ)
+  for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+    env.pop(k, None)
+  r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                      "--launcher-selftest"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+  assert r.returncode == 0, r.stderr[-2000:]
+  line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+  d = json.loads(line)
+  assert d["n_gpus"] == 2 and d["ranks_seen"] == [0, 1] and d["max_over_ranks_ok"] and d["steps"] == 3
+  # a launcher that started a different number of ranks than --gpus asks for is an error, not a silent n_gpus
+  env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+  r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launcher-selftest"], env=env2,
+                     stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+  assert r.returncode != 0 and "--gpus 2" in r.stderr
