@@ -142,8 +142,18 @@ int odt_set_source_size(odt_handle h, int src_height, int src_width);
  * ticket and fills `out`.  At most two tickets may be outstanding; with two in flight the H2D
  * of batch i+1 and the D2H of batch i-1 overlap the forward of batch i.
  * odt_ingest_buffer exposes the next slot's pinned input buffer so a decoder can write into
- * it directly (pass frames == NULL to odt_submit to use what was written there). */
+ * it directly (pass frames == NULL to odt_submit to use what was written there).
+ * odt_submit_ex: the same with a choice of what crosses PCIe on the way back (ODT_WANT_* bits).  The
+ * only consumer of fpn_box_feat on this path averages it to [M,C] (deep_sort/utils.py:27-28), so the
+ * tracking loop asks for ODT_WANT_POOLED only: 0.8 MB per 8-frame batch instead of the 40 MB of
+ * [M,256,7,7]; with nothing large to copy the D2H rides on the compute stream and the forward is a
+ * hipGraph replay (one cached graph per slot).  odt_submit == odt_submit_ex(..., ODT_WANT_ALL, ...). */
+#define ODT_WANT_FEATS  1   /* fpn_box_feat [M,C,7,7] */
+#define ODT_WANT_POOLED 2   /* its 7x7 mean [M,C] */
+#define ODT_WANT_MASKS  4   /* final_masks (add_mask models) */
+#define ODT_WANT_ALL    7
 int odt_submit(odt_handle h, const void* frames, int dtype, int* ticket);
+int odt_submit_ex(odt_handle h, const void* frames, int dtype, int want, int* ticket);
 int odt_collect(odt_handle h, int ticket, odt_outputs* out);
 int odt_ingest_buffer(odt_handle h, int dtype, void** buffer, size_t* bytes);
 

@@ -74,7 +74,7 @@ class OdtLib(object):
   SYMBOLS = [
       "odt_last_error", "odt_device_count", "odt_create", "odt_destroy",
       "odt_load_tensor", "odt_finalize_weights", "odt_forward",
-      "odt_forward_async", "odt_synchronize", "odt_submit", "odt_collect",
+      "odt_forward_async", "odt_synchronize", "odt_submit", "odt_submit_ex", "odt_collect",
       "odt_ingest_buffer", "odt_set_source_size", "odt_tap", "odt_profile_enable",
       "odt_profile_read", "odt_profile_layer", "odt_nn_cosine", "odt_op_conv2d", "odt_op_conv2d_cat",
       "odt_op_preprocess",
@@ -104,6 +104,7 @@ class OdtLib(object):
     d.odt_forward_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     d.odt_synchronize.argtypes = [C.c_void_p]
     d.odt_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    d.odt_submit_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
     d.odt_collect.argtypes = [C.c_void_p, C.c_int, C.POINTER(OdtOutputs)]
     d.odt_set_source_size.argtypes = [C.c_void_p, C.c_int, C.c_int]
     d.odt_ingest_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p),

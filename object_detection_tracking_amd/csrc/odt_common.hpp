@@ -245,7 +245,19 @@ int launch_detections(const DetectParams& p, hipStream_t stream);
 
 // ----------------------------------------------------------------- tracker (K15)
 // gal_n / det_n: device scratch for the L2-normalised copies ([G,D] / [N,D])
-int launch_nn_cosine(const float* gallery, int G, const int* seg, int T, const float* dets, int N,
-                     int D, float* gal_n, float* det_n, double* cost, hipStream_t stream);
+int launch_nn_cosine(const float* gallery, const int* seg, int T, const float* dets, int N, int D, double* cost,
+                     hipStream_t stream);
+// host-to-host cosine nearest-neighbour call with persistent scratch and a stream of its own (tracker.hip)
+struct CosineCtx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+  float* h_in = nullptr; float* d_in = nullptr; size_t cap_in = 0;        // packed [seg | gallery | detections]
+  double* h_cost = nullptr; double* d_cost = nullptr; size_t cap_cost = 0;
+  ~CosineCtx();
+  // gal_rows[G] / det_rows[N]: pointers to the D-float rows (gathered into the pinned record); seg[T+1]; cost[T*N]
+  int run(int dev, const float* const* gal_rows, int G, const int* seg, int T, const float* const* det_rows, int N,
+          int D, double* cost);
+};
 
 }  // namespace odt

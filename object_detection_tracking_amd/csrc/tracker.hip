@@ -1,55 +1,141 @@
 // DeepSORT appearance matching on gfx950: cosine nearest-neighbour distance between every
-// track's gallery and the frame's detections.
+// track's gallery and the frame's detections, ONE kernel per call.
 //
 // Restates reference deep_sort/nn_matching.py:31-54 (_cosine_distance: L2-normalise both
 // sides, 1 - a.b^T), :78-96 (_nn_cosine_distance: min over the track's gallery rows) and
 // :156-177 (NearestNeighborDistanceMetric.distance: the per-track Python loop).  fp32 math,
-// float64 cost matrix like the reference.  Latency-bound (a few MFLOP): one wave per row for
-// the normalisation (wavefront shuffles), one workgroup per track for the segmented min.
+// float64 cost matrix like the reference.
+//
+// Latency-bound (T = 64 tracks x budget 5 rows x N = 100 detections x D = 256: 8 MFLOP), so the
+// shape is: one workgroup per track (4 waves).  The track's gallery rows are normalised on the way
+// into LDS (one wave per row, wavefront shuffles for the norm); then every wave takes detections
+// j = wave, wave + 4, ...: the detection row is read coalesced (D floats = one 1-KB row per wave
+// instruction at D = 256), normalised in registers / the wave's private LDS strip, and dotted
+// against every staged gallery row with lane-strided partial sums + a shuffle tree; min over the
+// rows, 1 - dot, one float64 store per (track, detection).  Galleries larger than the LDS chunk
+// (no budget: the gallery grows by one row per matched frame) are walked in chunks of kRows rows.
+#include <cstring>
+
 #include "odt_common.hpp"
 
 namespace odt {
 namespace {
 
-__global__ void __launch_bounds__(64) normalize_rows_kernel(const float* in, int D, float* out) {
-  const int r = blockIdx.x, lane = threadIdx.x;
-  const float* src = in + (size_t)r * D;
-  float ss = 0.f;
-  for (int d = lane; d < D; d += 64) ss += src[d] * src[d];
+constexpr int kRows = 16;        // gallery rows staged per chunk
+constexpr int kMaxD = 1024;      // feature length bound of the LDS staging (the box head's is 256)
+
+__device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
-  const float nrm = sqrtf(ss);
-  for (int d = lane; d < D; d += 64) out[(size_t)r * D + d] = src[d] / nrm;
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
 }
 
-__global__ void __launch_bounds__(256) cosine_min_kernel(const float* gal_n, const int* seg,
-                                                         const float* det_n, int N, int D,
-                                                         double* cost) {
-  const int t = blockIdx.x;
+__global__ void __launch_bounds__(256) nn_cosine_kernel(const float* __restrict__ gal, const int* __restrict__ seg,
+                                                        const float* __restrict__ det, int N, int D,
+                                                        double* __restrict__ cost) {
+  __shared__ float rows[kRows * kMaxD];
+  __shared__ float dstrip[4 * kMaxD];
+  const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g0 = seg[t], g1 = seg[t + 1];
-  for (int j = threadIdx.x; j < N; j += blockDim.x) {
-    const float* dj = det_n + (size_t)j * D;
-    float best = 3.402823466e38f;
-    for (int g = g0; g < g1; ++g) {
-      const float* gr = gal_n + (size_t)g * D;
-      float dot = 0.f;
-      for (int d = 0; d < D; ++d) dot += gr[d] * dj[d];
-      best = fminf(best, 1.0f - dot);
+  float* mine = dstrip + wave * kMaxD;
+  for (int c0 = g0; c0 < g1; c0 += kRows) {
+    const int nr = g1 - c0 < kRows ? g1 - c0 : kRows;
+    if (c0 > g0) __syncthreads();                       // the previous chunk has been consumed
+    for (int r = wave; r < nr; r += 4) {                // a / ||a|| (nn_matching.py:48-50), one wave per row
+      const float* src = gal + (size_t)(c0 + r) * D;
+      float ss = 0.f;
+      for (int d = lane; d < D; d += 64) ss += src[d] * src[d];
+      const float nrm = sqrtf(wave_sum(ss));
+      for (int d = lane; d < D; d += 64) rows[r * kMaxD + d] = src[d] / nrm;
     }
-    cost[(size_t)t * N + j] = (double)best;
+    __syncthreads();
+    for (int j = wave; j < N; j += 4) {
+      const float* dj = det + (size_t)j * D;
+      float ss = 0.f;
+      for (int d = lane; d < D; d += 64) ss += dj[d] * dj[d];
+      const float nrm = sqrtf(wave_sum(ss));
+      for (int d = lane; d < D; d += 64) mine[d] = dj[d] / nrm;     // wave-private strip: same lanes read it back
+      float best = 3.402823466e38f;
+      for (int r = 0; r < nr; ++r) {
+        float dot = 0.f;
+        for (int d = lane; d < D; d += 64) dot += rows[r * kMaxD + d] * mine[d];
+        best = fminf(best, 1.0f - wave_sum(dot));
+      }
+      if (lane == 0) {
+        double* o = cost + (size_t)t * N + j;
+        *o = c0 == g0 ? (double)best : fmin(*o, (double)best);
+      }
+    }
   }
 }
 
 }  // namespace
 
-int launch_nn_cosine(const float* gallery, int G, const int* seg, int T, const float* dets, int N,
-                        int D, float* gal_n, float* det_n, double* cost, hipStream_t stream) {
-  if (G > 0) hipLaunchKernelGGL(normalize_rows_kernel, dim3(G), dim3(64), 0, stream, gallery, D, gal_n);
-  if (N > 0) hipLaunchKernelGGL(normalize_rows_kernel, dim3(N), dim3(64), 0, stream, dets, D, det_n);
+int launch_nn_cosine(const float* gallery, const int* seg, int T, const float* dets, int N, int D, double* cost,
+                     hipStream_t stream) {
+  ODT_CHECK(D > 0 && D <= kMaxD, "nn_cosine: feature length above 1024");
   if (T > 0 && N > 0)
-    hipLaunchKernelGGL(cosine_min_kernel, dim3(T), dim3(256), 0, stream, (const float*)gal_n, seg,
-                       (const float*)det_n, N, D, cost);
+    hipLaunchKernelGGL(nn_cosine_kernel, dim3(T), dim3(256), 0, stream, gallery, seg, dets, N, D, cost);
   ODT_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- CosineCtx: everything a host-to-host call needs, allocated once and grown on demand: pinned staging,
+// device buffers, a non-blocking stream of its own (a tracker must never serialise against a detector's
+// forward on the null stream) and an event to wait on.  No hipMalloc / hipFree / hipDeviceSynchronize per call.
+CosineCtx::~CosineCtx() {
+  if (device < 0) return;
+  (void)hipSetDevice(device);
+  if (h_in) (void)hipHostFree(h_in);
+  if (h_cost) (void)hipHostFree(h_cost);
+  if (d_in) (void)hipFree(d_in);
+  if (d_cost) (void)hipFree(d_cost);
+  if (done) (void)hipEventDestroy(done);
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+int CosineCtx::run(int dev, const float* const* gal_rows, int G, const int* seg, int T, const float* const* det_rows,
+                   int N, int D, double* cost) {
+  if (T == 0 || N == 0) return 0;
+  ODT_HIP(hipSetDevice(dev));
+  if (device != dev) {
+    ODT_CHECK(device < 0, "cosine context moved between devices");
+    device = dev;
+    ODT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    ODT_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+  }
+  // one packed input record: [seg (T+1 ints, padded to 4)][gallery G*D][detections N*D]
+  const size_t nseg = ((size_t)T + 1 + 3) & ~(size_t)3;
+  const size_t nin = nseg + (size_t)(G + N) * D, ncost = (size_t)T * N;
+  if (cap_in < nin) {
+    if (h_in) ODT_HIP(hipHostFree(h_in));
+    if (d_in) ODT_HIP(hipFree(d_in));
+    h_in = nullptr; d_in = nullptr; cap_in = 0;
+    const size_t want = nin + nin / 2;
+    ODT_HIP(hipHostMalloc((void**)&h_in, want * 4, 0));
+    ODT_HIP(hipMalloc((void**)&d_in, want * 4));
+    cap_in = want;
+  }
+  if (cap_cost < ncost) {
+    if (h_cost) ODT_HIP(hipHostFree(h_cost));
+    if (d_cost) ODT_HIP(hipFree(d_cost));
+    h_cost = nullptr; d_cost = nullptr; cap_cost = 0;
+    const size_t want = ncost + ncost / 2;
+    ODT_HIP(hipHostMalloc((void**)&h_cost, want * 8, 0));
+    ODT_HIP(hipMalloc((void**)&d_cost, want * 8));
+    cap_cost = want;
+  }
+  std::memcpy(h_in, seg, ((size_t)T + 1) * sizeof(int));
+  float* hg = h_in + nseg;
+  for (int g = 0; g < G; ++g) std::memcpy(hg + (size_t)g * D, gal_rows[g], sizeof(float) * D);
+  float* hd = hg + (size_t)G * D;
+  for (int j = 0; j < N; ++j) std::memcpy(hd + (size_t)j * D, det_rows[j], sizeof(float) * D);
+  ODT_HIP(hipMemcpyAsync(d_in, h_in, nin * 4, hipMemcpyHostToDevice, stream));
+  if (launch_nn_cosine(d_in + nseg, (const int*)d_in, T, d_in + nseg + (size_t)G * D, N, D, d_cost, stream)) return 1;
+  ODT_HIP(hipMemcpyAsync(h_cost, d_cost, ncost * 8, hipMemcpyDeviceToHost, stream));
+  ODT_HIP(hipEventRecord(done, stream));
+  ODT_HIP(hipEventSynchronize(done));
+  std::memcpy(cost, h_cost, ncost * 8);
   return 0;
 }
 

@@ -249,56 +249,37 @@ struct odt_tracker {
   int next_id = 1;
   std::vector<Trk> tracks;
   std::map<int, std::deque<std::vector<float>>> samples;     // nn_matching.py:125-154
-  // device scratch for the cosine kernel
-  float *d_gal = nullptr, *d_gal_n = nullptr, *d_det = nullptr, *d_det_n = nullptr;
-  int* d_seg = nullptr; double* d_cost = nullptr;
-  size_t cap_gal = 0, cap_det = 0, cap_seg = 0, cap_cost = 0;
-  ~odt_tracker() {
-    for (void* p : {(void*)d_gal, (void*)d_gal_n, (void*)d_det, (void*)d_det_n, (void*)d_seg, (void*)d_cost})
-      if (p) (void)hipFree(p);
-  }
+  // the appearance cost of ONE update(): every confirmed track x every detection, computed by one kernel
+  // call on the tracker's own stream (persistent pinned + device scratch: CosineCtx); the cascade levels
+  // read their sub-matrices from it (the reference recomputes the same entries level by level,
+  // tracker.py:94-104 -> nn_matching.py:156-177: an entry depends on its track and detection only)
+  CosineCtx cos;
+  std::vector<double> app_cost;          // [confirmed tracks at update start][N]
+  std::map<int, int> app_row;            // track id -> row of app_cost
+  int app_n = 0;
 };
 
 namespace {
 
-template <typename T>
-int ensure(T** p, size_t* cap, size_t n) {
-  if (*cap >= n) return 0;
-  if (*p) ODT_HIP(hipFree(*p));
-  *p = nullptr;
-  ODT_HIP(hipMalloc((void**)p, n * sizeof(T)));
-  *cap = n;
-  return 0;
-}
-
-// NearestNeighborDistanceMetric.distance over the gallery of `targets` (HIP kernel)
-int metric_distance(odt_tracker* t, const std::vector<Det>& dets, const std::vector<int>& det_idx,
-                    const std::vector<int>& target_ids, std::vector<double>* cost) {
-  const int T = (int)target_ids.size(), N = (int)det_idx.size(), D = t->D;
-  cost->assign((size_t)T * N, 0.0);
+// NearestNeighborDistanceMetric.distance of every confirmed track's gallery against all N detections
+// (one HIP kernel call per update)
+int appearance_costs(odt_tracker* t, const std::vector<Det>& dets, const std::vector<int>& confirmed) {
+  const int T = (int)confirmed.size(), N = (int)dets.size(), D = t->D;
+  t->app_row.clear(); t->app_n = N;
+  t->app_cost.assign((size_t)T * N, 0.0);
   if (T == 0 || N == 0) return 0;
-  std::vector<float> gal, det((size_t)N * D);
+  std::vector<const float*> gal, det(N);
   std::vector<int> seg(1, 0);
-  for (int id : target_ids) {
+  for (int r = 0; r < T; ++r) {
+    const int id = t->tracks[confirmed[r]].id;
     auto it = t->samples.find(id);
     ODT_CHECK(it != t->samples.end() && !it->second.empty(), "tracker: confirmed track without gallery samples");
-    for (const auto& f : it->second) gal.insert(gal.end(), f.begin(), f.end());
-    seg.push_back((int)(gal.size() / D));
+    for (const auto& f : it->second) gal.push_back(f.data());
+    seg.push_back((int)gal.size());
+    t->app_row[id] = r;
   }
-  for (int j = 0; j < N; ++j) std::memcpy(&det[(size_t)j * D], dets[det_idx[j]].feat, sizeof(float) * D);
-  const int G = seg.back();
-  ODT_HIP(hipSetDevice(t->device));
-  size_t c2 = t->cap_gal, c3 = t->cap_det;
-  if (ensure(&t->d_gal, &t->cap_gal, gal.size()) || ensure(&t->d_gal_n, &c2, gal.size())) return 1;
-  if (ensure(&t->d_det, &t->cap_det, det.size()) || ensure(&t->d_det_n, &c3, det.size())) return 1;
-  if (ensure(&t->d_seg, &t->cap_seg, seg.size()) || ensure(&t->d_cost, &t->cap_cost, cost->size())) return 1;
-  ODT_HIP(hipMemcpy(t->d_gal, gal.data(), gal.size() * sizeof(float), hipMemcpyHostToDevice));
-  ODT_HIP(hipMemcpy(t->d_det, det.data(), det.size() * sizeof(float), hipMemcpyHostToDevice));
-  ODT_HIP(hipMemcpy(t->d_seg, seg.data(), seg.size() * sizeof(int), hipMemcpyHostToDevice));
-  if (launch_nn_cosine(t->d_gal, G, t->d_seg, T, t->d_det, N, D, t->d_gal_n, t->d_det_n, t->d_cost, nullptr)) return 1;
-  ODT_HIP(hipDeviceSynchronize());
-  ODT_HIP(hipMemcpy(cost->data(), t->d_cost, cost->size() * sizeof(double), hipMemcpyDeviceToHost));
-  return 0;
+  for (int j = 0; j < N; ++j) det[j] = dets[j].feat;
+  return t->cos.run(t->device, gal.data(), (int)gal.size(), seg.data(), T, det.data(), N, D, t->app_cost.data());
 }
 
 typedef int (*CostFn)(odt_tracker*, const std::vector<Det>&, const std::vector<int>&, const std::vector<int>&,
@@ -307,10 +288,14 @@ typedef int (*CostFn)(odt_tracker*, const std::vector<Det>&, const std::vector<i
 // tracker.py:94-104 gated_metric
 int gated_metric_cost(odt_tracker* t, const std::vector<Det>& dets, const std::vector<int>& trk_idx,
                       const std::vector<int>& det_idx, std::vector<double>* cost) {
-  std::vector<int> ids;
-  for (int k : trk_idx) ids.push_back(t->tracks[k].id);
-  if (metric_distance(t, dets, det_idx, ids, cost)) return 1;
   const int N = (int)det_idx.size();
+  cost->assign(trk_idx.size() * (size_t)N, 0.0);
+  for (size_t r = 0; r < trk_idx.size(); ++r) {
+    auto it = t->app_row.find(t->tracks[trk_idx[r]].id);
+    ODT_CHECK(it != t->app_row.end(), "tracker: appearance cost of an unconfirmed track requested");
+    const double* src = &t->app_cost[(size_t)it->second * t->app_n];
+    for (int j = 0; j < N; ++j) (*cost)[r * N + j] = src[det_idx[j]];
+  }
   std::vector<double> meas((size_t)N * 4), g(N);
   for (int j = 0; j < N; ++j) std::memcpy(&meas[(size_t)j * 4], dets[det_idx[j]].xyah, 4 * sizeof(double));
   for (size_t r = 0; r < trk_idx.size(); ++r) {            // linear_assignment.py:148-194
@@ -445,6 +430,7 @@ int odt_tracker_update(odt_tracker_handle t, const double* tlwh, const double* c
   std::vector<int> confirmed, unconfirmed;
   for (int i = 0; i < (int)t->tracks.size(); ++i)
     (t->tracks[i].state == kConfirmed ? confirmed : unconfirmed).push_back(i);
+  if (appearance_costs(t, dets, confirmed)) return 1;
   // matching_cascade (linear_assignment.py:82-145)
   std::vector<int> unmatched_dets(N);
   for (int j = 0; j < N; ++j) unmatched_dets[j] = j;
@@ -557,7 +543,7 @@ struct STrk {
   int tracklet_len = 0, frame_id = 0, start_frame = 0;
   std::vector<float> smooth, curr;
   double det_tlwh[4], det_conf = 0.0;
-  float alpha = 0.9f;
+  double alpha = 0.9;                    // Python float (multitracker.py:34); cast per use, as numpy does
 
   void tlwh(double* o) const {           // multitracker.py:119-130
     if (!has_kf) { for (int i = 0; i < 4; ++i) o[i] = tlwh0[i]; return; }
@@ -591,7 +577,7 @@ void update_features(STrk& t, std::vector<float> feat, std::vector<float>* feat_
     t.smooth = t.curr;
     if (feat_inout) *feat_inout = t.curr;
   } else {
-    const float a = t.alpha, b = (float)(1.0 - (double)t.alpha);
+    const float a = (float)t.alpha, b = (float)(1.0 - t.alpha);     // float32(0.9), float32(1 - 0.9) = float32(0.1)
     for (size_t i = 0; i < feat.size(); ++i) t.smooth[i] = a * t.smooth[i] + b * feat[i];
     normalize_f32(t.smooth);
   }
@@ -666,7 +652,7 @@ std::vector<STrkP> sub_stracks(const std::vector<STrkP>& a, const std::vector<ST
 
 struct odt_tmot {
   double det_thresh, max_frame_lost, emb_max_dist, iou1, iou2;
-  float alpha;
+  double alpha;
   int frame_id = 0;
   std::vector<odt::STrkP> tracked, lost, removed, output;
 };
@@ -681,7 +667,7 @@ int odt_tmot_create(double conf_thres, double track_max_second_lost, double emb_
   t->det_thresh = conf_thres;
   t->max_frame_lost = track_max_second_lost * frame_rate / frame_gap;      // multitracker.py:187
   t->emb_max_dist = emb_max_dist; t->iou1 = iou_max_dist1; t->iou2 = iou_max_dist2;
-  t->alpha = (float)emb_smooth_alpha;
+  t->alpha = emb_smooth_alpha;
   *out = t;
   return 0;
 }

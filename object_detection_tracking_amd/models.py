@@ -140,9 +140,11 @@ class _Engine(object):
             self._feats[:total].copy() if want_feats else None,
             self._pooled[:total].copy() if want_pooled else None)
 
-  def submit(self, frames):
-    """Pipelined ingest (odt_submit): enqueue H2D + forward + D2H for one batch of host
-    frames and return a ticket at once; at most two tickets may be outstanding."""
+  def submit(self, frames, want_feats=True, want_pooled=True):
+    """Pipelined ingest (odt_submit_ex): enqueue H2D + forward + D2H for one batch of host
+    frames and return a ticket at once; at most two tickets may be outstanding.  Only what is
+    asked for crosses PCIe on the way back (the [M,C,7,7] features are 40 MB per 8-frame batch,
+    their 7x7 mean 0.8 MB)."""
     fr = np.ascontiguousarray(frames)
     if fr.dtype == np.uint8:
       dt = ODT_DTYPE_U8
@@ -151,7 +153,8 @@ class _Engine(object):
       dt = ODT_DTYPE_F32
     assert fr.shape == (self.batch, self.src_height, self.src_width, 3), fr.shape
     t = C.c_int()
-    self.lib.check(self.lib.dll.odt_submit(self.h, fr.ctypes.data_as(C.c_void_p), dt, C.byref(t)))
+    want = (1 if want_feats else 0) | (2 if want_pooled else 0) | (4 if self.add_mask else 0)
+    self.lib.check(self.lib.dll.odt_submit_ex(self.h, fr.ctypes.data_as(C.c_void_p), dt, want, C.byref(t)))
     return t.value
 
   def collect(self, ticket, want_feats=True, want_pooled=False):
@@ -168,12 +171,14 @@ class _Engine(object):
             self._feats[:total].copy() if want_feats else None,
             self._pooled[:total].copy() if want_pooled else None)
 
-  def forward_stream(self, batches, want_feats=True, want_pooled=False):
+  def forward_stream(self, batches, want_feats=False, want_pooled=True):
     """Generator over an iterable of frame batches with two batches in flight: the H2D of
-    batch i+1 and the D2H of batch i-1 overlap the forward of batch i."""
+    batch i+1 and the D2H of batch i-1 overlap the forward of batch i.  By default the appearance
+    features come back pooled ([M,C]: what create_obj_infos makes of fpn_box_feat anyway,
+    reference deep_sort/utils.py:27-28); want_feats=True returns the [M,C,7,7] tensor."""
     pending = []
     for fr in batches:
-      pending.append(self.submit(fr))
+      pending.append(self.submit(fr, want_feats, want_pooled))
       if len(pending) == 2:
         yield self.collect(pending.pop(0), want_feats, want_pooled)
     while pending:

@@ -35,6 +35,22 @@ def test_submit_collect_equals_forward(backend):
     assert np.array_equal(r0[0], want[0][0]) and np.array_equal(r1[0], want[1][0])
     with pytest.raises(OdtError, match="ticket"):
       e.collect(t0)
+    # the tracking loop's default: pooled features only (0.8 MB instead of 40 MB per 8-frame batch) -- the copies ride
+    # behind the forward on the compute stream and the whole batch replays as one cached hipGraph per slot
+    many = batches + batches
+    got = list(e.forward_stream(many))
+    assert len(got) == len(many)
+    for g, w in zip(got, want + want):
+      assert g[4] is None and np.array_equal(g[5], w[5])
+      for a, b in zip(g[:4], w[:4]):
+        assert np.array_equal(a, b)
+    # alternating with tickets that do carry the [M,C,7,7] features (copy stream + event waits)
+    ta = e.submit(batches[0], want_feats=True, want_pooled=False)
+    tb = e.submit(batches[1], want_feats=False, want_pooled=True)
+    ra = e.collect(ta, want_feats=True, want_pooled=False); rb = e.collect(tb, want_feats=False, want_pooled=True)
+    assert np.array_equal(ra[4], want[0][4]) and np.array_equal(rb[5], want[1][5])
+    with pytest.raises(OdtError, match="ODT_WANT_FEATS"):
+      e.collect(e.submit(batches[0], want_feats=False, want_pooled=True), want_feats=True)
   finally:
     m.close()
 
