@@ -34,7 +34,7 @@ def _check_trunk(e, ref, tol):
     assert _rel(rp[..., 3:15].reshape(rp.shape[:3] + (3, 4)), ref["rpn_deltas%d" % l]) < tol
 
 
-def _run_single(lib, cfg, H, W, tol=2e-5, box_tol=None):
+def _run_single(lib, cfg, H, W, tol=2e-5, box_tol=None, budget=0):
   w = weights_for(cfg)
   fr = synthetic_frames(1, H, W)
   ref = OracleModel(cfg, w).forward(fr[0])
@@ -50,10 +50,12 @@ def _run_single(lib, cfg, H, W, tol=2e-5, box_tol=None):
     assert n == ref["proposals"].shape[0]
     pm, rm = match_detections(e.tap("proposals")[0, 0, :n], np.zeros(n), np.zeros(n),
                               ref["proposals"], np.zeros(n), np.zeros(n), box_tol, 1)
-    assert pm + rm <= max(2, n // 50), "proposal sets differ: %d/%d of %d" % (pm, rm, n)
+    # mismatch budget: 0 -- every full-size configuration measured 0 unmatched proposals / detections on the MI355X in
+    # both arithmetic modes (profiles/r02_parity.json)
+    assert pm + rm <= budget, "proposal sets differ: %d/%d of %d" % (pm, rm, n)
     miss, extra = match_detections(boxes, labels, probs, ref["final_boxes"], ref["final_labels"],
                                    ref["final_probs"], box_tol, 1e-4)
-    assert miss + extra <= max(2, len(ref["final_boxes"]) // 25), (miss, extra)
+    assert miss + extra <= budget, (miss, extra)
     if miss + extra == 0 and np.array_equal(labels, ref["final_labels"]):
       np.testing.assert_allclose(boxes, ref["final_boxes"], rtol=0, atol=box_tol)
       assert _rel(feats, ref["fpn_box_feat"]) < 10 * tol
@@ -69,7 +71,7 @@ def test_forward_single_small(backend):
   assert miss == 0 and extra == 0
 
 
-def _run_multi(lib, cfg, B, H, W, tol=2e-5, w=None, info=None):
+def _run_multi(lib, cfg, B, H, W, tol=2e-5, w=None, info=None, budget=0):
   w = weights_for(cfg) if w is None else w
   fr = synthetic_frames(B, H, W)
   ref = OracleModel(cfg, w).forward_multi(fr)
@@ -92,7 +94,7 @@ def _run_multi(lib, cfg, B, H, W, tol=2e-5, w=None, info=None):
                                      ref["final_boxes"][b, :v], ref["final_labels"][b, :v],
                                      ref["final_probs"][b, :v], box_tol, 1e-4)
       tot += miss + extra
-    assert tot <= max(2, int(valid.sum()) // 25), tot
+    assert tot <= budget, tot
     if tot == 0 and np.array_equal(labels, ref["final_labels"]):
       assert _rel(feats, ref["fpn_box_feat"]) < 10 * tol
     return tot
@@ -152,7 +154,7 @@ def test_forward_multi_r101_b2_256x448(hip_lib):
 def test_forward_single_r101_1080p(hip_lib):
   """BASELINE config #2: 1920x1080, b=1, K=300."""
   cfg = make_config(rpn_test_post_nms_topk=300)
-  _run_single(hip_lib, cfg, 1080, 1920, tol=5e-5)
+  _run_single(hip_lib, cfg, 1080, 1920, tol=1e-5)
 
 
 @pytest.mark.gpu
@@ -160,7 +162,7 @@ def test_forward_multi_r101_b8_1080p(hip_lib):
   """BASELINE config #3, the benchmark workload itself: 8 frames of 1920x1080 through the
   batched graph, every stage tap and the final detections against the oracle."""
   cfg = make_config(rpn_test_post_nms_topk=300, im_batch_size=8)
-  _run_multi(hip_lib, cfg, 8, 1080, 1920, tol=5e-5)
+  _run_multi(hip_lib, cfg, 8, 1080, 1920, tol=1e-5)
 
 
 @pytest.mark.gpu
