@@ -277,6 +277,17 @@ int odt_op_detections(int device, int graph, int B, int K, int C,
                       float* boxes, float* probs, int32_t* labels,
                       int32_t* valid);
 
+/* the selection half of the tail alone, on caller-supplied boxes / scores: per-class NMS + merged top per_im
+ * (graph ODT_GRAPH_SINGLE: candidates are score > score_thresh, nms_return_masks + fastrcnn_predictions,
+ * models.py:1202-1223,1258-1304; ODT_GRAPH_MULTI: every one of the first ncand[b] rows is a candidate,
+ * tf.image.combined_non_max_suppression(score_threshold=-inf, clip_boxes=False), models.py:2959-2965, the other
+ * images' rows counting as zero-score padding slots).  boxes_in [B,N,C,4], scores_in [B,N,C] (foreground classes
+ * only), ncand [B]; labels come back 1-based.  For feeding the kernels TensorFlow's published known-answer vectors. */
+int odt_op_class_nms(int device, int graph, int B, int N, int C, const float* boxes_in,
+                     const float* scores_in, const int32_t* ncand, float score_thresh,
+                     float nms_thresh, int per_im, float* boxes, float* scores,
+                     int32_t* labels, int32_t* valid);
+
 #ifdef __cplusplus
 }
 #endif

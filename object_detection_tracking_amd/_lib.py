@@ -79,7 +79,7 @@ class OdtLib(object):
       "odt_profile_read", "odt_profile_layer", "odt_nn_cosine", "odt_op_conv2d", "odt_op_conv2d_cat",
       "odt_op_preprocess",
       "odt_op_maxpool", "odt_op_topk", "odt_op_nms", "odt_op_proposals",
-      "odt_op_roi_align", "odt_op_detections", "odt_tracker_create", "odt_tracker_destroy",
+      "odt_op_roi_align", "odt_op_detections", "odt_op_class_nms", "odt_tracker_create", "odt_tracker_destroy",
       "odt_tracker_predict", "odt_tracker_update", "odt_tracker_tracks", "odt_lsap",
       "odt_tmot_create", "odt_tmot_destroy", "odt_tmot_reset", "odt_tmot_update", "odt_tmot_tracks",
   ]
@@ -153,6 +153,8 @@ class OdtLib(object):
                                                     C.c_int, C.c_int, c_float_p, C.c_float,
                                                     C.c_float, C.c_float, C.c_int, c_float_p,
                                                     c_float_p, c_int_p, c_int_p]
+    d.odt_op_class_nms.argtypes = [C.c_int] * 5 + [c_float_p, c_float_p, c_int_p, C.c_float, C.c_float, C.c_int,
+                                                   c_float_p, c_float_p, c_int_p, c_int_p]
 
   def check(self, rc):
     if rc != 0:

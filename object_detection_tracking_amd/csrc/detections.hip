@@ -182,6 +182,19 @@ __global__ void __launch_bounds__(kSelThreads) final_select_kernel(DetectParams 
 
 }  // namespace
 
+// the selection half alone (per-class NMS + merged top result_per_im) over boxes / scores supplied by the caller:
+// the kernels behind tf.image.combined_non_max_suppression / nms_return_masks + fastrcnn_predictions, for tests that
+// feed them known-answer vectors (p.probs [B*K, C] with column 0 unused, p.dec_boxes [B*K, C-1, 4] filled)
+int launch_class_nms(const DetectParams& p, hipStream_t stream) {
+  ODT_CHECK(p.K >= 1 && p.K <= kMaxTopK, "class_nms: K must be in [1,1024]");
+  ODT_CHECK(p.C >= 2 && p.C <= 64, "class_nms: 2..64 classes");
+  ODT_CHECK((p.C - 1) * p.per_im <= kMaxFinal, "class_nms: (C-1)*result_per_im too large");
+  hipLaunchKernelGGL(class_nms_kernel, dim3(p.C - 1, p.B), dim3(kSelThreads), 0, stream, p);
+  hipLaunchKernelGGL(final_select_kernel, dim3(p.B), dim3(kSelThreads), 0, stream, p);
+  ODT_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_detections(const DetectParams& p, hipStream_t stream) {
   ODT_CHECK(p.K >= 1 && p.K <= kMaxTopK, "detections: K must be in [1,1024]");
   ODT_CHECK(p.C >= 2 && p.C <= 64, "detections: 2..64 classes");

@@ -1548,4 +1548,28 @@ int odt_op_detections(int device, int graph, int B, int K, int C, const float* c
   return ov.get(valid, B);
 }
 
+int odt_op_class_nms(int device, int graph, int B, int N, int C, const float* boxes_in, const float* scores_in,
+                     const int32_t* ncand, float score_thresh, float nms_thresh, int per_im, float* boxes,
+                     float* scores, int32_t* labels, int32_t* valid) {
+  ODT_CHECK(boxes_in && scores_in && ncand && boxes && scores && labels && valid, "odt_op_class_nms: null argument");
+  ODT_CHECK(C >= 1 && N >= 1, "odt_op_class_nms: bad sizes");
+  if (set_dev(device)) return 1;
+  const int rows = B * N, Cp = C + 1;
+  std::vector<float> pr((size_t)rows * Cp, 0.f);
+  for (int r = 0; r < rows; ++r) std::memcpy(&pr[(size_t)r * Cp + 1], &scores_in[(size_t)r * C], sizeof(float) * C);
+  DetectParams p; std::memset(&p, 0, sizeof(p));
+  Tmp<float> dd, dpr, ob, op; Tmp<int> dn, ck, cc, ol, ov;
+  if (dd.alloc((size_t)rows * C * 4) || dd.put(boxes_in) || dpr.alloc(pr.size()) || dpr.put(pr.data()) || dn.alloc(B) ||
+      dn.put(ncand) || ck.alloc((size_t)B * C * per_im) || cc.alloc((size_t)B * C) || ob.alloc((size_t)B * per_im * 4) ||
+      op.alloc((size_t)B * per_im) || ol.alloc((size_t)B * per_im) || ov.alloc(B)) return 1;
+  p.graph = graph; p.B = B; p.K = N; p.C = Cp; p.nprops = dn.d;
+  p.score_thresh = score_thresh; p.nms_thresh = nms_thresh; p.per_im = per_im;
+  p.dec_boxes = dd.d; p.probs = dpr.d; p.cls_keep = ck.d; p.cls_count = cc.d;
+  p.out_boxes = ob.d; p.out_probs = op.d; p.out_labels = ol.d; p.out_valid = ov.d;
+  if (launch_class_nms(p, nullptr)) return 1;
+  ODT_HIP(hipDeviceSynchronize());
+  if (ob.get(boxes, ob.n) || op.get(scores, op.n) || ol.get(labels, ol.n)) return 1;
+  return ov.get(valid, B);
+}
+
 }  // extern "C"

@@ -242,6 +242,7 @@ struct DetectParams {
   int* out_valid;              // [B]
 };
 int launch_detections(const DetectParams& p, hipStream_t stream);
+int launch_class_nms(const DetectParams& p, hipStream_t stream);
 
 // ----------------------------------------------------------------- tracker (K15)
 // gal_n / det_n: device scratch for the L2-normalised copies ([G,D] / [N,D])

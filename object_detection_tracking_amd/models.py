@@ -42,6 +42,38 @@ class TensorHandle(object):
     return "<odt tensor %s:0>" % self.name
 
 
+class _Graph(object):
+  """The part of ``tf.Graph`` the frozen-model route uses: tensors by name (reference
+  models.py:219-238 ``self.graph.get_tensor_by_name("%s/final_boxes:0" % var_prefix)``)."""
+
+  def __init__(self):
+    self._tensors = {}
+
+  def _register(self, prefix, handle):
+    self._tensors["%s/%s:0" % (prefix, handle.name)] = handle
+
+  def _unregister(self, prefix):
+    for k in [k for k in self._tensors if k.startswith(prefix + "/")]:
+      del self._tensors[k]
+
+  def get_tensor_by_name(self, name):
+    if name in self._tensors:
+      return self._tensors[name]
+    # un-prefixed "final_boxes:0" resolves when exactly one imported model carries it
+    hits = [h for k, h in self._tensors.items() if k.split("/", 1)[-1] == name]
+    if len(hits) == 1:
+      return hits[0]
+    raise KeyError("The name %r refers to a Tensor which does not exist%s" %
+                   (name, " (ambiguous: %d imported models)" % len(hits) if hits else ""))
+
+
+_DEFAULT_GRAPH = _Graph()
+
+
+def get_default_graph():
+  return _DEFAULT_GRAPH
+
+
 class _Engine(object):
   """One static plan (fixed batch, H, W) on one GPU."""
 
@@ -282,14 +314,24 @@ class _DetectorBase(object):
         raise NotImplementedError("--add_mask is built for the single-image graph (Mask_RCNN_FPN)")
       self.final_masks = TensorHandle(self, "final_masks")
 
+  # static plans kept per model: a plan owns its activations, a device copy of the weights and pinned staging
+  # (tens of GB at 8 x 1080p), so frames of ever-changing sizes (the reference's image-list drivers) must not
+  # accumulate them: least-recently-used plans beyond this many are closed
+  max_engines = 4
+
   def engine(self, batch, height, width, src_hw=None):
     key = (batch, height, width) if src_hw is None else (batch, height, width) + tuple(src_hw)
-    if key not in self._engines:
-      self._engines[key] = _Engine(self.lib, self.config, self.graph, batch, height, width,
-                                   self.weights, self.gpuid, num_class=self.head_num_class)
+    e = self._engines.pop(key, None)
+    if e is None:
+      while len(self._engines) >= max(1, int(self.max_engines)):
+        old = next(iter(self._engines))
+        self._engines.pop(old).close()
+      e = _Engine(self.lib, self.config, self.graph, batch, height, width,
+                  self.weights, self.gpuid, num_class=self.head_num_class)
       if src_hw is not None:
-        self._engines[key].set_source_size(*src_hw)
-    return self._engines[key]
+        e.set_source_size(*src_hw)
+    self._engines[key] = e           # (re)insert: dict order = recency
+    return e
 
   def engine_for_raw(self, batch, src_height, src_width):
     """Engine for frames as they come off the decoder: (engine, scale) with the plan sized by
@@ -402,11 +444,95 @@ class Session(object):
     return False
 
   def run(self, fetches, feed_dict=None):
-    single = isinstance(fetches, TensorHandle)
+    """Fetches / feed keys are tensor handles or TF tensor names ("model_0/final_boxes:0", or "final_boxes:0"
+    when one frozen model is imported): the reference's frozen route addresses everything by name."""
+    single = isinstance(fetches, (TensorHandle, str))
     fl = [fetches] if single else list(fetches)
+    fl = [_DEFAULT_GRAPH.get_tensor_by_name(f) if isinstance(f, str) else f for f in fl]
+    feed = {(_DEFAULT_GRAPH.get_tensor_by_name(k) if isinstance(k, str) else k): v
+            for k, v in (feed_dict or {}).items()}
     model = fl[0].model
-    out = model._fetch(fl, feed_dict)
+    out = model._fetch(fl, feed)
     return out[0] if single else out
+
+
+def config_from_weights(weights, add_mask=False, is_multi=False, **overrides):
+  """Architecture of a frozen model from its tensors (the reference's Mask_RCNN_FPN_frozen needs no config: the
+  graph is in the file; here the file is a weight container, so what the graph would say is read off the shapes):
+  bottlenecks per stage, classes, FPN / head widths, class-agnostic box head.  Everything that is a graph constant
+  rather than a tensor (rpn_test_post_nms_topk, thresholds, frame size) keeps the reference's defaults unless
+  overridden."""
+  from .config import make_config
+  blocks = [0, 0, 0, 0]
+  for k in weights:
+    parts = k.split("/")
+    if len(parts) >= 3 and parts[0].startswith("group") and parts[1].startswith("block") and parts[2] == "conv1":
+      g, b = int(parts[0][5:]), int(parts[1][5:])
+      blocks[g] = max(blocks[g], b + 1)
+  num_class = int(np.asarray(weights["fastrcnn/outputs/class/W"]).shape[-1])
+  nbox = int(np.asarray(weights["fastrcnn/outputs/box/W"]).shape[-1])
+  kw = dict(resnet_num_block=blocks, num_class=num_class, add_mask=bool(add_mask),
+            use_frcnn_class_agnostic=(nbox == 4 or nbox == 8) and num_class > 2,
+            im_batch_size=2 if is_multi else 1)
+  kw.update(overrides)
+  cfg = make_config(**kw)
+  cfg.fpn_num_channel = int(np.asarray(weights["fpn/lateral_1x1_c2/W"]).shape[-1])
+  cfg.fpn_frcnn_fc_head_dim = int(np.asarray(weights["fastrcnn/fc6/W"]).shape[-1])
+  return cfg
+
+
+class Mask_RCNN_FPN_frozen(object):
+  """``Mask_RCNN_FPN_frozen(modelpath, gpuid, add_mask, is_multi)`` (reference models.py:198-263): a frozen ``.pb``
+  imported under the name scope ``model_<gpuid>`` whose placeholders and outputs are looked up BY NAME --
+  ``model_0/image:0`` in, ``model_0/final_boxes:0``, ``final_labels:0``, ``final_probs:0``, ``fpn_box_feat:0``
+  (``final_valid_indices:0`` with is_multi, ``final_masks:0`` with add_mask) out -- and run with
+  ``sess.run([...], feed_dict=model.get_feed_dict_forward(img))``.  Same attributes, same feed-dict methods; the
+  tensors are also reachable through ``get_default_graph().get_tensor_by_name`` and as plain strings in
+  ``Session.run``.  The file is read without TensorFlow (frozen_pb.py); pass the driver's ``config`` for what is
+  a graph constant in the file (rpn_test_post_nms_topk ...), else config_from_weights() fills in the reference's
+  defaults."""
+
+  def __init__(self, modelpath, gpuid, add_mask=False, is_multi=False, config=None, lib=None):
+    self.graph = get_default_graph()
+    self.is_multi = is_multi
+    self.var_prefix = "model_%s" % gpuid
+    weights = load_frozen_pb(modelpath)
+    if config is None:
+      config = config_from_weights(weights, add_mask=add_mask, is_multi=is_multi)
+    cls = Mask_RCNN_FPN_multi if is_multi else Mask_RCNN_FPN
+    self._model = cls(config, gpuid=gpuid, weights=weights, lib=lib)
+    self.config = self._model.config
+    names = ["image", "final_boxes", "final_labels", "final_probs", "fpn_box_feat"]
+    if is_multi:
+      names.append("final_valid_indices")
+    if add_mask:
+      names.append("final_masks")
+    self.graph._unregister(self.var_prefix)             # re-import under the same scope replaces it
+    for n in names:
+      h = getattr(self._model, n)
+      self.graph._register(self.var_prefix, h)
+      setattr(self, n, self.graph.get_tensor_by_name("%s/%s:0" % (self.var_prefix, n)))
+
+  def get_feed_dict_forward(self, imgdata):              # reference models.py:241-255
+    if self.is_multi:
+      return {self.image: np.stack(imgdata, axis=0)}
+    return {self.image: imgdata}
+
+  def get_feed_dict_forward_multi(self, imgs):           # reference models.py:257-264
+    return {self.image: np.stack(imgs, axis=0)}
+
+  def predict(self, *a, **k):
+    return self._model.predict(*a, **k)
+
+  def predict_batch(self, *a, **k):
+    return self._model.predict_batch(*a, **k)
+
+  def engine(self, *a, **k):
+    return self._model.engine(*a, **k)
+
+  def close(self):
+    self.graph._unregister(self.var_prefix)
+    self._model.close()
 
 
 def get_model(config, gpuid=0, task=0, controller="/cpu:0", is_multi=False, weights=None,
@@ -418,6 +544,10 @@ def get_model(config, gpuid=0, task=0, controller="/cpu:0", is_multi=False, weig
   if getattr(config, "is_efficientdet", False):        # reference models.py:103-104,112-113
     from .efficientdet import EfficientDet
     return EfficientDet(config, gpuid=gpuid, weights=weights, lib=lib)
+  if weights is None and getattr(config, "is_load_from_pb", False):   # reference models.py:102-108
+    path = getattr(config, "load_from", None) or getattr(config, "model_path", None)
+    return Mask_RCNN_FPN_frozen(path, gpuid, add_mask=getattr(config, "add_mask", False), is_multi=is_multi,
+                                config=config, lib=lib)
   cls = Mask_RCNN_FPN_multi if is_multi else Mask_RCNN_FPN
   return cls(config, gpuid=gpuid, weights=weights, lib=lib)
 

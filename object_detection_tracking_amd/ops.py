@@ -156,6 +156,24 @@ def detections(graph, cls_logits, box_logits, props, nprops, img_hw, reg_weights
   return boxes, probs, labels, valid
 
 
+def class_nms(graph, boxes, scores, per_im, iou_thresh, score_thresh=0.0, ncand=None, lib=None, device=0):
+  """The selection half of the tail on caller-supplied data: per-class NMS + merged top ``per_im``
+  (tf.image.combined_non_max_suppression for graph ODT_GRAPH_MULTI, nms_return_masks + fastrcnn_predictions for
+  ODT_GRAPH_SINGLE).  boxes [B,N,C,4] (or [B,N,1,4], shared by the classes), scores [B,N,C].
+  Returns (boxes [B,per_im,4], scores [B,per_im], classes [B,per_im] 0-based, valid [B])."""
+  lib = _L(lib)
+  sc = f32(scores); B, N, Cn = sc.shape
+  bx = f32(boxes)
+  if bx.shape[2] == 1 and Cn > 1:
+    bx = f32(np.repeat(bx, Cn, axis=2))
+  nc = i32(ncand if ncand is not None else np.full((B,), N))
+  ob = np.zeros((B, per_im, 4), np.float32); os_ = np.zeros((B, per_im), np.float32)
+  ol = np.zeros((B, per_im), np.int32); ov = np.zeros((B,), np.int32)
+  lib.check(lib.dll.odt_op_class_nms(device, graph, B, N, Cn, fptr(bx), fptr(sc), iptr(nc), score_thresh, iou_thresh,
+                                     per_im, fptr(ob), fptr(os_), iptr(ol), iptr(ov)))
+  return ob, os_, ol - 1, ov
+
+
 def nn_cosine(gallery, seg_offsets, dets, lib=None, device=0):
   """NearestNeighborDistanceMetric.distance, cosine (reference
   deep_sort/nn_matching.py:156-177) -> float64 [T,N]."""

@@ -263,6 +263,66 @@ def test_get_model_from_frozen_pb_and_checkpoint_dir(emu_lib, tmp_path):
       m1.close()
 
 
+def test_frozen_model_named_tensor_contract(emu_lib, tmp_path):
+  """Mask_RCNN_FPN_frozen (reference models.py:198-263): the frozen file is imported under ``model_<gpuid>`` and
+  every placeholder / output is addressed BY NAME -- get_tensor_by_name("model_0/final_boxes:0"), sess.run with
+  handles or names, feed through get_feed_dict_forward[_multi]."""
+  from object_detection_tracking_amd.frozen_pb import write_frozen_pb
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1])
+  w = weights_for(cfg)
+  pb = str(tmp_path / "obj_v3.pb")
+  write_frozen_pb(pb, w)
+  fr = synthetic_frames(2, 64, 96)
+  m0 = models.get_model(cfg, 0, weights=w, lib=emu_lib)
+  want = m0.predict(fr[0]); m0.close()
+  m = models.Mask_RCNN_FPN_frozen(pb, 0, add_mask=False, is_multi=False, config=cfg, lib=emu_lib)
+  try:
+    g = models.get_default_graph()
+    assert m.var_prefix == "model_0" and m.image is g.get_tensor_by_name("model_0/image:0")
+    assert m.final_boxes is g.get_tensor_by_name("model_0/final_boxes:0")
+    with pytest.raises(KeyError):
+      g.get_tensor_by_name("model_0/final_valid_indices:0")        # single-image import does not carry it
+    sess = models.Session()
+    got = sess.run([m.final_boxes, m.final_labels, m.final_probs, m.fpn_box_feat],
+                   feed_dict=m.get_feed_dict_forward(fr[0]))
+    for a_, b_ in zip(want, got):
+      assert np.array_equal(a_, b_)
+    # by name, scoped and (one imported model) unscoped; a single fetch returns the array itself
+    got = sess.run(["model_0/final_boxes:0", "final_probs:0"], feed_dict={"model_0/image:0": fr[0]})
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[2])
+    assert np.array_equal(sess.run("final_labels:0", feed_dict={"image:0": fr[0]}), want[1])
+  finally:
+    m.close()
+  with pytest.raises(KeyError):
+    models.get_default_graph().get_tensor_by_name("model_0/final_boxes:0")    # closed models leave the graph
+  # the architecture read off the file when no config is given (reference: the graph is in the .pb)
+  c2 = models.config_from_weights(w)
+  assert list(c2.resnet_num_block) == [1, 1, 1, 1] and c2.num_class == cfg.num_class
+  # batched import: model_0/final_valid_indices:0 exists, feed through get_feed_dict_forward_multi
+  cfgm = small_config(resnet_num_block=[1, 1, 1, 1], im_batch_size=2, rpn_test_post_nms_topk=32)
+  mm = models.Mask_RCNN_FPN_frozen(pb, 0, is_multi=True, config=cfgm, lib=emu_lib)
+  try:
+    boxes, valid = models.Session().run(["model_0/final_boxes:0", "model_0/final_valid_indices:0"],
+                                        feed_dict=mm.get_feed_dict_forward_multi([fr[0], fr[1]]))
+    assert boxes.shape == (2, cfgm.result_per_im, 4) and valid.shape == (2,) and valid.dtype == np.int32
+  finally:
+    mm.close()
+
+
+def test_engine_cache_is_bounded(emu_lib):
+  """Frames of ever-changing sizes must not accumulate static plans (each owns activations + a weight copy)."""
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1], rpn_test_post_nms_topk=16)
+  m = models.get_model(cfg, 0, weights=weights_for(cfg), lib=emu_lib)
+  try:
+    m.max_engines = 2
+    e1 = m.engine(1, 64, 96); e2 = m.engine(1, 64, 128)
+    assert m.engine(1, 64, 96) is e1                       # hit: refreshed
+    e3 = m.engine(1, 96, 96)                               # evicts the least recently used: e2
+    assert len(m._engines) == 2 and e2.h is None and e1.h is not None and e3.h is not None
+  finally:
+    m.close()
+
+
 # ---- TF checkpoint route (reference obj_detect_tracking.py:404-416; obj_v3_model.tgz is one) ----
 def test_tf_checkpoint_reader_roundtrip(tmp_path):
   from object_detection_tracking_amd.tf_checkpoint import load_checkpoint, read_index, write_checkpoint
