@@ -191,12 +191,12 @@ def main():
       eng.synchronize(); e2.synchronize()
       extra["two_streams_per_gpu_fps"] = 2 * 6 * B / (time.perf_counter() - t1)
       m2.close()
-      # (d) the same step with every conv on the exact-f32 MFMA kernel (ODT_CONV_SPLIT=0): the
+      # (d) the same step with every conv on the exact-f32 MFMA kernel (config conv_arith = "f32"): the
       # other arithmetic mode of the library, measured in the same process on the same box
-      prev = os.environ.get("ODT_CONV_SPLIT")
       try:
-        os.environ["ODT_CONV_SPLIT"] = "0"
-        m3 = models.get_model(cfg, local_rank, weights=weights, is_multi=True)
+        cfg3 = make_config(rpn_test_post_nms_topk=args.topk, im_batch_size=B, max_size=max(H, W),
+                           short_edge_size=min(H, W), conv_arith="f32")
+        m3 = models.get_model(cfg3, local_rank, weights=weights, is_multi=True)
         e3 = m3.engine(B, H, W)
         for k in range(1 + 5):
           if k == 1:
@@ -204,14 +204,10 @@ def main():
           e3.forward_device_async(dev_frames.data_ptr(), ODT_DTYPE_U8)
         e3.synchronize()
         extra["exact_f32_mfma_only_fps"] = 5 * B / (time.perf_counter() - t1)
+        extra["exact_f32_mfma_only_handle"] = e3.describe()["conv_arith"]
         m3.close()
       except Exception as ex:     # never fatal: `value` above is already measured
         extra["exact_f32_mfma_only_fps"] = "failed: %r" % (ex,)
-      finally:
-        if prev is None:
-          os.environ.pop("ODT_CONV_SPLIT", None)
-        else:
-          os.environ["ODT_CONV_SPLIT"] = prev
     extra.update(detect_track_leg(eng, frames, B, local_rank))
     if world == 1 and S == 1:
       # (e) trained RPNs score most anchors negative, so images keep fewer than K proposals (zero-padded NMS slots,
@@ -298,6 +294,7 @@ def main():
                        "exact bf16 x bf16 MFMA products of a 3-way bf16 split of both f32 operands (error at the "
                        "exact-f32 kernel's level, DESIGN.md section 3; ODT_CONV_SPLIT=0: exact-f32 MFMA everywhere)"
                        % (fam["split"][0], fam["split"][0] + fam["f32"][0])),
+        "handle": eng.describe(),      # the arithmetic mode / kernel families as the handle itself reports them
         "data": "synthetic",
         "config": {"workload": "ResNet-101-dilated+FPN detector + RoI appearance features, "
                                "%dx%d, batch %d per GPU, rpn_post_nms_topk %d, 15 classes, "

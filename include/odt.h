@@ -70,7 +70,18 @@ typedef struct odt_config {
   int32_t eff_det;          /* -1: backbone only; 0..7: efficientdet-d0..d7 feature network + class / box nets */
   int32_t eff_topk;         /* efficientdet_max_detection_topk (5000)         */
   float eff_image_scale;    /* image_scale_to_original applied to the output boxes (wrapper :57) */
+  int32_t conv_arith;       /* ODT_ARITH_*: how the conv / FC products are evaluated (fixed per handle, see odt_describe) */
+  int32_t conv_split_family;/* 0 library default; 1..3 newest bf16x3 kernel family allowed (A/B runs)                 */
 } odt_config;
+
+/* conv_arith: all modes keep f32 tensors and f32 accumulation.  ODT_ARITH_F32: every product on the exact-f32 MFMA
+ * (v_mfma_f32_32x32x2_f32); ODT_ARITH_BF16X3: layers large enough to fill the chip evaluate each f32 product as six
+ * exact bf16 x bf16 MFMA products of a 3-way bf16 split of both operands (error at the f32 kernel's level; csrc/
+ * conv_split.hip); ODT_ARITH_DEFAULT = BF16X3.  The ODT_CONV_* environment variables are debug overrides, read once
+ * when the handle is created and reported by odt_describe. */
+#define ODT_ARITH_DEFAULT 0
+#define ODT_ARITH_F32 1
+#define ODT_ARITH_BF16X3 2
 
 /* Caller-owned host output buffers (capacities in elements of the row type).
  * Replaces the numpy arrays sess.run returns (models.py:965-973 / :2311-2320).
@@ -156,6 +167,10 @@ int odt_submit(odt_handle h, const void* frames, int dtype, int* ticket);
 int odt_submit_ex(odt_handle h, const void* frames, int dtype, int want, int* ticket);
 int odt_collect(odt_handle h, int ticket, odt_outputs* out);
 int odt_ingest_buffer(odt_handle h, int dtype, void** buffer, size_t* bytes);
+
+/* What this handle runs, as a JSON object: conv arithmetic mode, launches per kernel family, policy thresholds,
+ * number of ODT_CONV_* environment overrides that were applied at creation. */
+int odt_describe(odt_handle h, char* buf, int cap);
 
 /* Debug / parity taps: copy a named stage tensor (device layout: NHWC) to the
  * host.  shape_out receives up to 4 dims.  Names: "image_pad", "conv0",

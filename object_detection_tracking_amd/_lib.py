@@ -22,6 +22,7 @@ c_i64_p = C.POINTER(C.c_int64)
 c_double_p = C.POINTER(C.c_double)
 
 ODT_DTYPE_U8, ODT_DTYPE_F32 = 0, 1
+ODT_ARITH_DEFAULT, ODT_ARITH_F32, ODT_ARITH_BF16X3 = 0, 1, 2
 ODT_GRAPH_SINGLE, ODT_GRAPH_MULTI, ODT_GRAPH_EFFNET = 0, 1, 2
 RPN_CH = 16
 
@@ -38,7 +39,7 @@ class OdtConfig(C.Structure):
       ("bbox_reg_weights", C.c_float * 4), ("result_score_thresh", C.c_float),
       ("head_nms_thresh", C.c_float), ("add_mask", C.c_int32), ("mask_dim", C.c_int32),
       ("eff_backbone", C.c_int32), ("eff_det", C.c_int32), ("eff_topk", C.c_int32),
-      ("eff_image_scale", C.c_float),
+      ("eff_image_scale", C.c_float), ("conv_arith", C.c_int32), ("conv_split_family", C.c_int32),
   ]
 
 
@@ -74,7 +75,7 @@ class OdtLib(object):
   SYMBOLS = [
       "odt_last_error", "odt_device_count", "odt_create", "odt_destroy",
       "odt_load_tensor", "odt_finalize_weights", "odt_forward",
-      "odt_forward_async", "odt_synchronize", "odt_submit", "odt_submit_ex", "odt_collect",
+      "odt_forward_async", "odt_synchronize", "odt_describe", "odt_submit", "odt_submit_ex", "odt_collect",
       "odt_ingest_buffer", "odt_set_source_size", "odt_tap", "odt_profile_enable",
       "odt_profile_read", "odt_profile_layer", "odt_nn_cosine", "odt_op_conv2d", "odt_op_conv2d_cat",
       "odt_op_preprocess",
@@ -104,6 +105,7 @@ class OdtLib(object):
     d.odt_forward_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     d.odt_synchronize.argtypes = [C.c_void_p]
     d.odt_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    d.odt_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     d.odt_submit_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
     d.odt_collect.argtypes = [C.c_void_p, C.c_int, C.POINTER(OdtOutputs)]
     d.odt_set_source_size.argtypes = [C.c_void_p, C.c_int, C.c_int]

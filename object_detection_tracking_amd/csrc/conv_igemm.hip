@@ -645,11 +645,15 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
   // build a temporary one
   void* tmp_img = nullptr;
   // (a plan conv without an image stays on the exact-f32 kernel: no allocation on the hot path)
-  const bool split = q.wt_split != nullptr ? conv_split_mode() != 0 : (dev_params == nullptr && conv_split_wanted(q));
+  // (plan convs: the handle's policy decided at plan build -- an attached image means "split"; stand-alone calls:
+  // library defaults + ODT_CONV_* overrides, resolved per call)
+  ConvPolicy pol{};
+  if (q.wt_split == nullptr && dev_params == nullptr) pol = conv_policy_from_env(conv_policy_default());
+  const bool split = q.wt_split != nullptr ? true : (dev_params == nullptr && conv_split_wanted(q, pol));
   if (split && q.wt_split == nullptr) {
     const int Ksp = q.kh * q.kw * q.Cin + (q.in2 != nullptr ? q.Cin2 : 0);
     ODT_HIP(hipMalloc(&tmp_img, conv_split_weight_bytes(q.Cout, Ksp)));
-    conv_split_choose(q);
+    conv_split_choose(q, pol);
     if (conv_make_split_weights(q, tmp_img, stream)) { (void)hipFree(tmp_img); return 1; }
     q.wt_split = tmp_img; modified = true;
   }

@@ -1176,67 +1176,78 @@ bool conv_split_supported(const ConvParams& p) {
          p.in_ldc % 4 == 0 && wbytes < 2147483648.0;
 }
 
-// ---- policy: which convs take the split kernel (launch_conv and the plan builder ask)
-int conv_split_mode() {
-  // default ON (same-box A/B at b=8 1080p: 116.2 -> 143.1 FPS, parity suite green); ODT_CONV_SPLIT=0
-  // keeps every layer on the exact-f32 MFMA kernel.  Read per call: tests and A/B runs flip it.
-  const char* e = getenv("ODT_CONV_SPLIT");
-  return e != nullptr ? atoi(e) : 1;
+// ---- policy: which convs take the split kernels, and which family.  A model's policy is fixed when its handle is
+// created (odt_config.conv_arith / conv_split_family -> odt_create) and recorded with the handle (odt_describe); the
+// ODT_CONV_* environment variables are debug / A-B overrides on top of it, read ONCE per handle -- and per call only by
+// the stand-alone test entry points (odt_op_conv2d ...), which have no handle.
+ConvPolicy conv_policy_default() {
+  ConvPolicy q;
+  q.arith = 1;            // bf16x3 split where it pays (same-box A/B at b=8 1080p: 116 -> 178 FPS, parity suite green)
+  q.family = 3;           // conv_split3_kernel where its tiles fill the chip
+  q.min_tiles = 256;      // one- / two-stage kernels: A/B at b=8 and b=1: 256 > 384 > 128 >> 64
+  q.min_tiles3 = 200;
+  q.min_k = 64;           // A/B at b=8: K >= 256: 155.0, >= 128: 156.2, >= 64: 156.6 FPS
+  q.min_bn = 0; q.force_bm3 = 0; q.short_k = 0; q.src2 = true; q.res2 = true; q.env_overrides = 0;
+  return q;
 }
 
-bool conv_split_wanted(const ConvParams& p) {
-  if (conv_split_mode() == 0 || !conv_split_supported(p)) return false;
-  // 128 x 256 / 256 x 128 / 256 x 64 tiles, two workgroups per CU: below one workgroup per CU the
-  // exact-f32 kernel's smaller tiles fill the chip better (b=1 res4: 64 tiles)
-  const char* e = getenv("ODT_CONV_SPLIT_MINTILES");
-  const long min_tiles = e != nullptr ? atol(e) : 256L;   // A/B at b=8 and b=1: 256 > 384 > 128 >> 64
-  // (A/B at b=8: the split tile also wins on the short reductions -- K >= 256: 155.0, >= 128: 156.2,
-  // >= 64: 156.6 FPS; ODT_CONV_SPLIT_MINK is the tuning knob)
-  const char* ek = getenv("ODT_CONV_SPLIT_MINK");
-  if (p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0) < (ek != nullptr ? atoi(ek) : 64)) return false;
-  const char* e2 = getenv("ODT_CONV_SPLIT_SRC2");        // tuning knob: 0 keeps the fused stage-entry convs on the f32 kernel
-  if (p.in2 != nullptr && e2 != nullptr && e2[0] == '0') return false;
-  const char* er = getenv("ODT_CONV_SPLIT_RES2");        // tuning knob: 0 keeps the FPN laterals on the f32 kernel
-  if (p.res_mode == 2 && er != nullptr && er[0] == '0') return false;
+ConvPolicy conv_policy_from_env(ConvPolicy q) {
+  auto geti = [&](const char* name, long* dst) {
+    const char* e = getenv(name);
+    if (e != nullptr) { *dst = atol(e); ++q.env_overrides; }
+  };
+  long v;
+  v = q.arith; geti("ODT_CONV_SPLIT", &v); q.arith = v != 0 ? 1 : 0;
+  v = q.family; geti("ODT_CONV_SPLIT_PIPE", &v); q.family = v < 1 ? 1 : (v > 3 ? 3 : (int)v);
+  geti("ODT_CONV_SPLIT_MINTILES", &q.min_tiles);
+  geti("ODT_CONV_SPLIT3_MINTILES", &q.min_tiles3);
+  v = q.min_k; geti("ODT_CONV_SPLIT_MINK", &v); q.min_k = (int)v;
+  v = q.min_bn; geti("ODT_CONV_SPLIT_MINBN", &v); q.min_bn = (int)v;
+  v = q.force_bm3; geti("ODT_CONV_SPLIT3_BM", &v); q.force_bm3 = (int)v;
+  v = q.short_k; geti("ODT_CONV_SPLIT3_SHORTK", &v); q.short_k = (int)v;
+  v = 1; geti("ODT_CONV_SPLIT_SRC2", &v); q.src2 = v != 0;      // 0 keeps the fused stage-entry convs on the f32 kernel
+  v = 1; geti("ODT_CONV_SPLIT_RES2", &v); q.res2 = v != 0;      // 0 keeps the FPN laterals on the f32 kernel
+  return q;
+}
+
+bool conv_split_wanted(const ConvParams& p, const ConvPolicy& q) {
+  if (q.arith == 0 || !conv_split_supported(p)) return false;
+  // below one workgroup per CU the exact-f32 kernel's smaller tiles fill the chip better (b=1 res4: 64 tiles)
+  if (p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0) < q.min_k) return false;
+  if (p.in2 != nullptr && !q.src2) return false;
+  if (p.res_mode == 2 && !q.res2) return false;
   const long M = (long)p.B * p.Ho * p.Wo;
   const int bm = conv_split_bm(p.Cout), bn = conv_split_bn(p.Cout);
-  const char* eb = getenv("ODT_CONV_SPLIT_MINBN");      // tuning knob: 256 = only the 128 x 256 tile
-  if (eb != nullptr && bn < atoi(eb)) return false;
-  return ((M + bm - 1) / bm) * (p.Cout / bn) >= min_tiles;
+  if (bn < q.min_bn) return false;
+  return ((M + bm - 1) / bm) * (p.Cout / bn) >= q.min_tiles;
 }
 
-// ---- which kernel family takes a conv that conv_split_wanted() accepted
-// ODT_CONV_SPLIT_PIPE (tuning / A-B knob): 1 = one-stage BK = 32 kernel everywhere, 2 = two-stage 128 x 256 kernel
-// where it exists, 3 (default) = conv_split3_kernel where its tiles fill the chip.
-static int split_pipe_mode() {
-  const char* e = getenv("ODT_CONV_SPLIT_PIPE");
-  return e != nullptr ? atoi(e) : 3;
-}
-
-void conv_split_choose(ConvParams& p) {
-  const int bn = conv_split_bn(p.Cout), mode = split_pipe_mode();
+// which kernel family takes a conv that conv_split_wanted() accepted: family 1 = one-stage BK = 32 kernel everywhere,
+// 2 = two-stage 128 x 256 kernel where it exists, 3 (default) = conv_split3_kernel where its tiles fill the chip
+void conv_split_choose(ConvParams& p, const ConvPolicy& q) {
+  const int bn = conv_split_bn(p.Cout);
   const long M = (long)p.B * p.Ho * p.Wo;
-  p.wt_split_kind = 1; p.wt_split_bm = conv_split_bm(p.Cout);
+  p.wt_split_kind = 1; p.wt_split_bm = conv_split_bm(p.Cout); p.wt_split_bn = bn;
   const int K = p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0);
-  // (64-wide layers stay on the one-stage 256 x 64 tile: a 64 x 32 wave tile reads too many fragments per MFMA --
-  // same-box A/B at b=8: res2 conv2 132 vs 118 TF, conv0 136 vs 112; ODT_CONV_SPLIT3_BM forces split3 anyway)
-  if (mode >= 3 && p.kh * p.kw <= 32 && K >= 32 && (bn >= 128 || getenv("ODT_CONV_SPLIT3_BM") != nullptr)) {
-    // 256-row tiles when they give every CU work for most of a round; 128-row tiles (N >= 128) below that
-    const char* e = getenv("ODT_CONV_SPLIT3_MINTILES");
-    const long min_tiles = e != nullptr ? atol(e) : 200L;
-    const long t256 = ((M + 255) / 256) * (p.Cout / bn), t128 = ((M + 127) / 128) * (p.Cout / bn);
-    if (const char* eb = getenv("ODT_CONV_SPLIT3_BM")) {     // test / tuning knob: force the tile height
-      const int fb = atoi(eb);
-      if (fb == 256 || (fb == 128 && bn >= 128)) { p.wt_split_kind = 3; p.wt_split_bm = fb; return; }
-    }
-    if (t256 >= min_tiles) { p.wt_split_kind = 3; p.wt_split_bm = 256; return; }
-    if (bn >= 128 && t128 >= min_tiles) { p.wt_split_kind = 3; p.wt_split_bm = 128; return; }
+  if (q.family >= 3 && q.short_k > 0 && K <= q.short_k && p.Cout % 128 == 0 && p.Cout >= 512 && p.kh * p.kw <= 32 &&
+      ((M + 127) / 128) * (p.Cout / 128) >= 2 * q.min_tiles3) {
+    p.wt_split_kind = 3; p.wt_split_bm = 128; p.wt_split_bn = 128;
+    return;
   }
-  if (mode >= 2 && bn == 256) { p.wt_split_kind = 2; p.wt_split_bm = 128; }
+  // (64-wide layers stay on the one-stage 256 x 64 tile: a 64 x 32 wave tile reads too many fragments per MFMA --
+  // same-box A/B at b=8: res2 conv2 132 vs 118 TF, conv0 136 vs 112; force_bm3 forces split3 anyway)
+  if (q.family >= 3 && p.kh * p.kw <= 32 && K >= 32 && (bn >= 128 || q.force_bm3 != 0)) {
+    // 256-row tiles when they give every CU work for most of a round; 128-row tiles (N >= 128) below that
+    const long t256 = ((M + 255) / 256) * (p.Cout / bn), t128 = ((M + 127) / 128) * (p.Cout / bn);
+    if (q.force_bm3 == 256 || (q.force_bm3 == 128 && bn >= 128)) { p.wt_split_kind = 3; p.wt_split_bm = q.force_bm3; return; }
+    if (t256 >= q.min_tiles3) { p.wt_split_kind = 3; p.wt_split_bm = 256; return; }
+    if (bn >= 128 && t128 >= q.min_tiles3) { p.wt_split_kind = 3; p.wt_split_bm = 128; return; }
+  }
+  if (q.family >= 2 && bn == 256) { p.wt_split_kind = 2; p.wt_split_bm = 128; }
 }
 
 int conv_make_split_weights(const ConvParams& p, void* img_dev, hipStream_t stream) {
-  const int bn = conv_split_bn(p.Cout);
+  const int bn = p.wt_split_bn != 0 ? p.wt_split_bn : conv_split_bn(p.Cout);
   const int K = p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0);
   ODT_CHECK(bn != 0 && K % 32 == 0 && p.wt_split_kind >= 1 && p.wt_split_kind <= 3,
             "conv_make_split_weights: Cout % 64 == 0, K % 32 == 0 and a chosen kernel family required");
@@ -1261,7 +1272,7 @@ static void launch_split3(const ConvParams& p, const ConvParams* dev, unsigned g
 
 int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t stream) {
   const long M = (long)p.B * p.Ho * p.Wo;
-  const int bn = conv_split_bn(p.Cout);
+  const int bn = p.wt_split_bn != 0 ? p.wt_split_bn : conv_split_bn(p.Cout);
   if (p.wt_split_kind == 3) {
     const int bm = p.wt_split_bm;
     ODT_CHECK((bm == 256 || (bm == 128 && bn >= 128)) && p.Cin % 16 == 0 && p.kh * p.kw <= 32, "conv split3: unsupported tile / shape");

@@ -109,6 +109,7 @@ struct odt_model {
   // [M,C,7,7] features): set by odt_submit_ex for the duration of run_plan; part of the captured graph
   Slot* d2h_slot = nullptr; int d2h_want = 0;
   int graph_mode = -1;               // -1 undecided, 0 off, 1 on (ODT_GRAPH=0 disables)
+  ConvPolicy policy{};               // conv arithmetic / kernel-family policy of this handle (attach_split_weights)
   int eff_scaled_h = 0, eff_scaled_w = 0;   // EfficientDet: size of the resized frame inside the padded input
   float* final_masks = nullptr;   // [B*per_im, 28, 28] (add_mask)
   DetectParams det{};
@@ -292,27 +293,36 @@ int add_conv(odt_model* m, const std::string& name, const Tensor& in, int cin, c
 
 // bf16-piece weight images (conv_split.hip) for the plan's convs that the split kernel takes
 int attach_split_weights(odt_model* m) {
-  if (conv_split_mode() == 0) return 0;
+  // the handle's conv policy: odt_config first, ODT_CONV_* debug overrides on top (read once, here)
+  ConvPolicy pol = conv_policy_default();
+  if (m->cfg.conv_arith == ODT_ARITH_F32) pol.arith = 0;
+  else if (m->cfg.conv_arith == ODT_ARITH_BF16X3) pol.arith = 1;
+  if (m->cfg.conv_split_family >= 1 && m->cfg.conv_split_family <= 3) pol.family = m->cfg.conv_split_family;
+  pol = conv_policy_from_env(pol);
+  m->policy = pol;
+  if (pol.arith == 0) return 0;
   std::map<const float*, const void*> made;      // the RPN conv is shared by the five levels
   std::map<const float*, int> made_kind;
   for (ConvOp& c : m->convs) {
-    if (!conv_split_wanted(c.p)) continue;
+    if (!conv_split_wanted(c.p, pol)) continue;
     auto it = made.find(c.p.wt);
     if (it == made.end()) {
       const int K = c.p.kh * c.p.kw * c.p.Cin + (c.p.in2 != nullptr ? c.p.Cin2 : 0);
       float* img = m->alloc_f((conv_split_weight_bytes(c.p.Cout, K) + 3) / 4, false);
       ODT_CHECK(img != nullptr, "device allocation failed (split weights of " + c.name + ")");
-      conv_split_choose(c.p);
+      conv_split_choose(c.p, pol);
       if (conv_make_split_weights(c.p, img, 0)) return 1;
       it = made.emplace(c.p.wt, img).first;
-      made_kind[c.p.wt] = c.p.wt_split_kind;
+      made_kind[c.p.wt] = c.p.wt_split_kind + 16 * c.p.wt_split_bn;
     }
-    conv_split_choose(c.p);
+    conv_split_choose(c.p, pol);
     // shared weights (the RPN conv over five levels): one image, so one kernel family -- the first (largest) level's
-    if (c.p.wt_split_kind != made_kind[c.p.wt]) {
-      ODT_CHECK(made_kind[c.p.wt] != 3 || c.p.Cin % 16 == 0, "split weights: shared image of an unsupported layout");
-      c.p.wt_split_kind = made_kind[c.p.wt];
-      if (c.p.wt_split_kind == 3 && c.p.wt_split_bm == 0) c.p.wt_split_bm = 128;
+    if (c.p.wt_split_kind + 16 * c.p.wt_split_bn != made_kind[c.p.wt]) {
+      const int kind = made_kind[c.p.wt] % 16, bn = made_kind[c.p.wt] / 16;
+      ODT_CHECK(kind != 3 || c.p.Cin % 16 == 0, "split weights: shared image of an unsupported layout");
+      c.p.wt_split_kind = kind; c.p.wt_split_bn = bn;
+      if (kind == 3) c.p.wt_split_bm = bn >= 128 ? 128 : 256;
+      else c.p.wt_split_bm = kind == 2 ? 128 : conv_split_bm(c.p.Cout);
     }
     c.p.wt_split = it->second;
   }
@@ -1240,12 +1250,29 @@ int odt_profile_layer(odt_handle h, int index, char* name, int name_cap, double*
   if (index < 0 || index >= (int)h->convs.size()) return 0;
   const ConvOp& c = h->convs[index];
   if (name && name_cap > 0) {    // layers on the bf16x3 split kernel are tagged (bench.py / profile_layers.py group by it)
-    const std::string nm = c.name + (c.p.wt_split != nullptr && conv_split_mode() != 0 ? "[bf16x3]" : "");
+    const std::string nm = c.name + (c.p.wt_split != nullptr ? "[bf16x3]" : "");
     std::strncpy(name, nm.c_str(), name_cap - 1); name[name_cap - 1] = 0;
   }
   if (flops) *flops = conv_flops(c.p);
   if (ms) *ms = index < (int)h->prof_layer_ms.size() ? h->prof_layer_ms[index] : 0.0;
   if (mnk) { mnk[0] = (int64_t)c.p.B * c.p.Ho * c.p.Wo; mnk[1] = c.p.Cout; mnk[2] = (int64_t)c.p.kh * c.p.kw * c.p.Cin; }
+  return 0;
+}
+
+int odt_describe(odt_handle h, char* buf, int cap) {
+  ODT_CHECK(h != nullptr && buf != nullptr && cap > 0, "odt_describe: null argument");
+  int fam[4] = {0, 0, 0, 0};
+  for (const ConvOp& c : h->convs) fam[c.p.wt_split != nullptr ? c.p.wt_split_kind : 0] += 1;
+  char tmp[640];
+  std::snprintf(tmp, sizeof(tmp),
+                "{\"conv_arith\": \"%s\", \"conv_launches\": %d, \"exact_f32_mfma_launches\": %d, "
+                "\"bf16x3_split_launches\": %d, \"split_launches_by_family\": {\"split3_8wave_lds_dma\": %d, "
+                "\"two_stage_128x256\": %d, \"one_stage_bk32\": %d}, \"policy\": {\"family\": %d, \"min_tiles\": %ld, "
+                "\"min_tiles3\": %ld, \"min_k\": %d}, \"env_overrides_applied\": %d, \"graph_replay\": %d}",
+                h->policy.arith != 0 && fam[1] + fam[2] + fam[3] > 0 ? "f32 through bf16x3 split products" : "exact f32 MFMA",
+                (int)h->convs.size(), fam[0], fam[1] + fam[2] + fam[3], fam[3], fam[2], fam[1], h->policy.family,
+                h->policy.min_tiles, h->policy.min_tiles3, h->policy.min_k, h->policy.env_overrides, h->graph_mode);
+  std::strncpy(buf, tmp, cap - 1); buf[cap - 1] = 0;
   return 0;
 }
 

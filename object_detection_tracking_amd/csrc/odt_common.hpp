@@ -68,22 +68,38 @@ struct ConvParams {
   int wt_split_kind;   // which kernel family the image was laid out for: 1 one-stage BK = 32 (conv_split_kernel) |
                        // 2 two-stage BK = 16, 128 x 256 (conv_split2_kernel) | 3 conv_split3_kernel (8 waves, LDS-DMA)
   int wt_split_bm;     // kind 3: rows of the block tile (256, or 128 when 256-row tiles would not fill the chip)
+  int wt_split_bn;     // n-tile width the image was laid out for (kind 3 may use 128 on wider layers; 0: conv_split_bn(Cout))
 };
 // fills the derived fields (multiply-shift divisors); call before copying a record to the device
 void conv_prepare(ConvParams& p);
 // dev_params: device copy of `p` (plan-owned); nullptr = stage a temporary (stand-alone calls)
 int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_params = nullptr);
 double conv_flops(const ConvParams& p);   // algorithmic 2*M*N*K
-// bf16x3 split path (conv_split.hip).  conv_split_mode(): ODT_CONV_SPLIT (0 off | 1 on).
-// conv_split_wanted(): the layer is supported AND large enough to fill the chip with 128x256 tiles.
-int conv_split_mode();
+// bf16x3 split path (conv_split.hip).  ConvPolicy: which convs take it and which kernel family -- per handle, fixed at
+// odt_create from odt_config (+ ODT_CONV_* debug overrides, conv_policy_from_env); the stand-alone test entry points
+// resolve it per call.
+struct ConvPolicy {
+  int arith;            // 0 exact-f32 MFMA everywhere | 1 bf16x3 split kernels where they pay
+  int family;           // newest split kernel family allowed: 1 one-stage | 2 two-stage 128 x 256 | 3 conv_split3_kernel
+  long min_tiles;       // tiles a layer must offer the one- / two-stage kernels (256)
+  long min_tiles3;      // ... conv_split3_kernel's 256- / 128-row tiles (200)
+  int min_k, min_bn;    // shortest reduction / narrowest n-tile taken
+  int force_bm3;        // 0 auto | 128 | 256: force conv_split3_kernel with that tile height (tests)
+  int short_k;          // conv_split3_kernel: reductions up to this length on >= 512-wide layers run 128 x 128 tiles, two
+                        // workgroups per CU (one's prologue / store tail under the other's main loop); 0 = off
+  bool src2, res2;      // take the K-concatenated stage-entry convs / the 2x-upsampled-residual FPN laterals
+  int env_overrides;    // how many ODT_CONV_* variables were applied (recorded by odt_describe)
+};
+ConvPolicy conv_policy_default();
+ConvPolicy conv_policy_from_env(ConvPolicy q);
 bool conv_split_supported(const ConvParams& p);
-bool conv_split_wanted(const ConvParams& p);
+// the layer is supported AND large enough to fill the chip with the split tiles
+bool conv_split_wanted(const ConvParams& p, const ConvPolicy& q);
 size_t conv_split_weight_bytes(int Cout, int K);
 int conv_split_bn(int Cout);   // n-tile width of the split configuration for this Cout (0: none)
 int conv_split_bm(int Cout);
 // picks the split kernel family / tile for a conv that conv_split_wanted() accepted (fills wt_split_kind / wt_split_bm)
-void conv_split_choose(ConvParams& p);
+void conv_split_choose(ConvParams& p, const ConvPolicy& q);
 // builds the bf16-piece image of p.wt for p.wt_split_kind (conv_split_choose first)
 int conv_make_split_weights(const ConvParams& p, void* img_dev, hipStream_t stream);
 int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t stream);

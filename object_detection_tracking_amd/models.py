@@ -105,6 +105,10 @@ class _Engine(object):
     self.add_mask = bool(getattr(config, "add_mask", False))
     c.add_mask = int(self.add_mask)
     c.mask_dim = int(getattr(config, "mrcnn_head_dim", 256))
+    # arithmetic of the conv / FC products (include/odt.h ODT_ARITH_*): None / "default" | "f32" | "bf16x3"
+    arith = getattr(config, "conv_arith", None)
+    c.conv_arith = {None: 0, "default": 0, "f32": _lib.ODT_ARITH_F32, "bf16x3": _lib.ODT_ARITH_BF16X3}[arith]
+    c.conv_split_family = int(getattr(config, "conv_split_family", 0) or 0)
     self.h = C.c_void_p()
     lib.check(lib.dll.odt_create(C.byref(c), device, C.byref(self.h)))
     try:
@@ -223,6 +227,13 @@ class _Engine(object):
 
   def synchronize(self):
     self.lib.check(self.lib.dll.odt_synchronize(self.h))
+
+  def describe(self):
+    """What the handle runs (odt_describe): conv arithmetic mode, launches per kernel family, policy thresholds."""
+    import json
+    buf = C.create_string_buffer(1024)
+    self.lib.check(self.lib.dll.odt_describe(self.h, buf, 1024))
+    return json.loads(buf.value.decode())
 
   def profile(self, enable):
     self.lib.check(self.lib.dll.odt_profile_enable(self.h, int(enable)))
