@@ -110,6 +110,14 @@ struct odt_model {
   Slot* d2h_slot = nullptr; int d2h_want = 0;
   int graph_mode = -1;               // -1 undecided, 0 off, 1 on (ODT_GRAPH=0 disables)
   ConvPolicy policy{};               // conv arithmetic / kernel-family policy of this handle (attach_split_weights)
+  // tail overlap: the selection / ROIAlign / box-head / NMS kernels of forward i (a few dozen workgroups each,
+  // ~2 ms per 8-frame step) run on a side stream under the backbone of forward i+1.  The next forward's FPN stage
+  // (the first op that overwrites what the tail reads: P2..P5, the RPN outputs) waits for the previous tail.
+  int tail_overlap = -1;             // -1 undecided | 0 off | 1 on (ODT_TAIL_OVERLAP=0 disables; own stream only)
+  size_t op_first_fpn = 0, op_tail = 0;
+  hipStream_t tail_stream = nullptr, done_stream = nullptr;
+  hipEvent_t trunk_done = nullptr, tail_done = nullptr;
+  bool tail_pending = false;
   int eff_scaled_h = 0, eff_scaled_w = 0;   // EfficientDet: size of the resized frame inside the padded input
   float* final_masks = nullptr;   // [B*per_im, 28, 28] (add_mask)
   DetectParams det{};
@@ -386,6 +394,9 @@ int odt_destroy(odt_handle h) {
   }
   if (h->copy_in) (void)hipStreamDestroy(h->copy_in);
   if (h->copy_out) (void)hipStreamDestroy(h->copy_out);
+  if (h->tail_stream) (void)hipStreamDestroy(h->tail_stream);
+  if (h->trunk_done) (void)hipEventDestroy(h->trunk_done);
+  if (h->tail_done) (void)hipEventDestroy(h->tail_done);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return 0;
@@ -774,10 +785,12 @@ int build_plan(odt_model* m) {
 }
 
 // the op list of the static plan, launched on `st` (directly, or while the stream is being captured)
-static int run_ops(odt_model* m, const void* src, int dtype, hipStream_t st, size_t* ev_io) {
+static int run_ops(odt_model* m, const void* src, int dtype, hipStream_t st, size_t* ev_io, size_t begin = 0,
+                   size_t end = (size_t)-1) {
   const odt_config& cfg = m->cfg;
   size_t ev_i = *ev_io;
-  for (const Op& op : m->ops) {
+  for (size_t oi = begin; oi < end && oi < m->ops.size(); ++oi) {
+    const Op& op = m->ops[oi];
     switch (op.kind) {
       case OP_PRE:
         if (m->src_h == cfg.height && m->src_w == cfg.width) {
@@ -878,6 +891,25 @@ static int enqueue_small_d2h(odt_model* m, hipStream_t st) {
   return 0;
 }
 
+// profiling: close the step's total event on the stream the forward ends on, wait, accumulate the per-conv times
+static int finish_profile(odt_model* m, hipStream_t st) {
+  ODT_HIP(hipEventRecord(m->ev_total[1], st));
+  ODT_HIP(hipStreamSynchronize(st));
+  double ms = 0, fl = 0;
+  for (size_t i = 0; i < m->convs.size(); ++i) {
+    float t = 0;
+    ODT_HIP(hipEventElapsedTime(&t, m->ev[2 * i], m->ev[2 * i + 1]));
+    ms += t; fl += conv_flops(m->convs[i].p);
+    if (m->prof_layer_ms.size() < m->convs.size()) m->prof_layer_ms.resize(m->convs.size(), 0.0);
+    m->prof_layer_ms[i] += t;
+  }
+  float tt = 0;
+  ODT_HIP(hipEventElapsedTime(&tt, m->ev_total[0], m->ev_total[1]));
+  m->prof_conv_ms += ms; m->prof_conv_flops += fl; m->prof_launches += (int)m->convs.size();
+  m->prof_total_ms += tt;
+  return 0;
+}
+
 int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStream_t st) {
   const odt_config& cfg = m->cfg;
   ODT_CHECK(m->finalized, "odt_forward: call odt_finalize_weights first");
@@ -896,6 +928,42 @@ int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStre
     while (m->ev.size() < 2 * m->convs.size()) { hipEvent_t e; ODT_HIP(hipEventCreate(&e)); m->ev.push_back(e); }
     for (int i = 0; i < 2; ++i) if (!m->ev_total[i]) ODT_HIP(hipEventCreate(&m->ev_total[i]));
     ODT_HIP(hipEventRecord(m->ev_total[0], st));
+  }
+  // ---- tail overlap (own stream only: a caller's stream must see the whole forward in stream order)
+  if (m->tail_overlap < 0) {
+    const char* e = getenv("ODT_TAIL_OVERLAP");
+    m->tail_overlap = (cfg.graph != ODT_GRAPH_EFFNET && !(e && e[0] == '0')) ? 1 : 0;
+    m->op_first_fpn = m->op_tail = 0;
+    for (size_t i = 0; i < m->ops.size(); ++i) {
+      if (m->ops[i].kind == OP_PROPOSALS) { m->op_tail = i; break; }
+      if (m->op_first_fpn == 0 && m->ops[i].kind == OP_CONV && m->convs[m->ops[i].conv].name.compare(0, 4, "fpn/") == 0)
+        m->op_first_fpn = i;
+    }
+    if (m->op_tail == 0 || m->op_first_fpn == 0 || m->op_first_fpn >= m->op_tail) m->tail_overlap = 0;
+  }
+  m->done_stream = st;
+  if (m->tail_overlap == 1 && st == m->own_stream) {
+    if (!m->tail_stream) {
+      ODT_HIP(hipStreamCreate(&m->tail_stream));
+      ODT_HIP(hipEventCreateWithFlags(&m->trunk_done, hipEventDisableTiming));
+      ODT_HIP(hipEventCreateWithFlags(&m->tail_done, hipEventDisableTiming));
+    }
+    if (run_ops(m, src, dtype, st, &ev_i, 0, m->op_first_fpn)) return 1;
+    if (m->tail_pending) ODT_HIP(hipStreamWaitEvent(st, m->tail_done, 0));
+    if (run_ops(m, src, dtype, st, &ev_i, m->op_first_fpn, m->op_tail)) return 1;
+    ODT_HIP(hipEventRecord(m->trunk_done, st));
+    ODT_HIP(hipStreamWaitEvent(m->tail_stream, m->trunk_done, 0));
+    if (run_ops(m, src, dtype, m->tail_stream, &ev_i, m->op_tail)) return 1;
+    if (enqueue_small_d2h(m, m->tail_stream)) return 1;
+    ODT_HIP(hipEventRecord(m->tail_done, m->tail_stream));
+    m->tail_pending = true;
+    m->done_stream = m->tail_stream;
+    if (m->profile) return finish_profile(m, m->tail_stream);
+    return 0;
+  }
+  if (m->tail_pending) {          // a forward on another stream after overlapped ones: order it behind the last tail
+    ODT_HIP(hipStreamWaitEvent(st, m->tail_done, 0));
+    m->tail_pending = false;
   }
   // ---- graph replay (not while profiling, not when the pipelined ingest needs an event wait)
   if (m->graph_mode < 0) { const char* e = getenv("ODT_GRAPH"); m->graph_mode = (e && e[0] == '0') ? 0 : 1; }
@@ -940,22 +1008,7 @@ int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStre
   }
   if (run_ops(m, src, dtype, st, &ev_i)) return 1;
   if (enqueue_small_d2h(m, st)) return 1;
-  if (m->profile) {
-    ODT_HIP(hipEventRecord(m->ev_total[1], st));
-    ODT_HIP(hipStreamSynchronize(st));
-    double ms = 0, fl = 0;
-    for (size_t i = 0; i < m->convs.size(); ++i) {
-      float t = 0;
-      ODT_HIP(hipEventElapsedTime(&t, m->ev[2 * i], m->ev[2 * i + 1]));
-      ms += t; fl += conv_flops(m->convs[i].p);
-      if (m->prof_layer_ms.size() < m->convs.size()) m->prof_layer_ms.resize(m->convs.size(), 0.0);
-      m->prof_layer_ms[i] += t;
-    }
-    float tt = 0;
-    ODT_HIP(hipEventElapsedTime(&tt, m->ev_total[0], m->ev_total[1]));
-    m->prof_conv_ms += ms; m->prof_conv_flops += fl; m->prof_launches += (int)m->convs.size();
-    m->prof_total_ms += tt;
-  }
+  if (m->profile) return finish_profile(m, st);
   return 0;
 }
 
@@ -1012,6 +1065,7 @@ int odt_forward(odt_handle h, const void* frames, int dtype, int on_device, void
             "odt_forward: the backbone-only graph has no detection outputs (odt_forward_async + odt_tap)");
   hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
   if (run_plan(h, frames, dtype, on_device, st)) return 1;
+  st = h->done_stream;                 // (the tail may have run on the handle's side stream)
   if (h->cfg.graph == ODT_GRAPH_EFFNET) {
     // EfficientDet outputs (efficientdet_wrapper.py:28-35): boxes [R,4] x1y1x2y2 (scaled), probs,
     // labels 1..90, pooled = fpn_box_feat [R, fpn_num_filters]
@@ -1154,7 +1208,7 @@ int odt_submit_ex(odt_handle h, const void* frames, int dtype, int want, int* ti
     const int rc = run_plan(h, sl.dev_in, dtype, 1, st);
     h->d2h_slot = nullptr; h->d2h_want = 0;
     if (rc) return 1;
-    ODT_HIP(hipEventRecord(sl.d2h_done, st));
+    ODT_HIP(hipEventRecord(sl.d2h_done, h->done_stream));
     sl.ticket = t;
     *ticket = t;
     h->next_ticket = t + 1;
@@ -1164,7 +1218,7 @@ int odt_submit_ex(odt_handle h, const void* frames, int dtype, int want, int* ti
   // must not overwrite them before that copy is done
   h->wait_before_detect = (prev.ticket >= 0 && (prev.want & ODT_WANT_FEATS)) ? prev.d2h_done : nullptr;
   if (run_plan(h, sl.dev_in, dtype, 1, st)) return 1;
-  ODT_HIP(hipEventRecord(sl.fwd_done, st));
+  ODT_HIP(hipEventRecord(sl.fwd_done, h->done_stream));
   hipStream_t co = h->copy_out;
   ODT_HIP(hipStreamWaitEvent(co, sl.fwd_done, 0));
   ODT_HIP(hipMemcpyAsync(sl.pin_valid, h->det.out_valid, B * sizeof(int), hipMemcpyDeviceToHost, co));

@@ -3,7 +3,7 @@
 collected with tools/gpurun/pmc.sh into profiles/<round>_pmc_summary.{txt,json}."""
 import collections, csv, json, os, sys
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
-out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_pmc_summary"
+out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_pmc_summary"
 def load(tag):
   d = [x for x in os.listdir(src) if x.startswith("pmc_" + tag) and os.path.isdir(os.path.join(src, x))][0]
   return list(csv.DictReader(open(os.path.join(src, d, "pmc_counter_collection.csv"))))
@@ -13,7 +13,7 @@ def agg(rows, pred):
     if pred(r["Kernel_Name"]):
       tot[r["Counter_Name"]] += float(r["Counter_Value"]); disp.add(r["Dispatch_Id"])
   return tot, len(disp)
-is_conv = lambda k: "conv_igemm_kernel" in k or "conv_split_kernel" in k
+is_conv = lambda k: "conv_igemm_kernel" in k or "conv_split" in k
 is_pre = lambda k: "preprocess_kernel" in k
 f, nconv = agg(load("FETCH_SIZE"), is_conv)
 w, _ = agg(load("WRITE_SIZE"), is_conv)
@@ -22,7 +22,7 @@ try:
   i, _ = agg(load("SQ_INSTS"), is_conv)
 except IndexError:            # optional fourth pass
   i = collections.defaultdict(float)
-is_split = lambda k: "conv_split_kernel" in k
+is_split = lambda k: "conv_split" in k and "kernel" in k and "split_weights" not in k
 fs, nsplit = agg(load("FETCH_SIZE"), is_split)
 ws, _ = agg(load("WRITE_SIZE"), is_split)
 ms, _ = agg(load("SQ_VALU_MFMA"), is_split)
