@@ -644,6 +644,7 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
   // bf16x3 split path: plan convs carry their weight image; stand-alone calls (tests, tuning)
   // build a temporary one
   void* tmp_img = nullptr;
+  float* tmp_partial = nullptr;
   // (a plan conv without an image stays on the exact-f32 kernel: no allocation on the hot path)
   // (plan convs: the handle's policy decided at plan build -- an attached image means "split"; stand-alone calls:
   // library defaults + ODT_CONV_* overrides, resolved per call)
@@ -656,6 +657,8 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
     conv_split_choose(q, pol);
     if (conv_make_split_weights(q, tmp_img, stream)) { (void)hipFree(tmp_img); return 1; }
     q.wt_split = tmp_img; modified = true;
+    if (conv_split_partial_bytes(q) > 0) ODT_HIP(hipMalloc((void**)&tmp_partial, conv_split_partial_bytes(q)));
+    q.partial = tmp_partial;
   }
   // stand-alone calls (tests, tuning) and debug overrides: stage the record in a temporary
   ConvParams* tmp = nullptr;
@@ -670,6 +673,7 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
       ODT_HIP(hipStreamSynchronize(stream));
       if (tmp != nullptr) ODT_HIP(hipFree(tmp));
       if (tmp_img != nullptr) ODT_HIP(hipFree(tmp_img));
+      if (tmp_partial != nullptr) ODT_HIP(hipFree(tmp_partial));
     }
     return 0;
   }

@@ -803,6 +803,10 @@ __global__ void __launch_bounds__(512, 2) conv_split3_kernel(const ConvParams* _
     const int nwg = (int)gridDim.x, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
   }
+  // split-K: consecutive workgroups are the K ranges of one tile (they share its activation rows in L2)
+  const int splitk = p.splitk > 1 ? p.splitk : 1;
+  const int ks = wg % splitk;
+  wg /= splitk;
   const int mt = wg / ntn, nt = wg - mt * ntn;
   const int m0 = mt * BM, n0 = nt * BN;
   const int HoWo = p.Ho * p.Wo;
@@ -810,7 +814,10 @@ __global__ void __launch_bounds__(512, 2) conv_split3_kernel(const ConvParams* _
   const int ntaps = p.kh * p.kw;
   const int cpt = p.Cin >> 4;                                // 16-channel slices of the first source
   const int cpt2 = p.in2 != nullptr ? p.Cin2 >> 4 : 0;       // ... of the K-concatenated second source (1x1 only)
-  const int nsteps1 = ntaps * cpt, nsteps = nsteps1 + cpt2;
+  const int nsteps1 = ntaps * cpt, nsteps_all = nsteps1 + cpt2;
+  // this workgroup's stages [s_begin, s_begin + nsteps): split-K ranges are balanced to within one stage
+  const int s_begin = (int)(((long)nsteps_all * ks) / splitk);
+  const int nsteps = (int)(((long)nsteps_all * (ks + 1)) / splitk) - s_begin;
 
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.in, 0, (int)((unsigned)p.B * p.in_Ha * p.in_Wa * p.in_ldc * 4u), 0x00020000);
@@ -818,10 +825,10 @@ __global__ void __launch_bounds__(512, 2) conv_split3_kernel(const ConvParams* _
       (void*)(p.in2 != nullptr ? p.in2 : p.in), 0,
       (int)(p.in2 != nullptr ? (unsigned)p.B * p.in2_Ha * p.in2_Wa * p.in2_ldc * 4u : 0u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.wt_split, 0, (int)((unsigned)ntn * nsteps * (unsigned)STAGE_B), 0x00020000);
+      (void*)p.wt_split, 0, (int)((unsigned)ntn * nsteps_all * (unsigned)STAGE_B), 0x00020000);
 
   // ---- weights: wave w, instruction i copies the 1-KB piece i * 8 + w of the stage image
-  unsigned l_b = (unsigned)nt * (unsigned)nsteps * (unsigned)STAGE_B;
+  unsigned l_b = ((unsigned)nt * (unsigned)nsteps_all + (unsigned)s_begin) * (unsigned)STAGE_B;
   auto dma_b = [&](int st) {
 #pragma unroll
     for (int i = 0; i < (NCHUNK + 7) / 8; ++i) {
@@ -879,7 +886,9 @@ __global__ void __launch_bounds__(512, 2) conv_split3_kernel(const ConvParams* _
     }
   }
   // load stream position: (16-channel slice, tap) with the tap innermost; then the second source's slices
-  int l_cs = 0, l_tap = 0, l_kh = 0, l_kw = 0;
+  // (a split-K range starts inside the first source: launch_conv_split keeps split-K off for second-source convs)
+  int l_cs = s_begin / ntaps, l_tap = s_begin - l_cs * ntaps;
+  int l_kh = l_tap / p.kw, l_kw = l_tap - l_kh * p.kw;
   bool l_src2 = false;
   unsigned a_row[RA];
   auto set_rows = [&]() {
@@ -1043,6 +1052,34 @@ __global__ void __launch_bounds__(512, 2) conv_split3_kernel(const ConvParams* _
       (int)(p.res_mode != 0 ? (unsigned)p.B * p.res_H * p.res_W * p.res_ldc * 4u : 0u), 0x00020000);
   const int c4 = tid % C4, row0 = tid / C4;
   const int col = n0 + c4 * 4;
+  if (splitk > 1) {
+    // split-K: the raw partial tile, dense [M][Cout] rows of this range's slab (bias / residual / activation happen in
+    // split_reduce_kernel once all ranges are in)
+    const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.partial + (size_t)ks * M * p.Cout), 0, (int)((unsigned)M * p.Cout * 4u), 0x00020000);
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      if (pass > 0) ODT_BARRIER_LDS();
+      if (wm / WPP == pass) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              Ct[((wm % WPP) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * CS + wn * TN * 32 + j * 32 + fr] = acc[i][j][r];
+      }
+      ODT_BARRIER_LDS();
+#pragma unroll
+      for (int s2 = 0; s2 < NCH; ++s2) {
+        const int m = m0 + pass * RP + row0 + s2 * RSTEP;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[(row0 + s2 * RSTEP) * CS + c4 * 4]);
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_part, m < M ? (int)(((unsigned)m * p.Cout + col) * 4u) : (int)kOOB, 0, 0);
+      }
+    }
+    stamp(5);
+    return;
+  }
   const f32x4 bias4 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, col * 4, 0, 0);
   // (no barrier needed here: the last stage's barrier sits behind every fragment read of the ring)
   auto run = [&](auto act_c, auto res_c) {
@@ -1134,6 +1171,38 @@ __global__ void split_weights_kernel(const float* __restrict__ wt, int Cout, int
   }
 }
 
+// split-K combine: out = act(sum over ranges (in range order: deterministic) + bias (+ residual)); one thread per
+// 16-byte chunk of an output row
+__global__ void __launch_bounds__(256) split_reduce_kernel(const ConvParams* __restrict__ pp) {
+  const ConvParams p = *pp;
+  const int C4 = p.Cout >> 2;
+  const long M = (long)p.B * p.Ho * p.Wo;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * C4) return;
+  const int m = (int)(idx / C4), col = (int)(idx - (long)m * C4) * 4;
+  const size_t slab = (size_t)M * p.Cout;
+  f32x4 v = *reinterpret_cast<const f32x4*>(p.partial + (size_t)m * p.Cout + col);
+  for (int k = 1; k < p.splitk; ++k) v += *reinterpret_cast<const f32x4*>(p.partial + (size_t)k * slab + (size_t)m * p.Cout + col);
+  v += *reinterpret_cast<const f32x4*>(p.bias + col);
+  const int HoWo = p.Ho * p.Wo;
+  const int n = sfast_div(m, p.div_howo_mul, p.div_howo_sh), rr = m - n * HoWo;
+  const int ho = sfast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
+  if (p.res_mode != 0) {
+    const size_t rpix = p.res_mode == 2 ? ((size_t)n * p.res_H + (size_t)(ho >> 1)) * p.res_W + (size_t)(wo >> 1)
+                                        : ((size_t)n * p.res_H + (size_t)ho) * p.res_W + (size_t)wo;
+    v += *reinterpret_cast<const f32x4*>(p.res + rpix * p.res_ldc + col);
+  }
+  if (p.relu == 1) {
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+  } else if (p.relu == 2) {
+    for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f / (1.0f + expf(-v[e])));
+  } else if (p.relu == 3) {
+    for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
+  }
+  const size_t opix = ((size_t)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
+  *reinterpret_cast<f32x4*>(p.out + opix * p.out_ldc + col) = v;
+}
+
 // conv_split3_kernel's image: [n-tile][stage][piece][k-group 2][BN n][8 k], stage order = (16-channel slice, tap)
 // for the first source, then the second source's slices; wt is [Cout][tap][Cin] (+ [Cin2] behind it)
 __global__ void split_weights3_kernel(const float* __restrict__ wt, int Cout, int K, int SBN, int ntaps, int Cin,
@@ -1187,7 +1256,7 @@ ConvPolicy conv_policy_default() {
   q.min_tiles = 256;      // one- / two-stage kernels: A/B at b=8 and b=1: 256 > 384 > 128 >> 64
   q.min_tiles3 = 200;
   q.min_k = 64;           // A/B at b=8: K >= 256: 155.0, >= 128: 156.2, >= 64: 156.6 FPS
-  q.min_bn = 0; q.force_bm3 = 0; q.short_k = 0; q.src2 = true; q.res2 = true; q.env_overrides = 0;
+  q.min_bn = 0; q.force_bm3 = 0; q.short_k = 0; q.splitk_max = 8; q.force_splitk = 0; q.src2 = true; q.res2 = true; q.env_overrides = 0;
   return q;
 }
 
@@ -1205,20 +1274,54 @@ ConvPolicy conv_policy_from_env(ConvPolicy q) {
   v = q.min_bn; geti("ODT_CONV_SPLIT_MINBN", &v); q.min_bn = (int)v;
   v = q.force_bm3; geti("ODT_CONV_SPLIT3_BM", &v); q.force_bm3 = (int)v;
   v = q.short_k; geti("ODT_CONV_SPLIT3_SHORTK", &v); q.short_k = (int)v;
+  v = q.splitk_max; geti("ODT_CONV_SPLIT3_SPLITK", &v); q.splitk_max = v < 1 ? 1 : (v > 16 ? 16 : (int)v);
+  v = q.force_splitk; geti("ODT_CONV_SPLIT3_FORCE_SPLITK", &v); q.force_splitk = v < 0 ? 0 : (v > 16 ? 16 : (int)v);
   v = 1; geti("ODT_CONV_SPLIT_SRC2", &v); q.src2 = v != 0;      // 0 keeps the fused stage-entry convs on the f32 kernel
   v = 1; geti("ODT_CONV_SPLIT_RES2", &v); q.res2 = v != 0;      // 0 keeps the FPN laterals on the f32 kernel
   return q;
 }
 
+// conv_split3_kernel's way of filling the chip with this layer, if it has one: 256-row tiles, 128-row tiles, or 128-row
+// tiles with the reduction cut into split-K ranges (layers of few output rows: everything at b=1 below res3, the box
+// head's FC layers, the coarse pyramid levels)
+static bool split3_fit(const ConvParams& p, const ConvPolicy& q, int* bm, int* bn, int* sk) {
+  const int bn0 = conv_split_bn(p.Cout);
+  const int K = p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0);
+  if (q.family < 3 || bn0 == 0 || p.kh * p.kw > 32 || K < 32 || p.Cin % 16 != 0) return false;
+  const long M = (long)p.B * p.Ho * p.Wo;
+  const int nsteps = K >> 4;
+  *bn = bn0; *sk = 1;
+  auto with_forced_sk = [&]() {
+    if (q.force_splitk > 1 && p.in2 == nullptr && nsteps >= q.force_splitk) *sk = q.force_splitk;
+    return true;
+  };
+  if (q.force_bm3 == 256 || (q.force_bm3 == 128 && bn0 >= 128)) { *bm = q.force_bm3; return with_forced_sk(); }
+  // (64-wide layers stay on the one-stage 256 x 64 tile: a 64 x 32 wave tile reads too many fragments per MFMA --
+  // same-box A/B at b=8: res2 conv2 132 vs 118 TF, conv0 136 vs 112)
+  if (bn0 < 128) return false;
+  const long t256 = ((M + 255) / 256) * (p.Cout / bn0), t128 = ((M + 127) / 128) * (p.Cout / bn0);
+  if (t256 >= q.min_tiles3) { *bm = 256; return with_forced_sk(); }
+  if (t128 >= q.min_tiles3) { *bm = 128; return with_forced_sk(); }
+  if (q.splitk_max > 1 && p.in2 == nullptr) {
+    int k = (int)((q.min_tiles3 + t128 - 1) / t128);
+    if (k > q.splitk_max) k = q.splitk_max;
+    while (k > 1 && nsteps / k < 8) --k;            // at least eight stages per range
+    if (k > 1 && t128 * k >= q.min_tiles3 / 2) { *bm = 128; *sk = k; return true; }
+  }
+  return false;
+}
+
 bool conv_split_wanted(const ConvParams& p, const ConvPolicy& q) {
   if (q.arith == 0 || !conv_split_supported(p)) return false;
-  // below one workgroup per CU the exact-f32 kernel's smaller tiles fill the chip better (b=1 res4: 64 tiles)
   if (p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0) < q.min_k) return false;
   if (p.in2 != nullptr && !q.src2) return false;
   if (p.res_mode == 2 && !q.res2) return false;
   const long M = (long)p.B * p.Ho * p.Wo;
   const int bm = conv_split_bm(p.Cout), bn = conv_split_bn(p.Cout);
   if (bn < q.min_bn) return false;
+  int b3, n3, k3;
+  if (split3_fit(p, q, &b3, &n3, &k3)) return true;
+  // one- / two-stage kernels: below one workgroup per CU the exact-f32 kernel's smaller tiles fill the chip better
   return ((M + bm - 1) / bm) * (p.Cout / bn) >= q.min_tiles;
 }
 
@@ -1227,23 +1330,23 @@ bool conv_split_wanted(const ConvParams& p, const ConvPolicy& q) {
 void conv_split_choose(ConvParams& p, const ConvPolicy& q) {
   const int bn = conv_split_bn(p.Cout);
   const long M = (long)p.B * p.Ho * p.Wo;
-  p.wt_split_kind = 1; p.wt_split_bm = conv_split_bm(p.Cout); p.wt_split_bn = bn;
+  p.wt_split_kind = 1; p.wt_split_bm = conv_split_bm(p.Cout); p.wt_split_bn = bn; p.splitk = 1;
   const int K = p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0);
   if (q.family >= 3 && q.short_k > 0 && K <= q.short_k && p.Cout % 128 == 0 && p.Cout >= 512 && p.kh * p.kw <= 32 &&
       ((M + 127) / 128) * (p.Cout / 128) >= 2 * q.min_tiles3) {
     p.wt_split_kind = 3; p.wt_split_bm = 128; p.wt_split_bn = 128;
     return;
   }
-  // (64-wide layers stay on the one-stage 256 x 64 tile: a 64 x 32 wave tile reads too many fragments per MFMA --
-  // same-box A/B at b=8: res2 conv2 132 vs 118 TF, conv0 136 vs 112; force_bm3 forces split3 anyway)
-  if (q.family >= 3 && p.kh * p.kw <= 32 && K >= 32 && (bn >= 128 || q.force_bm3 != 0)) {
-    // 256-row tiles when they give every CU work for most of a round; 128-row tiles (N >= 128) below that
-    const long t256 = ((M + 255) / 256) * (p.Cout / bn), t128 = ((M + 127) / 128) * (p.Cout / bn);
-    if (q.force_bm3 == 256 || (q.force_bm3 == 128 && bn >= 128)) { p.wt_split_kind = 3; p.wt_split_bm = q.force_bm3; return; }
-    if (t256 >= q.min_tiles3) { p.wt_split_kind = 3; p.wt_split_bm = 256; return; }
-    if (bn >= 128 && t128 >= q.min_tiles3) { p.wt_split_kind = 3; p.wt_split_bm = 128; return; }
+  int b3, n3, k3;
+  if (split3_fit(p, q, &b3, &n3, &k3)) {
+    p.wt_split_kind = 3; p.wt_split_bm = b3; p.wt_split_bn = n3; p.splitk = k3;
+    return;
   }
   if (q.family >= 2 && bn == 256) { p.wt_split_kind = 2; p.wt_split_bm = 128; }
+}
+
+size_t conv_split_partial_bytes(const ConvParams& p) {
+  return p.wt_split_kind == 3 && p.splitk > 1 ? (size_t)p.splitk * p.B * p.Ho * p.Wo * p.Cout * sizeof(float) : 0;
 }
 
 int conv_make_split_weights(const ConvParams& p, void* img_dev, hipStream_t stream) {
@@ -1276,7 +1379,10 @@ int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t st
   if (p.wt_split_kind == 3) {
     const int bm = p.wt_split_bm;
     ODT_CHECK((bm == 256 || (bm == 128 && bn >= 128)) && p.Cin % 16 == 0 && p.kh * p.kw <= 32, "conv split3: unsupported tile / shape");
-    const unsigned grid = (unsigned)(((M + bm - 1) / bm) * (p.Cout / bn));
+    const int sk = p.splitk > 1 ? p.splitk : 1;
+    ODT_CHECK(sk == 1 || (p.partial != nullptr && p.in2 == nullptr && (p.kh * p.kw * p.Cin >> 4) >= sk),
+              "conv split3: split-K needs a partial buffer, a single source and at least one stage per range");
+    const unsigned grid = (unsigned)(((M + bm - 1) / bm) * (p.Cout / bn) * sk);
     if (bm == 256) {
       if (bn == 256) launch_split3<4, 2, 4>(p, dev, grid, stream);
       else if (bn == 128) launch_split3<4, 2, 2>(p, dev, grid, stream);
@@ -1284,6 +1390,10 @@ int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t st
     } else {
       if (bn == 256) launch_split3<2, 4, 2>(p, dev, grid, stream);
       else launch_split3<2, 4, 1>(p, dev, grid, stream);
+    }
+    if (sk > 1) {
+      const long chunks = M * (p.Cout / 4);
+      hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, dev);
     }
     ODT_HIP(hipGetLastError());
     return 0;

@@ -311,6 +311,7 @@ int attach_split_weights(odt_model* m) {
   if (pol.arith == 0) return 0;
   std::map<const float*, const void*> made;      // the RPN conv is shared by the five levels
   std::map<const float*, int> made_kind;
+  size_t need_partial = 0;                        // split-K scratch: one buffer, the plan's layers run one after another
   for (ConvOp& c : m->convs) {
     if (!conv_split_wanted(c.p, pol)) continue;
     auto it = made.find(c.p.wt);
@@ -326,13 +327,24 @@ int attach_split_weights(odt_model* m) {
     conv_split_choose(c.p, pol);
     // shared weights (the RPN conv over five levels): one image, so one kernel family -- the first (largest) level's
     if (c.p.wt_split_kind + 16 * c.p.wt_split_bn != made_kind[c.p.wt]) {
+      // (the image depends on the kernel family and the n-tile width only: tile height and split-K stay this level's)
       const int kind = made_kind[c.p.wt] % 16, bn = made_kind[c.p.wt] / 16;
       ODT_CHECK(kind != 3 || c.p.Cin % 16 == 0, "split weights: shared image of an unsupported layout");
+      if (c.p.wt_split_kind != kind) {
+        c.p.splitk = 1;
+        if (kind == 3) c.p.wt_split_bm = bn >= 128 ? 128 : 256;
+        else c.p.wt_split_bm = kind == 2 ? 128 : conv_split_bm(c.p.Cout);
+      }
       c.p.wt_split_kind = kind; c.p.wt_split_bn = bn;
-      if (kind == 3) c.p.wt_split_bm = bn >= 128 ? 128 : 256;
-      else c.p.wt_split_bm = kind == 2 ? 128 : conv_split_bm(c.p.Cout);
     }
+    need_partial = std::max(need_partial, conv_split_partial_bytes(c.p));
     c.p.wt_split = it->second;
+  }
+  if (need_partial > 0) {
+    float* part = m->alloc_f((need_partial + 3) / 4, false);
+    ODT_CHECK(part != nullptr, "device allocation failed (split-K partial sums)");
+    for (ConvOp& c : m->convs)
+      if (conv_split_partial_bytes(c.p) > 0) c.p.partial = part;
   }
   ODT_HIP(hipDeviceSynchronize());
   return 0;
@@ -1315,16 +1327,19 @@ int odt_profile_layer(odt_handle h, int index, char* name, int name_cap, double*
 
 int odt_describe(odt_handle h, char* buf, int cap) {
   ODT_CHECK(h != nullptr && buf != nullptr && cap > 0, "odt_describe: null argument");
-  int fam[4] = {0, 0, 0, 0};
-  for (const ConvOp& c : h->convs) fam[c.p.wt_split != nullptr ? c.p.wt_split_kind : 0] += 1;
+  int fam[4] = {0, 0, 0, 0}, nsk = 0;
+  for (const ConvOp& c : h->convs) {
+    fam[c.p.wt_split != nullptr ? c.p.wt_split_kind : 0] += 1;
+    if (c.p.wt_split != nullptr && c.p.splitk > 1) ++nsk;
+  }
   char tmp[640];
   std::snprintf(tmp, sizeof(tmp),
                 "{\"conv_arith\": \"%s\", \"conv_launches\": %d, \"exact_f32_mfma_launches\": %d, "
                 "\"bf16x3_split_launches\": %d, \"split_launches_by_family\": {\"split3_8wave_lds_dma\": %d, "
-                "\"two_stage_128x256\": %d, \"one_stage_bk32\": %d}, \"policy\": {\"family\": %d, \"min_tiles\": %ld, "
+                "\"two_stage_128x256\": %d, \"one_stage_bk32\": %d, \"of_split3_with_split_k\": %d}, \"policy\": {\"family\": %d, \"min_tiles\": %ld, "
                 "\"min_tiles3\": %ld, \"min_k\": %d}, \"env_overrides_applied\": %d, \"graph_replay\": %d}",
                 h->policy.arith != 0 && fam[1] + fam[2] + fam[3] > 0 ? "f32 through bf16x3 split products" : "exact f32 MFMA",
-                (int)h->convs.size(), fam[0], fam[1] + fam[2] + fam[3], fam[3], fam[2], fam[1], h->policy.family,
+                (int)h->convs.size(), fam[0], fam[1] + fam[2] + fam[3], fam[3], fam[2], fam[1], nsk, h->policy.family,
                 h->policy.min_tiles, h->policy.min_tiles3, h->policy.min_k, h->policy.env_overrides, h->graph_mode);
   std::strncpy(buf, tmp, cap - 1); buf[cap - 1] = 0;
   return 0;

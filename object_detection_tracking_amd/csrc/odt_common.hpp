@@ -69,6 +69,11 @@ struct ConvParams {
                        // 2 two-stage BK = 16, 128 x 256 (conv_split2_kernel) | 3 conv_split3_kernel (8 waves, LDS-DMA)
   int wt_split_bm;     // kind 3: rows of the block tile (256, or 128 when 256-row tiles would not fill the chip)
   int wt_split_bn;     // n-tile width the image was laid out for (kind 3 may use 128 on wider layers; 0: conv_split_bn(Cout))
+  // split-K (conv_split3_kernel only): the reduction is cut into `splitk` contiguous ranges of stages, one workgroup per
+  // (tile, range); each writes its raw f32 partial tile to partial[range][M][Cout] and split_reduce_kernel adds them in
+  // range order (deterministic) and applies bias / residual / activation.  For layers whose tiles cannot fill the chip.
+  int splitk;          // 0 / 1: off
+  float* partial;      // scratch [splitk][M][Cout] (plan-owned, shared by the plan's split-K layers)
 };
 // fills the derived fields (multiply-shift divisors); call before copying a record to the device
 void conv_prepare(ConvParams& p);
@@ -85,6 +90,8 @@ struct ConvPolicy {
   long min_tiles3;      // ... conv_split3_kernel's 256- / 128-row tiles (200)
   int min_k, min_bn;    // shortest reduction / narrowest n-tile taken
   int force_bm3;        // 0 auto | 128 | 256: force conv_split3_kernel with that tile height (tests)
+  int splitk_max;       // conv_split3_kernel: largest split-K factor the policy may choose (1 = off)
+  int force_splitk;     // 0 auto | k: force that split-K factor wherever conv_split3_kernel runs (tests)
   int short_k;          // conv_split3_kernel: reductions up to this length on >= 512-wide layers run 128 x 128 tiles, two
                         // workgroups per CU (one's prologue / store tail under the other's main loop); 0 = off
   bool src2, res2;      // take the K-concatenated stage-entry convs / the 2x-upsampled-residual FPN laterals
@@ -103,6 +110,7 @@ void conv_split_choose(ConvParams& p, const ConvPolicy& q);
 // builds the bf16-piece image of p.wt for p.wt_split_kind (conv_split_choose first)
 int conv_make_split_weights(const ConvParams& p, void* img_dev, hipStream_t stream);
 int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t stream);
+size_t conv_split_partial_bytes(const ConvParams& p);   // scratch a split-K conv needs (0: none)
 
 // ------------------------------------------------------------ elementwise (K1,K4)
 int launch_preprocess(const void* frames, int dtype, int B, int H, int W, int pad_t, int pad_l,

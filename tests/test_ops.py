@@ -488,7 +488,8 @@ SPLIT_CASES = [
 # kernel families of the split path (conv_split_choose): "3/256", "3/128": conv_split3_kernel (8 waves, LDS-DMA weight
 # stages, three-stage ring; the default) with 256- / 128-row tiles; "2": the two-stage 128 x 256 loop; "1": the
 # one-stage BK = 32 loop of round 1
-SPLIT_PIPES = ["3/256", "3/128", "2", "1"]
+# "3/128/k3": the same with the reduction cut into three split-K ranges + split_reduce_kernel
+SPLIT_PIPES = ["3/256", "3/128", "3/128/k3", "2", "1"]
 
 
 def _split_env(monkeypatch, pipe="3/256"):
@@ -496,10 +497,15 @@ def _split_env(monkeypatch, pipe="3/256"):
   monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1")
   monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "1")
   monkeypatch.setenv("ODT_CONV_SPLIT_PIPE", pipe[0])
-  if "/" in pipe:
-    monkeypatch.setenv("ODT_CONV_SPLIT3_BM", pipe.split("/")[1])
+  f = pipe.split("/")
+  if len(f) > 1:
+    monkeypatch.setenv("ODT_CONV_SPLIT3_BM", f[1])
   else:
     monkeypatch.delenv("ODT_CONV_SPLIT3_BM", raising=False)
+  if len(f) > 2:
+    monkeypatch.setenv("ODT_CONV_SPLIT3_FORCE_SPLITK", f[2][1:])
+  else:
+    monkeypatch.delenv("ODT_CONV_SPLIT3_FORCE_SPLITK", raising=False)
 
 
 @pytest.mark.parametrize("pipe", SPLIT_PIPES)
@@ -617,7 +623,7 @@ def test_conv_fuzz_split(backend, pipe, monkeypatch):
     _fuzz_case(rng, lib, big=name == "hip", couts=[64, 128, 192, 256, 384])
 
 
-@pytest.mark.parametrize("pipe", ["3/256", "3/128", "2"])
+@pytest.mark.parametrize("pipe", ["3/256", "3/128", "3/128/k3", "2"])
 def test_conv2d_split_16wide_stage_extras(backend, pipe, monkeypatch):
   """BK = 16 stage kernels: 96- and 160-channel sources (odd numbers of 16-channel slices), residual, second
   source at stride 2."""
