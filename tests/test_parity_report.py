@@ -207,7 +207,9 @@ def test_split_kernel_at_model_shapes_vs_f64(hip_lib, mode, monkeypatch):
     shapes.append((8, 272, 480, 256, 256, 3, False))
   for sh in shapes:
     esp, e32 = _sampled_conv_errors(hip_lib, *sh, rng, monkeypatch, mode)
-    assert esp <= 1.5 * e32 + 1.2e-7 and esp < 1e-6, (sh, esp, e32)
+    # (the older one- / two-stage loops start their accumulators at the residual, so their products are summed on top of
+    # an O(1) value: same absolute bound, no relative one)
+    assert esp < 1e-6 and (mode != "3" or esp <= 1.5 * e32 + 1.2e-7), (sh, esp, e32)
 
 
 @pytest.mark.gpu
