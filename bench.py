@@ -209,6 +209,9 @@ def main():
       except Exception as ex:     # never fatal: `value` above is already measured
         extra["exact_f32_mfma_only_fps"] = "failed: %r" % (ex,)
     extra.update(detect_track_leg(eng, frames, B, local_rank))
+    fast = detect_track_leg(eng, frames, B, local_rank, arrays=True)
+    extra["detect_track_arrays_fps"] = fast["detect_track_fps"]        # create_obj_arrays + Tracker.update_arrays
+    extra["detect_track_arrays_host_ms_per_frame"] = fast["detect_track"]["host_tracking_ms_per_frame"]
     if world == 1 and S == 1:
       # (e) trained RPNs score most anchors negative, so images keep fewer than K proposals (zero-padded NMS slots,
       # models.py:2487-2520); the synthetic weights' +1 RPN class bias keeps all K alive.  Same step with the bias
@@ -363,7 +366,7 @@ def cpu_baseline(cfg, weights, frames, nframes):
                     % (n, frames.shape[0])}
 
 
-def detect_track_leg(eng, frames, B, device, nbatches=8):
+def detect_track_leg(eng, frames, B, device, nbatches=8, arrays=False):
   """BASELINE config #3 end to end: pipelined ingest (uint8 frames from host memory, pooled appearance features
   back) -> create_obj_infos -> tracker-side NMS -> native DeepSORT Tracker.predict / update, two tracked classes,
   frame by frame (reference obj_detect_tracking.py:597-760).  With random-init weights the detector's labels carry
@@ -372,7 +375,8 @@ def detect_track_leg(eng, frames, B, device, nbatches=8):
   repeats its frames the tracks persist (T ~ N): the matching cascade, gating, assignment and the cosine kernel
   all run at the size config #3 names."""
   from object_detection_tracking_amd.application_util import preprocessing
-  from object_detection_tracking_amd.deep_sort import NearestNeighborDistanceMetric, Tracker, create_obj_infos
+  from object_detection_tracking_amd.deep_sort import (NearestNeighborDistanceMetric, Tracker, create_obj_arrays,
+                                                       create_obj_infos)
   id2class = {i: ("Person" if i % 2 else "Vehicle") for i in range(0, 1024)}
   trackers = {c: Tracker(NearestNeighborDistanceMetric("cosine", 0.5, 5), max_iou_distance=0.5, max_age=60, n_init=1,
                          device=device) for c in ("Person", "Vehicle")}
@@ -387,6 +391,13 @@ def detect_track_leg(eng, frames, B, device, nbatches=8):
       fb, fl, fp, ff = boxes[b, :v], labels[b, :v], probs[b, :v], pooled[off:off + v]
       off += v
       for cname, trk in trackers.items():
+        if arrays:          # same selection / arithmetic on arrays, no Detection objects
+          tl, cf, ft = create_obj_arrays(fb, fp, fl, ff, id2class, [cname], 0.0, 0, 1.0)
+          keep = preprocessing.non_max_suppression(tl, 0.85, cf)
+          trk.predict()
+          trk.update_arrays(tl[keep], cf[keep], ft[keep])
+          nd.append(len(keep))
+          continue
         dets = create_obj_infos(nframes, fb, fp, fl, ff, id2class, [cname], 0.0, 0, 1.0)
         keep = preprocessing.non_max_suppression(np.array([d.tlwh for d in dets]).reshape(-1, 4), 0.85,
                                                  np.array([d.confidence for d in dets]))

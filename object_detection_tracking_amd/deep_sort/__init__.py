@@ -5,4 +5,4 @@ filter / matching cascade / assignment / track life cycle.
 from .detection import Detection  # noqa: F401
 from .nn_matching import NearestNeighborDistanceMetric  # noqa: F401
 from .tracker import Tracker  # noqa: F401
-from .utils import create_obj_infos  # noqa: F401
+from .utils import create_obj_arrays, create_obj_infos  # noqa: F401

@@ -94,6 +94,20 @@ class Tracker(object):
       self._lib.check(self._lib.dll.odt_tracker_update(self._h, None, None, None, 0, 0))
     self._tracks = None
 
+  def update_arrays(self, tlwh, confidence, features):
+    """``update`` on arrays (tlwh [n,4] float64, confidence [n], features [n,D] float32) -- what
+    ``deep_sort.utils.create_obj_arrays`` returns -- without building ``Detection`` objects."""
+    tlwh = np.ascontiguousarray(tlwh, dtype=np.float64).reshape(-1, 4)
+    n = tlwh.shape[0]
+    if n:
+      conf = np.ascontiguousarray(confidence, dtype=np.float64)
+      feats = f32(features)
+      self._lib.check(self._lib.dll.odt_tracker_update(
+          self._h, tlwh.ctypes.data_as(c_double_p), conf.ctypes.data_as(c_double_p), fptr(feats), n, feats.shape[1]))
+    else:
+      self._lib.check(self._lib.dll.odt_tracker_update(self._h, None, None, None, 0, 0))
+    self._tracks = None
+
   @property
   def tracks(self):
     if self._tracks is None:

@@ -40,3 +40,27 @@ def create_obj_infos(cur_frame, final_boxes, final_probs, final_labels, box_feat
       feat = np.mean(feat, axis=(1, 2))
     detections.append(Detection([box[0], box[1], box[2], box[3]], conf, feat))
   return detections
+
+
+def create_obj_arrays(final_boxes, final_probs, final_labels, box_feats, targetid2class, tracking_objs,
+                      min_confidence, min_detection_height, scale, is_coco_model=False,
+                      coco_to_actev_mapping=None):
+  """The same selection and arithmetic as :func:`create_obj_infos`, vectorised: returns
+  (tlwh [n,4] float64, confidence [n] float64, feature [n,D] float32) instead of ``Detection`` objects, for
+  ``Tracker.update_arrays`` (a frame's ~100 Python objects cost more than the tracker update itself)."""
+  boxes = np.asarray(final_boxes) / scale
+  probs = np.asarray(final_probs)
+  labels = np.asarray(final_labels)
+  names = [targetid2class[int(l)] for l in labels]
+  if is_coco_model:
+    names = [coco_to_actev_mapping.get(n) for n in names]
+  conf = np.round(probs, 7).astype(np.float64) if probs.dtype == np.float32 else np.asarray([float(round(p, 7)) for p in probs])
+  keep = np.asarray([n in tracking_objs for n in names], bool) & (conf >= min_confidence) if len(names) else np.zeros(0, bool)
+  b = boxes[keep].copy()
+  b[:, 2] -= b[:, 0]
+  b[:, 3] -= b[:, 1]
+  tall = ~(b[:, 3] < min_detection_height)
+  feats = np.asarray(box_feats)[keep][tall]
+  if feats.ndim > 2:
+    feats = np.mean(feats, axis=(2, 3))
+  return b[tall].astype(np.float64), conf[keep][tall], np.ascontiguousarray(feats, dtype=np.float32)
