@@ -341,10 +341,26 @@ int attach_split_weights(odt_model* m) {
     c.p.wt_split = it->second;
   }
   if (need_partial > 0) {
-    float* part = m->alloc_f((need_partial + 3) / 4, false);
-    ODT_CHECK(part != nullptr, "device allocation failed (split-K partial sums)");
-    for (ConvOp& c : m->convs)
-      if (conv_split_partial_bytes(c.p) > 0) c.p.partial = part;
+    // split-K scratch: the layers of one stream run one after another and share a buffer -- but the tail ops (box-head
+    // FCs ...) of forward i run on the side stream UNDER the trunk of forward i+1 (tail overlap), so the two groups get
+    // a buffer each
+    std::vector<char> in_tail(m->convs.size(), 0);
+    bool tail = false;
+    for (const Op& op : m->ops) {
+      if (op.kind == OP_PROPOSALS) tail = true;
+      if (op.kind == OP_CONV && tail) in_tail[op.conv] = 1;
+    }
+    size_t need[2] = {0, 0};
+    for (size_t i = 0; i < m->convs.size(); ++i)
+      need[in_tail[i]] = std::max(need[in_tail[i]], conv_split_partial_bytes(m->convs[i].p));
+    float* part[2] = {nullptr, nullptr};
+    for (int g = 0; g < 2; ++g) {
+      if (need[g] == 0) continue;
+      part[g] = m->alloc_f((need[g] + 3) / 4, false);
+      ODT_CHECK(part[g] != nullptr, "device allocation failed (split-K partial sums)");
+    }
+    for (size_t i = 0; i < m->convs.size(); ++i)
+      if (conv_split_partial_bytes(m->convs[i].p) > 0) m->convs[i].p.partial = part[in_tail[i]];
   }
   ODT_HIP(hipDeviceSynchronize());
   return 0;

@@ -164,3 +164,26 @@ def test_create_destroy_does_not_leak_device_memory(hip_lib):
   torch.cuda.synchronize()
   free1 = torch.cuda.mem_get_info(0)[0]
   assert free0 - free1 < 8 << 20, "device memory shrank by %d bytes over 6 create/destroy cycles" % (free0 - free1)
+
+
+@pytest.mark.gpu
+def test_back_to_back_forwards_with_split_k_in_trunk_and_tail(hip_lib):
+  """b=4 at 1080p: res5 (trunk) and the box-head FCs (tail) both run split-K, and the tail of forward i runs on the
+  side stream under the trunk of forward i+1 -- the two groups must not share a partial-sum buffer.  Pipelined
+  batches must equal the blocking forward bit for bit."""
+  from object_detection_tracking_amd.config import make_config
+  cfg = make_config(rpn_test_post_nms_topk=300, im_batch_size=4)
+  m = models.get_model(cfg, 0, weights=weights_for(cfg), lib=hip_lib, is_multi=True)
+  try:
+    e = m.engine(4, 1080, 1920)
+    d = e.describe()
+    assert d["split_launches_by_family"]["of_split3_with_split_k"] >= 2, d
+    batches = [synthetic_frames(4, 1080, 1920, seed=s) for s in (1, 2, 3)]
+    want = [e.forward(b, want_feats=False, want_pooled=True) for b in batches]
+    got = list(e.forward_stream(batches * 2))
+    for g, w in zip(got, want + want):
+      for a, b in zip(g[:4], w[:4]):
+        assert np.array_equal(a, b)
+      assert np.array_equal(g[5], w[5])
+  finally:
+    m.close()
