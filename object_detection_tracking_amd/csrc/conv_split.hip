@@ -58,6 +58,9 @@ struct SplitCfg {
   static constexpr int NB = STAGE_B / 4096;                   // B 16-B chunks per thread and slice
 };
 
+// Cout rounded up to the 64-wide n-tile granule: layers whose channel count is not a multiple of 64 (EfficientNet's
+// 240, 432, 864 ...) run with zero weight rows and a zero bias in the padding; their tensors' pixel stride covers it
+__host__ __device__ __forceinline__ int cout_padded(int cout) { return (cout + 63) & ~63; }
 __device__ __forceinline__ int sfast_div(int n, unsigned mul, unsigned sh) {
   return mul ? (int)(__umulhi((unsigned)n, mul) >> sh) : n;
 }
@@ -112,7 +115,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
       p.trace[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
     }
   }
-  const int ntn = p.Cout / SBN;
+  const int ntn = cout_padded(p.Cout) / SBN;
   // XCD-aware tile order (see conv_igemm.hip): one contiguous run of tiles per XCD
   int wg = (int)blockIdx.x;
   {
@@ -410,7 +413,7 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvParams* _
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int ntn = p.Cout / SBN;
+  const int ntn = cout_padded(p.Cout) / SBN;
   int wg = (int)blockIdx.x;
   {
     const int nwg = (int)gridDim.x, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
@@ -797,7 +800,7 @@ __global__ void __launch_bounds__(512, 2) conv_split3_kernel(const ConvParams* _
       p.trace[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
     }
   }
-  const int ntn = p.Cout / BN;
+  const int ntn = cout_padded(p.Cout) / BN;
   int wg = (int)blockIdx.x;
   {
     const int nwg = (int)gridDim.x, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
@@ -1056,7 +1059,7 @@ __global__ void __launch_bounds__(512, 2) conv_split3_kernel(const ConvParams* _
     // split-K: the raw partial tile, dense [M][Cout] rows of this range's slab (bias / residual / activation happen in
     // split_reduce_kernel once all ranges are in)
     const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.partial + (size_t)ks * M * p.Cout), 0, (int)((unsigned)M * p.Cout * 4u), 0x00020000);
+        (void*)(p.partial + (size_t)ks * M * cout_padded(p.Cout)), 0, (int)((unsigned)M * cout_padded(p.Cout) * 4u), 0x00020000);
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
       if (pass > 0) ODT_BARRIER_LDS();
@@ -1074,7 +1077,7 @@ __global__ void __launch_bounds__(512, 2) conv_split3_kernel(const ConvParams* _
       for (int s2 = 0; s2 < NCH; ++s2) {
         const int m = m0 + pass * RP + row0 + s2 * RSTEP;
         const f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[(row0 + s2 * RSTEP) * CS + c4 * 4]);
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_part, m < M ? (int)(((unsigned)m * p.Cout + col) * 4u) : (int)kOOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_part, m < M ? (int)(((unsigned)m * cout_padded(p.Cout) + col) * 4u) : (int)kOOB, 0, 0);
       }
     }
     stamp(5);
@@ -1155,14 +1158,14 @@ __global__ void __launch_bounds__(512, 2) conv_split3_kernel(const ConvParams* _
 // f32 weights [Cout][K] -> per-stage image of bf16 pieces (one thread per 8 consecutive k of a row)
 __global__ void split_weights_kernel(const float* __restrict__ wt, int Cout, int K, int SBN, int bk, unsigned short* __restrict__ img) {
   const int nsl = K / bk, kgs = bk >> 3;     // stages along K, k-groups of 8 per stage
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;       // (n, k8)
-  const long total = (long)Cout * (K >> 3);
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;       // (n, k8), n over the padded Cout
+  const long total = (long)cout_padded(Cout) * (K >> 3);
   if (idx >= total) return;
   const int n = (int)(idx / (K >> 3)), k8 = (int)(idx - (long)n * (K >> 3));
   const int tn = n / SBN, nn = n - tn * SBN, sl = k8 / kgs, kg = k8 - sl * kgs;
   for (int e = 0; e < 8; e += 2) {
     unsigned piece[3];
-    split2(wt[(size_t)n * K + k8 * 8 + e], wt[(size_t)n * K + k8 * 8 + e + 1], piece[0], piece[1], piece[2]);
+    split2(n < Cout ? wt[(size_t)n * K + k8 * 8 + e] : 0.f, n < Cout ? wt[(size_t)n * K + k8 * 8 + e + 1] : 0.f, piece[0], piece[1], piece[2]);
     for (int q = 0; q < 3; ++q) {
       const size_t at = ((((size_t)(tn * nsl + sl) * 3 + q) * kgs + kg) * SBN + nn) * 8 + e;
       img[at] = (unsigned short)(piece[q] & 0xffffu);
@@ -1175,15 +1178,15 @@ __global__ void split_weights_kernel(const float* __restrict__ wt, int Cout, int
 // 16-byte chunk of an output row
 __global__ void __launch_bounds__(256) split_reduce_kernel(const ConvParams* __restrict__ pp) {
   const ConvParams p = *pp;
-  const int C4 = p.Cout >> 2;
+  const int Np = cout_padded(p.Cout), C4 = Np >> 2;
   const long M = (long)p.B * p.Ho * p.Wo;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= M * C4) return;
   const int m = (int)(idx / C4), col = (int)(idx - (long)m * C4) * 4;
-  const size_t slab = (size_t)M * p.Cout;
-  f32x4 v = *reinterpret_cast<const f32x4*>(p.partial + (size_t)m * p.Cout + col);
-  for (int k = 1; k < p.splitk; ++k) v += *reinterpret_cast<const f32x4*>(p.partial + (size_t)k * slab + (size_t)m * p.Cout + col);
-  v += *reinterpret_cast<const f32x4*>(p.bias + col);
+  const size_t slab = (size_t)M * Np;
+  f32x4 v = *reinterpret_cast<const f32x4*>(p.partial + (size_t)m * Np + col);
+  for (int k = 1; k < p.splitk; ++k) v += *reinterpret_cast<const f32x4*>(p.partial + (size_t)k * slab + (size_t)m * Np + col);
+  for (int e = 0; e < 4; ++e) v[e] += col + e < p.Cout ? p.bias[col + e] : 0.f;
   const int HoWo = p.Ho * p.Wo;
   const int n = sfast_div(m, p.div_howo_mul, p.div_howo_sh), rr = m - n * HoWo;
   const int ho = sfast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
@@ -1209,7 +1212,7 @@ __global__ void split_weights3_kernel(const float* __restrict__ wt, int Cout, in
                                       unsigned short* __restrict__ img) {
   const int nst = K >> 4, nst1 = ntaps * (Cin >> 4);
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;       // (n, stage, k-group)
-  const long total = (long)Cout * nst * 2;
+  const long total = (long)cout_padded(Cout) * nst * 2;       // n over the padded Cout: zero rows behind the last channel
   if (idx >= total) return;
   const int n = (int)(idx / (nst * 2)), rem = (int)(idx - (long)n * (nst * 2)), st = rem >> 1, kg = rem & 1;
   int k0;
@@ -1219,7 +1222,7 @@ __global__ void split_weights3_kernel(const float* __restrict__ wt, int Cout, in
   const int tn = n / SBN, nn = n - tn * SBN;
   for (int e = 0; e < 8; e += 2) {
     unsigned piece[3];
-    split2(wt[(size_t)n * K + k0 + e], wt[(size_t)n * K + k0 + e + 1], piece[0], piece[1], piece[2]);
+    split2(n < Cout ? wt[(size_t)n * K + k0 + e] : 0.f, n < Cout ? wt[(size_t)n * K + k0 + e + 1] : 0.f, piece[0], piece[1], piece[2]);
     for (int q = 0; q < 3; ++q) {
       const size_t at = ((((size_t)(tn * nst + st) * 3 + q) * 2 + kg) * SBN + nn) * 8 + e;
       img[at] = (unsigned short)(piece[q] & 0xffffu);
@@ -1230,18 +1233,21 @@ __global__ void split_weights3_kernel(const float* __restrict__ wt, int Cout, in
 
 }  // namespace
 
-size_t conv_split_weight_bytes(int Cout, int K) { return (size_t)Cout * K * 6; }
+size_t conv_split_weight_bytes(int Cout, int K) { return (size_t)cout_padded(Cout) * K * 6; }
 
 // n-tile width of the configuration that takes a layer with this Cout (0: none)
-int conv_split_bn(int Cout) { return Cout % 256 == 0 ? 256 : (Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 0)); }
-int conv_split_bm(int Cout) { return Cout % 256 == 0 ? 128 : 256; }
+int conv_split_bn(int Cout) { const int n = cout_padded(Cout); return n % 256 == 0 ? 256 : (n % 128 == 0 ? 128 : 64); }
+int conv_split_bm(int Cout) { return cout_padded(Cout) % 256 == 0 ? 128 : 256; }
 
 bool conv_split_supported(const ConvParams& p) {
   const double wbytes = (double)p.Cout * (p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0)) * 6.0;
   const bool res_ok = p.res_mode == 0 || (p.res_mode == 1 && p.res_H == p.Ho && p.res_W == p.Wo) ||
                       (p.res_mode == 2 && 2 * p.res_H >= p.Ho && 2 * p.res_W >= p.Wo);
   const bool src2_ok = p.in2 == nullptr || (p.kh == 1 && p.kw == 1 && p.Cin2 % 32 == 0 && p.in2_ldc % 4 == 0);
-  return conv_split_bn(p.Cout) != 0 && p.Cin % 32 == 0 && src2_ok && res_ok && p.out_ldc % 4 == 0 &&
+  // a channel count that is not a multiple of 64 needs room for the padded n-tile in the output (and residual) rows
+  const int np = cout_padded(p.Cout);
+  const bool pad_ok = np == p.Cout || (p.Cout >= 16 && p.out_ldc >= np && (p.res_mode == 0 || p.res_ldc >= np));
+  return pad_ok && p.Cin % 32 == 0 && src2_ok && res_ok && p.out_ldc % 4 == 0 &&
          p.in_ldc % 4 == 0 && wbytes < 2147483648.0;
 }
 
@@ -1299,7 +1305,7 @@ static bool split3_fit(const ConvParams& p, const ConvPolicy& q, int* bm, int* b
   // (64-wide layers stay on the one-stage 256 x 64 tile: a 64 x 32 wave tile reads too many fragments per MFMA --
   // same-box A/B at b=8: res2 conv2 132 vs 118 TF, conv0 136 vs 112)
   if (bn0 < 128) return false;
-  const long t256 = ((M + 255) / 256) * (p.Cout / bn0), t128 = ((M + 127) / 128) * (p.Cout / bn0);
+  const long t256 = ((M + 255) / 256) * (cout_padded(p.Cout) / bn0), t128 = ((M + 127) / 128) * (cout_padded(p.Cout) / bn0);
   if (t256 >= q.min_tiles3) { *bm = 256; return with_forced_sk(); }
   if (t128 >= q.min_tiles3) { *bm = 128; return with_forced_sk(); }
   if (q.splitk_max > 1 && p.in2 == nullptr) {
@@ -1322,7 +1328,7 @@ bool conv_split_wanted(const ConvParams& p, const ConvPolicy& q) {
   int b3, n3, k3;
   if (split3_fit(p, q, &b3, &n3, &k3)) return true;
   // one- / two-stage kernels: below one workgroup per CU the exact-f32 kernel's smaller tiles fill the chip better
-  return ((M + bm - 1) / bm) * (p.Cout / bn) >= q.min_tiles;
+  return ((M + bm - 1) / bm) * (cout_padded(p.Cout) / bn) >= q.min_tiles;
 }
 
 // which kernel family takes a conv that conv_split_wanted() accepted: family 1 = one-stage BK = 32 kernel everywhere,
@@ -1346,7 +1352,7 @@ void conv_split_choose(ConvParams& p, const ConvPolicy& q) {
 }
 
 size_t conv_split_partial_bytes(const ConvParams& p) {
-  return p.wt_split_kind == 3 && p.splitk > 1 ? (size_t)p.splitk * p.B * p.Ho * p.Wo * p.Cout * sizeof(float) : 0;
+  return p.wt_split_kind == 3 && p.splitk > 1 ? (size_t)p.splitk * p.B * p.Ho * p.Wo * cout_padded(p.Cout) * sizeof(float) : 0;
 }
 
 int conv_make_split_weights(const ConvParams& p, void* img_dev, hipStream_t stream) {
@@ -1355,11 +1361,11 @@ int conv_make_split_weights(const ConvParams& p, void* img_dev, hipStream_t stre
   ODT_CHECK(bn != 0 && K % 32 == 0 && p.wt_split_kind >= 1 && p.wt_split_kind <= 3,
             "conv_make_split_weights: Cout % 64 == 0, K % 32 == 0 and a chosen kernel family required");
   if (p.wt_split_kind == 3) {
-    const long total = (long)p.Cout * (K >> 4) * 2;
+    const long total = (long)cout_padded(p.Cout) * (K >> 4) * 2;
     hipLaunchKernelGGL(split_weights3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p.wt, p.Cout, K,
                        bn, p.kh * p.kw, p.Cin, (unsigned short*)img_dev);
   } else {
-    const long total = (long)p.Cout * (K >> 3);
+    const long total = (long)cout_padded(p.Cout) * (K >> 3);
     hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p.wt, p.Cout, K,
                        bn, p.wt_split_kind == 2 ? 16 : 32, (unsigned short*)img_dev);
   }
@@ -1382,7 +1388,7 @@ int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t st
     const int sk = p.splitk > 1 ? p.splitk : 1;
     ODT_CHECK(sk == 1 || (p.partial != nullptr && p.in2 == nullptr && (p.kh * p.kw * p.Cin >> 4) >= sk),
               "conv split3: split-K needs a partial buffer, a single source and at least one stage per range");
-    const unsigned grid = (unsigned)(((M + bm - 1) / bm) * (p.Cout / bn) * sk);
+    const unsigned grid = (unsigned)(((M + bm - 1) / bm) * (cout_padded(p.Cout) / bn) * sk);
     if (bm == 256) {
       if (bn == 256) launch_split3<4, 2, 4>(p, dev, grid, stream);
       else if (bn == 128) launch_split3<4, 2, 2>(p, dev, grid, stream);
@@ -1392,14 +1398,14 @@ int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t st
       else launch_split3<2, 4, 1>(p, dev, grid, stream);
     }
     if (sk > 1) {
-      const long chunks = M * (p.Cout / 4);
+      const long chunks = M * (cout_padded(p.Cout) / 4);
       hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, dev);
     }
     ODT_HIP(hipGetLastError());
     return 0;
   }
   const int bm = conv_split_bm(p.Cout);
-  const unsigned grid = (unsigned)(((M + bm - 1) / bm) * (p.Cout / bn));
+  const unsigned grid = (unsigned)(((M + bm - 1) / bm) * (cout_padded(p.Cout) / bn));
   if (p.wt_split_kind == 2) {
     ODT_CHECK(bn == 256, "conv split: the 16-wide stage image belongs to the 128 x 256 tile");
     hipLaunchKernelGGL(conv_split2_kernel, dim3(grid), dim3(256), 0, stream, dev);

@@ -189,6 +189,20 @@ def test_efficientdet_d0_end_to_end(backend):
   _det_e2e(lib, "efficientdet-d0", 136, 152 if name == "emu" else 200, topk=300 if name == "emu" else 1000)
 
 
+@pytest.mark.parametrize("mode", ["split_forced", "f32_32ch"])
+def test_efficientdet_d0_arithmetic_and_stride_modes(backend, mode, monkeypatch):
+  """The two ways the EfficientDet plan can run its 1x1 convs: every one of them forced onto the bf16x3 split kernels
+  (channel counts that are not multiples of 64 -- 40, 72, 144, 240, 432 ... -- go through the padded n-tile: zero weight
+  rows, zero bias, 64-channel tensor strides), and the exact-f32 kernel with 32-channel strides (ODT_EFFDET_SPLIT=0)."""
+  name, lib = backend
+  if mode == "split_forced":
+    monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1"); monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "1")
+  else:
+    monkeypatch.setenv("ODT_EFFDET_SPLIT", "0")
+  _backbone_parity(lib, "efficientnet-b0", 64, 96)
+  _det_e2e(lib, "efficientdet-d0", 136, 152 if name == "emu" else 200, topk=300 if name == "emu" else 1000)
+
+
 def test_efficientdet_d0_partial_classes(emu_lib):
   """--use_partial_classes on the EfficientDet path (efficientdet_wrapper.py:243-250, 402-410):
   labels are 1..len(partial) in the order of partial_class_idxs."""
