@@ -763,6 +763,133 @@ __global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvParams* _
 #define ODT_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #endif
 
+#define ODT_STAMP(i) do { if constexpr (TRACE) { if (tid == 0) p.trace[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } } while (0)
+// Epilogue shared by the conv_split3 kernels: accumulators of the 8 waves (wave tile 64 x 32 TN at (wm, wn)) -> LDS ->
+// rows of 16-byte chunks -> bias (+ residual) + activation -> global, or the raw partial tile of a split-K range.
+template <int WM, int WN, int TN, int LDSB, bool TRACE>
+__device__ __forceinline__ void split3_epilogue(const ConvParams& p, f32x16 (&acc)[2][TN], unsigned char* lds, int m0, int n0,
+                                                int M, int HoWo, int ks, int splitk, int tid, int wm, int wn, int fr, int fg) {
+  constexpr int BM = 64 * WM, BN = 32 * TN * WN;
+  // ---- epilogue: the C tile goes through LDS in passes of RP rows; per 16-byte row chunk: bias (+ residual)
+  // + activation, 16-byte stores (a wave writes whole row segments).  The residual chunks of a pass are fetched
+  // before the pass is staged, so their latency hides behind the LDS round trip.
+  constexpr int CS = BN + 4;
+  constexpr int FIT = LDSB / (CS * 4);                    // rows of the C tile the ring's LDS holds
+  constexpr int RP = FIT >= BM ? BM : (FIT >= BM / 2 ? BM / 2 : (FIT >= BM / 4 ? BM / 4 : 64));   // rows per pass
+  constexpr int NPASS = BM / RP, WPP = RP / 64;
+  constexpr int C4 = BN / 4, RSTEP = 512 / C4, NCH = RP / RSTEP;
+  static_assert(RP >= 64 && BM % RP == 0 && RP % RSTEP == 0, "epilogue passes");
+  float* Ct = reinterpret_cast<float*>(lds);
+  const bool dense_io = p.out_oy == 0 && p.out_ox == 0 && p.out_H == p.Ho && p.out_W == p.Wo &&
+                        (p.res_mode == 0 || (p.res_mode == 1 && p.res_H == p.Ho && p.res_W == p.Wo));
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.out, 0, (int)((unsigned)p.B * p.out_H * p.out_W * p.out_ldc * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_bias =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (int)((unsigned)p.Cout * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.res_mode != 0 ? p.res : p.bias), 0,
+      (int)(p.res_mode != 0 ? (unsigned)p.B * p.res_H * p.res_W * p.res_ldc * 4u : 0u), 0x00020000);
+  const int c4 = tid % C4, row0 = tid / C4;
+  const int col = n0 + c4 * 4;
+  if (splitk > 1) {
+    // split-K: the raw partial tile, dense [M][Cout] rows of this range's slab (bias / residual / activation happen in
+    // split_reduce_kernel once all ranges are in)
+    const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.partial + (size_t)ks * M * cout_padded(p.Cout)), 0, (int)((unsigned)M * cout_padded(p.Cout) * 4u), 0x00020000);
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      if (pass > 0) ODT_BARRIER_LDS();
+      if (wm / WPP == pass) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              Ct[((wm % WPP) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * CS + wn * TN * 32 + j * 32 + fr] = acc[i][j][r];
+      }
+      ODT_BARRIER_LDS();
+#pragma unroll
+      for (int s2 = 0; s2 < NCH; ++s2) {
+        const int m = m0 + pass * RP + row0 + s2 * RSTEP;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[(row0 + s2 * RSTEP) * CS + c4 * 4]);
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_part, m < M ? (int)(((unsigned)m * cout_padded(p.Cout) + col) * 4u) : (int)kOOB, 0, 0);
+      }
+    }
+    ODT_STAMP(5);
+    return;
+  }
+  const f32x4 bias4 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, col * 4, 0, 0);
+  // (no barrier needed here: the last stage's barrier sits behind every fragment read of the ring)
+  auto run = [&](auto act_c, auto res_c) {
+    constexpr int ACT = decltype(act_c)::value;
+    constexpr bool RES = decltype(res_c)::value;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      unsigned ooff[NCH];
+      f32x4 rres[RES ? NCH : 1];
+#pragma unroll
+      for (int s2 = 0; s2 < NCH; ++s2) {
+        const int m = m0 + pass * RP + row0 + s2 * RSTEP;
+        const bool ok = m < M;
+        unsigned opix = (unsigned)m, rpix = (unsigned)m;
+        if (!dense_io) {
+          const int mm = ok ? m : 0;
+          const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), rr = mm - n * HoWo;
+          const int ho = sfast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
+          opix = ((unsigned)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
+          rpix = p.res_mode == 2 ? ((unsigned)n * p.res_H + (unsigned)(ho >> 1)) * p.res_W + (unsigned)(wo >> 1)
+                                 : ((unsigned)n * p.res_H + (unsigned)ho) * p.res_W + (unsigned)wo;
+        }
+        ooff[s2] = ok ? (opix * p.out_ldc + col) * 4u : kOOB;
+        if constexpr (RES)
+          rres[s2] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_res, ok ? (int)((rpix * p.res_ldc + col) * 4u) : (int)kOOB, 0, 0);
+      }
+      if (pass > 0) ODT_BARRIER_LDS();        // the previous pass has been read
+      if (wm / WPP == pass) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              Ct[((wm % WPP) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * CS + wn * TN * 32 + j * 32 + fr] = acc[i][j][r];
+      }
+      ODT_BARRIER_LDS();
+      if (pass == 0) ODT_STAMP(3);
+#pragma unroll
+      for (int s2 = 0; s2 < NCH; ++s2) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[(row0 + s2 * RSTEP) * CS + c4 * 4]);
+        v += bias4;
+        if constexpr (RES) v += rres[s2];
+        if (ACT == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (ACT == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f / (1.0f + expf(-v[e])));
+        } else if (ACT == 3) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
+        }
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)ooff[s2], 0, 0);
+      }
+      if (pass == 0) ODT_STAMP(4);
+    }
+  };
+  if (p.res_mode != 0) {
+    if (p.relu == 1) run(std::integral_constant<int, 1>{}, std::true_type{});
+    else if (p.relu == 0) run(std::integral_constant<int, 0>{}, std::true_type{});
+    else if (p.relu == 2) run(std::integral_constant<int, 2>{}, std::true_type{});
+    else run(std::integral_constant<int, 3>{}, std::true_type{});
+  } else {
+    if (p.relu == 1) run(std::integral_constant<int, 1>{}, std::false_type{});
+    else if (p.relu == 0) run(std::integral_constant<int, 0>{}, std::false_type{});
+    else if (p.relu == 2) run(std::integral_constant<int, 2>{}, std::false_type{});
+    else run(std::integral_constant<int, 3>{}, std::false_type{});
+  }
+}
+
 template <int WM, int WN, int TN>
 struct Split3Cfg {
   static constexpr int BM = 64 * WM, BN = 32 * TN * WN;
@@ -1033,125 +1160,293 @@ __global__ void __launch_bounds__(512, 2) conv_split3_kernel(const ConvParams* _
 #undef ODT_MF
 #undef ODT_FENCE
   stamp(2);
+  split3_epilogue<WM, WN, TN, G::LDS, TRACE>(p, acc, lds, m0, n0, M, HoWo, ks, splitk, tid, wm, wn, fr, fg);
+  stamp(5);
+}
 
-  // ---- epilogue: the C tile goes through LDS in passes of RP rows; per 16-byte row chunk: bias (+ residual)
-  // + activation, 16-byte stores (a wave writes whole row segments).  The residual chunks of a pass are fetched
-  // before the pass is staged, so their latency hides behind the LDS round trip.
-  constexpr int CS = BN + 4;
-  constexpr int FIT = G::LDS / (CS * 4);                    // rows of the C tile the ring's LDS holds
-  constexpr int RP = FIT >= BM ? BM : (FIT >= BM / 2 ? BM / 2 : (FIT >= BM / 4 ? BM / 4 : 64));   // rows per pass
-  constexpr int NPASS = BM / RP, WPP = RP / 64;
-  constexpr int C4 = BN / 4, RSTEP = 512 / C4, NCH = RP / RSTEP;
-  static_assert(RP >= 64 && BM % RP == 0 && RP % RSTEP == 0, "epilogue passes");
-  float* Ct = reinterpret_cast<float*>(lds);
-  const bool dense_io = p.out_oy == 0 && p.out_ox == 0 && p.out_H == p.Ho && p.out_W == p.Wo &&
-                        (p.res_mode == 0 || (p.res_mode == 1 && p.res_H == p.Ho && p.res_W == p.Wo));
-  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.out, 0, (int)((unsigned)p.B * p.out_H * p.out_W * p.out_ldc * 4u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_bias =
-      __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (int)((unsigned)p.Cout * 4u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.res_mode != 0 ? p.res : p.bias), 0,
-      (int)(p.res_mode != 0 ? (unsigned)p.B * p.res_H * p.res_W * p.res_ldc * 4u : 0u), 0x00020000);
-  const int c4 = tid % C4, row0 = tid / C4;
-  const int col = n0 + c4 * 4;
-  if (splitk > 1) {
-    // split-K: the raw partial tile, dense [M][Cout] rows of this range's slab (bias / residual / activation happen in
-    // split_reduce_kernel once all ranges are in)
-    const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.partial + (size_t)ks * M * cout_padded(p.Cout)), 0, (int)((unsigned)M * cout_padded(p.Cout) * 4u), 0x00020000);
-#pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-      if (pass > 0) ODT_BARRIER_LDS();
-      if (wm / WPP == pass) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              Ct[((wm % WPP) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * CS + wn * TN * 32 + j * 32 + fr] = acc[i][j][r];
-      }
-      ODT_BARRIER_LDS();
-#pragma unroll
-      for (int s2 = 0; s2 < NCH; ++s2) {
-        const int m = m0 + pass * RP + row0 + s2 * RSTEP;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[(row0 + s2 * RSTEP) * CS + c4 * 4]);
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_part, m < M ? (int)(((unsigned)m * cout_padded(p.Cout) + col) * 4u) : (int)kOOB, 0, 0);
-      }
-    }
-    stamp(5);
-    return;
-  }
-  const f32x4 bias4 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, col * 4, 0, 0);
-  // (no barrier needed here: the last stage's barrier sits behind every fragment read of the ring)
-  auto run = [&](auto act_c, auto res_c) {
-    constexpr int ACT = decltype(act_c)::value;
-    constexpr bool RES = decltype(res_c)::value;
-#pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-      unsigned ooff[NCH];
-      f32x4 rres[RES ? NCH : 1];
-#pragma unroll
-      for (int s2 = 0; s2 < NCH; ++s2) {
-        const int m = m0 + pass * RP + row0 + s2 * RSTEP;
-        const bool ok = m < M;
-        unsigned opix = (unsigned)m, rpix = (unsigned)m;
-        if (!dense_io) {
-          const int mm = ok ? m : 0;
-          const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), rr = mm - n * HoWo;
-          const int ho = sfast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
-          opix = ((unsigned)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
-          rpix = p.res_mode == 2 ? ((unsigned)n * p.res_H + (unsigned)(ho >> 1)) * p.res_W + (unsigned)(wo >> 1)
-                                 : ((unsigned)n * p.res_H + (unsigned)ho) * p.res_W + (unsigned)wo;
-        }
-        ooff[s2] = ok ? (opix * p.out_ldc + col) * 4u : kOOB;
-        if constexpr (RES)
-          rres[s2] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_res, ok ? (int)((rpix * p.res_ldc + col) * 4u) : (int)kOOB, 0, 0);
-      }
-      if (pass > 0) ODT_BARRIER_LDS();        // the previous pass has been read
-      if (wm / WPP == pass) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              Ct[((wm % WPP) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * CS + wn * TN * 32 + j * 32 + fr] = acc[i][j][r];
-      }
-      ODT_BARRIER_LDS();
-      if (pass == 0) stamp(3);
-#pragma unroll
-      for (int s2 = 0; s2 < NCH; ++s2) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[(row0 + s2 * RSTEP) * CS + c4 * 4]);
-        v += bias4;
-        if constexpr (RES) v += rres[s2];
-        if (ACT == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (ACT == 2) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f / (1.0f + expf(-v[e])));
-        } else if (ACT == 3) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
-        }
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)ooff[s2], 0, 0);
-      }
-      if (pass == 0) stamp(4);
+// ---------------------------------------------------------------------------------------------------------
+// conv_split3k_kernel: conv_split3_kernel for stride-1 KH x 3 convs whose input rows have the output's pitch
+// (in_Wa == Wo: the 3x3 layers of res3 / res4, the FPN post-hoc and RPN convs) -- the three kw taps of a
+// (16-channel slice, kh) group read ONE staged, once-split run of input pixels at row offsets 0, dil, 2 dil instead
+// of fetching and splitting the activations per tap.  Ablation on the MI355X (A work on every third stage only,
+// profiles/r02_ablate_a_third.txt): P2-level 3x3 229 -> 296 TF, res4 conv2 227 -> 253, all conv launches -7 %.
+//   * the 256 output pixels of a tile are consecutive in (n, ho, wo); within an image their tap-(kh, 0) input pixels are
+//     consecutive too (stride 1, equal pitch), so a group's stage is the run [first - pad_l, last - pad_l + 2 dil];
+//     a tile that crosses an image boundary stages two runs back to back (capacity 256 + 2 x 2 dil rows);
+//   * taps that fall outside the image (left / right / top / bottom border, rows past M) read a zero row of the
+//     stage instead: a per-lane 9-bit validity mask picks the fragment address -- no masking of data;
+//   * A stages: two buffers (this group / next group), B stages: the three-deep DMA ring as before; the group's
+//     fetch (3 x 16 B per thread) is issued in its first stage, split + stored in the second and third.
+// Same arithmetic, same K order, same weight image and epilogue as conv_split3_kernel: results are bit-identical.
+template <int TN>
+struct Split3kCfg {
+  static constexpr int BM = 256, BN = 64 * TN;
+  static constexpr int PR = 272;                             // stage rows: 256 + 2 runs x 2 dil (dil <= 2) + the zero row, padded
+  static constexpr int ZR = PR - 1;                          // the zero row
+  static constexpr int AKG = PR * 16 + 64, APL = 2 * AKG, ABUF = 3 * APL;
+  static constexpr int BKG = BN * 16, BPL = 2 * BKG, STAGE_B = 3 * BPL;
+  static constexpr int BOFF = 2 * ABUF;
+  static constexpr int RING = BOFF + 3 * STAGE_B;
+  static constexpr int CTILE = 128 * (BN + 4) * 4;            // two 128-row epilogue passes
+  static constexpr int LDS = RING > CTILE ? RING : CTILE;
+  static constexpr int NCHUNK = STAGE_B / 1024;
+  static_assert(LDS <= 160 * 1024, "LDS");
+};
+
+template <int TN, bool TRACE = false, bool KWR_LATE = true>
+__global__ void __launch_bounds__(512, 2) conv_split3k_kernel(const ConvParams* __restrict__ pp) {
+  using G = Split3kCfg<TN>;
+  constexpr int WM = 4, WN = 2, KW = 3;
+  constexpr int BM = G::BM, BN = G::BN, AKG = G::AKG, APL = G::APL, ABUF = G::ABUF, BKG = G::BKG, BPL = G::BPL;
+  constexpr int STAGE_B = G::STAGE_B, BOFF = G::BOFF, NCHUNK = G::NCHUNK, ZR = G::ZR;
+  const ConvParams p = *pp;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  auto stamp = [&](int i) {
+    if constexpr (TRACE) {
+      if (tid == 0) p.trace[(size_t)blockIdx.x * 16 + i] = wall_clock64();
     }
   };
-  if (p.res_mode != 0) {
-    if (p.relu == 1) run(std::integral_constant<int, 1>{}, std::true_type{});
-    else if (p.relu == 0) run(std::integral_constant<int, 0>{}, std::true_type{});
-    else if (p.relu == 2) run(std::integral_constant<int, 2>{}, std::true_type{});
-    else run(std::integral_constant<int, 3>{}, std::true_type{});
-  } else {
-    if (p.relu == 1) run(std::integral_constant<int, 1>{}, std::false_type{});
-    else if (p.relu == 0) run(std::integral_constant<int, 0>{}, std::false_type{});
-    else if (p.relu == 2) run(std::integral_constant<int, 2>{}, std::false_type{});
-    else run(std::integral_constant<int, 3>{}, std::false_type{});
+  stamp(0);
+  if constexpr (TRACE) {
+    if (tid == 0) {
+      p.trace[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+      p.trace[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
   }
+  const int ntn = cout_padded(p.Cout) / BN;
+  int wg = (int)blockIdx.x;
+  {
+    const int nwg = (int)gridDim.x, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  const int mt = wg / ntn, nt = wg - mt * ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int HoWo = p.Ho * p.Wo;
+  const int M = p.B * HoWo;
+  const int cpt = p.Cin >> 4;
+  const int nsteps = p.kh * KW * cpt, ngroups = p.kh * cpt;
+  const int halo = (KW - 1) * p.dil;
+
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.in, 0, (int)((unsigned)p.B * p.in_Ha * p.in_Wa * p.in_ldc * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.wt_split, 0, (int)((unsigned)ntn * nsteps * (unsigned)STAGE_B), 0x00020000);
+
+  // ---- weights: as conv_split3_kernel
+  unsigned l_b = (unsigned)nt * (unsigned)nsteps * (unsigned)STAGE_B;
+  auto dma_b = [&](int boff) {
+#pragma unroll
+    for (int i = 0; i < (NCHUNK + 7) / 8; ++i) {
+      if ((i + 1) * 8 <= NCHUNK || i * 8 + wave < NCHUNK)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, ODT_LDS_PTR(lds + boff + (i * 8 + wave) * 1024), 16,
+                                                 lane * 16 + (i * 8 + wave) * 1024, (int)l_b, 0, 0);
+    }
+    l_b += (unsigned)STAGE_B;
+  };
+  constexpr int NW = (NCHUNK + 7) / 8;
+  const bool dma_full = (NCHUNK % 8) == 0 || wave < (NCHUNK % 8);
+  constexpr int RA = 3;                      // A fetch instructions per thread and group
+  // wait_stage<A, Y>: this wave's DMA of the stage the barrier publishes has landed (+ all its LDS stores); Y: this
+  // stage's DMA was issued behind it and may stay in flight; A: so may the group fetch (RA loads) issued in this stage
+  auto wait_stage = [&](auto AF, auto YF) {
+    constexpr bool a = decltype(AF)::value, y = decltype(YF)::value;
+    if constexpr (!y) {
+      ODT_WAIT_VM_LGKM0(0);
+    } else if constexpr (a) {
+      if (dma_full) ODT_WAIT_VM_LGKM0(RA + NW); else ODT_WAIT_VM_LGKM0(RA + NW - 1);
+    } else {
+      if (dma_full) ODT_WAIT_VM_LGKM0(NW); else ODT_WAIT_VM_LGKM0(NW - 1 > 0 ? NW - 1 : 0);
+    }
+  };
+  dma_b(BOFF);
+  if (nsteps > 1) dma_b(BOFF + STAGE_B);
+
+  // ---- the tile's two runs of input pixels (tap (kh, 0) of row r: run0 for r < len0, run1 behind it)
+  const int pix_bytes = p.in_ldc * 4;
+  const int n_first = sfast_div(m0, p.div_howo_mul, p.div_howo_sh), r_img = m0 - n_first * HoWo;
+  const int len0 = HoWo - r_img < BM ? HoWo - r_img : BM;
+  const int pix0 = (n_first * p.in_Ha - p.pad_t) * p.in_Wa + r_img - p.pad_l;          // (pitch == Wo: r_img = ho * Wo + wo)
+  const int pix1 = ((n_first + 1) * p.in_Ha - p.pad_t) * p.in_Wa - p.pad_l;
+  // loader: thread -> stage row (t >> 2) + 128 j, 16-byte column t & 3
+  const int a_c = tid & 3, a_r = tid >> 2;
+  int a_base[RA];
+#pragma unroll
+  for (int j = 0; j < RA; ++j) {
+    const int pr = a_r + 128 * j;
+    const int pix = pr < len0 + halo ? pix0 + pr : pix1 + (pr - len0 - halo);
+    a_base[j] = pr < BM + 2 * halo ? pix * pix_bytes + a_c * 16 : (int)kOOB;
+  }
+  int l_cs = 0, l_kh = 0;                    // next group to fetch
+  f32x4 ga[RA];
+  auto load_group = [&]() {
+    const int khoff = l_kh * p.dil * p.in_Wa * pix_bytes;
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+      const unsigned v = (unsigned)a_base[j] == kOOB ? kOOB : (unsigned)(a_base[j] + khoff);
+      ga[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)v, l_cs * 64, 0);
+    }
+    if (++l_kh == p.kh) { l_kh = 0; ++l_cs; }
+  };
+  auto store_slot = [&](int abuf, int j) {
+    const int pr = a_r + 128 * j;
+    if (pr < BM + 2 * halo) {
+      unsigned h0, m0_, l0, h1, m1, l1;
+      split2(ga[j][0], ga[j][1], h0, m0_, l0);
+      split2(ga[j][2], ga[j][3], h1, m1, l1);
+      unsigned char* d = lds + abuf + (a_c >> 1) * AKG + pr * 16 + (a_c & 1) * 8;
+      *reinterpret_cast<u32x2*>(d + 0 * APL) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(d + 1 * APL) = u32x2{m0_, m1};
+      *reinterpret_cast<u32x2*>(d + 2 * APL) = u32x2{l0, l1};
+    }
+  };
+  // the zero rows of both A buffers (never overwritten: stage rows stop at 256 + 2 halo <= ZR)
+  if (tid < 12) {
+    const int b = tid / 6, q = (tid % 6) >> 1, kg = tid & 1;
+    *reinterpret_cast<u32x4*>(lds + b * ABUF + q * APL + kg * AKG + ZR * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+
+  // ---- fragment rows of this lane: stage row of (row, tap kw = 0) and the 9-bit tap validity
+  const int fr = lane & 31, fg = lane >> 5;
+  int fa_base[2];
+  unsigned fa_mask[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int row = wm * 64 + t * 32 + fr, m = m0 + row;
+    const bool ok = m < M;
+    const int mm = ok ? m : 0;
+    const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), r = mm - n * HoWo;
+    const int ho = sfast_div(r, p.div_wo_mul, p.div_wo_sh), wo = r - ho * p.Wo;
+    unsigned mk = 0;
+    for (int khh = 0; khh < p.kh; ++khh)
+      for (int kww = 0; kww < KW; ++kww) {
+        const int hi = ho - p.pad_t + khh * p.dil, wi = wo - p.pad_l + kww * p.dil;
+        if (ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) mk |= 1u << (khh * KW + kww);
+      }
+    fa_mask[t] = mk;
+    fa_base[t] = fg * AKG + (row < len0 ? row : row + halo) * 16;
+  }
+  const int fa_zero = fg * AKG + ZR * 16;
+  const int b_rd = fg * BKG + (wn * TN * 32 + fr) * 16;
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- prologue: group 0 staged, B stages 0 / 1 in flight
+  load_group();
+  stamp(6);
+#pragma unroll
+  for (int j = 0; j < RA; ++j) store_slot(0, j);
+  if (nsteps > 1) {
+    if (dma_full) ODT_WAIT_VM_LGKM0(NW); else ODT_WAIT_VM_LGKM0(NW - 1 > 0 ? NW - 1 : 0);
+  } else {
+    ODT_WAIT_VM_LGKM0(0);
+  }
+  __builtin_amdgcn_s_barrier();
+  stamp(7); stamp(1);
+
+  bf16x8 fa[3][2], fb[3];
+  int fa_addr[2];                            // this stage's fragment addresses (A buffer + row + tap, or the zero row)
+  int c_kh = 0;                              // kh of the group being computed
+  auto tap_addr = [&](int abuf, int khh, int kww) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      fa_addr[t] = abuf + (((fa_mask[t] >> (khh * KW + kww)) & 1u) ? fa_base[t] + kww * p.dil * 16 : fa_zero);
+  };
+  auto rdA = [&](int q) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) fa[q][t] = *reinterpret_cast<const bf16x8*>(lds + q * APL + fa_addr[t]);
+  };
+  auto rdB = [&](int boff, int q, int j) {
+    fb[q] = *reinterpret_cast<const bf16x8*>(lds + boff + q * BPL + b_rd + j * 512);
+  };
+  int a_cur = 0, a_nxt = ABUF;
+  int b_cur = BOFF, b_nxt = BOFF + STAGE_B, b_nn = BOFF + 2 * STAGE_B;
+  tap_addr(a_cur, 0, 0);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) rdA(q);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) rdB(b_cur, q, 0);
+
+#define ODT_MF(qa, qb, j) { acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][0], fb[qb], acc[0][j], 0, 0, 0); \
+                            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][1], fb[qb], acc[1][j], 0, 0, 0); }
+#define ODT_FENCE() __builtin_amdgcn_sched_barrier(0)
+  // One stage = tap kw = KWI of the current group.  NEXT / PRE as in conv_split3_kernel (stage c+1 / c+2 exist);
+  // GN: a next group exists (fetch it in the first stage, split + store it in the second and third)
+  auto step = [&](auto KWIC, auto NEXT, auto PRE, auto GNC) {
+    constexpr int KWI = decltype(KWIC)::value;
+    constexpr bool next = decltype(NEXT)::value, pre = decltype(PRE)::value, gn = decltype(GNC)::value;
+    ODT_FENCE();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const bool last = j == TN - 1, first = j == 0;
+      if (last) {
+        wait_stage(std::integral_constant<bool, (KWI == 0 && gn)>{}, std::integral_constant<bool, pre>{});
+        __builtin_amdgcn_s_barrier();
+        // fragment addresses of the next stage: next tap of this group, or tap 0 of the next group's buffer
+        if constexpr (next) {
+          if constexpr (KWI + 1 < KW) tap_addr(a_cur, c_kh, KWI + 1);
+          else tap_addr(a_nxt, c_kh + 1 == p.kh ? 0 : c_kh + 1, 0);
+        }
+        ODT_FENCE();
+      }
+      ODT_MF(2, 0, j); ODT_FENCE();
+      if (last) { if constexpr (next) rdA(2); }
+      else if constexpr (gn) {
+        // the next group's run: registers -> LDS.  LATE (default): all of it in the group's third stage, two stages
+        // behind the fetch (the P2-level runs come from HBM / MALL: one stage of lead left the split waiting)
+        if constexpr (KWR_LATE) {
+          if constexpr (KWI == 2) {
+            if (TN > 2) { if (j < 3) store_slot(a_nxt, j); }
+            else if (first) { store_slot(a_nxt, 0); store_slot(a_nxt, 1); store_slot(a_nxt, 2); }
+          }
+        } else if (first) {
+          if constexpr (KWI == 1) { store_slot(a_nxt, 0); store_slot(a_nxt, 1); }
+          if constexpr (KWI == 2) store_slot(a_nxt, 2);
+        }
+      }
+      ODT_FENCE();
+      ODT_MF(1, 0, j); ODT_MF(0, 0, j); ODT_FENCE();
+      if (!last) rdB(b_cur, 0, j + 1); else if constexpr (next) rdB(b_nxt, 0, 0);
+      ODT_FENCE();
+      ODT_MF(1, 1, j); ODT_FENCE();
+      if (last) { if constexpr (next) rdA(1); }
+      else if (first) { if constexpr (gn && KWI == 0) load_group(); }
+      ODT_FENCE();
+      ODT_MF(0, 1, j); ODT_FENCE();
+      if (!last) rdB(b_cur, 1, j + 1); else if constexpr (next) rdB(b_nxt, 1, 0);
+      if (!last && j == (TN > 2 ? 1 : 0)) { if constexpr (pre) dma_b(b_nn); }
+      ODT_FENCE();
+      ODT_MF(0, 2, j); ODT_FENCE();
+      if (!last) rdB(b_cur, 2, j + 1); else if constexpr (next) { rdA(0); rdB(b_nxt, 2, 0); }
+      ODT_FENCE();
+    }
+    const int t = b_cur; b_cur = b_nxt; b_nxt = b_nn; b_nn = t;
+    if constexpr (KWI == KW - 1) {
+      const int u = a_cur; a_cur = a_nxt; a_nxt = u;
+      if (++c_kh == p.kh) c_kh = 0;
+    }
+  };
+  {
+    using T = std::true_type; using F = std::false_type;
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+    for (int g = 0; g + 1 < ngroups; ++g) { step(K0{}, T{}, T{}, T{}); step(K1{}, T{}, T{}, T{}); step(K2{}, T{}, T{}, T{}); }
+    step(K0{}, T{}, T{}, F{});
+    step(K1{}, T{}, F{}, F{});
+    step(K2{}, F{}, F{}, F{});
+  }
+#undef ODT_MF
+#undef ODT_FENCE
+  stamp(2);
+  split3_epilogue<WM, WN, TN, G::LDS, TRACE>(p, acc, lds, m0, n0, M, HoWo, 0, 1, tid, wm, wn, fr, fg);
   stamp(5);
 }
 
@@ -1262,7 +1557,7 @@ ConvPolicy conv_policy_default() {
   q.min_tiles = 256;      // one- / two-stage kernels: A/B at b=8 and b=1: 256 > 384 > 128 >> 64
   q.min_tiles3 = 200;
   q.min_k = 64;           // A/B at b=8: K >= 256: 155.0, >= 128: 156.2, >= 64: 156.6 FPS
-  q.min_bn = 0; q.force_bm3 = 0; q.short_k = 0; q.splitk_max = 8; q.force_splitk = 0; q.src2 = true; q.res2 = true; q.env_overrides = 0;
+  q.min_bn = 0; q.force_bm3 = 0; q.short_k = 0; q.splitk_max = 8; q.force_splitk = 0; q.kw_reuse = true; q.src2 = true; q.res2 = true; q.env_overrides = 0;
   return q;
 }
 
@@ -1281,6 +1576,7 @@ ConvPolicy conv_policy_from_env(ConvPolicy q) {
   v = q.force_bm3; geti("ODT_CONV_SPLIT3_BM", &v); q.force_bm3 = (int)v;
   v = q.short_k; geti("ODT_CONV_SPLIT3_SHORTK", &v); q.short_k = (int)v;
   v = q.splitk_max; geti("ODT_CONV_SPLIT3_SPLITK", &v); q.splitk_max = v < 1 ? 1 : (v > 16 ? 16 : (int)v);
+  v = 1; geti("ODT_CONV_SPLIT3_KWR", &v); q.kw_reuse = v != 0;
   v = q.force_splitk; geti("ODT_CONV_SPLIT3_FORCE_SPLITK", &v); q.force_splitk = v < 0 ? 0 : (v > 16 ? 16 : (int)v);
   v = 1; geti("ODT_CONV_SPLIT_SRC2", &v); q.src2 = v != 0;      // 0 keeps the fused stage-entry convs on the f32 kernel
   v = 1; geti("ODT_CONV_SPLIT_RES2", &v); q.res2 = v != 0;      // 0 keeps the FPN laterals on the f32 kernel
@@ -1336,7 +1632,7 @@ bool conv_split_wanted(const ConvParams& p, const ConvPolicy& q) {
 void conv_split_choose(ConvParams& p, const ConvPolicy& q) {
   const int bn = conv_split_bn(p.Cout);
   const long M = (long)p.B * p.Ho * p.Wo;
-  p.wt_split_kind = 1; p.wt_split_bm = conv_split_bm(p.Cout); p.wt_split_bn = bn; p.splitk = 1;
+  p.wt_split_kind = 1; p.wt_split_bm = conv_split_bm(p.Cout); p.wt_split_bn = bn; p.splitk = 1; p.wt_split_kwr = 0;
   const int K = p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0);
   if (q.family >= 3 && q.short_k > 0 && K <= q.short_k && p.Cout % 128 == 0 && p.Cout >= 512 && p.kh * p.kw <= 32 &&
       ((M + 127) / 128) * (p.Cout / 128) >= 2 * q.min_tiles3) {
@@ -1346,6 +1642,9 @@ void conv_split_choose(ConvParams& p, const ConvPolicy& q) {
   int b3, n3, k3;
   if (split3_fit(p, q, &b3, &n3, &k3)) {
     p.wt_split_kind = 3; p.wt_split_bm = b3; p.wt_split_bn = n3; p.splitk = k3;
+    // stride-1 KH x 3 convs over rows of the output's pitch: the kw taps share a staged run of pixels
+    p.wt_split_kwr = (q.kw_reuse && b3 == 256 && k3 == 1 && n3 >= 128 && p.kw == 3 && p.stride == 1 && p.in_Wa == p.Wo &&
+                      p.in2 == nullptr && 2 * p.dil <= 4 && p.Ho * p.Wo >= 256 && p.kh * 3 <= 30) ? 1 : 0;
     return;
   }
   if (q.family >= 2 && bn == 256) { p.wt_split_kind = 2; p.wt_split_bm = 128; }
@@ -1389,7 +1688,20 @@ int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t st
     ODT_CHECK(sk == 1 || (p.partial != nullptr && p.in2 == nullptr && (p.kh * p.kw * p.Cin >> 4) >= sk),
               "conv split3: split-K needs a partial buffer, a single source and at least one stage per range");
     const unsigned grid = (unsigned)(((M + bm - 1) / bm) * (cout_padded(p.Cout) / bn) * sk);
-    if (bm == 256) {
+    if (p.wt_split_kwr) {
+      ODT_CHECK(bm == 256 && bn >= 128 && sk == 1 && p.kw == 3 && p.stride == 1 && p.in_Wa == p.Wo && p.in2 == nullptr,
+                "conv split3k: unsupported shape");
+      static const bool early = getenv("ODT_CONV_SPLIT3_KWR_EARLY") != nullptr;     // A/B knob: split + store one stage behind the fetch
+      if (bn == 256) {
+        if (p.trace != nullptr) hipLaunchKernelGGL((conv_split3k_kernel<4, true>), dim3(grid), dim3(512), 0, stream, dev);
+        else if (early) hipLaunchKernelGGL((conv_split3k_kernel<4, false, false>), dim3(grid), dim3(512), 0, stream, dev);
+        else hipLaunchKernelGGL((conv_split3k_kernel<4, false>), dim3(grid), dim3(512), 0, stream, dev);
+      } else {
+        if (p.trace != nullptr) hipLaunchKernelGGL((conv_split3k_kernel<2, true>), dim3(grid), dim3(512), 0, stream, dev);
+        else if (early) hipLaunchKernelGGL((conv_split3k_kernel<2, false, false>), dim3(grid), dim3(512), 0, stream, dev);
+        else hipLaunchKernelGGL((conv_split3k_kernel<2, false>), dim3(grid), dim3(512), 0, stream, dev);
+      }
+    } else if (bm == 256) {
       if (bn == 256) launch_split3<4, 2, 4>(p, dev, grid, stream);
       else if (bn == 128) launch_split3<4, 2, 2>(p, dev, grid, stream);
       else launch_split3<4, 2, 1>(p, dev, grid, stream);

@@ -72,6 +72,7 @@ struct ConvParams {
   // split-K (conv_split3_kernel only): the reduction is cut into `splitk` contiguous ranges of stages, one workgroup per
   // (tile, range); each writes its raw f32 partial tile to partial[range][M][Cout] and split_reduce_kernel adds them in
   // range order (deterministic) and applies bias / residual / activation.  For layers whose tiles cannot fill the chip.
+  int wt_split_kwr;    // kind 3: 1 = conv_split3k_kernel (the three kw taps of a (slice, kh) group share one staged run of pixels)
   int splitk;          // 0 / 1: off
   float* partial;      // scratch [splitk][M][Cout] (plan-owned, shared by the plan's split-K layers)
 };
@@ -91,6 +92,7 @@ struct ConvPolicy {
   int min_k, min_bn;    // shortest reduction / narrowest n-tile taken
   int force_bm3;        // 0 auto | 128 | 256: force conv_split3_kernel with that tile height (tests)
   int splitk_max;       // conv_split3_kernel: largest split-K factor the policy may choose (1 = off)
+  bool kw_reuse;        // conv_split3k_kernel for the stride-1 KH x 3 layers it fits (ODT_CONV_SPLIT3_KWR=0: off)
   int force_splitk;     // 0 auto | k: force that split-K factor wherever conv_split3_kernel runs (tests)
   int short_k;          // conv_split3_kernel: reductions up to this length on >= 512-wide layers run 128 x 128 tiles, two
                         // workgroups per CU (one's prologue / store tail under the other's main loop); 0 = off

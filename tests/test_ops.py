@@ -482,6 +482,10 @@ SPLIT_CASES = [
     (1, 18, 17, 32, 384, 3, 1, 1, 1, 1, 18, 17, False),      # 256 x 128 tile, three N tiles, M = 306
     (1, 17, 19, 64, 64, 3, 1, 1, 1, 1, 17, 19, True),        # 256 x 64 tile (res2 conv2), M = 323
     (1, 9, 30, 256, 64, 1, 1, 1, 0, 0, 9, 30, True),         # 256 x 64 tile, dense 1x1 (res2 conv1), M = 270
+    # stride-1 3x3 over several images: tiles cross image boundaries (two staged runs), borders on every side
+    (3, 17, 19, 32, 256, 3, 1, 1, 1, 1, 17, 19, True),       # M = 969: 4 tiles, boundaries inside tiles 1, 2 and 3
+    (2, 20, 21, 96, 128, 3, 1, 2, 2, 2, 20, 21, False),      # dilation 2 (res5 conv2 class), N = 128, six 16-channel slices
+    (2, 19, 17, 32, 256, 3, 1, 1, 0, 1, 17, 17, True),       # VALID rows (no top / bottom pad), SAME columns
 ]
 
 
@@ -489,7 +493,8 @@ SPLIT_CASES = [
 # stages, three-stage ring; the default) with 256- / 128-row tiles; "2": the two-stage 128 x 256 loop; "1": the
 # one-stage BK = 32 loop of round 1
 # "3/128/k3": the same with the reduction cut into three split-K ranges + split_reduce_kernel
-SPLIT_PIPES = ["3/256", "3/128", "3/128/k3", "2", "1"]
+# "3/256/nokwr": 256-row tiles with the kw-reuse kernel (conv_split3k_kernel, the default for stride-1 KH x 3 convs) off
+SPLIT_PIPES = ["3/256", "3/256/nokwr", "3/128", "3/128/k3", "2", "1"]
 
 
 def _split_env(monkeypatch, pipe="3/256"):
@@ -502,10 +507,12 @@ def _split_env(monkeypatch, pipe="3/256"):
     monkeypatch.setenv("ODT_CONV_SPLIT3_BM", f[1])
   else:
     monkeypatch.delenv("ODT_CONV_SPLIT3_BM", raising=False)
-  if len(f) > 2:
+  monkeypatch.delenv("ODT_CONV_SPLIT3_FORCE_SPLITK", raising=False)
+  monkeypatch.delenv("ODT_CONV_SPLIT3_KWR", raising=False)
+  if len(f) > 2 and f[2] == "nokwr":
+    monkeypatch.setenv("ODT_CONV_SPLIT3_KWR", "0")
+  elif len(f) > 2:
     monkeypatch.setenv("ODT_CONV_SPLIT3_FORCE_SPLITK", f[2][1:])
-  else:
-    monkeypatch.delenv("ODT_CONV_SPLIT3_FORCE_SPLITK", raising=False)
 
 
 @pytest.mark.parametrize("pipe", SPLIT_PIPES)
