@@ -1389,6 +1389,15 @@ __global__ void __launch_bounds__(512, 2) conv_split3k_kernel(const ConvParams* 
     for (int j = 0; j < TN; ++j) {
       const bool last = j == TN - 1, first = j == 0;
       if (last) {
+        if (TN == 1) {
+          // single column group: the stage's side work precedes the barrier (fetch before the DMA: the counted wait
+          // assumes that issue order)
+          if constexpr (gn) {
+            if constexpr (KWI == 0) load_group();
+            if constexpr (KWI == 2) { store_slot(a_nxt, 0); store_slot(a_nxt, 1); store_slot(a_nxt, 2); }
+          }
+          if constexpr (pre) dma_b(b_nn);
+        }
         wait_stage(std::integral_constant<bool, (KWI == 0 && gn)>{}, std::integral_constant<bool, pre>{});
         __builtin_amdgcn_s_barrier();
         // fragment addresses of the next stage: next tap of this group, or tap 0 of the next group's buffer
@@ -1557,7 +1566,7 @@ ConvPolicy conv_policy_default() {
   q.min_tiles = 256;      // one- / two-stage kernels: A/B at b=8 and b=1: 256 > 384 > 128 >> 64
   q.min_tiles3 = 200;
   q.min_k = 64;           // A/B at b=8: K >= 256: 155.0, >= 128: 156.2, >= 64: 156.6 FPS
-  q.min_bn = 0; q.force_bm3 = 0; q.short_k = 0; q.splitk_max = 8; q.force_splitk = 0; q.kw_reuse = true; q.src2 = true; q.res2 = true; q.env_overrides = 0;
+  q.min_bn = 0; q.force_bm3 = 0; q.short_k = 0; q.splitk_max = 8; q.force_splitk = 0; q.kw_reuse = true; q.kwr_n64 = true; q.src2 = true; q.res2 = true; q.env_overrides = 0;
   return q;
 }
 
@@ -1577,6 +1586,7 @@ ConvPolicy conv_policy_from_env(ConvPolicy q) {
   v = q.short_k; geti("ODT_CONV_SPLIT3_SHORTK", &v); q.short_k = (int)v;
   v = q.splitk_max; geti("ODT_CONV_SPLIT3_SPLITK", &v); q.splitk_max = v < 1 ? 1 : (v > 16 ? 16 : (int)v);
   v = 1; geti("ODT_CONV_SPLIT3_KWR", &v); q.kw_reuse = v != 0;
+  v = q.kwr_n64; geti("ODT_CONV_SPLIT3_KWR_N64", &v); q.kwr_n64 = v != 0;
   v = q.force_splitk; geti("ODT_CONV_SPLIT3_FORCE_SPLITK", &v); q.force_splitk = v < 0 ? 0 : (v > 16 ? 16 : (int)v);
   v = 1; geti("ODT_CONV_SPLIT_SRC2", &v); q.src2 = v != 0;      // 0 keeps the fused stage-entry convs on the f32 kernel
   v = 1; geti("ODT_CONV_SPLIT_RES2", &v); q.res2 = v != 0;      // 0 keeps the FPN laterals on the f32 kernel
@@ -1600,9 +1610,14 @@ static bool split3_fit(const ConvParams& p, const ConvPolicy& q, int* bm, int* b
   if (q.force_bm3 == 256 || (q.force_bm3 == 128 && bn0 >= 128)) { *bm = q.force_bm3; return with_forced_sk(); }
   // (64-wide layers stay on the one-stage 256 x 64 tile: a 64 x 32 wave tile reads too many fragments per MFMA --
   // same-box A/B at b=8: res2 conv2 132 vs 118 TF, conv0 136 vs 112)
-  if (bn0 < 128) return false;
+  // ... except where the kw-reuse kernel applies: with a third of the A-side work the 64-wide 3x3 layers (res2 conv2)
+  // come out ahead on it (same-box A/B in profiles/r02_kw_reuse_n64_ab.txt)
+  const bool kwr_ok = q.kw_reuse && q.kwr_n64 && p.kw == 3 && p.stride == 1 && p.in_Wa == p.Wo && p.in2 == nullptr && 2 * p.dil <= 4 &&
+                      p.Ho * p.Wo >= 256;
+  if (bn0 < 128 && !kwr_ok) return false;
   const long t256 = ((M + 255) / 256) * (cout_padded(p.Cout) / bn0), t128 = ((M + 127) / 128) * (cout_padded(p.Cout) / bn0);
   if (t256 >= q.min_tiles3) { *bm = 256; return with_forced_sk(); }
+  if (bn0 < 128) return false;
   if (t128 >= q.min_tiles3) { *bm = 128; return with_forced_sk(); }
   if (q.splitk_max > 1 && p.in2 == nullptr) {
     int k = (int)((q.min_tiles3 + t128 - 1) / t128);
@@ -1643,7 +1658,7 @@ void conv_split_choose(ConvParams& p, const ConvPolicy& q) {
   if (split3_fit(p, q, &b3, &n3, &k3)) {
     p.wt_split_kind = 3; p.wt_split_bm = b3; p.wt_split_bn = n3; p.splitk = k3;
     // stride-1 KH x 3 convs over rows of the output's pitch: the kw taps share a staged run of pixels
-    p.wt_split_kwr = (q.kw_reuse && b3 == 256 && k3 == 1 && n3 >= 128 && p.kw == 3 && p.stride == 1 && p.in_Wa == p.Wo &&
+    p.wt_split_kwr = (q.kw_reuse && b3 == 256 && k3 == 1 && (n3 >= 128 || q.kwr_n64) && p.kw == 3 && p.stride == 1 && p.in_Wa == p.Wo &&
                       p.in2 == nullptr && 2 * p.dil <= 4 && p.Ho * p.Wo >= 256 && p.kh * 3 <= 30) ? 1 : 0;
     return;
   }
@@ -1689,17 +1704,19 @@ int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t st
               "conv split3: split-K needs a partial buffer, a single source and at least one stage per range");
     const unsigned grid = (unsigned)(((M + bm - 1) / bm) * (cout_padded(p.Cout) / bn) * sk);
     if (p.wt_split_kwr) {
-      ODT_CHECK(bm == 256 && bn >= 128 && sk == 1 && p.kw == 3 && p.stride == 1 && p.in_Wa == p.Wo && p.in2 == nullptr,
+      ODT_CHECK(bm == 256 && sk == 1 && p.kw == 3 && p.stride == 1 && p.in_Wa == p.Wo && p.in2 == nullptr,
                 "conv split3k: unsupported shape");
       static const bool early = getenv("ODT_CONV_SPLIT3_KWR_EARLY") != nullptr;     // A/B knob: split + store one stage behind the fetch
       if (bn == 256) {
         if (p.trace != nullptr) hipLaunchKernelGGL((conv_split3k_kernel<4, true>), dim3(grid), dim3(512), 0, stream, dev);
         else if (early) hipLaunchKernelGGL((conv_split3k_kernel<4, false, false>), dim3(grid), dim3(512), 0, stream, dev);
         else hipLaunchKernelGGL((conv_split3k_kernel<4, false>), dim3(grid), dim3(512), 0, stream, dev);
-      } else {
+      } else if (bn == 128) {
         if (p.trace != nullptr) hipLaunchKernelGGL((conv_split3k_kernel<2, true>), dim3(grid), dim3(512), 0, stream, dev);
         else if (early) hipLaunchKernelGGL((conv_split3k_kernel<2, false, false>), dim3(grid), dim3(512), 0, stream, dev);
         else hipLaunchKernelGGL((conv_split3k_kernel<2, false>), dim3(grid), dim3(512), 0, stream, dev);
+      } else {
+        hipLaunchKernelGGL((conv_split3k_kernel<1, false>), dim3(grid), dim3(512), 0, stream, dev);
       }
     } else if (bm == 256) {
       if (bn == 256) launch_split3<4, 2, 4>(p, dev, grid, stream);

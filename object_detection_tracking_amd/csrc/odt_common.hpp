@@ -93,6 +93,7 @@ struct ConvPolicy {
   int force_bm3;        // 0 auto | 128 | 256: force conv_split3_kernel with that tile height (tests)
   int splitk_max;       // conv_split3_kernel: largest split-K factor the policy may choose (1 = off)
   bool kw_reuse;        // conv_split3k_kernel for the stride-1 KH x 3 layers it fits (ODT_CONV_SPLIT3_KWR=0: off)
+  bool kwr_n64;         // ... also for 64-wide layers (256 x 64 tile, wave tile 64 x 32)
   int force_splitk;     // 0 auto | k: force that split-K factor wherever conv_split3_kernel runs (tests)
   int short_k;          // conv_split3_kernel: reductions up to this length on >= 512-wide layers run 128 x 128 tiles, two
                         // workgroups per CU (one's prologue / store tail under the other's main loop); 0 = off
