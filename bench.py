@@ -210,7 +210,7 @@ def main():
         extra["exact_f32_mfma_only_fps"] = "failed: %r" % (ex,)
     extra.update(detect_track_leg(eng, frames, B, local_rank))
     fast = detect_track_leg(eng, frames, B, local_rank, arrays=True)
-    extra["detect_track_arrays_fps"] = fast["detect_track_fps"]        # create_obj_arrays + Tracker.update_arrays
+    extra["detect_track_arrays_fps"] = fast["detect_track_fps"]        # create_obj_arrays + native tracker NMS + Tracker.update_arrays
     extra["detect_track_arrays_host_ms_per_frame"] = fast["detect_track"]["host_tracking_ms_per_frame"]
     if world == 1 and S == 1:
       # (e) trained RPNs score most anchors negative, so images keep fewer than K proposals (zero-padded NMS slots,
@@ -393,7 +393,7 @@ def detect_track_leg(eng, frames, B, device, nbatches=8, arrays=False):
       for cname, trk in trackers.items():
         if arrays:          # same selection / arithmetic on arrays, no Detection objects
           tl, cf, ft = create_obj_arrays(fb, fp, fl, ff, id2class, [cname], 0.0, 0, 1.0)
-          keep = preprocessing.non_max_suppression(tl, 0.85, cf)
+          keep = preprocessing.non_max_suppression_native(tl, 0.85, cf)
           trk.predict()
           trk.update_arrays(tl[keep], cf[keep], ft[keep])
           nd.append(len(keep))

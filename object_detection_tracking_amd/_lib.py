@@ -81,7 +81,7 @@ class OdtLib(object):
       "odt_op_preprocess",
       "odt_op_maxpool", "odt_op_topk", "odt_op_nms", "odt_op_proposals",
       "odt_op_roi_align", "odt_op_detections", "odt_op_class_nms", "odt_tracker_create", "odt_tracker_destroy",
-      "odt_tracker_predict", "odt_tracker_update", "odt_tracker_tracks", "odt_lsap",
+      "odt_tracker_predict", "odt_tracker_update", "odt_tracker_tracks", "odt_lsap", "odt_tracker_nms",
       "odt_tmot_create", "odt_tmot_destroy", "odt_tmot_reset", "odt_tmot_update", "odt_tmot_tracks",
   ]
 
@@ -143,6 +143,7 @@ class OdtLib(object):
     d.odt_tracker_tracks.argtypes = [C.c_void_p, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p,
                                      c_double_p, c_double_p, C.POINTER(C.c_int)]
     d.odt_lsap.argtypes = [c_double_p, C.c_int, C.c_int, c_int_p, c_int_p, C.POINTER(C.c_int)]
+    d.odt_tracker_nms.argtypes = [c_double_p, c_double_p, C.c_int, C.c_double, c_int_p, C.POINTER(C.c_int)]
     d.odt_tmot_create.argtypes = [C.c_double] * 8 + [C.POINTER(C.c_void_p)]
     d.odt_tmot_destroy.argtypes = [C.c_void_p]
     d.odt_tmot_reset.argtypes = [C.c_void_p]

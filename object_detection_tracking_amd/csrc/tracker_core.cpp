@@ -375,6 +375,37 @@ int min_cost_matching(odt_tracker* t, CostFn fn, double max_distance, const std:
 
 extern "C" {
 
+int odt_tracker_nms(const double* boxes, const double* scores, int n, double max_overlap, int32_t* pick, int* npick) {
+  ODT_CHECK(npick != nullptr && (n == 0 || (boxes != nullptr && pick != nullptr)), "odt_tracker_nms: null argument");
+  *npick = 0;
+  if (n <= 0) return 0;
+  std::vector<double> x2(n), y2(n), area(n);
+  for (int i = 0; i < n; ++i) {
+    x2[i] = boxes[4 * i] + boxes[4 * i + 2]; y2[i] = boxes[4 * i + 1] + boxes[4 * i + 3];
+    area[i] = (x2[i] - boxes[4 * i] + 1) * (y2[i] - boxes[4 * i + 1] + 1);
+  }
+  // np.argsort (quicksort, not stable; the reference's inputs are detector scores: ties are broken here by index, which
+  // is what numpy's introsort does for the short arrays it hands to insertion sort)
+  std::vector<int> order(n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  const double* key = scores != nullptr ? scores : y2.data();
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
+  while (!order.empty()) {
+    const int i = order.back();
+    order.pop_back();
+    pick[(*npick)++] = i;
+    std::vector<int> rest;
+    rest.reserve(order.size());
+    for (int j : order) {
+      const double iw = std::max(0.0, std::min(x2[i], x2[j]) - std::max(boxes[4 * i], boxes[4 * j]) + 1);
+      const double ih = std::max(0.0, std::min(y2[i], y2[j]) - std::max(boxes[4 * i + 1], boxes[4 * j + 1]) + 1);
+      if (!((iw * ih) / area[j] > max_overlap)) rest.push_back(j);
+    }
+    order.swap(rest);
+  }
+  return 0;
+}
+
 int odt_lsap(const double* cost, int nr, int nc, int32_t* rows, int32_t* cols, int* n) {
   ODT_CHECK(rows && cols && n && (cost || nr * nc == 0), "odt_lsap: null argument");
   std::vector<int> r, c;
