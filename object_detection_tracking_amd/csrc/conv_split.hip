@@ -1566,7 +1566,7 @@ ConvPolicy conv_policy_default() {
   q.min_tiles = 256;      // one- / two-stage kernels: A/B at b=8 and b=1: 256 > 384 > 128 >> 64
   q.min_tiles3 = 200;
   q.min_k = 64;           // A/B at b=8: K >= 256: 155.0, >= 128: 156.2, >= 64: 156.6 FPS
-  q.min_bn = 0; q.force_bm3 = 0; q.short_k = 0; q.splitk_max = 8; q.force_splitk = 0; q.kw_reuse = true; q.kwr_n64 = true; q.src2 = true; q.res2 = true; q.env_overrides = 0;
+  q.min_bn = 0; q.force_bm3 = 0; q.short_k = 0; q.short_k2 = 0; q.splitk_max = 8; q.force_splitk = 0; q.kw_reuse = true; q.kwr_n64 = true; q.src2 = true; q.res2 = true; q.env_overrides = 0;
   return q;
 }
 
@@ -1584,6 +1584,7 @@ ConvPolicy conv_policy_from_env(ConvPolicy q) {
   v = q.min_bn; geti("ODT_CONV_SPLIT_MINBN", &v); q.min_bn = (int)v;
   v = q.force_bm3; geti("ODT_CONV_SPLIT3_BM", &v); q.force_bm3 = (int)v;
   v = q.short_k; geti("ODT_CONV_SPLIT3_SHORTK", &v); q.short_k = (int)v;
+  v = q.short_k2; geti("ODT_CONV_SPLIT2_SHORTK", &v); q.short_k2 = (int)v;
   v = q.splitk_max; geti("ODT_CONV_SPLIT3_SPLITK", &v); q.splitk_max = v < 1 ? 1 : (v > 16 ? 16 : (int)v);
   v = 1; geti("ODT_CONV_SPLIT3_KWR", &v); q.kw_reuse = v != 0;
   v = q.kwr_n64; geti("ODT_CONV_SPLIT3_KWR_N64", &v); q.kwr_n64 = v != 0;
@@ -1652,6 +1653,12 @@ void conv_split_choose(ConvParams& p, const ConvPolicy& q) {
   if (q.family >= 3 && q.short_k > 0 && K <= q.short_k && p.Cout % 128 == 0 && p.Cout >= 512 && p.kh * p.kw <= 32 &&
       ((M + 127) / 128) * (p.Cout / 128) >= 2 * q.min_tiles3) {
     p.wt_split_kind = 3; p.wt_split_bm = 128; p.wt_split_bn = 128;
+    return;
+  }
+  // A/B knob (off): short reductions on 256-wide tiles through the two-stage 128 x 256 kernel, two workgroups per CU.
+  // Same-box result (profiles/r02_shortk_persistent_stagger_ab.txt): res4 conv3 5.17 -> 4.94 ms, res2 conv3 slower, +-0 overall.
+  if (q.family >= 2 && q.short_k2 > 0 && K <= q.short_k2 && bn == 256 && ((M + 127) / 128) * (cout_padded(p.Cout) / 256) >= 2 * q.min_tiles3) {
+    p.wt_split_kind = 2; p.wt_split_bm = 128;
     return;
   }
   int b3, n3, k3;

@@ -2,6 +2,7 @@
 // declared here and defined in the per-kernel .hip translation units.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 
 #include <cstdint>
 #include <cstdio>
@@ -95,6 +96,7 @@ struct ConvPolicy {
   bool kw_reuse;        // conv_split3k_kernel for the stride-1 KH x 3 layers it fits (ODT_CONV_SPLIT3_KWR=0: off)
   bool kwr_n64;         // ... also for 64-wide layers (256 x 64 tile, wave tile 64 x 32)
   int force_splitk;     // 0 auto | k: force that split-K factor wherever conv_split3_kernel runs (tests)
+  int short_k2;         // reductions up to this length on 256-wide layers run the two-stage 128 x 256 kernel (two workgroups per CU)
   int short_k;          // conv_split3_kernel: reductions up to this length on >= 512-wide layers run 128 x 128 tiles, two
                         // workgroups per CU (one's prologue / store tail under the other's main loop); 0 = off
   bool src2, res2;      // take the K-concatenated stage-entry convs / the 2x-upsampled-residual FPN laterals
@@ -282,6 +284,7 @@ struct CosineCtx {
   hipEvent_t done = nullptr;
   float* h_in = nullptr; float* d_in = nullptr; size_t cap_in = 0;        // packed [seg | gallery | detections]
   double* h_cost = nullptr; double* d_cost = nullptr; size_t cap_cost = 0;
+  std::vector<void*> retired_host, retired_dev;      // outgrown buffers: released with the context (hipFree waits for the device)
   ~CosineCtx();
   // gal_rows[G] / det_rows[N]: pointers to the D-float rows (gathered into the pinned record); seg[T+1]; cost[T*N]
   int run(int dev, const float* const* gal_rows, int G, const int* seg, int T, const float* const* det_rows, int N,

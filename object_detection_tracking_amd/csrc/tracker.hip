@@ -17,6 +17,9 @@
 #include <cstring>
 
 #include "odt_common.hpp"
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
 
 namespace odt {
 namespace {
@@ -90,6 +93,8 @@ CosineCtx::~CosineCtx() {
   if (h_cost) (void)hipHostFree(h_cost);
   if (d_in) (void)hipFree(d_in);
   if (d_cost) (void)hipFree(d_cost);
+  for (void* q : retired_host) (void)hipHostFree(q);
+  for (void* q : retired_dev) (void)hipFree(q);
   if (done) (void)hipEventDestroy(done);
   if (stream) (void)hipStreamDestroy(stream);
 }
@@ -107,35 +112,55 @@ int CosineCtx::run(int dev, const float* const* gal_rows, int G, const int* seg,
   // one packed input record: [seg (T+1 ints, padded to 4)][gallery G*D][detections N*D]
   const size_t nseg = ((size_t)T + 1 + 3) & ~(size_t)3;
   const size_t nin = nseg + (size_t)(G + N) * D, ncost = (size_t)T * N;
+  // Capacity: sized generously at first use and doubled when outgrown; an outgrown buffer is only retired -- hipFree /
+  // hipHostFree wait for the whole device, i.e. for the detector's forward in flight (measured: 1.9 ms per update,
+  // averaged, while the buffers of a young tracker grew next to a busy detector; 0.13 ms with this).
   if (cap_in < nin) {
-    if (h_in) ODT_HIP(hipHostFree(h_in));
-    if (d_in) ODT_HIP(hipFree(d_in));
+    if (h_in) retired_host.push_back(h_in);
+    if (d_in) retired_dev.push_back(d_in);
     h_in = nullptr; d_in = nullptr; cap_in = 0;
-    const size_t want = nin + nin / 2;
+    const size_t want = std::max<size_t>(2 * nin, (size_t)1 << 20);
     ODT_HIP(hipHostMalloc((void**)&h_in, want * 4, 0));
     ODT_HIP(hipMalloc((void**)&d_in, want * 4));
     cap_in = want;
   }
   if (cap_cost < ncost) {
-    if (h_cost) ODT_HIP(hipHostFree(h_cost));
-    if (d_cost) ODT_HIP(hipFree(d_cost));
+    if (h_cost) retired_host.push_back(h_cost);
+    if (d_cost) retired_dev.push_back(d_cost);
     h_cost = nullptr; d_cost = nullptr; cap_cost = 0;
-    const size_t want = ncost + ncost / 2;
+    const size_t want = std::max<size_t>(2 * ncost, (size_t)1 << 18);
     ODT_HIP(hipHostMalloc((void**)&h_cost, want * 8, 0));
     ODT_HIP(hipMalloc((void**)&d_cost, want * 8));
     cap_cost = want;
   }
+  static const bool timing = getenv("ODT_TRACKER_TIMING") != nullptr;      // tuning aid: where a call's wall time goes
+  static double acc_t[5] = {0, 0, 0, 0, 0}; static long acc_n = 0;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double c0 = timing ? now() : 0.0;
   std::memcpy(h_in, seg, ((size_t)T + 1) * sizeof(int));
   float* hg = h_in + nseg;
   for (int g = 0; g < G; ++g) std::memcpy(hg + (size_t)g * D, gal_rows[g], sizeof(float) * D);
   float* hd = hg + (size_t)G * D;
   for (int j = 0; j < N; ++j) std::memcpy(hd + (size_t)j * D, det_rows[j], sizeof(float) * D);
+  const double c1 = timing ? now() : 0.0;
   ODT_HIP(hipMemcpyAsync(d_in, h_in, nin * 4, hipMemcpyHostToDevice, stream));
+  const double c2 = timing ? now() : 0.0;
   if (launch_nn_cosine(d_in + nseg, (const int*)d_in, T, d_in + nseg + (size_t)G * D, N, D, d_cost, stream)) return 1;
+  const double c3 = timing ? now() : 0.0;
   ODT_HIP(hipMemcpyAsync(h_cost, d_cost, ncost * 8, hipMemcpyDeviceToHost, stream));
   ODT_HIP(hipEventRecord(done, stream));
+  const double c4 = timing ? now() : 0.0;
   ODT_HIP(hipEventSynchronize(done));
+  const double c5 = timing ? now() : 0.0;
   std::memcpy(cost, h_cost, ncost * 8);
+  if (timing) {
+    acc_t[0] += c1 - c0; acc_t[1] += c2 - c1; acc_t[2] += c3 - c2; acc_t[3] += c4 - c3; acc_t[4] += c5 - c4;
+    if (++acc_n % 160 == 0) {
+      fprintf(stderr, "[cosine] per call over 160 (us): pack %.1f  h2d-enqueue %.1f  launch %.1f  d2h-enqueue+record %.1f  wait %.1f   (G=%d T=%d N=%d)\n",
+              acc_t[0] / 160 * 1e6, acc_t[1] / 160 * 1e6, acc_t[2] / 160 * 1e6, acc_t[3] / 160 * 1e6, acc_t[4] / 160 * 1e6, G, T, N);
+      for (double& v : acc_t) v = 0;
+    }
+  }
   return 0;
 }
 

@@ -19,6 +19,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <limits>
@@ -449,6 +451,10 @@ int odt_tracker_update(odt_tracker_handle t, const double* tlwh, const double* c
     ODT_CHECK(t->D == 0 || t->D == D, "odt_tracker_update: feature dimension changed");
     t->D = D;
   }
+  static const bool timing = getenv("ODT_TRACKER_TIMING") != nullptr;     // tuning aid: where an update's wall time goes (stderr, every 160 updates)
+  static double tacc[4] = {0, 0, 0, 0}; static long tn = 0;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double u0 = timing ? now() : 0;
   std::vector<Det> dets(N);
   for (int j = 0; j < N; ++j) {
     Det& d = dets[j];
@@ -461,7 +467,9 @@ int odt_tracker_update(odt_tracker_handle t, const double* tlwh, const double* c
   std::vector<int> confirmed, unconfirmed;
   for (int i = 0; i < (int)t->tracks.size(); ++i)
     (t->tracks[i].state == kConfirmed ? confirmed : unconfirmed).push_back(i);
+  const double u1 = timing ? now() : 0;
   if (appearance_costs(t, dets, confirmed)) return 1;
+  const double u2 = timing ? now() : 0;
   // matching_cascade (linear_assignment.py:82-145)
   std::vector<int> unmatched_dets(N);
   for (int j = 0; j < N; ++j) unmatched_dets[j] = j;
@@ -488,6 +496,7 @@ int odt_tracker_update(odt_tracker_handle t, const double* tlwh, const double* c
   if (min_cost_matching(t, iou_cost, t->max_iou, dets, iou_cand, unmatched_dets, &mb)) return 1;
   matches.insert(matches.end(), mb.matches.begin(), mb.matches.end());
   unmatched_tracks.insert(unmatched_tracks.end(), mb.unmatched_tracks.begin(), mb.unmatched_tracks.end());
+  const double u3 = timing ? now() : 0;
   // ---- update track set (tracker.py:70-78)
   for (auto& pr : matches) {
     Trk& tr = t->tracks[pr.first];
@@ -527,6 +536,15 @@ int odt_tracker_update(odt_tracker_handle t, const double* tlwh, const double* c
   }
   for (auto it = t->samples.begin(); it != t->samples.end();)
     it = active.count(it->first) ? std::next(it) : t->samples.erase(it);
+  if (timing) {
+    const double u4 = now();
+    tacc[0] += u1 - u0; tacc[1] += u2 - u1; tacc[2] += u3 - u2; tacc[3] += u4 - u3;
+    if (++tn % 160 == 0) {
+      fprintf(stderr, "[tracker] per update over 160 (us): setup %.1f  appearance %.1f  matching %.1f  track set + gallery %.1f  (tracks %d, N %d)\n",
+              tacc[0] / 160 * 1e6, tacc[1] / 160 * 1e6, tacc[2] / 160 * 1e6, tacc[3] / 160 * 1e6, (int)t->tracks.size(), N);
+      for (double& v : tacc) v = 0;
+    }
+  }
   return 0;
 }
 

@@ -397,6 +397,24 @@ def test_nn_cosine(backend):
   assert ops.nn_cosine(gal, seg, np.zeros((0, D), F), lib=lib).shape == (T, 0)
 
 
+def test_nn_cosine_scratch_growth(backend):
+  """The call's persistent scratch (pinned + device, CosineCtx) starts at 2^20 floats and is doubled when outgrown;
+  outgrown buffers are retired, not freed (a hipFree would wait for a detector's forward in flight).  Small call,
+  a call past the initial capacity, small call again: all three correct."""
+  name, lib = backend
+  rng = np.random.default_rng(13)
+  def check(T, per, N, D):
+    seg = (np.arange(T + 1) * per).astype(np.int32)
+    gal = rng.standard_normal((T * per, D)).astype(F); det = rng.standard_normal((N, D)).astype(F)
+    got = ops.nn_cosine(gal, seg, det, lib=lib)
+    a = gal / np.linalg.norm(gal, axis=1, keepdims=True); b = det / np.linalg.norm(det, axis=1, keepdims=True)
+    ref = (1. - a.astype(np.float64) @ b.astype(np.float64).T).reshape(T, per, N).min(axis=1)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=3e-6)
+  check(5, 2, 9, 128)
+  check(300, 3, 140, 1024)          # (900 + 140) x 1024 floats > 2^20
+  check(4, 5, 17, 256)
+
+
 # ---- randomized conv coverage: every kernel instantiation (tile x stages x loop style) ----------
 def _fuzz_case(rng, lib, big, couts=None):
   B = int(rng.integers(1, 3)); k = int(rng.choice([1, 1, 3])); stride = int(rng.choice([1, 1, 2]))

@@ -12,7 +12,11 @@ def main():
   ap.add_argument("--steps", type=int, default=3)
   ap.add_argument("--height", type=int, default=1080)
   ap.add_argument("--width", type=int, default=1920)
+  ap.add_argument("--effdet", default="", help="profile an EfficientDet model (e.g. efficientdet-d7, batch 1, native size) instead")
+  ap.add_argument("--top", type=int, default=0)
   a = ap.parse_args()
+  if a.effdet:
+    return effdet(a)
   from object_detection_tracking_amd import models
   from object_detection_tracking_amd.config import make_config
   from object_detection_tracking_amd.weights import synthetic_frames, synthetic_weights
@@ -40,6 +44,38 @@ def main():
   print("conv total %.2f ms/step, %.1f TFLOP/s (%.3f of peak); step %.2f ms" %
         (cms, tot["conv_flops"] / a.steps / (cms * 1e-3) / 1e12, tot["conv_flops"] / a.steps / (cms * 1e-3) / 1e12 / 157.3, tot["total_ms"] / a.steps))
   m.close()
+
+def effdet(a):
+  from object_detection_tracking_amd import models
+  from object_detection_tracking_amd.config import make_config
+  from object_detection_tracking_amd.efficientdet import arch
+  from object_detection_tracking_amd.weights import synthetic_frames
+  S = arch.det_config(a.effdet)["image_size"]
+  cfg = make_config(is_efficientdet=True, efficientdet_modelname=a.effdet, efficientdet_max_detection_topk=5000, short_edge_size=S, max_size=S)
+  cfg.max_size = S
+  m = models.get_model(cfg, 0, weights=arch.synthetic_det_weights(a.effdet, 0))
+  fr = synthetic_frames(1, S, S)[0]
+  e = m.engine((S, S))
+  m.predict(fr)
+  E = models._Engine                     # (the profiling entry points only need .lib and .h)
+  E.profile(e, True)
+  for _ in range(a.steps):
+    m.predict(fr)
+  rows = E.profile_layers(e)
+  tot = E.profile_read(e)
+  groups = collections.OrderedDict()
+  for name, fl, ms, mnk in rows:
+    g = groups.setdefault(mnk, [0, 0.0, 0.0, name])
+    g[0] += 1; g[1] += fl; g[2] += ms / a.steps
+  print("%-60s %5s %9s %7s %7s %9s %8s %9s" % ("first layer of shape", "n", "M", "N", "K", "ms/step", "TFLOP/s", "us/launch"))
+  srt = sorted(groups.items(), key=lambda kv: -kv[1][2])
+  for mnk, (n, fl, ms, name) in (srt[:a.top] if a.top else srt):
+    tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0
+    print("%-60s %5d %9d %7d %7d %9.3f %8.1f %9.1f" % (name[:60], n, mnk[0], mnk[1], mnk[2], ms, tf, ms * 1e3 / n))
+  cms = tot["conv_ms"] / a.steps
+  print("conv total %.2f ms/step, %.1f TFLOP/s; step %.2f ms" % (cms, tot["conv_flops"] / a.steps / (cms * 1e-3) / 1e12, tot["total_ms"] / a.steps))
+  m.close()
+
 
 if __name__ == "__main__":
   main()
