@@ -1460,7 +1460,9 @@ __global__ void __launch_bounds__(512, 2) conv_split3k_kernel(const ConvParams* 
 }
 
 // f32 weights [Cout][K] -> per-stage image of bf16 pieces (one thread per 8 consecutive k of a row)
-__global__ void split_weights_kernel(const float* __restrict__ wt, int Cout, int K, int SBN, int bk, unsigned short* __restrict__ img) {
+// (kscale != nullptr: the row is multiplied by kscale[k] first -- a per-input-channel gate folded into a 1x1 conv's weights)
+__global__ void split_weights_kernel(const float* __restrict__ wt, int Cout, int K, int SBN, int bk, unsigned short* __restrict__ img,
+                                     const float* __restrict__ kscale) {
   const int nsl = K / bk, kgs = bk >> 3;     // stages along K, k-groups of 8 per stage
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;       // (n, k8), n over the padded Cout
   const long total = (long)cout_padded(Cout) * (K >> 3);
@@ -1469,7 +1471,9 @@ __global__ void split_weights_kernel(const float* __restrict__ wt, int Cout, int
   const int tn = n / SBN, nn = n - tn * SBN, sl = k8 / kgs, kg = k8 - sl * kgs;
   for (int e = 0; e < 8; e += 2) {
     unsigned piece[3];
-    split2(n < Cout ? wt[(size_t)n * K + k8 * 8 + e] : 0.f, n < Cout ? wt[(size_t)n * K + k8 * 8 + e + 1] : 0.f, piece[0], piece[1], piece[2]);
+    float w0 = n < Cout ? wt[(size_t)n * K + k8 * 8 + e] : 0.f, w1 = n < Cout ? wt[(size_t)n * K + k8 * 8 + e + 1] : 0.f;
+    if (kscale != nullptr) { w0 = w0 * kscale[k8 * 8 + e]; w1 = w1 * kscale[k8 * 8 + e + 1]; }
+    split2(w0, w1, piece[0], piece[1], piece[2]);
     for (int q = 0; q < 3; ++q) {
       const size_t at = ((((size_t)(tn * nsl + sl) * 3 + q) * kgs + kg) * SBN + nn) * 8 + e;
       img[at] = (unsigned short)(piece[q] & 0xffffu);
@@ -1513,7 +1517,7 @@ __global__ void __launch_bounds__(256) split_reduce_kernel(const ConvParams* __r
 // conv_split3_kernel's image: [n-tile][stage][piece][k-group 2][BN n][8 k], stage order = (16-channel slice, tap)
 // for the first source, then the second source's slices; wt is [Cout][tap][Cin] (+ [Cin2] behind it)
 __global__ void split_weights3_kernel(const float* __restrict__ wt, int Cout, int K, int SBN, int ntaps, int Cin,
-                                      unsigned short* __restrict__ img) {
+                                      unsigned short* __restrict__ img, const float* __restrict__ kscale) {
   const int nst = K >> 4, nst1 = ntaps * (Cin >> 4);
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;       // (n, stage, k-group)
   const long total = (long)cout_padded(Cout) * nst * 2;       // n over the padded Cout: zero rows behind the last channel
@@ -1526,7 +1530,9 @@ __global__ void split_weights3_kernel(const float* __restrict__ wt, int Cout, in
   const int tn = n / SBN, nn = n - tn * SBN;
   for (int e = 0; e < 8; e += 2) {
     unsigned piece[3];
-    split2(n < Cout ? wt[(size_t)n * K + k0 + e] : 0.f, n < Cout ? wt[(size_t)n * K + k0 + e + 1] : 0.f, piece[0], piece[1], piece[2]);
+    float w0 = n < Cout ? wt[(size_t)n * K + k0 + e] : 0.f, w1 = n < Cout ? wt[(size_t)n * K + k0 + e + 1] : 0.f;
+    if (kscale != nullptr) { w0 = w0 * kscale[k0 + e]; w1 = w1 * kscale[k0 + e + 1]; }
+    split2(w0, w1, piece[0], piece[1], piece[2]);
     for (int q = 0; q < 3; ++q) {
       const size_t at = ((((size_t)(tn * nst + st) * 3 + q) * 2 + kg) * SBN + nn) * 8 + e;
       img[at] = (unsigned short)(piece[q] & 0xffffu);
@@ -1676,19 +1682,35 @@ size_t conv_split_partial_bytes(const ConvParams& p) {
   return p.wt_split_kind == 3 && p.splitk > 1 ? (size_t)p.splitk * p.B * p.Ho * p.Wo * cout_padded(p.Cout) * sizeof(float) : 0;
 }
 
-int conv_make_split_weights(const ConvParams& p, void* img_dev, hipStream_t stream) {
+// f32 weights [Cout][K] times a per-k gate (the exact-f32 kernel's form of the folded gate)
+__global__ void __launch_bounds__(256) scale_weights_kernel(const float* __restrict__ wt, const float* __restrict__ kscale, long total, int K,
+                                                            float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) out[i] = wt[i] * kscale[(int)(i % K)];
+}
+
+int conv_scale_weights(const float* wt, const float* kscale, int Cout, int K, float* out, hipStream_t stream) {
+  const long total = (long)Cout * K;
+  hipLaunchKernelGGL(scale_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, wt, kscale, total, K, out);
+  ODT_HIP(hipGetLastError());
+  return 0;
+}
+
+int conv_make_split_weights(const ConvParams& p, void* img_dev, hipStream_t stream, const float* wt_src, const float* kscale) {
+  const float* src = wt_src != nullptr ? wt_src : p.wt;
+  ODT_CHECK(kscale == nullptr || (p.kh == 1 && p.kw == 1 && p.in2 == nullptr), "conv_make_split_weights: a folded gate belongs to a single-source 1x1 conv");
   const int bn = p.wt_split_bn != 0 ? p.wt_split_bn : conv_split_bn(p.Cout);
   const int K = p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0);
   ODT_CHECK(bn != 0 && K % 32 == 0 && p.wt_split_kind >= 1 && p.wt_split_kind <= 3,
             "conv_make_split_weights: Cout % 64 == 0, K % 32 == 0 and a chosen kernel family required");
   if (p.wt_split_kind == 3) {
     const long total = (long)cout_padded(p.Cout) * (K >> 4) * 2;
-    hipLaunchKernelGGL(split_weights3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p.wt, p.Cout, K,
-                       bn, p.kh * p.kw, p.Cin, (unsigned short*)img_dev);
+    hipLaunchKernelGGL(split_weights3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, p.Cout, K,
+                       bn, p.kh * p.kw, p.Cin, (unsigned short*)img_dev, kscale);
   } else {
     const long total = (long)cout_padded(p.Cout) * (K >> 3);
-    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p.wt, p.Cout, K,
-                       bn, p.wt_split_kind == 2 ? 16 : 32, (unsigned short*)img_dev);
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, p.Cout, K,
+                       bn, p.wt_split_kind == 2 ? 16 : 32, (unsigned short*)img_dev, kscale);
   }
   ODT_HIP(hipGetLastError());
   return 0;

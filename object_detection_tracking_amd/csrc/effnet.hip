@@ -91,58 +91,78 @@ __global__ void __launch_bounds__(256) preprocess_rgb_resize_kernel(const T* __r
   }
 }
 
-// depthwise k x k conv (k = 3 or 5), TF 'SAME' padding, stride 1 or 2, folded BN, optional swish.
-// One thread = 4 channels (16-byte accesses, channels innermost) of PX horizontally adjacent
-// output pixels: the (PX-1)*S+K input columns of a kernel row are loaded once and reused by all PX
-// outputs, the K*K weights once per thread.  Taps outside the image contribute 0 * w; the sum runs
-// ky-major, kx inner for every output.
+// depthwise k x k conv (k = 3 or 5), TF 'SAME' padding, stride 1 or 2, folded BN, optional swish, optional fused
+// squeeze (spatial mean of the output for the squeeze-excite gate).
+// Workgroup = (block of 16 channel quads, pixel split, image); thread = one channel quad (16-byte accesses, channels
+// innermost: 16 lanes read 256 contiguous bytes of a pixel) x one of 16 pixel groups, taking every 16th block of PX
+// horizontally adjacent outputs of the split (one or two blocks per thread: the parallelism is in the grid).  The
+// (PX-1) S + K input columns of a kernel row are loaded once and reused by all PX outputs.  Taps outside the image
+// contribute nothing; every output sums ky-major, kx inner.  The squeeze is deterministic: per-thread sums in walk
+// order, a fixed tree over the pixel groups -> sum_part[b][split][c]; channel_mean_fold_kernel adds the splits.
+// (Folding in here by "the last workgroup to finish" was tried: the device-scope release / acquire fences it needs
+// write back and invalidate the XCD's L2 per workgroup on this multi-die part -- 4x slower kernels.)
 template <int K, int S, int PX>
 __global__ void __launch_bounds__(256) dwconv_kernel(DwConvParams p) {
   constexpr int NC = (PX - 1) * S + K;
-  const int c4n = p.ldc >> 2;
-  const int wob = (p.Wo + PX - 1) / PX;
-  const long total = (long)p.B * p.Ho * wob * c4n;
+  __shared__ f32x4 red[256];
+  const int tid = threadIdx.x;
+  const int cq = tid & 15, pg = tid >> 4;
+  const int c4 = blockIdx.x * 16 + cq, c4n = p.ldc >> 2;
+  const bool cok = c4 < c4n;
+  const int sp = blockIdx.y, b = blockIdx.z;
+  const int nxb = (p.Wo + PX - 1) / PX, units = nxb * p.Ho;
+  const int per = (units + p.nsplit - 1) / p.nsplit;
+  const int lo = sp * per, hi = lo + per < units ? lo + per : units;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % c4n);
-    long t = i / c4n;
-    const int xb = (int)(t % wob); t /= wob;
-    const int yo = (int)(t % p.Ho);
-    const int b = (int)(t / p.Ho);
-    const int xo0 = xb * PX, x0 = xo0 * S - p.pad_l;
-    f32x4 acc[PX];
-#pragma unroll
-    for (int q = 0; q < PX; ++q) acc[q] = zero;
-#pragma unroll
-    for (int ky = 0; ky < K; ++ky) {
-      const int y = yo * S + ky - p.pad_t;
-      if ((unsigned)y >= (unsigned)p.H) continue;
-      const float* row = p.in + (((long)b * p.H + y) * p.W) * p.ldc + c4 * 4;
-      f32x4 col[NC];
-#pragma unroll
-      for (int cidx = 0; cidx < NC; ++cidx) {
-        const int x = x0 + cidx;
-        col[cidx] = (unsigned)x < (unsigned)p.W ? *reinterpret_cast<const f32x4*>(row + (long)x * p.ldc) : zero;
-      }
-#pragma unroll
-      for (int kx = 0; kx < K; ++kx) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(p.wt + (long)(ky * K + kx) * p.ldc + c4 * 4);
-#pragma unroll
-        for (int q = 0; q < PX; ++q) acc[q] += col[q * S + kx] * w;
-      }
-    }
+  f32x4 sum = zero;
+  if (cok) {
     const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + c4 * 4);
+    for (int u = lo + pg; u < hi; u += 16) {
+      const int yo = u / nxb, xb = u - yo * nxb;
+      const int xo0 = xb * PX, x0 = xo0 * S - p.pad_l;
+      f32x4 acc[PX];
 #pragma unroll
-    for (int q = 0; q < PX; ++q) {
-      const int xo = xo0 + q;
-      if (xo >= p.Wo) break;
-      f32x4 v = acc[q] + bias;
-      if (p.act == 2) {
+      for (int q = 0; q < PX; ++q) acc[q] = zero;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = swishf(v[e]);
+      for (int ky = 0; ky < K; ++ky) {
+        const int y = yo * S + ky - p.pad_t;
+        if ((unsigned)y >= (unsigned)p.H) continue;
+        const float* row = p.in + (((long)b * p.H + y) * p.W) * p.ldc + c4 * 4;
+        f32x4 col[NC];
+#pragma unroll
+        for (int cidx = 0; cidx < NC; ++cidx) {
+          const int x = x0 + cidx;
+          col[cidx] = (unsigned)x < (unsigned)p.W ? *reinterpret_cast<const f32x4*>(row + (long)x * p.ldc) : zero;
+        }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(p.wt + (long)(ky * K + kx) * p.ldc + c4 * 4);
+#pragma unroll
+          for (int q = 0; q < PX; ++q) acc[q] += col[q * S + kx] * w;
+        }
       }
-      *reinterpret_cast<f32x4*>(p.out + (((long)b * p.Ho + yo) * p.Wo + xo) * p.ldc + c4 * 4) = v;
+#pragma unroll
+      for (int q = 0; q < PX; ++q) {
+        const int xo = xo0 + q;
+        if (xo >= p.Wo) break;
+        f32x4 v = acc[q] + bias;
+        if (p.act == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = swishf(v[e]);
+        }
+        *reinterpret_cast<f32x4*>(p.out + (((long)b * p.Ho + yo) * p.Wo + xo) * p.ldc + c4 * 4) = v;
+        sum += v;
+      }
     }
+  }
+  if (p.sum_part == nullptr) return;
+  red[tid] = sum;
+  __syncthreads();
+  if (pg == 0 && cok) {
+    f32x4 t = red[cq];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) t += red[g * 16 + cq];               // fixed order
+    *reinterpret_cast<f32x4*>(p.sum_part + ((long)b * p.nsplit + sp) * p.ldc + c4 * 4) = t;
   }
 }
 
@@ -345,16 +365,45 @@ int launch_preprocess_rgb_resize(const void* frames, int dtype, int B, int Hs, i
   return 0;
 }
 
-int launch_dwconv(const DwConvParams& p, hipStream_t stream) {
-  ODT_CHECK(p.ldc % 4 == 0 && (p.k == 3 || p.k == 5) && (p.stride == 1 || p.stride == 2), "dwconv: bad geometry");
-  constexpr int PX1 = 4, PX2 = 2;
-  const int px = p.stride == 1 ? PX1 : PX2;
-  const long total = (long)p.B * p.Ho * ((p.Wo + px - 1) / px) * (p.ldc >> 2);
-  const dim3 g(grid_for(total)), t(256);
-  if (p.k == 3 && p.stride == 1) hipLaunchKernelGGL((dwconv_kernel<3, 1, PX1>), g, t, 0, stream, p);
-  else if (p.k == 3) hipLaunchKernelGGL((dwconv_kernel<3, 2, PX2>), g, t, 0, stream, p);
-  else if (p.stride == 1) hipLaunchKernelGGL((dwconv_kernel<5, 1, PX1>), g, t, 0, stream, p);
-  else hipLaunchKernelGGL((dwconv_kernel<5, 2, PX2>), g, t, 0, stream, p);
+namespace {
+constexpr int kDwPX2 = 2;
+// outputs per thread along x at stride 1: 8 (k = 5: 10.6 loads per output against 16.3 at 4; D7 same-box A/B 66.7 -> 67.6
+// FPS); ODT_DW_PX=4 is the A/B knob, read once
+int dw_px1() {
+  static const int v = [] { const char* e = getenv("ODT_DW_PX"); return e != nullptr && atoi(e) == 4 ? 4 : 8; }();
+  return v;
+}
+}  // namespace
+
+static int dwconv_cblocks(const DwConvParams& p) { return ((p.ldc >> 2) + 15) / 16; }
+
+// pixel splits: one or two output blocks per thread (16 pixel groups per workgroup), at most 4096 workgroups in all
+int dwconv_splits(const DwConvParams& p) {
+  const int px = p.stride == 1 ? dw_px1() : kDwPX2;
+  const long units = (long)((p.Wo + px - 1) / px) * p.Ho;
+  // (with the fused squeeze every split is a partial sum the fold kernel has to add up: at most 1024 of them)
+  static const long sumcap = [] { const char* e = getenv("ODT_DW_SUMCAP"); return e != nullptr ? atol(e) : 2048L; }();   // A/B knob (1024 ... 8192: +-0.5 %)
+  const long cap = std::max<long>(1, (p.sum_part != nullptr ? sumcap : 4096) / ((long)dwconv_cblocks(p) * p.B));
+  return (int)std::max<long>(1, std::min(std::min<long>(cap, 1024), (units + 15) / 16));
+}
+
+int launch_dwconv(const DwConvParams& p0, hipStream_t stream) {
+  ODT_CHECK(p0.ldc % 4 == 0 && (p0.k == 3 || p0.k == 5) && (p0.stride == 1 || p0.stride == 2), "dwconv: bad geometry");
+  DwConvParams p = p0;
+  p.cqn = 16; p.nsplit = dwconv_splits(p);
+  const dim3 g(dwconv_cblocks(p), p.nsplit, p.B), t(256);
+  const bool wide = dw_px1() == 8;
+  if (p.k == 3 && p.stride == 1) {
+    if (wide) hipLaunchKernelGGL((dwconv_kernel<3, 1, 8>), g, t, 0, stream, p);
+    else hipLaunchKernelGGL((dwconv_kernel<3, 1, 4>), g, t, 0, stream, p);
+  } else if (p.k == 3) {
+    hipLaunchKernelGGL((dwconv_kernel<3, 2, kDwPX2>), g, t, 0, stream, p);
+  } else if (p.stride == 1) {
+    if (wide) hipLaunchKernelGGL((dwconv_kernel<5, 1, 8>), g, t, 0, stream, p);
+    else hipLaunchKernelGGL((dwconv_kernel<5, 1, 4>), g, t, 0, stream, p);
+  } else {
+    hipLaunchKernelGGL((dwconv_kernel<5, 2, kDwPX2>), g, t, 0, stream, p);
+  }
   ODT_HIP(hipGetLastError());
   return 0;
 }
@@ -384,6 +433,16 @@ int launch_se_gate(const float* in, const SeGateParams& p0, int B, float* scratc
   hipLaunchKernelGGL(channel_sum_kernel, dim3((p.ldc + 63) / 64, B, p.nsplit), dim3(256), 0, stream, in, p.HW, p.ldc,
                      p.nsplit, scratch);
   ODT_CHECK(p.ldc <= kSeMaxC && p.se <= kSeMaxR, "se_gate: channel count too large for the LDS staging");
+  hipLaunchKernelGGL(channel_mean_fold_kernel, dim3((p.ldc + 63) / 64, B), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(se_reduce_kernel, dim3((p.se + 3) / 4, B), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(se_expand_kernel, dim3((p.mid + 255) / 256, B), dim3(256), 0, stream, p);
+  ODT_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_se_gate_from_parts(const SeGateParams& p, int B, hipStream_t stream) {
+  ODT_CHECK(p.ldc <= kSeMaxC && p.se <= kSeMaxR, "se_gate: channel count too large for the LDS staging");
+  ODT_CHECK(p.part != nullptr && p.nsplit >= 1, "se_gate: partial sums missing");
   hipLaunchKernelGGL(channel_mean_fold_kernel, dim3((p.ldc + 63) / 64, B), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(se_reduce_kernel, dim3((p.se + 3) / 4, B), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(se_expand_kernel, dim3((p.mid + 255) / 256, B), dim3(256), 0, stream, p);

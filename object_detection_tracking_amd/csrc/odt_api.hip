@@ -60,7 +60,8 @@ struct ConvOp {
 };
 
 enum OpKind { OP_PRE, OP_CONV, OP_POOL, OP_SUB2, OP_PROPOSALS, OP_ROI_HEAD, OP_DETECT, OP_ROI_FINAL,
-              OP_ROI_MASK, OP_MASK_SELECT, OP_PRE_RGB, OP_DW, OP_CMEAN, OP_CSCALE, OP_FUSE, OP_EFF_POST, OP_ROI_EFF, OP_SE_GATE };
+              OP_ROI_MASK, OP_MASK_SELECT, OP_PRE_RGB, OP_DW, OP_CMEAN, OP_CSCALE, OP_FUSE, OP_EFF_POST, OP_ROI_EFF, OP_SE_GATE,
+              OP_SE_GATE_MEAN, OP_WSCALE };
 struct Op {
   OpKind kind;
   int conv = -1;        // index into convs
@@ -68,7 +69,8 @@ struct Op {
   DwConvParams dw{};    // OP_DW
   FuseParams fuse{};    // OP_FUSE
   SeGateParams se{};    // OP_SE_GATE (aux2 = partial-sum scratch)
-  float* aux = nullptr; // OP_CMEAN: means out [B,ldc]; OP_CSCALE: gates in [B,ldc]
+  float* aux = nullptr; // OP_CMEAN: means out [B,ldc]; OP_CSCALE / OP_WSCALE: gates in [B,ldc]
+  const float* wt0 = nullptr;   // OP_WSCALE: the conv's unscaled weights [Cout][K] (conv = index of the conv whose weights are rebuilt)
   float* aux2 = nullptr;   // OP_CMEAN: partial-sum scratch
   int pad_t = 0, pad_l = 0;   // OP_PRE_RGB
 };
@@ -887,6 +889,19 @@ static int run_ops(odt_model* m, const void* src, int dtype, hipStream_t st, siz
       case OP_SE_GATE:
         if (launch_se_gate(op.in.d, op.se, op.in.B, op.aux2, st)) return 1;
         break;
+      case OP_SE_GATE_MEAN:       // the partial sums came out of the depthwise kernel
+        if (launch_se_gate_from_parts(op.se, cfg.batch, st)) return 1;
+        break;
+      case OP_WSCALE: {           // batch 1: the gate goes into the projection's weights instead of a pass over the activations
+        const ConvParams& cp = m->convs[op.conv].p;
+        const int K = cp.Cin;
+        if (cp.wt_split != nullptr) {
+          if (conv_make_split_weights(cp, const_cast<void*>(cp.wt_split), st, op.wt0, op.aux)) return 1;
+        } else if (conv_scale_weights(op.wt0, op.aux, cp.Cout, K, const_cast<float*>(cp.wt), st)) {
+          return 1;
+        }
+        break;
+      }
       case OP_ROI_EFF:
         if (launch_roi_align(m->roi_eff, st)) return 1;
         break;

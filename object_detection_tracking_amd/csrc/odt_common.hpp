@@ -113,7 +113,11 @@ int conv_split_bm(int Cout);
 // picks the split kernel family / tile for a conv that conv_split_wanted() accepted (fills wt_split_kind / wt_split_bm)
 void conv_split_choose(ConvParams& p, const ConvPolicy& q);
 // builds the bf16-piece image of p.wt for p.wt_split_kind (conv_split_choose first)
-int conv_make_split_weights(const ConvParams& p, void* img_dev, hipStream_t stream);
+// wt_src: source weights if not p.wt; kscale[K]: per-k factor folded into the weights first (single-source 1x1 convs: a
+// per-input-channel gate, e.g. squeeze-excite, applied to the weights instead of the activations)
+int conv_make_split_weights(const ConvParams& p, void* img_dev, hipStream_t stream, const float* wt_src = nullptr,
+                            const float* kscale = nullptr);
+int conv_scale_weights(const float* wt, const float* kscale, int Cout, int K, float* out, hipStream_t stream);
 int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t stream);
 size_t conv_split_partial_bytes(const ConvParams& p);   // scratch a split-K conv needs (0: none)
 
@@ -133,8 +137,13 @@ struct DwConvParams {
   float* out;          // [B,Ho,Wo,ldc]
   int B, H, W, Ho, Wo, ldc, k, stride, pad_t, pad_l;
   int act;             // 0 none | 2 swish
+  // optional fused squeeze (MBConv): per-workgroup sums of the OUTPUT per (image, channel) for the squeeze-excite gate,
+  // sum_part[b][split][c] (fixed order); channel_mean_fold_kernel (launch_se_gate_from_parts) adds the splits
+  float* sum_part;     // [B][dwconv_splits()][ldc] or nullptr
+  int cqn, nsplit;     // filled by launch_dwconv: channel quads per workgroup (16), pixel splits
 };
 int launch_dwconv(const DwConvParams& p, hipStream_t stream);
+int dwconv_splits(const DwConvParams& p);       // pixel splits launch_dwconv will use (sizes sum_part)
 struct FuseParams {
   const float* in[3];
   int ih[3], iw[3], mode[3];     // mode 0 same size | 1 nearest resize | 2 max-pool 3x3 s2 'SAME'
@@ -154,7 +163,7 @@ int launch_preprocess_rgb_resize(const void* frames, int dtype, int B, int Hs, i
 int launch_channel_mean(const float* in, int B, int HW, int ldc, float* scratch, float* out, hipStream_t stream);
 int launch_channel_scale(float* x, const float* s, int B, int HW, int ldc, hipStream_t stream);
 struct SeGateParams {
-  const float* part; int nsplit;      // filled by launch_se_gate
+  const float* part; int nsplit;      // filled by launch_se_gate (launch_se_gate_from_parts: by the caller)
   int HW, ldc, mid, se;
   const float* w1;   // [se][ldc]   reduce weights (pad channels zero)
   const float* b1;   // [se]
@@ -165,6 +174,8 @@ struct SeGateParams {
   float* mean;       // [B][ldc]    spatial mean (scratch)
 };
 int launch_se_gate(const float* in, const SeGateParams& p, int B, float* scratch, hipStream_t stream);
+// the gate from the depthwise kernel's fused partial sums (p.part / p.nsplit set by the caller): fold + reduce + expand
+int launch_se_gate_from_parts(const SeGateParams& p, int B, hipStream_t stream);
 
 // ------------------------------------------------------- EfficientDet tail (effdet_post.hip)
 struct EffPostParams {

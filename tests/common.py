@@ -58,3 +58,34 @@ def match_detections(b1, l1, p1, b2, l2, p2, tol_box=1e-3, tol_prob=1e-4):
     else:
       miss += 1
   return miss, int((~used).sum())
+
+
+def tie_swaps(b1, l1, p1, b2, l2, p2, tol_box, tol_prob, iou_thr=0.5):
+  """Of the detections match_detections leaves unmatched on both sides, the number of PAIRS that are one NMS decision
+  between near-tied competitors: same label, scores within tol_prob, boxes overlapping by more than the NMS threshold
+  (so exactly one of the two survives, and which one is decided by score differences below the f32 noise of any
+  implementation -- random-init heads produce such plateaus).  Greedy one-to-one."""
+  def unmatched(ba, la, pa, bb, lb, pb):
+    used = np.zeros(len(bb), bool); left = []
+    for i in range(len(ba)):
+      d = np.abs(bb - ba[i]).max(1)
+      j = np.where((~used) & (lb == la[i]) & (d <= tol_box) & (np.abs(pb - pa[i]) <= tol_prob))[0]
+      if j.size:
+        used[j[0]] = True
+      else:
+        left.append(i)
+    return left, list(np.where(~used)[0])
+  m1, m2 = unmatched(b1, l1, p1, b2, l2, p2)
+  def iou(a, b):
+    iw = max(0.0, min(a[2], b[2]) - max(a[0], b[0])); ih = max(0.0, min(a[3], b[3]) - max(a[1], b[1]))
+    inter = iw * ih
+    return inter / ((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter + 1e-12)
+  taken = set(); ties = 0
+  for i in m1:
+    for j in m2:
+      if j in taken or l1[i] != l2[j] or abs(float(p1[i]) - float(p2[j])) > tol_prob:
+        continue
+      if iou(b1[i], b2[j]) > iou_thr:
+        taken.add(j); ties += 1
+        break
+  return ties
