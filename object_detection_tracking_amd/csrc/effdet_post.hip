@@ -32,11 +32,15 @@ __global__ void __launch_bounds__(256) eff_pack_kernel(const float* __restrict__
 }
 
 // state[0] = prefix of the score key (high word), state[1] = prefix of ~index (low word),
-// state[2] = k still to find among the elements matching the prefix, state[3] = compaction counter
+// state[2] = k still to find among the elements matching the prefix, state[3] = compaction counter,
+// state[4] = 1 once the threshold is final: after the four score passes, when exactly the elements still to find carry
+// the threshold score (no tie to break by index -- the usual case), the four index passes have nothing to do and leave
+// at once (the low word stays 0: every index qualifies)
 __global__ void __launch_bounds__(256) eff_hist_kernel(const unsigned* __restrict__ keys, long n, int pass,
                                                        const unsigned* __restrict__ state,
                                                        unsigned* __restrict__ hist) {
   __shared__ unsigned h[256];
+  if (pass >= 4 && state[4] != 0u) return;
   h[threadIdx.x] = 0;
   __syncthreads();
   const unsigned phi = state[0], plo = state[1];
@@ -57,11 +61,12 @@ __global__ void __launch_bounds__(256) eff_hist_kernel(const unsigned* __restric
 
 __global__ void eff_init_kernel(unsigned* __restrict__ state, unsigned* __restrict__ hist, int k) {
   hist[threadIdx.x] = 0;
-  if (threadIdx.x < 4) state[threadIdx.x] = threadIdx.x == 2 ? (unsigned)k : 0u;
+  if (threadIdx.x < 5) state[threadIdx.x] = threadIdx.x == 2 ? (unsigned)k : 0u;
 }
 
 __global__ void eff_scan_kernel(unsigned* __restrict__ hist, int pass, unsigned* __restrict__ state) {
   if (threadIdx.x != 0) return;
+  if (pass >= 4 && state[4] != 0u) return;
   unsigned need = state[2], acc = 0;
   int d = 255;
   for (; d > 0; --d) {
@@ -73,6 +78,7 @@ __global__ void eff_scan_kernel(unsigned* __restrict__ hist, int pass, unsigned*
   if (pass < 4) state[0] = (pass == 0 ? 0u : (state[0] & ~(0xFFFFFFFFu >> (8 * pass)))) | ((unsigned)d << sh);
   else state[1] = (pass == 4 ? 0u : (state[1] & ~(0xFFFFFFFFu >> (8 * (pass - 4))))) | ((unsigned)d << sh);
   state[2] = need;
+  if (pass == 3 && hist[d] == need) state[4] = 1u;       // the whole threshold bucket is wanted: no index passes
   for (int i = 0; i < 256; ++i) hist[i] = 0;
 }
 

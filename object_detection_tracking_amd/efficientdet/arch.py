@@ -199,8 +199,15 @@ def det_variable_shapes(model_name, num_classes=NUM_CLASSES):
   return v
 
 
-def synthetic_det_weights(model_name, seed=0, num_classes=NUM_CLASSES):
-  """Backbone + feature network + heads, seeded, TF names."""
+def bench_gain(model_name):
+  """Kernel gain that keeps random-init activations O(1) through the model's depth (synthetic benchmarks only)."""
+  return 0.7 if det_config(model_name)["fpn_cell_repeats"] >= 8 else 1.0
+
+
+def synthetic_det_weights(model_name, seed=0, num_classes=NUM_CLASSES, gain=1.0):
+  """Backbone + feature network + heads, seeded, TF names.  ``gain`` scales the standard deviation of the feature
+  network's / heads' conv kernels: the deep models that fuse by plain sums (D7: eight cells of 'sum' nodes) need < 1 for
+  the random-init activations to stay finite (``bench_gain``)."""
   c = det_config(model_name)
   w = synthetic_backbone_weights(c["backbone"], seed)
   rng = np.random.default_rng(seed + 1)
@@ -209,7 +216,7 @@ def synthetic_det_weights(model_name, seed=0, num_classes=NUM_CLASSES):
     if base.startswith("WSM"):
       w[k] = np.asarray(rng.uniform(0.5, 1.5), np.float32)
     elif base in ("kernel", "pointwise_kernel"):
-      w[k] = (rng.standard_normal(shp) * np.sqrt(1.5 / shp[2])).astype(np.float32)
+      w[k] = (rng.standard_normal(shp) * (gain * np.sqrt(1.5 / shp[2]))).astype(np.float32)
     elif base == "depthwise_kernel":
       w[k] = (rng.standard_normal(shp) * np.sqrt(1.5 / 9)).astype(np.float32)
     elif base == "bias":

@@ -53,7 +53,7 @@ def effdet(a):
   S = arch.det_config(a.effdet)["image_size"]
   cfg = make_config(is_efficientdet=True, efficientdet_modelname=a.effdet, efficientdet_max_detection_topk=5000, short_edge_size=S, max_size=S)
   cfg.max_size = S
-  m = models.get_model(cfg, 0, weights=arch.synthetic_det_weights(a.effdet, 0))
+  m = models.get_model(cfg, 0, weights=arch.synthetic_det_weights(a.effdet, 0, gain=arch.bench_gain(a.effdet)))
   fr = synthetic_frames(1, S, S)[0]
   e = m.engine((S, S))
   m.predict(fr)
