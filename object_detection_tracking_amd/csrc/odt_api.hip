@@ -301,6 +301,20 @@ int add_conv(odt_model* m, const std::string& name, const Tensor& in, int cin, c
 }
 
 
+// A handle's side streams (tail, H2D, D2H) are created with the highest stream priority.  Not for the arbitration: the
+// runtime multiplexes all streams of ONE priority onto a few hardware queues in creation order, and a side stream that
+// lands on the main stream's queue is serialised behind the forward it is meant to overlap (seen with the tracker's
+// stream: tools/experiments/track_stream_collision.py); streams of another priority get queues of their own.
+// ODT_SIDE_STREAM_PRIORITY=0: plain streams (A/B).
+int create_side_stream(hipStream_t* s) {
+  static const bool flat = getenv("ODT_SIDE_STREAM_PRIORITY") != nullptr && getenv("ODT_SIDE_STREAM_PRIORITY")[0] == '0';
+  if (flat) { ODT_HIP(hipStreamCreate(s)); return 0; }
+  int least = 0, greatest = 0;
+  ODT_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  ODT_HIP(hipStreamCreateWithPriority(s, hipStreamDefault, greatest));
+  return 0;
+}
+
 // bf16-piece weight images (conv_split.hip) for the plan's convs that the split kernel takes
 int attach_split_weights(odt_model* m) {
   // the handle's conv policy: odt_config first, ODT_CONV_* debug overrides on top (read once, here)
@@ -987,7 +1001,7 @@ int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStre
   m->done_stream = st;
   if (m->tail_overlap == 1 && st == m->own_stream) {
     if (!m->tail_stream) {
-      ODT_HIP(hipStreamCreate(&m->tail_stream));
+      if (create_side_stream(&m->tail_stream)) return 1;
       ODT_HIP(hipEventCreateWithFlags(&m->trunk_done, hipEventDisableTiming));
       ODT_HIP(hipEventCreateWithFlags(&m->tail_done, hipEventDisableTiming));
     }
@@ -1153,8 +1167,8 @@ int odt_forward(odt_handle h, const void* frames, int dtype, int on_device, void
 static int slot_prepare(odt_handle h, odt_model::Slot& sl, size_t in_bytes) {
   const odt_config& cfg = h->cfg;
   const size_t B = cfg.batch, per = cfg.result_per_im, FC = cfg.fpn_channels;
-  if (!h->copy_in) ODT_HIP(hipStreamCreate(&h->copy_in));
-  if (!h->copy_out) ODT_HIP(hipStreamCreate(&h->copy_out));
+  if (!h->copy_in && create_side_stream(&h->copy_in)) return 1;
+  if (!h->copy_out && create_side_stream(&h->copy_out)) return 1;
   if (sl.pin_in_bytes < in_bytes) {
     if (sl.pin_in) ODT_HIP(hipHostFree(sl.pin_in));
     if (sl.dev_in) ODT_HIP(hipFree(sl.dev_in));

@@ -106,7 +106,15 @@ int CosineCtx::run(int dev, const float* const* gal_rows, int G, const int* seg,
   if (device != dev) {
     ODT_CHECK(device < 0, "cosine context moved between devices");
     device = dev;
-    ODT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    // The highest stream priority, for the hardware queue it comes with: the runtime multiplexes all streams of one
+    // priority onto a few hardware queues in creation order, and a tracker stream that lands on the queue of a
+    // detector's stream waits for the whole forward in flight (seen in bench.py, where earlier handles had shifted the
+    // assignment: 6 ms of "tracking" per frame instead of 0.5).  Streams of another priority get queues of their own.
+    int prio_least = 0, prio_greatest = 0;
+    ODT_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    static const bool flat = getenv("ODT_COSINE_STREAM_PRIORITY") != nullptr && getenv("ODT_COSINE_STREAM_PRIORITY")[0] == '0';   // A/B knob
+    if (flat) ODT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    else ODT_HIP(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio_greatest));
     ODT_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
   }
   // one packed input record: [seg (T+1 ints, padded to 4)][gallery G*D][detections N*D]

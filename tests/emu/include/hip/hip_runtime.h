@@ -380,8 +380,10 @@ inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = 0) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
-enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+enum { hipStreamDefault = 0, hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = -1; return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 // ---- graphs: not emulated; capture reports failure and the library falls back to direct launches
 typedef struct hipGraph_s* hipGraph_t;

@@ -33,3 +33,17 @@ cd $R
 python tools/pmc_summary.py gpurun_out gpurun_out/r02_pmc_summary_split > gpurun_out/pmc_summary.log 2>&1
 find gpurun_out -name "*.db" -size +20M -delete; find gpurun_out -name "*.csv" -size +20M -delete
 grep -E "fetch_GB|write_GB|mfma_busy|hbm_bytes_per_launch_fetch" gpurun_out/r02_pmc_summary_split.txt | cut -c1-120
+# ---- EfficientDet-D7 (config #5): bench incl. the detect + TMOT leg and the CPU restatement, per-kernel and per-layer tables
+(timeout 600 python tools/bench_efficientdet.py --steps 20 2>gpurun_out/effdet_err.log | tail -1) > gpurun_out/bench_efficientdet_d7.json
+python -c "
+import json; d=json.load(open('gpurun_out/bench_efficientdet_d7.json')); print('D7 FPS %.1f ms %.2f frac %.3f' % (d['value'], d['ms_per_step'], d['roofline']['frac']), d['extra'], d['cpu_baseline'])"
+(timeout 300 python tools/profile_layers.py --effdet efficientdet-d7 --steps 3 2>&1 | tail -45) > gpurun_out/effdet_d7_conv_layers.txt 2>&1
+cd /tmp
+rm -rf $R/gpurun_out/prof_effdet
+(timeout 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_effdet -o eff -- python $R/tools/bench_efficientdet.py --no-cpu-baseline --steps 10 --warmup 2 2>&1 | tail -1) > $R/gpurun_out/effdet_rocprof.log 2>&1
+cd $R
+python tools/kernel_stats.py gpurun_out/prof_effdet > gpurun_out/kernel_stats_effdet_d7.txt 2>&1
+find gpurun_out/prof_effdet -name "*.db" -size +20M -delete
+head -8 gpurun_out/kernel_stats_effdet_d7.txt | cut -c1-170
+(timeout 280 python tools/profile_detect_track.py 2>&1 | grep -E "arrays=|pieces|idle" ) > gpurun_out/detect_track_pieces.txt 2>&1
+cat gpurun_out/detect_track_pieces.txt
