@@ -6,8 +6,9 @@
 1920x1080 case of the benchmark), otherwise it is resized with bilinear interpolation.  The
 reference calls ``cv2.resize(..., interpolation=cv2.INTER_LINEAR)``; OpenCV is not a dependency
 here, so the same sampling rule is restated in numpy (pixel centres at (i + 0.5) * scale - 0.5,
-source index clamped to the image, weights (1 - f, f)) -- unpinned against cv2, which is not
-installed in the build container.
+source index clamped to the image, weights (1 - f, f)); cv2 is not installed in the build container:
+the rule is pinned by its published 2x2 -> 4x4 table and, through oracle/imgproc.py, by torch's
+bilinear / align_corners=False (tests/test_oracle_golden.py).
 """
 import numpy as np
 

@@ -77,6 +77,13 @@ def _raw_vs_host_resize(lib, src_hw, dtype, short_edge, max_size):
     assert np.array_equal(b0, b1) and np.array_equal(l0, l1) and np.array_equal(p0, p1)
     assert np.array_equal(f0, f1)
     assert len(b0) > 0
+    # ... and against the ORACLE's resize (oracle/imgproc.py: float64, pixel by pixel; pinned in test_oracle_golden):
+    # the frames differ by rounding only (<= 6.2e-5 on the 0..255 scale), so the detections agree as a set within the path's tolerance
+    from oracle import imgproc
+    from common import match_detections
+    b2, l2, p2, f2 = m.predict(imgproc.resize_image(frame.astype(np.float32), short_edge, max_size))
+    miss, extra = match_detections(b1, l1, p1, b2, l2, p2, 1e-3 * max(1.0, max(newh, neww) / 128.0), 1e-4)
+    assert miss + extra <= max(1, len(b2) // 50), (miss, extra, len(b2))
   finally:
     m.close()
 
