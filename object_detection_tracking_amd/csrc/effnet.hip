@@ -275,6 +275,50 @@ __global__ void __launch_bounds__(256) channel_scale_kernel(float* __restrict__ 
 // either at the node's resolution, nearest-neighbour upsampled (TF1 rule: src = min(floor(dst *
 // in/out), in-1)) or 3x3 / stride-2 / 'SAME' max-pooled on the fly.  'fastattn' weights follow the
 // graph's operand order ((x * w) / (sum_w + 1e-4)); 'sum' adds left to right.
+// the node's fused value for channel quad c4 at pixel (y, x) of image b
+__device__ __forceinline__ f32x4 bifpn_fuse_at(const FuseParams& p, int b, int y, int x, int c4) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (k >= p.n) break;
+    const float* src = p.in[k] + (long)b * p.ih[k] * p.iw[k] * p.ldc + c4 * 4;
+    f32x4 v;
+    if (p.mode[k] == 0) {
+      v = *reinterpret_cast<const f32x4*>(src + ((long)y * p.iw[k] + x) * p.ldc);
+    } else if (p.mode[k] == 1) {
+      int sy = (int)floorf((float)y * p.sy[k]), sx = (int)floorf((float)x * p.sx[k]);
+      sy = sy < p.ih[k] - 1 ? sy : p.ih[k] - 1; sx = sx < p.iw[k] - 1 ? sx : p.iw[k] - 1;
+      v = *reinterpret_cast<const f32x4*>(src + ((long)sy * p.iw[k] + sx) * p.ldc);
+    } else {
+      const float ninf = -3.402823466e38f;
+      v = f32x4{ninf, ninf, ninf, ninf};
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int yy = 2 * y + dy - p.pt[k];
+        if ((unsigned)yy >= (unsigned)p.ih[k]) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int xx = 2 * x + dx - p.pl[k];
+          if ((unsigned)xx >= (unsigned)p.iw[k]) continue;
+          const f32x4 q = *reinterpret_cast<const f32x4*>(src + ((long)yy * p.iw[k] + xx) * p.ldc);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], q[e]);
+        }
+      }
+    }
+    if (p.weighted) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] * p.wgt[k] / p.denom;
+    }
+    if (k == 0) acc = v; else acc += v;
+  }
+  if (p.act == 2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = swishf(acc[e]);
+  }
+  return acc;
+}
+
 __global__ void __launch_bounds__(256) bifpn_fuse_kernel(FuseParams p) {
   const int c4n = p.ldc >> 2;
   const long total = (long)p.B * p.h * p.w * c4n;
@@ -284,46 +328,56 @@ __global__ void __launch_bounds__(256) bifpn_fuse_kernel(FuseParams p) {
     const int x = (int)(t % p.w); t /= p.w;
     const int y = (int)(t % p.h);
     const int b = (int)(t / p.h);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(p.out + (((long)b * p.h + y) * p.w + x) * p.ldc + c4 * 4) = bifpn_fuse_at(p, b, y, x, c4);
+  }
+}
+
+// BiFPN node without the fused tensor: dwconv_kernel<3, 1, PX>'s walk (same thread mapping, same summation order per
+// output), its column loads replaced by the fused value at that pixel (zero outside the image, as the 'SAME' padding of
+// the fused tensor).  A fused value is evaluated once per kernel row that uses it (3 (PX + 2) / PX per output).
+template <int PX>
+__global__ void __launch_bounds__(256) bifpn_fuse_dw_kernel(FuseParams p, const float* __restrict__ dwt, const float* __restrict__ dbias,
+                                                            float* __restrict__ out, int nsplit) {
+  constexpr int K = 3, NC = PX - 1 + K;
+  const int tid = threadIdx.x;
+  const int cq = tid & 15, pg = tid >> 4;
+  const int c4 = blockIdx.x * 16 + cq, c4n = p.ldc >> 2;
+  if (c4 >= c4n) return;
+  const int sp = blockIdx.y, b = blockIdx.z;
+  const int nxb = (p.w + PX - 1) / PX, units = nxb * p.h;
+  const int per = (units + nsplit - 1) / nsplit;
+  const int lo = sp * per, hi = lo + per < units ? lo + per : units;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(dbias + c4 * 4);
+  for (int u = lo + pg; u < hi; u += 16) {
+    const int yo = u / nxb, xb = u - yo * nxb;
+    const int xo0 = xb * PX, x0 = xo0 - 1;
+    f32x4 acc[PX];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      if (k >= p.n) break;
-      const float* src = p.in[k] + (long)b * p.ih[k] * p.iw[k] * p.ldc + c4 * 4;
-      f32x4 v;
-      if (p.mode[k] == 0) {
-        v = *reinterpret_cast<const f32x4*>(src + ((long)y * p.iw[k] + x) * p.ldc);
-      } else if (p.mode[k] == 1) {
-        int sy = (int)floorf((float)y * p.sy[k]), sx = (int)floorf((float)x * p.sx[k]);
-        sy = sy < p.ih[k] - 1 ? sy : p.ih[k] - 1; sx = sx < p.iw[k] - 1 ? sx : p.iw[k] - 1;
-        v = *reinterpret_cast<const f32x4*>(src + ((long)sy * p.iw[k] + sx) * p.ldc);
-      } else {
-        const float ninf = -3.402823466e38f;
-        v = f32x4{ninf, ninf, ninf, ninf};
+    for (int q = 0; q < PX; ++q) acc[q] = zero;
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-          const int yy = 2 * y + dy - p.pt[k];
-          if ((unsigned)yy >= (unsigned)p.ih[k]) continue;
+    for (int ky = 0; ky < K; ++ky) {
+      const int y = yo + ky - 1;
+      if ((unsigned)y >= (unsigned)p.h) continue;
+      f32x4 col[NC];
 #pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            const int xx = 2 * x + dx - p.pl[k];
-            if ((unsigned)xx >= (unsigned)p.iw[k]) continue;
-            const f32x4 q = *reinterpret_cast<const f32x4*>(src + ((long)yy * p.iw[k] + xx) * p.ldc);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], q[e]);
-          }
-        }
+      for (int cidx = 0; cidx < NC; ++cidx) {
+        const int x = x0 + cidx;
+        col[cidx] = (unsigned)x < (unsigned)p.w ? bifpn_fuse_at(p, b, y, x, c4) : zero;
       }
-      if (p.weighted) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] * p.wgt[k] / p.denom;
+      for (int kx = 0; kx < K; ++kx) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(dwt + (long)(ky * K + kx) * p.ldc + c4 * 4);
+#pragma unroll
+        for (int q = 0; q < PX; ++q) acc[q] += col[q + kx] * w;
       }
-      if (k == 0) acc = v; else acc += v;
     }
-    if (p.act == 2) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] = swishf(acc[e]);
+    for (int q = 0; q < PX; ++q) {
+      const int xo = xo0 + q;
+      if (xo >= p.w) break;
+      *reinterpret_cast<f32x4*>(out + (((long)b * p.h + yo) * p.w + xo) * p.ldc + c4 * 4) = acc[q] + bias;
     }
-    *reinterpret_cast<f32x4*>(p.out + (((long)b * p.h + y) * p.w + x) * p.ldc + c4 * 4) = acc;
   }
 }
 
@@ -347,6 +401,18 @@ int launch_bifpn_fuse(const FuseParams& p, hipStream_t stream) {
   ODT_CHECK(p.n >= 1 && p.n <= 3 && p.ldc % 4 == 0, "bifpn_fuse: bad arguments");
   const long total = (long)p.B * p.h * p.w * (p.ldc >> 2);
   hipLaunchKernelGGL(bifpn_fuse_kernel, dim3(grid_for(total)), dim3(256), 0, stream, p);
+  ODT_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_bifpn_fuse_dw(const FuseParams& p, const float* dwt, const float* dbias, float* out, hipStream_t stream) {
+  ODT_CHECK(p.n >= 1 && p.n <= 3 && p.ldc % 4 == 0 && dwt && dbias && out, "bifpn_fuse_dw: bad arguments");
+  constexpr int PX = 4;
+  const long units = (long)((p.w + PX - 1) / PX) * p.h;
+  const int cblocks = ((p.ldc >> 2) + 15) / 16;
+  const long cap = std::max<long>(1, 4096 / ((long)cblocks * p.B));
+  const int nsplit = (int)std::max<long>(1, std::min(cap, (units + 15) / 16));
+  hipLaunchKernelGGL((bifpn_fuse_dw_kernel<PX>), dim3(cblocks, nsplit, p.B), dim3(256), 0, stream, p, dwt, dbias, out, nsplit);
   ODT_HIP(hipGetLastError());
   return 0;
 }

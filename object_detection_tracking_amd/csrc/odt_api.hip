@@ -61,7 +61,7 @@ struct ConvOp {
 
 enum OpKind { OP_PRE, OP_CONV, OP_POOL, OP_SUB2, OP_PROPOSALS, OP_ROI_HEAD, OP_DETECT, OP_ROI_FINAL,
               OP_ROI_MASK, OP_MASK_SELECT, OP_PRE_RGB, OP_DW, OP_CMEAN, OP_CSCALE, OP_FUSE, OP_EFF_POST, OP_ROI_EFF, OP_SE_GATE,
-              OP_SE_GATE_MEAN, OP_WSCALE };
+              OP_SE_GATE_MEAN, OP_WSCALE, OP_FUSE_DW };
 struct Op {
   OpKind kind;
   int conv = -1;        // index into convs
@@ -896,6 +896,9 @@ static int run_ops(odt_model* m, const void* src, int dtype, hipStream_t st, siz
         break;
       case OP_FUSE:
         if (launch_bifpn_fuse(op.fuse, st)) return 1;
+        break;
+      case OP_FUSE_DW:            // BiFPN node: fusion evaluated inside the depthwise conv (op.dw carries wt / bias / out)
+        if (launch_bifpn_fuse_dw(op.fuse, op.dw.wt, op.dw.bias, op.dw.out, st)) return 1;
         break;
       case OP_EFF_POST:
         if (launch_effdet_post(m->eff_post, st)) return 1;

@@ -155,6 +155,9 @@ struct FuseParams {
   float* out;
 };
 int launch_bifpn_fuse(const FuseParams& p, hipStream_t stream);
+// BiFPN node in one kernel: the fused value (FuseParams, `out` unused) is evaluated where the 3x3 stride-1 'SAME'
+// depthwise conv behind it needs it -- no fused tensor in memory.  dwt [9][ldc], dbias [ldc], out [B,h,w,ldc]
+int launch_bifpn_fuse_dw(const FuseParams& p, const float* dwt, const float* dbias, float* out, hipStream_t stream);
 int launch_preprocess_rgb(const void* frames, int dtype, int B, int H, int W, int pad_t, int pad_l, int Hp, int Wp,
                           float* out, hipStream_t stream);
 int channel_mean_splits(int HW, int ldc, int B);
