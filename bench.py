@@ -164,7 +164,7 @@ def main():
   # odt_forward -> host outputs incl. [M,256,7,7] features): PCIe-inclusive rate; (b) the DeepSORT
   # appearance matching kernel at BASELINE config #3 size (T=64 tracks x budget 5, N=100 dets).
   extra = {}
-  if rank == 0 and not args.no_extras:
+  if rank == 0 and not args.no_extras and world == 1:        # (N > 1: the scaling runs report the timed region only)
     from object_detection_tracking_amd import ops
     t1 = time.perf_counter()
     for _ in range(3):
