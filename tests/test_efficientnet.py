@@ -131,7 +131,7 @@ def test_efficientdet_d1_nets_parity_odd_size(hip_lib):
   _det_parity(hip_lib, "efficientdet-d1", 270, 350)
 
 
-def _det_e2e(lib, model, H, W, topk, score_thr=0.02, tol_box=2e-2, src_hw=None, partial=None):
+def _det_e2e(lib, model, H, W, topk, score_thr=0.02, tol_box=2e-2, src_hw=None, partial=None, wmod=None):
   """Full EfficientDet forward through get_model / Session.run against the oracle."""
   import torch
   from object_detection_tracking_amd import models
@@ -140,6 +140,8 @@ def _det_e2e(lib, model, H, W, topk, score_thr=0.02, tol_box=2e-2, src_hw=None, 
   from oracle import effnet
   c = arch.det_config(model)
   w = arch.synthetic_det_weights(model, 0)
+  if wmod is not None:
+    wmod(w)
   if src_hw is None:
     fr = synthetic_frames(1, H, W, seed=13)[0]
     x, scale = effnet.preprocess(fr[None]), 1.0
@@ -209,6 +211,20 @@ def test_efficientdet_d0_arithmetic_and_stride_modes(backend, mode, monkeypatch)
     monkeypatch.setenv("ODT_EFFDET_SPLIT", "0")
   _backbone_parity(lib, "efficientnet-b0", 64, 96)
   _det_e2e(lib, "efficientdet-d0", 136, 152 if name == "emu" else 200, topk=300 if name == "emu" else 1000)
+
+
+def test_efficientdet_d0_topk_threshold_ties(backend):
+  """Exact score ties at the top-k threshold: with a zero class-predict kernel every anchor position carries the same
+  logit per (anchor shape, class) channel, so the k-th score is shared by hundreds of candidates and the selection has to
+  fall back on the index order (tf.nn.top_k: lowest index first) -- the radix select's index passes, which the other
+  tests (distinct scores: the passes leave at once) never run."""
+  name, lib = backend
+  def zero_class_kernel(w):
+    for k in ("class_net/class-predict/pointwise_kernel", "class_net/class-predict/depthwise_kernel"):
+      w[k] = np.zeros_like(w[k])
+    rng = np.random.default_rng(3)
+    w["class_net/class-predict/bias"] = rng.uniform(-4.0, -1.0, w["class_net/class-predict/bias"].shape).astype(np.float32)
+  _det_e2e(lib, "efficientdet-d0", 136, 152, topk=300, wmod=zero_class_kernel)
 
 
 def test_efficientdet_d0_partial_classes(emu_lib):
