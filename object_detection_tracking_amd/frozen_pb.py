@@ -14,7 +14,10 @@ the ``.npz`` route; only ``Const`` payloads are used.
 The field numbers are those of tensorflow/core/framework/{graph,node_def,attr_value,tensor,
 tensor_shape}.proto; no real frozen model ships with the reference or is reachable offline, so the
 reader is exercised against files produced by :func:`write_frozen_pb` (same wire format, written
-by hand) -- unpinned against TensorFlow's own serializer.
+by hand) and against GraphDefs serialised by Google's protobuf runtime from those message definitions
+(tests/tf_protos.py, tests/test_drop_in.py: every payload form, op nodes and non-float constants in
+between) -- the encoder is then the official one; a file written by TensorFlow itself has still not
+been read.
 """
 from __future__ import annotations
 

@@ -344,3 +344,81 @@ def test_tf_checkpoint_reader_roundtrip(tmp_path):
   open(prefix + ".index", "ab").write(b"x")
   with pytest.raises(ValueError):
     load_checkpoint(prefix)
+
+
+def test_frozen_pb_written_by_the_protobuf_runtime(emu_lib, tmp_path):
+  """The .pb reader on a GraphDef serialised by Google's protobuf runtime (tests/tf_protos.py declares TensorFlow's
+  messages from their published field numbers) instead of this repository's own writer: Const nodes in every payload
+  form TF uses (tensor_content, packed float_val / double_val / half_val, a splat constant), between nodes a real
+  frozen graph also holds (Placeholder, Conv2D with list / string / shape attributes, an int32 Const) -- and the
+  same file through get_model(load_from_pb): outputs identical to the .npz route."""
+  import tf_protos as T
+  from object_detection_tracking_amd.frozen_pb import load_frozen_pb
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1])
+  w = weights_for(cfg)
+  g = T.MESSAGES["GraphDef"]()
+  g.versions.producer = 134; g.versions.min_consumer = 12
+  ph = g.node.add(); ph.name = "image"; ph.op = "Placeholder"
+  ph.attr["dtype"].type = T.DT_FLOAT
+  ph.attr["shape"].shape.dim.add().size = -1
+  ph.attr["shape"].shape.dim.add().size = -1
+  ph.attr["shape"].shape.dim.add().size = 3
+  ic = g.node.add(); ic.name = "some/int/constant"; ic.op = "Const"
+  ic.attr["dtype"].type = T.DT_INT32
+  ic.attr["value"].tensor.dtype = T.DT_INT32
+  ic.attr["value"].tensor.tensor_shape.dim.add().size = 2
+  ic.attr["value"].tensor.int_val.extend([3, 4])
+  names = sorted(w)
+  forms = {}
+  for i, k in enumerate(names):
+    a = w[k]
+    if k == "conv0/bn/gamma":
+      T.const_node(g, k, a, T.DT_FLOAT, "vals"); forms[k] = "float_val"
+    elif k == "fastrcnn/fc6/W":
+      T.const_node(g, k, a.astype(np.float16), T.DT_HALF, "vals"); forms[k] = "half_val"
+    elif k == "fastrcnn/fc7/W":
+      T.const_node(g, k, a.astype(np.float16), T.DT_HALF, "content"); forms[k] = "half content"
+    elif k == "rpn/conv0/b":
+      T.const_node(g, k, a.astype(np.float64), T.DT_DOUBLE, "vals"); forms[k] = "double_val"
+    else:
+      T.const_node(g, k, a, T.DT_FLOAT, "content")
+    if i == 3:                                  # an op node in the middle, with the attribute kinds Conv2D carries
+      cv = g.node.add(); cv.name = "conv0/Conv2D"; cv.op = "Conv2D"
+      cv.input.extend(["image", "conv0/W"]); cv.device = "/device:GPU:0"
+      cv.attr["T"].type = T.DT_FLOAT
+      cv.attr["strides"].list.i.extend([1, 1, 2, 2])
+      cv.attr["padding"].s = b"VALID"
+      cv.attr["data_format"].s = b"NCHW"
+      cv.attr["use_cudnn_on_gpu"].b = True
+  splat = np.full((5, 7), 0.25, np.float32)
+  T.const_node(g, "some/splat", splat, T.DT_FLOAT, "splat")
+  path = str(tmp_path / "by_protobuf.pb")
+  with open(path, "wb") as fh:
+    fh.write(g.SerializeToString())
+  got = load_frozen_pb(path)
+  assert set(got) == set(names) | {"some/splat"}                     # the int32 Const and the op nodes are not weights
+  assert np.array_equal(got["some/splat"], splat)
+  for k in names:
+    want = w[k]
+    if forms.get(k, "").startswith("half"):
+      want = want.astype(np.float16).astype(np.float32)
+    assert got[k].dtype == np.float32 and got[k].shape == want.shape, k
+    assert np.array_equal(got[k], want), (k, forms.get(k))
+  # ... and as a model: the half-precision entries replaced by exact ones so that both routes see the same numbers
+  g2 = T.MESSAGES["GraphDef"]()
+  for k in names:
+    T.const_node(g2, k, w[k], T.DT_FLOAT, "vals" if k.endswith("/b") else "content")
+  path2 = str(tmp_path / "model_by_protobuf.pb")
+  with open(path2, "wb") as fh:
+    fh.write(g2.SerializeToString())
+  fr = synthetic_frames(1, 64, 96)[0]
+  cfg_pb = small_config(resnet_num_block=[1, 1, 1, 1], is_load_from_pb=True, model_path=path2, load_from=path2)
+  m1 = models.get_model(cfg, 0, weights=w, lib=emu_lib)
+  m2 = models.get_model(cfg_pb, 0, lib=emu_lib)
+  try:
+    o1, o2 = m1.predict(fr), m2.predict(fr)
+    for a, b in zip(o1, o2):
+      assert np.array_equal(a, b)
+    assert len(o1[0]) > 0
+  finally:
+    m1.close(); m2.close()
