@@ -147,8 +147,10 @@ def _table_block(entries, restart_interval=16):
   return body + b"".join(struct.pack("<I", r) for r in restarts) + struct.pack("<I", len(restarts))
 
 
-def write_checkpoint(prefix, variables, per_block=7):
-  """Write {name: array} as a one-shard V2 checkpoint + the ``checkpoint`` state file."""
+def write_checkpoint(prefix, variables, per_block=7, encode_entry=None, encode_header=None):
+  """Write {name: array} as a one-shard V2 checkpoint + the ``checkpoint`` state file.  ``encode_entry(dtype_enum,
+  shape, offset, size) -> bytes`` / ``encode_header() -> bytes`` let a test substitute another serialiser for the
+  BundleEntryProto / BundleHeaderProto values (the protobuf runtime, tests/tf_protos.py)."""
   data, recs = b"", []
   for name in sorted(variables):
     a = np.asarray(variables[name])
@@ -158,8 +160,11 @@ def write_checkpoint(prefix, variables, per_block=7):
     shape = b"".join(_ld(2, _vi(1, int(d))) for d in a.shape)
     entry = _vi(1, dt) + _ld(2, shape) + _vi(4, len(data)) + _vi(5, len(raw)) + \
         _enc_varint((6 << 3) | 5) + struct.pack("<I", 0)
+    if encode_entry is not None:
+      entry = encode_entry(dt, [int(d) for d in a.shape], len(data), len(raw))
     recs.append((name.encode(), entry)); data += raw
-  recs = [(b"", _vi(1, 1) + _ld(3, _vi(1, 1)))] + recs        # BundleHeaderProto{num_shards=1, version}
+  header = _vi(1, 1) + _ld(3, _vi(1, 1))                         # BundleHeaderProto{num_shards=1, version}
+  recs = [(b"", encode_header() if encode_header is not None else header)] + recs
   with open(prefix + ".data-00000-of-00001", "wb") as fh:
     fh.write(data)
   out, index_entries = b"", []

@@ -422,3 +422,33 @@ def test_frozen_pb_written_by_the_protobuf_runtime(emu_lib, tmp_path):
     assert len(o1[0]) > 0
   finally:
     m1.close(); m2.close()
+
+
+def test_checkpoint_index_values_by_the_protobuf_runtime(tmp_path):
+  """V2 checkpoint whose .index VALUES (BundleHeaderProto / BundleEntryProto) come from Google's protobuf runtime
+  (tests/tf_protos.py) -- offset 0, shard 0 and empty shapes are then omitted as the official encoder omits defaults,
+  crc32c is a fixed32 -- inside this repository's table writer (prefix-compressed keys, several blocks)."""
+  import tf_protos as T
+  from object_detection_tracking_amd.tf_checkpoint import load_checkpoint, write_checkpoint
+  rng = np.random.default_rng(9)
+  names = ["group0/block0/conv1/W", "group0/block0/conv1/bn/gamma", "group0/block0/conv1/bn/beta", "group0/block0/conv2/W",
+           "conv0/W", "fastrcnn/fc6/W", "fastrcnn/fc6/b", "fpn/lateral_1x1_c2/W", "scalar_like"]
+  w = {k: rng.standard_normal((3, 4, 5)[:1 + i % 3]).astype(np.float32) for i, k in enumerate(names)}
+  w["scalar_like"] = np.asarray(rng.standard_normal((1,)), np.float32)
+  w["global_step"] = np.asarray([77], np.int64)                       # skipped by name
+  def entry(dt, shape, offset, size):
+    e = T.MESSAGES["BundleEntryProto"]()
+    e.dtype = dt; e.offset = offset; e.size = size; e.crc32c = 0x9a3b5c01
+    for d in shape:
+      e.shape.dim.add().size = d
+    return e.SerializeToString()
+  def header():
+    h = T.MESSAGES["BundleHeaderProto"]()
+    h.num_shards = 1; h.version.producer = 1
+    return h.SerializeToString()
+  ck = tmp_path / "ck"; ck.mkdir()
+  write_checkpoint(str(ck / "model-5"), w, per_block=3, encode_entry=entry, encode_header=header)
+  got = load_checkpoint(str(ck))
+  assert set(got) == set(names)
+  for k in names:
+    assert got[k].dtype == np.float32 and np.array_equal(got[k], w[k]), k

@@ -71,10 +71,23 @@ def _build():
   gd = fd.message_type.add(); gd.name = "GraphDef"
   _field(gd, "node", 1, _T.TYPE_MESSAGE, _T.LABEL_REPEATED, ".odt_tf.NodeDef")
   _field(gd, "versions", 4, _T.TYPE_MESSAGE, type_name=".odt_tf.VersionDef")
+  # tensorflow/core/protobuf/tensor_bundle.proto: the values of a V2 checkpoint's .index table
+  # BundleHeaderProto { int32 num_shards = 1; Endianness endianness = 2; VersionDef version = 3; }
+  bh = fd.message_type.add(); bh.name = "BundleHeaderProto"
+  _field(bh, "num_shards", 1, _T.TYPE_INT32); _field(bh, "endianness", 2, _T.TYPE_INT32)
+  _field(bh, "version", 3, _T.TYPE_MESSAGE, type_name=".odt_tf.VersionDef")
+  # BundleEntryProto { DataType dtype = 1; TensorShapeProto shape = 2; int32 shard_id = 3; int64 offset = 4; int64 size = 5;
+  #                    fixed32 crc32c = 6; repeated TensorSliceProto slices = 7; }
+  be = fd.message_type.add(); be.name = "BundleEntryProto"
+  _field(be, "dtype", 1, _T.TYPE_INT32)
+  _field(be, "shape", 2, _T.TYPE_MESSAGE, type_name=".odt_tf.TensorShapeProto")
+  _field(be, "shard_id", 3, _T.TYPE_INT32); _field(be, "offset", 4, _T.TYPE_INT64); _field(be, "size", 5, _T.TYPE_INT64)
+  _field(be, "crc32c", 6, _T.TYPE_FIXED32)
   pool = descriptor_pool.DescriptorPool()
   pool.Add(fd)
   get = lambda n: message_factory.GetMessageClass(pool.FindMessageTypeByName("odt_tf." + n))
-  return {n: get(n) for n in ("GraphDef", "NodeDef", "AttrValue", "TensorProto", "TensorShapeProto", "VersionDef")}
+  return {n: get(n) for n in ("GraphDef", "NodeDef", "AttrValue", "TensorProto", "TensorShapeProto", "VersionDef",
+                              "BundleHeaderProto", "BundleEntryProto")}
 
 
 MESSAGES = _build()
