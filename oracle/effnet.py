@@ -58,6 +58,20 @@ def preprocess(frames_bgr_u8):
   return torch.from_numpy(np.ascontiguousarray(x.transpose(0, 3, 1, 2)))
 
 
+def tf1_resize_bilinear(x, sh, sw):
+  """tf.image.resize_images(x, [sh, sw], BILINEAR) of TF 1.x (align_corners False, no half-pixel centres: in = out *
+  in_size / out_size, lower = floor, upper = min(lower + 1, size - 1)) on a float32 [h,w,c] image.  Pinned by the
+  vectors of TensorFlow's resize_bilinear_op_test.cc (tests/test_oracle_golden.py)."""
+  h, w = x.shape[:2]
+  fy = np.arange(sh, dtype=F) * (F(h) / F(sh)); fx = np.arange(sw, dtype=F) * (F(w) / F(sw))
+  y0 = np.floor(fy).astype(np.int64); x0 = np.floor(fx).astype(np.int64)
+  y1 = np.minimum(y0 + 1, h - 1); x1 = np.minimum(x0 + 1, w - 1)
+  ly = (fy - y0.astype(F))[:, None, None]; lx = (fx - x0.astype(F))[None, :, None]
+  top = x[y0][:, x0] + (x[y0][:, x1] - x[y0][:, x0]) * lx
+  bot = x[y1][:, x0] + (x[y1][:, x1] - x[y1][:, x0]) * lx
+  return (top + (bot - top) * ly).astype(F)
+
+
 def preprocess_resized(frame_bgr, out_hw):
   """efficientdet_wrapper.py:45-60 for one frame of any size: normalise, scale by min(out_w / w,
   out_h / h) (float32, sizes by truncation), tf.image.resize_images BILINEAR with the TF-1.x legacy
@@ -68,13 +82,7 @@ def preprocess_resized(frame_bgr, out_hw):
   sc = min(F(out_hw[1]) / F(w), F(out_hw[0]) / F(h))
   sh, sw = int(F(h) * sc), int(F(w) * sc)
   if (sh, sw) != (h, w):
-    fy = np.arange(sh, dtype=F) * (F(h) / F(sh)); fx = np.arange(sw, dtype=F) * (F(w) / F(sw))
-    y0 = np.floor(fy).astype(np.int64); x0 = np.floor(fx).astype(np.int64)
-    y1 = np.minimum(y0 + 1, h - 1); x1 = np.minimum(x0 + 1, w - 1)
-    ly = (fy - y0.astype(F))[:, None, None]; lx = (fx - x0.astype(F))[None, :, None]
-    top = x[y0][:, x0] + (x[y0][:, x1] - x[y0][:, x0]) * lx
-    bot = x[y1][:, x0] + (x[y1][:, x1] - x[y1][:, x0]) * lx
-    x = (top + (bot - top) * ly).astype(F)
+    x = tf1_resize_bilinear(x, sh, sw)
   out = np.zeros((out_hw[0], out_hw[1], 3), F)
   out[:sh, :sw] = x
   return torch.from_numpy(np.ascontiguousarray(out.transpose(2, 0, 1)[None])), F(1.0) / sc
