@@ -86,9 +86,14 @@ def main():
     cdt = time.perf_counter() - t2
     cpu = {"value": 1.0 / cdt, "unit": "frames/s", "cores": int(_t.get_num_threads()), "kind": "port",
            "sample": "one frame through oracle.effnet (torch-CPU fp32 + numpy tail), one pass, %.1f s" % cdt}
+  traffic = None
+  pmc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_pmc_summary_effdet_d7.json")
+  if a.model == "efficientdet-d7" and S == 1536 and os.path.exists(pmc):
+    # HBM bytes per forward from the committed rocprofv3 --pmc passes (tools/gpurun/r2_effdet_pmc.sh), FETCH_SIZE doubled
+    traffic = json.load(open(pmc))["hbm_GB_per_forward_fetch_x2"] * 1e9
   print(json.dumps({"roofline": {"bound": "hbm", "kernel": "whole network (depthwise / SE / fusion kernels are HBM-bound, "
                     "the 1x1 convs small-K MFMA)", "achieved": algo_bytes / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
-                    "frac": algo_bytes / dt / 1e9 / 8000.0, "traffic": None,
+                    "frac": algo_bytes / dt / 1e9 / 8000.0, "traffic": traffic,
                     "algorithmic_bytes_per_frame": algo_bytes},
                     "cpu_baseline": cpu, "metric": "%s FPS @%dx%d input per MI355X" % (a.model, S, S), "value": 1.0 / dt, "unit": "frames/s",
                     "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3, "dtype": "f32",
