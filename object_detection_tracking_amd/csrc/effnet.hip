@@ -107,9 +107,22 @@ __global__ void __launch_bounds__(256) dwconv_kernel(DwConvParams p) {
   __shared__ f32x4 red[256];
   const int tid = threadIdx.x;
   const int cq = tid & 15, pg = tid >> 4;
-  const int c4 = blockIdx.x * 16 + cq, c4n = p.ldc >> 2;
+  // workgroup -> (channel block, pixel split, image).  Launch order goes round the 8 XCDs (each with its own L2), and
+  // vertically adjacent splits share their halo rows: every XCD gets one contiguous band of the (image, split, channel
+  // block) sequence, so that a halo row is fetched from HBM once per band instead of once per neighbour
+  // (profiles/r02_pmc_summary_effdet_d7.json: the depthwise kernels fetched 1.6x their input before this).
+  int cb = (int)blockIdx.x, sp = (int)blockIdx.y, b = (int)blockIdx.z;
+  if (p.xcd_bands) {
+    const unsigned nb = gridDim.x * gridDim.y, total = nb * gridDim.z;
+    const unsigned lg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const unsigned xcd = lg & 7u, q = total >> 3, r = total & 7u;
+    const unsigned nl = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lg >> 3);
+    b = (int)(nl / nb);
+    const unsigned rem = nl - (unsigned)b * nb;
+    sp = (int)(rem / gridDim.x); cb = (int)(rem - (unsigned)sp * gridDim.x);
+  }
+  const int c4 = cb * 16 + cq, c4n = p.ldc >> 2;
   const bool cok = c4 < c4n;
-  const int sp = blockIdx.y, b = blockIdx.z;
   const int nxb = (p.Wo + PX - 1) / PX, units = nxb * p.Ho;
   const int per = (units + p.nsplit - 1) / p.nsplit;
   const int lo = sp * per, hi = lo + per < units ? lo + per : units;
@@ -457,6 +470,8 @@ int launch_dwconv(const DwConvParams& p0, hipStream_t stream) {
   ODT_CHECK(p0.ldc % 4 == 0 && (p0.k == 3 || p0.k == 5) && (p0.stride == 1 || p0.stride == 2), "dwconv: bad geometry");
   DwConvParams p = p0;
   p.cqn = 16; p.nsplit = dwconv_splits(p);
+  static const bool bands = !(getenv("ODT_DW_XCD") != nullptr && getenv("ODT_DW_XCD")[0] == '0');     // A/B knob
+  p.xcd_bands = bands ? 1 : 0;
   const dim3 g(dwconv_cblocks(p), p.nsplit, p.B), t(256);
   const bool wide = dw_px1() == 8;
   if (p.k == 3 && p.stride == 1) {

@@ -141,6 +141,7 @@ struct DwConvParams {
   // sum_part[b][split][c] (fixed order); channel_mean_fold_kernel (launch_se_gate_from_parts) adds the splits
   float* sum_part;     // [B][dwconv_splits()][ldc] or nullptr
   int cqn, nsplit;     // filled by launch_dwconv: channel quads per workgroup (16), pixel splits
+  int xcd_bands;       // filled by launch_dwconv: 1 = contiguous band of workgroups per XCD (halo rows shared in its L2)
 };
 int launch_dwconv(const DwConvParams& p, hipStream_t stream);
 int dwconv_splits(const DwConvParams& p);       // pixel splits launch_dwconv will use (sizes sum_part)
