@@ -218,10 +218,13 @@ int odt_tracker_tracks(odt_tracker_handle t, int cap, int32_t* ids, int32_t* sta
 /* scipy.optimize.linear_sum_assignment(cost[nr,nc]) -> n = min(nr,nc) (row, col) pairs by row */
 int odt_lsap(const double* cost, int nr, int nc, int32_t* rows, int32_t* cols, int* n);
 /* application_util/preprocessing.py:6-73 non_max_suppression (the tracker-side duplicate filter of obj_detect_tracking.py:
- * 662-668): boxes (x, y, w, h) float64 [n,4], scores [n] (NULL: order by bottom edge), visited by ascending-argsort order
- * from the back, overlap = intersection / area of the lower-ranked box with the +1 pixel convention, suppressed when
- * overlap > max_overlap.  pick receives the kept indices in pick order. */
-int odt_tracker_nms(const double* boxes_xywh, const double* scores, int n, double max_overlap, int32_t* pick, int* npick);
+ * 662-668): boxes (x, y, w, h) float64 [n,4]; candidates are visited from the back of `order` [n] (the caller's
+ * np.argsort of the scores -- or of the bottom edges when the reference is called without scores -- so that ties keep
+ * numpy's order; NULL: a stable ascending sort of `scores`, or of the bottom edges when scores is NULL too); overlap =
+ * intersection / area of the lower-ranked box with the +1 pixel convention, suppressed when overlap > max_overlap.
+ * pick receives the kept indices in pick order. */
+int odt_tracker_nms(const double* boxes_xywh, const double* scores, const int32_t* order, int n, double max_overlap, int32_t* pick,
+                    int* npick);
 
 /* ---- TMOT / JDE tracker core (reference tmot/multitracker.py JDETracker; driver
  * obj_detect_tracking_multi_queuer_tmot.py:543-583, :707-714).  Host C++ like the DeepSORT core.

@@ -143,7 +143,7 @@ class OdtLib(object):
     d.odt_tracker_tracks.argtypes = [C.c_void_p, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p,
                                      c_double_p, c_double_p, C.POINTER(C.c_int)]
     d.odt_lsap.argtypes = [c_double_p, C.c_int, C.c_int, c_int_p, c_int_p, C.POINTER(C.c_int)]
-    d.odt_tracker_nms.argtypes = [c_double_p, c_double_p, C.c_int, C.c_double, c_int_p, C.POINTER(C.c_int)]
+    d.odt_tracker_nms.argtypes = [c_double_p, c_double_p, c_int_p, C.c_int, C.c_double, c_int_p, C.POINTER(C.c_int)]
     d.odt_tmot_create.argtypes = [C.c_double] * 8 + [C.POINTER(C.c_void_p)]
     d.odt_tmot_destroy.argtypes = [C.c_void_p]
     d.odt_tmot_reset.argtypes = [C.c_void_p]

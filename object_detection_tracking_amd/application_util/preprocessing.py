@@ -30,8 +30,9 @@ def non_max_suppression(boxes, max_bbox_overlap, scores=None):
 
 
 def non_max_suppression_native(boxes, max_bbox_overlap, scores=None, lib=None):
-  """The same filter through the native core (``odt_tracker_nms``): identical picks, no per-pick numpy round trips
-  (1 ms per call in the loop above for a frame's ~50 boxes)."""
+  """The same filter through the native core (``odt_tracker_nms``): identical picks -- the visiting order is the same
+  ``np.argsort`` call, so ties fall as in the loop above -- without the per-pick numpy round trips (1 ms per call
+  for a frame's ~50 boxes)."""
   import ctypes as C
   from .. import _lib
   lib = lib if lib is not None else _lib.get_lib()
@@ -39,8 +40,8 @@ def non_max_suppression_native(boxes, max_bbox_overlap, scores=None, lib=None):
   n = b.shape[0]
   if n == 0:
     return []
-  s = np.ascontiguousarray(scores, dtype=np.float64) if scores is not None else None
+  order = np.ascontiguousarray(np.argsort(scores) if scores is not None else np.argsort(b[:, 1] + b[:, 3]), dtype=np.int32)
   pick = np.zeros(n, np.int32); k = C.c_int()
-  lib.check(lib.dll.odt_tracker_nms(b.ctypes.data_as(_lib.c_double_p), s.ctypes.data_as(_lib.c_double_p) if s is not None else None,
-                                    n, float(max_bbox_overlap), _lib.iptr(pick), C.byref(k)))
+  lib.check(lib.dll.odt_tracker_nms(b.ctypes.data_as(_lib.c_double_p), None, _lib.iptr(order), n, float(max_bbox_overlap),
+                                    _lib.iptr(pick), C.byref(k)))
   return [int(i) for i in pick[:k.value]]

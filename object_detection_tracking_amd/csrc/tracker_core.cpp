@@ -377,7 +377,8 @@ int min_cost_matching(odt_tracker* t, CostFn fn, double max_distance, const std:
 
 extern "C" {
 
-int odt_tracker_nms(const double* boxes, const double* scores, int n, double max_overlap, int32_t* pick, int* npick) {
+int odt_tracker_nms(const double* boxes, const double* scores, const int32_t* order_in, int n, double max_overlap, int32_t* pick,
+                    int* npick) {
   ODT_CHECK(npick != nullptr && (n == 0 || (boxes != nullptr && pick != nullptr)), "odt_tracker_nms: null argument");
   *npick = 0;
   if (n <= 0) return 0;
@@ -386,12 +387,19 @@ int odt_tracker_nms(const double* boxes, const double* scores, int n, double max
     x2[i] = boxes[4 * i] + boxes[4 * i + 2]; y2[i] = boxes[4 * i + 1] + boxes[4 * i + 3];
     area[i] = (x2[i] - boxes[4 * i] + 1) * (y2[i] - boxes[4 * i + 1] + 1);
   }
-  // np.argsort (quicksort, not stable; the reference's inputs are detector scores: ties are broken here by index, which
-  // is what numpy's introsort does for the short arrays it hands to insertion sort)
+  // visiting order: the caller's np.argsort (ties then keep numpy's order), else a stable ascending sort
   std::vector<int> order(n);
-  for (int i = 0; i < n; ++i) order[i] = i;
-  const double* key = scores != nullptr ? scores : y2.data();
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
+  if (order_in != nullptr) {
+    std::vector<char> seen(n, 0);
+    for (int i = 0; i < n; ++i) {
+      ODT_CHECK(order_in[i] >= 0 && order_in[i] < n && !seen[order_in[i]], "odt_tracker_nms: order is not a permutation");
+      seen[order_in[i]] = 1; order[i] = order_in[i];
+    }
+  } else {
+    for (int i = 0; i < n; ++i) order[i] = i;
+    const double* key = scores != nullptr ? scores : y2.data();
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
+  }
   while (!order.empty()) {
     const int i = order.back();
     order.pop_back();
