@@ -165,85 +165,88 @@ def main():
   # appearance matching kernel at BASELINE config #3 size (T=64 tracks x budget 5, N=100 dets).
   extra = {}
   if rank == 0 and not args.no_extras and world == 1:        # (N > 1: the scaling runs report the timed region only)
-    from object_detection_tracking_amd import ops
-    t1 = time.perf_counter()
-    for _ in range(3):
-      eng.forward(frames)
-    extra["pcie_inclusive_fps"] = 3 * B / (time.perf_counter() - t1)
-    # same, through the pipelined ingest (pinned double-buffered staging, H2D / D2H on copy
-    # streams overlapping the forward; odt_submit / odt_collect)
-    t1 = time.perf_counter()
-    n = 0
-    for _ in eng.forward_stream([frames] * 10):
-      n += 1
-    extra["pcie_inclusive_pipelined_fps"] = n * B / (time.perf_counter() - t1)
-    if world == 1 and S == 1:
-      # (c) two independent video streams (two handles, one HIP stream each) sharing the GPU: the
-      # tails / low-occupancy layers of one forward overlap with the other stream's kernels
-      m2 = models.get_model(cfg, local_rank, weights=weights, is_multi=True)
-      e2 = m2.engine(B, H, W)
-      d2 = torch.from_numpy(synthetic_frames(B, H, W, seed=99)).cuda(local_rank)
-      for k in range(2 + 6):
-        if k == 2:
-          eng.synchronize(); e2.synchronize(); t1 = time.perf_counter()
-        eng.forward_device_async(dev_frames.data_ptr(), ODT_DTYPE_U8)
-        e2.forward_device_async(d2.data_ptr(), ODT_DTYPE_U8)
-      eng.synchronize(); e2.synchronize()
-      extra["two_streams_per_gpu_fps"] = 2 * 6 * B / (time.perf_counter() - t1)
-      m2.close()
-      # (d) the same step with every conv on the exact-f32 MFMA kernel (config conv_arith = "f32"): the
-      # other arithmetic mode of the library, measured in the same process on the same box
-      try:
-        cfg3 = make_config(rpn_test_post_nms_topk=args.topk, im_batch_size=B, max_size=max(H, W),
-                           short_edge_size=min(H, W), conv_arith="f32")
-        m3 = models.get_model(cfg3, local_rank, weights=weights, is_multi=True)
-        e3 = m3.engine(B, H, W)
-        for k in range(1 + 5):
-          if k == 1:
-            e3.synchronize(); t1 = time.perf_counter()
-          e3.forward_device_async(dev_frames.data_ptr(), ODT_DTYPE_U8)
-        e3.synchronize()
-        extra["exact_f32_mfma_only_fps"] = 5 * B / (time.perf_counter() - t1)
-        extra["exact_f32_mfma_only_handle"] = e3.describe()["conv_arith"]
-        m3.close()
-      except Exception as ex:     # never fatal: `value` above is already measured
-        extra["exact_f32_mfma_only_fps"] = "failed: %r" % (ex,)
     try:
-      extra.update(detect_track_leg(eng, frames, B, local_rank))
-      fast = detect_track_leg(eng, frames, B, local_rank, arrays=True)
-      extra["detect_track_arrays_fps"] = fast["detect_track_fps"]        # create_obj_arrays + native tracker NMS + Tracker.update_arrays
-      extra["detect_track_arrays_host_ms_per_frame"] = fast["detect_track"]["host_tracking_ms_per_frame"]
-    except Exception as ex:       # never fatal: `value` above is already measured
-      extra["detect_track_fps"] = "failed: %r" % (ex,)
-    if world == 1 and S == 1:
-      # (e) trained RPNs score most anchors negative, so images keep fewer than K proposals (zero-padded NMS slots,
-      # models.py:2487-2520); the synthetic weights' +1 RPN class bias keeps all K alive.  Same step with the bias
-      # shifted by -3 (less box-head work, every selection kernel on its short-list path)
+      from object_detection_tracking_amd import ops
+      t1 = time.perf_counter()
+      for _ in range(3):
+        eng.forward(frames)
+      extra["pcie_inclusive_fps"] = 3 * B / (time.perf_counter() - t1)
+      # same, through the pipelined ingest (pinned double-buffered staging, H2D / D2H on copy
+      # streams overlapping the forward; odt_submit / odt_collect)
+      t1 = time.perf_counter()
+      n = 0
+      for _ in eng.forward_stream([frames] * 10):
+        n += 1
+      extra["pcie_inclusive_pipelined_fps"] = n * B / (time.perf_counter() - t1)
+      if world == 1 and S == 1:
+        # (c) two independent video streams (two handles, one HIP stream each) sharing the GPU: the
+        # tails / low-occupancy layers of one forward overlap with the other stream's kernels
+        m2 = models.get_model(cfg, local_rank, weights=weights, is_multi=True)
+        e2 = m2.engine(B, H, W)
+        d2 = torch.from_numpy(synthetic_frames(B, H, W, seed=99)).cuda(local_rank)
+        for k in range(2 + 6):
+          if k == 2:
+            eng.synchronize(); e2.synchronize(); t1 = time.perf_counter()
+          eng.forward_device_async(dev_frames.data_ptr(), ODT_DTYPE_U8)
+          e2.forward_device_async(d2.data_ptr(), ODT_DTYPE_U8)
+        eng.synchronize(); e2.synchronize()
+        extra["two_streams_per_gpu_fps"] = 2 * 6 * B / (time.perf_counter() - t1)
+        m2.close()
+        # (d) the same step with every conv on the exact-f32 MFMA kernel (config conv_arith = "f32"): the
+        # other arithmetic mode of the library, measured in the same process on the same box
+        try:
+          cfg3 = make_config(rpn_test_post_nms_topk=args.topk, im_batch_size=B, max_size=max(H, W),
+                             short_edge_size=min(H, W), conv_arith="f32")
+          m3 = models.get_model(cfg3, local_rank, weights=weights, is_multi=True)
+          e3 = m3.engine(B, H, W)
+          for k in range(1 + 5):
+            if k == 1:
+              e3.synchronize(); t1 = time.perf_counter()
+            e3.forward_device_async(dev_frames.data_ptr(), ODT_DTYPE_U8)
+          e3.synchronize()
+          extra["exact_f32_mfma_only_fps"] = 5 * B / (time.perf_counter() - t1)
+          extra["exact_f32_mfma_only_handle"] = e3.describe()["conv_arith"]
+          m3.close()
+        except Exception as ex:     # never fatal: `value` above is already measured
+          extra["exact_f32_mfma_only_fps"] = "failed: %r" % (ex,)
       try:
-        w2 = dict(weights)
-        w2["rpn/class/b"] = (w2["rpn/class/b"] - 3.0).astype(np.float32)
-        m4 = models.get_model(cfg, local_rank, weights=w2, is_multi=True)
-        e4 = m4.engine(B, H, W)
-        for k in range(1 + 5):
-          if k == 1:
-            e4.synchronize(); t1 = time.perf_counter()
-          e4.forward_device_async(dev_frames.data_ptr(), ODT_DTYPE_U8)
-        e4.synchronize()
-        extra["negative_rpn_bias_fps"] = 5 * B / (time.perf_counter() - t1)
-        extra["negative_rpn_bias_nproposals"] = [int(v) for v in e4.tap("nproposals").reshape(-1)]
-        m4.close()
-      except Exception as ex:
-        extra["negative_rpn_bias_fps"] = "failed: %r" % (ex,)
-    rng = np.random.default_rng(0)
-    gal = rng.standard_normal((320, 256)).astype(np.float32)
-    seg = (np.arange(65) * 5).astype(np.int32)
-    det = rng.standard_normal((100, 256)).astype(np.float32)
-    ops.nn_cosine(gal, seg, det, device=local_rank)
-    t1 = time.perf_counter()
-    for _ in range(50):
+        extra.update(detect_track_leg(eng, frames, B, local_rank))
+        fast = detect_track_leg(eng, frames, B, local_rank, arrays=True)
+        extra["detect_track_arrays_fps"] = fast["detect_track_fps"]        # create_obj_arrays + native tracker NMS + Tracker.update_arrays
+        extra["detect_track_arrays_host_ms_per_frame"] = fast["detect_track"]["host_tracking_ms_per_frame"]
+      except Exception as ex:       # never fatal: `value` above is already measured
+        extra["detect_track_fps"] = "failed: %r" % (ex,)
+      if world == 1 and S == 1:
+        # (e) trained RPNs score most anchors negative, so images keep fewer than K proposals (zero-padded NMS slots,
+        # models.py:2487-2520); the synthetic weights' +1 RPN class bias keeps all K alive.  Same step with the bias
+        # shifted by -3 (less box-head work, every selection kernel on its short-list path)
+        try:
+          w2 = dict(weights)
+          w2["rpn/class/b"] = (w2["rpn/class/b"] - 3.0).astype(np.float32)
+          m4 = models.get_model(cfg, local_rank, weights=w2, is_multi=True)
+          e4 = m4.engine(B, H, W)
+          for k in range(1 + 5):
+            if k == 1:
+              e4.synchronize(); t1 = time.perf_counter()
+            e4.forward_device_async(dev_frames.data_ptr(), ODT_DTYPE_U8)
+          e4.synchronize()
+          extra["negative_rpn_bias_fps"] = 5 * B / (time.perf_counter() - t1)
+          extra["negative_rpn_bias_nproposals"] = [int(v) for v in e4.tap("nproposals").reshape(-1)]
+          m4.close()
+        except Exception as ex:
+          extra["negative_rpn_bias_fps"] = "failed: %r" % (ex,)
+      rng = np.random.default_rng(0)
+      gal = rng.standard_normal((320, 256)).astype(np.float32)
+      seg = (np.arange(65) * 5).astype(np.int32)
+      det = rng.standard_normal((100, 256)).astype(np.float32)
       ops.nn_cosine(gal, seg, det, device=local_rank)
-    extra["nn_matching_ms_per_call_host_to_host"] = 1e3 * (time.perf_counter() - t1) / 50
+      t1 = time.perf_counter()
+      for _ in range(50):
+        ops.nn_cosine(gal, seg, det, device=local_rank)
+      extra["nn_matching_ms_per_call_host_to_host"] = 1e3 * (time.perf_counter() - t1) / 50
 
+    except Exception as ex:       # the extras are never fatal: `value` is already measured
+      extra["extras_failed"] = repr(ex)
   if rank == 0:
     fps = world * S * B * args.steps / dt
     common = {
