@@ -40,7 +40,12 @@ def main():
   ap.add_argument("--height", type=int, default=1080)
   ap.add_argument("--width", type=int, default=1920)
   ap.add_argument("--topk", type=int, default=300, help="rpn_test_post_nms_topk (BASELINE: 300)")
+  ap.add_argument("--graph", default="multi", choices=["multi", "single"],
+                  help="multi = Mask_RCNN_FPN_multi (batched graph, the headline); single = Mask_RCNN_FPN (BASELINE config #2: "
+                       "the b=1 graph of obj_detect_tracking.py -- min-size filter, prob > 1e-4, per-class NMS; needs --batch 1)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-d7", action="store_true", help="skip the EfficientDet-D7 leg of `extra` (BASELINE config #5)")
+  ap.add_argument("--no-affinity", action="store_true", help="N > 1: do not pin the ranks to the CPUs next to their GPU")
   ap.add_argument("--no-extras", action="store_true", help="skip the `extra` measurements (A/B runs)")
   ap.add_argument("--cpu-frames", type=int, default=1, help="frames in the bounded CPU sample (7 passes: 2 warm-up + 5 timed)")
   ap.add_argument("--profile-steps", type=int, default=2)
@@ -84,6 +89,13 @@ def main():
                      "--dist-backend gloo --device 0 shares one GPU for debugging)"
                      % (world, world, torch.cuda.device_count()))
   torch.cuda.set_device(local_rank)
+  # host placement: with several ranks on one host each is pinned to its share of the CPUs next to its GPU (N = 1
+  # keeps the whole host: the CPU baseline below uses every core); reported per rank either way
+  from object_detection_tracking_amd.parallel import bind_rank_to_gpu_numa
+  try:
+    affinity = bind_rank_to_gpu_numa(local_rank, max(world, 1), apply=(world > 1 and not args.no_affinity and args.device is None))
+  except Exception as ex:          # never fatal
+    affinity = {"bound": False, "error": repr(ex)}
   if world > 1:
     if args.dist_backend == "nccl":
       dist.init_process_group("nccl", rank=rank, world_size=world,
@@ -97,11 +109,14 @@ def main():
   from object_detection_tracking_amd.weights import synthetic_frames, synthetic_weights
 
   B, H, W = args.batch, args.height, args.width
+  multi = args.graph == "multi"
+  if not multi and B != 1:
+    raise SystemExit("bench.py: --graph single is the b=1 graph (obj_detect_tracking.py:241-242): pass --batch 1")
   cfg = make_config(rpn_test_post_nms_topk=args.topk, im_batch_size=B, max_size=max(H, W),
                     short_edge_size=min(H, W))
   weights = synthetic_weights(cfg, seed=0)
   S = max(1, args.streams)
-  all_models = [models.get_model(cfg, local_rank, weights=weights, is_multi=True) for _ in range(S)]
+  all_models = [models.get_model(cfg, local_rank, weights=weights, is_multi=multi) for _ in range(S)]
   engs = [m.engine(B, H, W) for m in all_models]
   model, eng = all_models[0], engs[0]
   # one video stream per handle: each gets its own seeded frames
@@ -139,6 +154,10 @@ def main():
   dt, ranks_seen, rank_dts = reduce_timing(dt, rank, world, "cuda" if args.dist_backend == "nccl" else "cpu")
   rank_fps = [S * B * args.steps / t for t in rank_dts]
 
+  # the timed region, checked: the outputs the LAST replayed forward of every stream left in HBM must equal, bit for
+  # bit, a blocking odt_forward of the same frames through the host boundary -- and must be a non-trivial detection set
+  verified = verify_timed_region(engs, all_frames)
+
   # roofline of the dominant kernel family (implicit-GEMM conv, ~99% of the FLOPs): HIP events
   # around every launch on the launch stream, outside the timed region.
   eng.profile(True)
@@ -160,6 +179,25 @@ def main():
     return f[1] * nprof / (f[2] * 1e-3) / 1e12 if f[2] > 0 else 0.0
   split_tf, f32_tf = tf(fam["split"]), tf(fam["f32"])
 
+  sustained = None
+  if rank == 0:
+    sustained = sustained_peak(eng.lib, local_rank)
+
+  # every rank: the PCIe-inclusive pipelined rate of its own stream (the figure that degrades with host contention when
+  # N ranks share one host; `value` above is HBM-resident) -- measured by all ranks at the same time
+  per_rank = None
+  if world > 1:
+    barrier()
+    mine = {"rank": rank, "local_rank": local_rank, "affinity": affinity}
+    try:
+      mine.update(pipelined_leg(eng, frames, B, nbatches=6))
+    except Exception as ex:
+      mine["pipelined_failed"] = repr(ex)
+    mine["device_resident_fps"] = rank_fps[rank] if rank < len(rank_fps) else None
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    per_rank = sorted(gathered, key=lambda d: d["rank"])
+
   # Not part of `value`: (a) the same step through the host boundary (pageable host frames ->
   # odt_forward -> host outputs incl. [M,256,7,7] features): PCIe-inclusive rate; (b) the DeepSORT
   # appearance matching kernel at BASELINE config #3 size (T=64 tracks x budget 5, N=100 dets).
@@ -173,15 +211,11 @@ def main():
       extra["pcie_inclusive_fps"] = 3 * B / (time.perf_counter() - t1)
       # same, through the pipelined ingest (pinned double-buffered staging, H2D / D2H on copy
       # streams overlapping the forward; odt_submit / odt_collect)
-      t1 = time.perf_counter()
-      n = 0
-      for _ in eng.forward_stream([frames] * 10):
-        n += 1
-      extra["pcie_inclusive_pipelined_fps"] = n * B / (time.perf_counter() - t1)
+      extra.update(pipelined_leg(eng, frames, B, nbatches=10))
       if world == 1 and S == 1:
         # (c) two independent video streams (two handles, one HIP stream each) sharing the GPU: the
         # tails / low-occupancy layers of one forward overlap with the other stream's kernels
-        m2 = models.get_model(cfg, local_rank, weights=weights, is_multi=True)
+        m2 = models.get_model(cfg, local_rank, weights=weights, is_multi=multi)
         e2 = m2.engine(B, H, W)
         d2 = torch.from_numpy(synthetic_frames(B, H, W, seed=99)).cuda(local_rank)
         for k in range(2 + 6):
@@ -197,7 +231,7 @@ def main():
         try:
           cfg3 = make_config(rpn_test_post_nms_topk=args.topk, im_batch_size=B, max_size=max(H, W),
                              short_edge_size=min(H, W), conv_arith="f32")
-          m3 = models.get_model(cfg3, local_rank, weights=weights, is_multi=True)
+          m3 = models.get_model(cfg3, local_rank, weights=weights, is_multi=multi)
           e3 = m3.engine(B, H, W)
           for k in range(1 + 5):
             if k == 1:
@@ -223,7 +257,7 @@ def main():
         try:
           w2 = dict(weights)
           w2["rpn/class/b"] = (w2["rpn/class/b"] - 3.0).astype(np.float32)
-          m4 = models.get_model(cfg, local_rank, weights=w2, is_multi=True)
+          m4 = models.get_model(cfg, local_rank, weights=w2, is_multi=multi)
           e4 = m4.engine(B, H, W)
           for k in range(1 + 5):
             if k == 1:
@@ -235,6 +269,12 @@ def main():
           m4.close()
         except Exception as ex:
           extra["negative_rpn_bias_fps"] = "failed: %r" % (ex,)
+      if world == 1 and S == 1 and multi and (B, H, W) == (8, 1080, 1920):
+        # (f) BASELINE config #2 on the graph the config names: Mask_RCNN_FPN (models.py:488-973), batch 1
+        try:
+          extra.update(single_graph_leg(models, make_config, weights, args.topk, H, W, local_rank))
+        except Exception as ex:
+          extra["b1_single_graph_fps"] = "failed: %r" % (ex,)
       rng = np.random.default_rng(0)
       gal = rng.standard_normal((320, 256)).astype(np.float32)
       seg = (np.arange(65) * 5).astype(np.int32)
@@ -282,6 +322,11 @@ def main():
       roofline = dict(f32_family)
       roofline.update({"bound": "mfma", "traffic": pmc_traffic("f32") if (B, H, W) == (8, 1080, 1920) else None})
     roofline.update(common)
+    if sustained is not None and "bf16_tflops" in sustained and fam["split"][0] > 0:
+      # what the bf16 matrix pipe of THIS box sustains on the split kernels' own MFMA mix (random operands, >= 300 ms
+      # of back-to-back launches, measured a moment ago in this process): the ceiling under the box's power budget
+      roofline["sustained_peak"] = sustained
+      roofline["frac_of_sustained"] = split_tf / (sustained["bf16_tflops"] / SPLIT_PRODUCTS)
     out = {
         "metric": "detector FPS @%dx%d b=%d per MI355X" % (W, H, B),
         "value": fps,
@@ -289,6 +334,9 @@ def main():
         "n_gpus": world,
         "ranks_seen": ranks_seen,
         "per_rank_fps": rank_fps,
+        "per_rank": per_rank if per_rank is not None else [{"rank": 0, "local_rank": local_rank, "affinity": affinity}],
+        "verified": bool(verified.get("ok")),
+        "verification": verified,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,
@@ -309,12 +357,19 @@ def main():
                                "%dx%d, batch %d per GPU, rpn_post_nms_topk %d, 15 classes, "
                                "random-init weights, frames resident in HBM (uint8)" %
                                (W, H, B, args.topk),
-                   "graph": "Mask_RCNN_FPN_multi", "streams_per_gpu": S},
+                   "graph": "Mask_RCNN_FPN_multi" if multi else "Mask_RCNN_FPN", "streams_per_gpu": S},
         "roofline": roofline,
     }
     out["extra"] = extra
     if world == 1 and not args.no_cpu_baseline:
-      out["cpu_baseline"] = cpu_baseline(cfg, weights, frames, args.cpu_frames)
+      out["cpu_baseline"] = cpu_baseline(cfg, weights, frames, args.cpu_frames, multi)
+    if world == 1 and S == 1 and not args.no_extras and not args.no_d7 and (B, H, W) == (8, 1080, 1920):
+      # (g) BASELINE config #5: EfficientDet-D7 at 1536 x 1536 + the TMOT tracker, its own roofline (HBM) and CPU baseline
+      # (in a child process with a time limit: whatever happens there, the headline line above is printed)
+      for m in all_models:
+        m.close()
+      all_models = []
+      extra["efficientdet_d7"] = efficientdet_leg(local_rank, not args.no_cpu_baseline)
     print(json.dumps(out), flush=True)
   for m in all_models:
     m.close()
@@ -346,7 +401,129 @@ def cpu_model_name():
   return "unknown"
 
 
-def cpu_baseline(cfg, weights, frames, nframes):
+def verify_timed_region(engs, all_frames):
+  """Outputs of the last timed (replayed, device-resident) forward of every stream vs a blocking forward of the same
+  frames from host memory: every array bit-equal, detections present.  Returns the `verification` object."""
+  import zlib
+  res = {"ok": True, "streams": []}
+  for e, fr in zip(engs, all_frames):
+    got = e.read_outputs(want_feats=True, want_pooled=True)
+    nprop = e.tap("nproposals").reshape(-1)
+    ref = e.forward(fr, want_feats=True, want_pooled=True)
+    names = ("final_boxes", "final_labels", "final_probs", "final_valid_indices", "fpn_box_feat", "pooled")
+    equal = {n: bool(np.array_equal(a, b)) for n, a, b in zip(names, got, ref)}
+    crc = 0
+    for a in got[:4]:
+      crc = zlib.crc32(np.ascontiguousarray(a).tobytes(), crc)
+    ndet = int(got[3].sum())
+    ok = all(equal.values()) and ndet > 0 and int(nprop.min()) > 0 and bool(np.isfinite(got[0]).all())
+    res["streams"].append({"bit_equal_to_blocking_forward": equal, "detections": ndet,
+                           "proposals_per_frame": [int(v) for v in nprop], "checksum_crc32": "%08x" % (crc & 0xffffffff)})
+    res["ok"] = res["ok"] and ok
+  res["what"] = ("outputs left in HBM by the last forward of the timed loop (odt_read_outputs) == blocking odt_forward of the "
+                 "same frames from host memory, all six output arrays bit for bit; detections > 0; proposals > 0 per frame")
+  return res
+
+
+def sustained_peak(lib, device):
+  """roofline.sustained_peak: odt_probe_mfma_bf16 (csrc/probe.hip) -- the split kernels' MFMA mix on random register
+  operands, 100 ms warm-up + >= 300 ms timed back-to-back; once more with the kernels' LDS fragment reads."""
+  import ctypes as C
+  out = {}
+  try:
+    for key, lds in (("", 0), ("with_lds_fragment_reads_", 1)):
+      tf = C.c_double(); ghz = C.c_double(); ms = C.c_double(); n = C.c_int()
+      lib.check(lib.dll.odt_probe_mfma_bf16(device, 100.0, 300.0, lds, C.byref(tf), C.byref(ghz), C.byref(ms), C.byref(n)))
+      out[key + "bf16_tflops"] = tf.value
+      out[key + "clock_ghz"] = ghz.value
+      out[key + "measured_ms"] = ms.value
+    out["f32_work_tflops"] = out["bf16_tflops"] / SPLIT_PRODUCTS
+    out["frac_of_datasheet_bf16_peak"] = out["bf16_tflops"] / BF16_MFMA_PEAK_TFLOPS
+    out["what"] = ("v_mfma_f32_32x32x16_bf16 in the split kernels' mix (2 x 4 accumulator tiles per wave, 6 products per k16 "
+                   "step, one 8-wave workgroup per CU), random bf16 operands in registers, no memory traffic; "
+                   "back-to-back launches, 100 ms warm-up, >= 300 ms timed")
+  except Exception as ex:
+    out["failed"] = repr(ex)
+  return out
+
+
+def pipelined_leg(eng, frames, B, nbatches=10):
+  """PCIe-inclusive rates of the ingest pipeline (odt_submit_ex / odt_collect, pooled features back):
+  (a) frames handed over in pageable host memory (one staging copy into the pinned slot per batch);
+  (b) frames already in the slot's pinned ingest buffer (odt_ingest_buffer: the decoder's output buffer IS the staging
+      buffer -- submit(NULL)), i.e. with a pinned frame source."""
+  t1 = time.perf_counter()
+  n = 0
+  for _ in eng.forward_stream([frames] * nbatches):
+    n += 1
+  out = {"pcie_inclusive_pipelined_fps": n * B / (time.perf_counter() - t1)}
+  try:
+    pending = []
+    for k in range(2):                # fill both slots' pinned buffers once (a decoder would write every batch there)
+      np.copyto(eng.ingest_buffer(frames.dtype), frames)
+      pending.append(eng.submit(None, want_feats=False, want_pooled=True))
+    for t in pending:
+      eng.collect(t)
+    t1 = time.perf_counter()
+    pending, n = [], 0
+    for k in range(nbatches):
+      eng.ingest_buffer(frames.dtype)           # (selects the slot; its buffer still holds the frames)
+      pending.append(eng.submit(None, want_feats=False, want_pooled=True))
+      if len(pending) == 2:
+        eng.collect(pending.pop(0)); n += 1
+    while pending:
+      eng.collect(pending.pop(0)); n += 1
+    out["pcie_inclusive_pipelined_pinned_source_fps"] = n * B / (time.perf_counter() - t1)
+  except Exception as ex:
+    out["pcie_inclusive_pipelined_pinned_source_fps"] = "failed: %r" % (ex,)
+  return out
+
+
+def single_graph_leg(models, make_config, weights, topk, H, W, device, steps=20, warmup=3):
+  """BASELINE config #2: ResNet-101-dilated+FPN, 1920x1080, batch 1, on `Mask_RCNN_FPN` (reference models.py:488-973:
+  min-size filter, prob > 1e-4, per-class tf.image.non_max_suppression) -- device-resident like the headline."""
+  import torch
+  from object_detection_tracking_amd._lib import ODT_DTYPE_U8
+  from object_detection_tracking_amd.weights import synthetic_frames
+  cfg1 = make_config(rpn_test_post_nms_topk=topk, im_batch_size=1, max_size=max(H, W), short_edge_size=min(H, W))
+  m = models.get_model(cfg1, device, weights=weights, is_multi=False)
+  try:
+    e = m.engine(1, H, W)
+    fr = synthetic_frames(1, H, W, seed=1234)
+    d = torch.from_numpy(fr).cuda(device)
+    for k in range(warmup + steps):
+      if k == warmup:
+        e.synchronize(); t1 = time.perf_counter()
+      e.forward_device_async(d.data_ptr(), ODT_DTYPE_U8)
+    e.synchronize()
+    dt = (time.perf_counter() - t1) / steps
+    got = e.read_outputs(want_feats=False, want_pooled=True)
+    ref = e.forward(fr, want_feats=False, want_pooled=True)
+    ok = all(np.array_equal(a, b) for a, b in zip(got[:4], ref[:4])) and int(got[3].sum()) > 0
+    return {"b1_single_graph_fps": 1.0 / dt, "b1_single_graph": {"graph": "Mask_RCNN_FPN", "ms_per_frame": 1e3 * dt, "steps": steps,
+                                                               "detections": int(got[3].sum()), "verified": bool(ok),
+                                                               "handle": e.describe()}}
+  finally:
+    m.close()
+
+
+def efficientdet_leg(device, with_cpu_baseline, timeout=420):
+  """tools/bench_efficientdet.py (EfficientDet-D7 @1536x1536 + TMOT) as a child process; its JSON object, or a
+  {"failed": ...} record -- never an exception."""
+  import subprocess
+  cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_efficientdet.py"), "--model", "efficientdet-d7", "--steps", "20",
+         "--warmup", "3", "--device", str(device)] + ([] if with_cpu_baseline else ["--no-cpu-baseline"])
+  try:
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+      return {"failed": "rc %d: %s" % (r.returncode, r.stderr[-400:])}
+    return json.loads(lines[-1])
+  except Exception as ex:
+    return {"failed": repr(ex)}
+
+
+def cpu_baseline(cfg, weights, frames, nframes, multi=True):
   """Oracle (CPU restatement of the TF graph; NOT TensorFlow) on a bounded sample, by the protocol of
   BASELINE.md section 3: all host cores, 2 warm-up passes, median of 5 timed passes."""
   import torch
@@ -359,7 +536,10 @@ def cpu_baseline(cfg, weights, frames, nframes):
   times = []
   for i in range(2 + 5):
     t0 = time.perf_counter()
-    om.forward_multi(frames[:n])
+    if multi:
+      om.forward_multi(frames[:n])
+    else:
+      om.forward(frames[0])
     if i >= 2:
       times.append(time.perf_counter() - t0)
   med = float(np.median(times))
@@ -367,9 +547,9 @@ def cpu_baseline(cfg, weights, frames, nframes):
           "cpu_model": cpu_model_name(), "torch": torch.__version__,
           "kind": "port",
           "protocol": "2 warm-up + median of 5 timed passes", "pass_seconds": [round(t, 3) for t in times],
-          "sample": "%d of the step's %d frames through oracle.graph.OracleModel.forward_multi "
+          "sample": "%d of the step's %d frames through oracle.graph.OracleModel.forward%s "
                     "(torch-CPU fp32 conv/matmul + numpy selection ops: a CPU restatement of the TF graph, not TensorFlow)"
-                    % (n, frames.shape[0])}
+                    % (n, frames.shape[0], "_multi" if multi else "")}
 
 
 def detect_track_leg(eng, frames, B, device, nbatches=8, arrays=False):
@@ -443,9 +623,18 @@ def reduce_timing(dt, rank, world, cdev):
 def launcher_selftest(args, rank, world):
   """The launch / rendezvous / reduction path of a real run without a GPU (gloo)."""
   import torch.distributed as dist
+  from object_detection_tracking_amd.parallel import bind_rank_to_gpu_numa
   if world > 1:
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dist.barrier()
+  # the per-rank record of a real run: who ran where (no GPU here: the affinity plan comes back unbound)
+  mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+          "affinity": bind_rank_to_gpu_numa(int(os.environ.get("LOCAL_RANK", "0")), world, bdfs=[None] * world, apply=False)}
+  per_rank = [mine]
+  if world > 1:
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, mine)
+    per_rank = sorted(per_rank, key=lambda d: d["rank"])
   t0 = time.perf_counter()
   time.sleep(0.01 * (1 + rank))            # ranks finish at different times: the max must win
   if world > 1:
@@ -453,7 +642,7 @@ def launcher_selftest(args, rank, world):
   dt = time.perf_counter() - t0
   dt, seen, dts = reduce_timing(dt, rank, world, "cpu")
   if rank == 0:
-    print(json.dumps({"launcher_selftest": True, "n_gpus": world, "ranks_seen": seen,
+    print(json.dumps({"launcher_selftest": True, "n_gpus": world, "ranks_seen": seen, "per_rank": per_rank,
                       "max_over_ranks_ok": bool(dt >= max(dts) - 1e-12), "steps": args.steps, "warmup": args.warmup}),
           flush=True)
   if world > 1:

@@ -134,6 +134,10 @@ int odt_forward(odt_handle h, const void* frames, int dtype, int on_device,
 int odt_forward_async(odt_handle h, const void* frames, int dtype,
                       int on_device, void* stream);
 int odt_synchronize(odt_handle h);
+/* The outputs of the most recently enqueued forward (odt_forward_async, or an odt_forward whose host copies are no
+ * longer at hand): waits for it and copies the device result buffers to `out` exactly as odt_forward does.  bench.py
+ * uses it to check the replayed, device-resident forwards of its timed region against a blocking odt_forward. */
+int odt_read_outputs(odt_handle h, odt_outputs* out);
 
 /* Source frames of a different size than the plan's input (reference obj_detect_tracking.py:597-608:
  * frame.astype("float32") -> resizeImage(frame, short_edge_size, max_size) = cv2.resize(...,
@@ -190,6 +194,17 @@ int odt_profile_read(odt_handle h, double* conv_ms, double* conv_flops,
  * since odt_profile_enable, GEMM view M, N, K. */
 int odt_profile_layer(odt_handle h, int index, char* name, int name_cap,
                       double* flops, double* ms, int64_t* mnk, int* count);
+
+/* Measurement support (bench.py's `roofline.sustained_peak`; no model code calls it): what the bf16 matrix pipe of this
+ * device sustains on the instruction mix of the bf16x3 split conv kernels (csrc/conv_split.hip: six
+ * v_mfma_f32_32x32x16_bf16 products per f32 MAC, a 2 x 4 accumulator-tile wave, one 8-wave workgroup per CU) with
+ * random bf16 operands held in registers -- the upper bound of that kernel family under this box's power budget.
+ * Runs back-to-back launches: `warm_ms` uncounted, then at least `min_ms` timed as one region.  lds_reads != 0: the
+ * 18 operand fragments of every k16 step are re-read from LDS as the conv kernels do.  tflops_bf16 = executed bf16
+ * TFLOP/s (divide by 6 for the f32-work ceiling); clock_ghz = shader clock read in the kernel (s_memtime per
+ * s_memrealtime). */
+int odt_probe_mfma_bf16(int device, double warm_ms, double min_ms, int lds_reads, double* tflops_bf16,
+                        double* clock_ghz, double* measured_ms, int* launches);
 
 /* NearestNeighborDistanceMetric.distance (deep_sort/nn_matching.py:156-177,
  * _nn_cosine_distance :78-96): gallery [G,D] float32 rows of all tracks

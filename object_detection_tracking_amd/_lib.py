@@ -75,9 +75,9 @@ class OdtLib(object):
   SYMBOLS = [
       "odt_last_error", "odt_device_count", "odt_create", "odt_destroy",
       "odt_load_tensor", "odt_finalize_weights", "odt_forward",
-      "odt_forward_async", "odt_synchronize", "odt_describe", "odt_submit", "odt_submit_ex", "odt_collect",
+      "odt_forward_async", "odt_synchronize", "odt_read_outputs", "odt_describe", "odt_submit", "odt_submit_ex", "odt_collect",
       "odt_ingest_buffer", "odt_set_source_size", "odt_tap", "odt_profile_enable",
-      "odt_profile_read", "odt_profile_layer", "odt_nn_cosine", "odt_op_conv2d", "odt_op_conv2d_cat",
+      "odt_profile_read", "odt_profile_layer", "odt_probe_mfma_bf16", "odt_nn_cosine", "odt_op_conv2d", "odt_op_conv2d_cat",
       "odt_op_preprocess",
       "odt_op_maxpool", "odt_op_topk", "odt_op_nms", "odt_op_proposals",
       "odt_op_roi_align", "odt_op_detections", "odt_op_class_nms", "odt_tracker_create", "odt_tracker_destroy",
@@ -104,6 +104,7 @@ class OdtLib(object):
                               C.POINTER(OdtOutputs)]
     d.odt_forward_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     d.odt_synchronize.argtypes = [C.c_void_p]
+    d.odt_read_outputs.argtypes = [C.c_void_p, C.POINTER(OdtOutputs)]
     d.odt_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     d.odt_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     d.odt_submit_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
@@ -118,6 +119,8 @@ class OdtLib(object):
                                    C.POINTER(C.c_int), c_double_p]
     d.odt_profile_layer.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, c_double_p,
                                     c_double_p, c_i64_p, C.POINTER(C.c_int)]
+    d.odt_probe_mfma_bf16.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, c_double_p, c_double_p, c_double_p,
+                                      C.POINTER(C.c_int)]
     d.odt_nn_cosine.argtypes = [C.c_int, c_float_p, c_int_p, C.c_int, c_float_p, C.c_int,
                                 C.c_int, c_double_p]
     d.odt_op_conv2d.argtypes = [C.c_int, c_float_p] + [C.c_int] * 4 + [c_float_p, c_float_p] + \

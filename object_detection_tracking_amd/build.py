@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["odt_api.hip", "conv_igemm.hip", "conv_split.hip", "elementwise.hip", "proposals.hip",
-           "roi_align.hip", "detections.hip", "tracker.hip", "tracker_core.cpp", "effnet.hip", "effdet_post.hip"]
+           "roi_align.hip", "detections.hip", "tracker.hip", "tracker_core.cpp", "effnet.hip", "effdet_post.hip", "probe.hip"]
 HEADERS = ["odt_common.hpp", "select_device.hpp", "effdet_plan.inc", os.path.join(ROOT, "include", "odt.h")]
 LIB_HIP = os.path.join(HERE, "libodt_hip.so")
 LIB_EMU = os.path.join(ROOT, "tests", "emu", "libodt_emu.so")

@@ -120,6 +120,7 @@ struct odt_model {
   hipStream_t tail_stream = nullptr, done_stream = nullptr;
   hipEvent_t trunk_done = nullptr, tail_done = nullptr;
   bool tail_pending = false;
+  unsigned long long forwards_enqueued = 0;
   int eff_scaled_h = 0, eff_scaled_w = 0;   // EfficientDet: size of the resized frame inside the padded input
   float* final_masks = nullptr;   // [B*per_im, 28, 28] (add_mask)
   DetectParams det{};
@@ -1002,6 +1003,7 @@ int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStre
     if (m->op_tail == 0 || m->op_first_fpn == 0 || m->op_first_fpn >= m->op_tail) m->tail_overlap = 0;
   }
   m->done_stream = st;
+  ++m->forwards_enqueued;
   if (m->tail_overlap == 1 && st == m->own_stream) {
     if (!m->tail_stream) {
       if (create_side_stream(&m->tail_stream)) return 1;
@@ -1125,7 +1127,16 @@ int odt_forward(odt_handle h, const void* frames, int dtype, int on_device, void
             "odt_forward: the backbone-only graph has no detection outputs (odt_forward_async + odt_tap)");
   hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
   if (run_plan(h, frames, dtype, on_device, st)) return 1;
-  st = h->done_stream;                 // (the tail may have run on the handle's side stream)
+  return odt_read_outputs(h, out);
+}
+
+int odt_read_outputs(odt_handle h, odt_outputs* out) {
+  ODT_CHECK(h != nullptr && out != nullptr, "null argument");
+  ODT_CHECK(h->finalized && h->forwards_enqueued > 0, "odt_read_outputs: no forward has been enqueued on this handle");
+  ODT_CHECK(h->cfg.graph != ODT_GRAPH_EFFNET || h->cfg.eff_det >= 0,
+            "odt_read_outputs: the backbone-only graph has no detection outputs (odt_tap)");
+  ODT_HIP(hipSetDevice(h->device));
+  hipStream_t st = h->done_stream;     // (the tail may have run on the handle's side stream)
   if (h->cfg.graph == ODT_GRAPH_EFFNET) {
     // EfficientDet outputs (efficientdet_wrapper.py:28-35): boxes [R,4] x1y1x2y2 (scaled), probs,
     // labels 1..90, pooled = fpn_box_feat [R, fpn_num_filters]

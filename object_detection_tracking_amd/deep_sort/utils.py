@@ -51,6 +51,11 @@ def create_obj_arrays(final_boxes, final_probs, final_labels, box_feats, targeti
   boxes = np.asarray(final_boxes) / scale
   probs = np.asarray(final_probs)
   labels = np.asarray(final_labels)
+  if boxes.size == 0 or len(labels) == 0:       # a frame without detections (also as empty lists / 1-D empty arrays)
+    feats = np.asarray(box_feats, dtype=np.float32)
+    dim = feats.shape[1] if feats.ndim >= 2 else 0
+    return np.zeros((0, 4), np.float64), np.zeros((0,), np.float64), np.zeros((0, dim), np.float32)
+  boxes = boxes.reshape(-1, 4)
   names = [targetid2class[int(l)] for l in labels]
   if is_coco_model:
     names = [coco_to_actev_mapping.get(n) for n in names]

@@ -231,10 +231,16 @@ def synthetic_det_weights(model_name, seed=0, num_classes=NUM_CLASSES, gain=1.0)
   return w
 
 
-def algorithmic_traffic_and_flops(model_name, height, width, num_classes=NUM_CLASSES):
+def algorithmic_traffic_and_flops(model_name, height, width, num_classes=NUM_CLASSES, fused=False):
   """(bytes, flops) of one forward with every operator reading its inputs and writing its output
   exactly once in fp32 (unpadded channel counts, weights read once) -- the unfused HBM floor the
-  kernels are measured against -- and 2*MAC flops.  Walks the same graph as the plan builder."""
+  kernels are measured against -- and 2*MAC flops.  Walks the same graph as the plan builder.
+  fused=True: the byte count of the best fusion the graph allows instead -- an MBConv block as two passes
+  (expand -> depthwise -> squeeze sums | gate * project + skip: the squeeze-excite mean is a global reduction, so
+  the depthwise output has to reach memory once), a BiFPN node (resample + fusion + separable conv) and a class /
+  box net layer (depthwise + pointwise) as one pass each; same flops."""
+  if fused:
+    return _fused_traffic(model_name, height, width, num_classes), algorithmic_traffic_and_flops(model_name, height, width, num_classes)[1]
   c = det_config(model_name)
   sp = backbone_spec(c["backbone"])
   F_ = c["fpn_num_filters"]
@@ -288,3 +294,48 @@ def algorithmic_traffic_and_flops(model_name, height, width, num_classes=NUM_CLA
   nlog = sum(sizes[l][0] * sizes[l][1] for l in range(3, 8)) * NUM_ANCHORS * num_classes
   by += 4 * nlog * 10                                   # pack + 8 radix passes + compaction over the logits
   return by, fl
+
+
+def _fused_traffic(model_name, height, width, num_classes=NUM_CLASSES):
+  c = det_config(model_name)
+  sp = backbone_spec(c["backbone"])
+  F_ = c["fpn_num_filters"]
+  by = 0
+  def t(h, w, ch):
+    return 4 * h * w * ch
+  h, w = -(-height // 2), -(-width // 2)
+  by += height * width * 3 + t(h, w, sp["stem"])
+  red = {}
+  for b in sp["blocks"]:
+    mid = b["cin"] * b["expand"]
+    ho, wo = (-(-h // 2), -(-w // 2)) if b["stride"] == 2 else (h, w)
+    # pass 1: block input -> (expand, depthwise) -> depthwise output + squeeze sums; pass 2: depthwise output (+ skip) -> out
+    by += t(h, w, b["cin"]) + t(ho, wo, mid) + 4 * (b["cin"] * mid if b["expand"] != 1 else 0) + 4 * mid * b["kernel"] ** 2
+    by += t(ho, wo, mid) + t(ho, wo, b["cout"]) + 4 * mid * b["cout"] + 8 * mid * b["se"]
+    if b["stride"] == 1 and b["cin"] == b["cout"]:
+      by += t(ho, wo, b["cout"])
+    h, w = ho, wo
+    if b["reduction"]:
+      red[b["reduction"]] = (h, w, b["cout"])
+  sizes = feat_sizes(height, width)
+  chans = [red[3][2], red[4][2], red[5][2], F_, F_]
+  by += t(*red[5]) + t(sizes[6][0], sizes[6][1], F_) + t(sizes[7][0], sizes[7][1], F_)      # P6 (1x1 + pool), P7 (pool)
+  for rep in range(c["fpn_cell_repeats"]):
+    ch = list(chans) if rep == 0 else [F_] * 5
+    lv = [3, 4, 5, 6, 7]
+    for lvl, offs in BIFPN_NODES:
+      hh, ww = sizes[lvl]
+      for off in offs:
+        hs, ws = sizes[lv[off]]
+        by += t(hs, ws, ch[off]) + (4 * ch[off] * F_ if ch[off] != F_ else 0)
+      by += t(hh, ww, F_) + 4 * F_ * (9 + F_)
+      ch.append(F_); lv.append(lvl)
+  for lvl in range(3, 8):
+    hh, ww = sizes[lvl]
+    for nout in (num_classes * NUM_ANCHORS, 4 * NUM_ANCHORS):
+      for _ in range(c["box_class_repeats"]):
+        by += 2 * t(hh, ww, F_) + 4 * F_ * (9 + F_)
+      by += t(hh, ww, F_) + t(hh, ww, nout) + 4 * F_ * (9 + nout)
+  nlog = sum(sizes[l][0] * sizes[l][1] for l in range(3, 8)) * NUM_ANCHORS * num_classes
+  by += 4 * nlog * 2                                    # one read of the logits for the select, keys of the survivors
+  return by

@@ -132,6 +132,38 @@ class EfficientDet(object):
     r = int(valid[0])
     return boxes[0, :r].copy(), labels[0, :r].copy(), probs[0, :r].copy(), pooled[:r].copy()
 
+  def predict_async(self, frame):
+    """Enqueue the forward of one frame and return at once (odt_forward_async on the handle's stream): the host is free
+    -- e.g. to run the tracker on the PREVIOUS frame's detections (the reference's queuer loop does the detector call
+    and the tracker update back to back, obj_detect_tracking_multi_queuer_tmot.py:536-583) -- until predict_collect()."""
+    import ctypes as C
+    from .._lib import ODT_DTYPE_F32, ODT_DTYPE_U8
+    frame = np.asarray(frame)
+    e = self.engine(frame.shape[:2])
+    fr = np.ascontiguousarray(frame[None])
+    dt = ODT_DTYPE_U8 if fr.dtype == np.uint8 else ODT_DTYPE_F32
+    if dt == ODT_DTYPE_F32:
+      fr = np.ascontiguousarray(fr, np.float32)
+    self.lib.check(self.lib.dll.odt_forward_async(e.h, fr.ctypes.data_as(C.c_void_p), dt, 0, None))
+    self._inflight = (e, fr)
+
+  def predict_collect(self):
+    """Wait for the forward of predict_async() and return predict()'s tuple (odt_read_outputs)."""
+    import ctypes as C
+    e, _ = self._inflight
+    self._inflight = None
+    per = int(getattr(self.config, "result_per_im", 100))
+    F_ = self.cfg["fpn_num_filters"]
+    boxes = np.zeros((1, per, 4), np.float32); probs = np.zeros((1, per), np.float32)
+    labels = np.zeros((1, per), np.int32); valid = np.zeros((1,), np.int32)
+    pooled = np.zeros((per, F_), np.float32)
+    out = OdtOutputs()
+    out.boxes = fptr(boxes); out.probs = fptr(probs); out.labels = iptr(labels); out.valid = iptr(valid)
+    out.feats = None; out.pooled = fptr(pooled); out.masks = None
+    self.lib.check(self.lib.dll.odt_read_outputs(e.h, C.byref(out)))
+    r = int(valid[0])
+    return boxes[0, :r].copy(), labels[0, :r].copy(), probs[0, :r].copy(), pooled[:r].copy()
+
   def _fetch(self, fetches, feed_dict):
     boxes, labels, probs, feats = self.predict(feed_dict[self.image])
     table = {"final_boxes": boxes, "final_labels": labels, "final_probs": probs, "fpn_box_feat": feats}

@@ -129,6 +129,8 @@ class _Engine(object):
     self._feats = np.zeros((B * P, Cn, 7, 7), np.float32)
     self._pooled = np.zeros((B * P, Cn), np.float32)
     self._masks = np.zeros((B * P, 28, 28), np.float32) if self.add_mask else None
+    self._ticket_want = {}           # ticket -> (want_feats, want_pooled) as submitted
+    self._ingest_dtype = ODT_DTYPE_U8
 
   def set_source_size(self, src_height, src_width):
     """Frames of [B, src_height, src_width, 3] from now on; the bilinear resize to the plan's
@@ -148,14 +150,35 @@ class _Engine(object):
       self.lib.dll.odt_destroy(self.h)
       self.h = None
 
+  def __getattribute__(self, name):
+    # a closed engine (model.close(), or evicted from the model's plan cache) fails loudly instead of passing a null handle
+    if name in ("forward", "submit", "collect", "read_outputs", "forward_device_async", "tap", "set_source_size",
+                "profile", "describe") and object.__getattribute__(self, "h") is None:
+      raise _lib.OdtError("engine closed (model.close(), or evicted from the model's plan cache: _DetectorBase.max_engines)")
+    return object.__getattribute__(self, name)
+
   def __del__(self):
     try:
       self.close()
     except Exception:
       pass
 
-  def forward(self, frames, want_feats=True, want_pooled=False):
-    """frames: [B,H,W,3] uint8/float32 BGR host array.  Returns fresh arrays."""
+  def _outputs(self, want_feats, want_pooled):
+    out = OdtOutputs()
+    out.boxes = fptr(self._boxes); out.probs = fptr(self._probs)
+    out.labels = iptr(self._labels); out.valid = iptr(self._valid)
+    out.feats = fptr(self._feats) if want_feats else None
+    out.pooled = fptr(self._pooled) if want_pooled else None
+    out.masks = fptr(self._masks) if self.add_mask else None
+    return out
+
+  def _result(self, want_feats, want_pooled):
+    total = int(self._valid.sum())
+    return (self._boxes.copy(), self._labels.copy(), self._probs.copy(), self._valid.copy(),
+            self._feats[:total].copy() if want_feats else None,
+            self._pooled[:total].copy() if want_pooled else None)
+
+  def _frames(self, frames):
     fr = np.ascontiguousarray(frames)
     if fr.dtype == np.uint8:
       dt = ODT_DTYPE_U8
@@ -163,49 +186,62 @@ class _Engine(object):
       fr = np.ascontiguousarray(fr, dtype=np.float32)
       dt = ODT_DTYPE_F32
     assert fr.shape == (self.batch, self.src_height, self.src_width, 3), fr.shape
-    out = OdtOutputs()
-    out.boxes = fptr(self._boxes); out.probs = fptr(self._probs)
-    out.labels = iptr(self._labels); out.valid = iptr(self._valid)
-    out.feats = fptr(self._feats) if want_feats else None
-    out.pooled = fptr(self._pooled) if want_pooled else None
-    out.masks = fptr(self._masks) if self.add_mask else None
+    return fr, dt
+
+  def forward(self, frames, want_feats=True, want_pooled=False):
+    """frames: [B,H,W,3] uint8/float32 BGR host array.  Returns fresh arrays."""
+    fr, dt = self._frames(frames)
+    out = self._outputs(want_feats, want_pooled)
     self.lib.check(self.lib.dll.odt_forward(self.h, fr.ctypes.data_as(C.c_void_p), dt, 0, None,
                                             C.byref(out)))
-    total = int(self._valid.sum())
-    return (self._boxes.copy(), self._labels.copy(), self._probs.copy(), self._valid.copy(),
-            self._feats[:total].copy() if want_feats else None,
-            self._pooled[:total].copy() if want_pooled else None)
+    return self._result(want_feats, want_pooled)
+
+  def read_outputs(self, want_feats=True, want_pooled=False):
+    """The outputs of the most recently enqueued forward (odt_read_outputs): what :meth:`forward` would have
+    returned for the frames of the last :meth:`forward_device_async`."""
+    out = self._outputs(want_feats, want_pooled)
+    self.lib.check(self.lib.dll.odt_read_outputs(self.h, C.byref(out)))
+    return self._result(want_feats, want_pooled)
 
   def submit(self, frames, want_feats=True, want_pooled=True):
     """Pipelined ingest (odt_submit_ex): enqueue H2D + forward + D2H for one batch of host
     frames and return a ticket at once; at most two tickets may be outstanding.  Only what is
     asked for crosses PCIe on the way back (the [M,C,7,7] features are 40 MB per 8-frame batch,
     their 7x7 mean 0.8 MB)."""
-    fr = np.ascontiguousarray(frames)
-    if fr.dtype == np.uint8:
-      dt = ODT_DTYPE_U8
+    if frames is None:                # the frames were written into ingest_buffer(): no staging copy
+      fr, dt = None, self._ingest_dtype
     else:
-      fr = np.ascontiguousarray(fr, dtype=np.float32)
-      dt = ODT_DTYPE_F32
-    assert fr.shape == (self.batch, self.src_height, self.src_width, 3), fr.shape
+      fr, dt = self._frames(frames)
     t = C.c_int()
     want = (1 if want_feats else 0) | (2 if want_pooled else 0) | (4 if self.add_mask else 0)
-    self.lib.check(self.lib.dll.odt_submit_ex(self.h, fr.ctypes.data_as(C.c_void_p), dt, want, C.byref(t)))
+    self.lib.check(self.lib.dll.odt_submit_ex(self.h, fr.ctypes.data_as(C.c_void_p) if fr is not None else None, dt, want,
+                                              C.byref(t)))
+    self._ticket_want[t.value] = (bool(want_feats), bool(want_pooled))
     return t.value
 
-  def collect(self, ticket, want_feats=True, want_pooled=False):
-    """Wait for a ticket of :meth:`submit`; same return value as :meth:`forward`."""
-    out = OdtOutputs()
-    out.boxes = fptr(self._boxes); out.probs = fptr(self._probs)
-    out.labels = iptr(self._labels); out.valid = iptr(self._valid)
-    out.feats = fptr(self._feats) if want_feats else None
-    out.pooled = fptr(self._pooled) if want_pooled else None
-    out.masks = fptr(self._masks) if self.add_mask else None
+  def ingest_buffer(self, dtype=np.uint8):
+    """The NEXT ticket's pinned host input buffer as a numpy array [B,Hs,Ws,3] (odt_ingest_buffer): a decoder writes
+    its frames straight into it and calls ``submit(None)`` -- the pageable -> pinned staging copy of
+    ``submit(frames)`` disappears (what 8 co-hosted ranks contend on first is host memory bandwidth)."""
+    dt = ODT_DTYPE_U8 if np.dtype(dtype) == np.uint8 else ODT_DTYPE_F32
+    buf = C.c_void_p(); nbytes = C.c_size_t()
+    self.lib.check(self.lib.dll.odt_ingest_buffer(self.h, dt, C.byref(buf), C.byref(nbytes)))
+    self._ingest_dtype = dt
+    ctype = C.c_uint8 if dt == ODT_DTYPE_U8 else C.c_float
+    n = nbytes.value // C.sizeof(ctype)
+    arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(ctype)), shape=(n,))
+    return arr.reshape(self.batch, self.src_height, self.src_width, 3)
+
+  def collect(self, ticket, want_feats=None, want_pooled=None):
+    """Wait for a ticket of :meth:`submit`; same return value as :meth:`forward`.  By default what comes back is what
+    the ticket was submitted with (features and / or their 7x7 mean); asking for more than that is an error."""
+    sub = self._ticket_want.get(ticket, (True, False))
+    want_feats = sub[0] if want_feats is None else want_feats
+    want_pooled = sub[1] if want_pooled is None else want_pooled
+    out = self._outputs(want_feats, want_pooled)
     self.lib.check(self.lib.dll.odt_collect(self.h, ticket, C.byref(out)))
-    total = int(self._valid.sum())
-    return (self._boxes.copy(), self._labels.copy(), self._probs.copy(), self._valid.copy(),
-            self._feats[:total].copy() if want_feats else None,
-            self._pooled[:total].copy() if want_pooled else None)
+    self._ticket_want.pop(ticket, None)
+    return self._result(want_feats, want_pooled)
 
   def forward_stream(self, batches, want_feats=False, want_pooled=True):
     """Generator over an iterable of frame batches with two batches in flight: the H2D of
@@ -334,8 +370,14 @@ class _DetectorBase(object):
     key = (batch, height, width) if src_hw is None else (batch, height, width) + tuple(src_hw)
     e = self._engines.pop(key, None)
     if e is None:
+      # evict least-recently-used plans beyond the cap -- but never one with tickets in flight (its pinned results
+      # would be destroyed under the caller): those stay until collected, even if that exceeds the cap.  An engine
+      # object a caller kept from an earlier engine() call is closed by its eviction; its next use raises OdtError
+      # ("engine closed") -- hold at most `max_engines` plan sizes at a time, or raise the cap.
       while len(self._engines) >= max(1, int(self.max_engines)):
-        old = next(iter(self._engines))
+        old = next((k for k, v in self._engines.items() if not v._ticket_want), None)
+        if old is None:
+          break
         self._engines.pop(old).close()
       e = _Engine(self.lib, self.config, self.graph, batch, height, width,
                   self.weights, self.gpuid, num_class=self.head_num_class)

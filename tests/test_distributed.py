@@ -83,3 +83,52 @@ def test_bench_gpus_flag_starts_that_many_ranks():
   r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launcher-selftest"], env=env2,
                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
   assert r.returncode != 0 and "--gpus 2" in r.stderr
+
+
+def test_bench_self_launch_world_8():
+  """The launch / rendezvous / reduction path at the size the driver's scaling run uses: 8 ranks on 127.0.0.1 (gloo,
+  no GPU work), all seen, max-over-ranks timing."""
+  import json
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ)
+  for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+    env.pop(k, None)
+  env["OMP_NUM_THREADS"] = "1"
+  r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                      "--launcher-selftest"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+  assert r.returncode == 0, r.stderr[-2000:]
+  d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+  assert d["n_gpus"] == 8 and d["ranks_seen"] == list(range(8)) and d["max_over_ranks_ok"]
+  assert len(d["per_rank"]) == 8 and [p["rank"] for p in d["per_rank"]] == list(range(8))
+  assert all("affinity" in p for p in d["per_rank"])
+
+
+def test_rank_cpu_affinity_plan(tmp_path):
+  """Each rank gets its share of the CPUs local to its GPU's NUMA node (sysfs numa_node / local_cpulist); ranks on one
+  node do not overlap; without topology information the affinity is left alone."""
+  from object_detection_tracking_amd import parallel as P
+  bdfs = ["0000:%02x:00.0" % (0x10 + i) for i in range(8)]
+  for i, b in enumerate(bdfs):
+    d = tmp_path / b
+    d.mkdir()
+    (d / "numa_node").write_text("%d\n" % (i // 4))
+    (d / "local_cpulist").write_text("0-31,64-95\n" if i < 4 else "32-63,96-127\n")
+  topo = P.gpu_numa_topology(bdfs, str(tmp_path))
+  assert [t[0] for t in topo] == [0, 0, 0, 0, 1, 1, 1, 1] and len(topo[0][1]) == 64 and topo[5][1][0] == 32
+  plans = P.plan_rank_cpus(topo, range(128))
+  assert all(len(p) == 16 for p in plans)
+  for a in range(8):
+    assert set(plans[a]) <= set(topo[a][1])
+    for b in range(a + 1, 8):
+      assert not set(plans[a]) & set(plans[b])
+  # a restricted cpuset (container): only allowed CPUs are used
+  plans = P.plan_rank_cpus(topo, range(0, 40))
+  assert set(plans[0]) <= set(range(32)) and set(plans[4]) <= set(range(32, 40))
+  # no topology -> everything allowed, and bind_rank_to_gpu_numa reports bound = False without touching the affinity
+  before = os.sched_getaffinity(0)
+  info = P.bind_rank_to_gpu_numa(0, 2, sysfs=str(tmp_path / "nope"), bdfs=["0000:aa:00.0", "0000:ab:00.0"])
+  assert info["bound"] is False and os.sched_getaffinity(0) == before
+  info = P.bind_rank_to_gpu_numa(5, 8, sysfs=str(tmp_path), bdfs=bdfs, apply=False)
+  assert info["numa_node"] == 1 and info["bound"] is False and info["pci"] == bdfs[5]

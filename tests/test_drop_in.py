@@ -14,6 +14,8 @@ import types
 import numpy as np
 import pytest
 
+from object_detection_tracking_amd._lib import OdtError
+
 from common import small_config, weights_for
 from object_detection_tracking_amd import models
 from object_detection_tracking_amd.application_util import preprocessing
@@ -319,6 +321,20 @@ def test_engine_cache_is_bounded(emu_lib):
     assert m.engine(1, 64, 96) is e1                       # hit: refreshed
     e3 = m.engine(1, 96, 96)                               # evicts the least recently used: e2
     assert len(m._engines) == 2 and e2.h is None and e1.h is not None and e3.h is not None
+    # an evicted engine a caller still holds fails loudly, not with a null handle inside the library
+    with pytest.raises(OdtError, match="engine closed"):
+      e2.forward(synthetic_frames(1, 64, 128))
+    # an engine with a ticket in flight is never evicted (its pinned results were destroyed under the caller)
+    fr = synthetic_frames(1, 64, 96)
+    want = e1.forward(fr, want_feats=False, want_pooled=True)
+    t = e1.submit(fr, want_feats=False, want_pooled=True)
+    m.engine(1, 96, 96)                                    # e3 most recent, e1 least recent -- but in flight
+    e4 = m.engine(1, 64, 160)                              # evicts e3 instead
+    assert e1.h is not None and e3.h is None and e4.h is not None
+    got = e1.collect(t)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[5], want[5])
+    m.engine(1, 64, 192)                                   # nothing in flight any more: plain LRU again
+    assert len(m._engines) == 2
   finally:
     m.close()
 

@@ -272,3 +272,67 @@ def test_anchor_known_answers():
   np.testing.assert_allclose(a[1], [4 - 32 * 0.7 / 2, 4 - 32 * 1.4 / 2, 4 + 32 * 0.7 / 2, 4 + 32 * 1.4 / 2], rtol=1e-6)
   assert np.array_equal(a, effnet.generate_anchors((512, 512), 4.0))
   assert generate_anchors(1536, 1536, 5.0).shape == (441936, 4)          # D7
+
+
+def _det_full_parity(lib, model, H, W, topk, thr, gain, stem_tol=2e-5, stage_tol=1e-3):
+  """Stage taps (stem, first BiFPN node, pyramid levels, per-level class / box logits) + the final detections as a matched
+  set, of one EfficientDet forward through get_model().predict(), against ONE pass of oracle.effnet."""
+  import torch
+  from common import match_detections, tie_swaps
+  from object_detection_tracking_amd import models
+  from object_detection_tracking_amd.config import make_config
+  from object_detection_tracking_amd.weights import synthetic_frames
+  from oracle import effnet
+  c = arch.det_config(model)
+  w = arch.synthetic_det_weights(model, 0, gain=gain)
+  fr = synthetic_frames(1, H, W, seed=13)[0]
+  btaps, ftaps = {}, {}
+  red = effnet.backbone_forward(c["backbone"], w, effnet.preprocess(fr[None]), btaps)
+  fpn = effnet.feature_network(model, w, {l: torch.from_numpy(red[l]) for l in (3, 4, 5)}, (H, W), ftaps)
+  cb = effnet.class_box_nets(model, w, fpn)
+  rb, rs, rc, rl, _ = effnet.detect(model, cb, (H, W), image_scale=1.0, topk=topk, score_thr=thr)
+  cfg = make_config(is_efficientdet=True, efficientdet_modelname=model, efficientdet_max_detection_topk=topk,
+                    short_edge_size=H, max_size=W, threshold_conf=thr)
+  cfg.max_size = W; cfg.result_score_thres = thr
+  m = models.get_model(cfg, 0, weights=w, lib=lib)
+  try:
+    boxes, labels, probs, feats = m.predict(fr)
+    e = m.engine((H, W))
+    F_ = c["fpn_num_filters"]
+    def rel(a, b):
+      return float(np.abs(a - b).max() / max(1e-6, np.abs(b).max()))
+    errs = {}
+    rs_ = btaps["stem"].transpose(0, 2, 3, 1)
+    errs["stem"] = rel(e.tap("stem")[..., :rs_.shape[-1]], rs_)
+    n0 = ftaps["cell0_fnode0"].transpose(0, 2, 3, 1)
+    errs["cell0_fnode0"] = rel(e.tap("cell0_fnode0")[..., :F_], n0)
+    for lvl in range(3, 8):
+      errs["fpn_%d" % lvl] = rel(e.tap("fpn_%d" % lvl)[..., :F_], fpn[lvl].numpy().transpose(0, 2, 3, 1))
+      errs["class_%d" % lvl] = rel(e.tap("class_%d" % lvl)[..., :cb[lvl][0].shape[-1]], cb[lvl][0])
+      errs["box_%d" % lvl] = rel(e.tap("box_%d" % lvl)[..., :36], cb[lvl][1])
+    # 45 MBConv blocks + 8 BiFPN cells + 5-layer heads of f32 arithmetic in two summation orders: stage errors grow with
+    # depth; the bound is 30x the per-layer tolerance of the small-model tests (3e-5), as _det_parity uses for D0 / D1
+    assert errs["stem"] < stem_tol, errs
+    assert max(errs.values()) < stage_tol, errs
+    assert len(boxes) == len(rb) and len(boxes) > 3, (len(boxes), len(rb))
+    assert np.isfinite(boxes).all() and np.isfinite(feats).all()
+    miss, extra = match_detections(boxes, labels, probs, rb, rc, rs, 5e-2, 5e-5)
+    ties = tie_swaps(boxes, labels, probs, rb, rc, rs, 5e-2, 5e-5)
+    assert (miss - ties) + (extra - ties) <= max(2, len(rb) // 25), (miss, extra, ties, errs)
+    print("%s @%dx%d parity:" % (model, H, W) + " stage rel errors %s; detections %d, unmatched %d/%d (%d tie swaps)" %
+          ({k: "%.1e" % v for k, v in errs.items()}, len(boxes), miss, extra, ties))
+  finally:
+    m.close()
+
+
+def test_efficientdet_full_parity_d0_small(emu_lib):
+  """The D7 test's checker on a size the simulator finishes."""
+  _det_full_parity(emu_lib, "efficientdet-d0", 136, 152, topk=300, thr=0.02, gain=1.0)
+
+
+@pytest.mark.gpu
+def test_efficientdet_d7_1536_parity(hip_lib):
+  """BASELINE config #5 at its own size: EfficientDet-D7 (EfficientNet-B6 backbone, 384 filters, 8 BiFPN cells of 'sum'
+  nodes, 5-layer heads) at 1536 x 1536, the reference's top-k of 5000, on the weights bench.py runs (VERDICT round 2:
+  the tests stopped at D2 / B6-512)."""
+  _det_full_parity(hip_lib, "efficientdet-d7", 1536, 1536, topk=5000, thr=0.02, gain=arch.bench_gain("efficientdet-d7"))

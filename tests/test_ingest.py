@@ -55,6 +55,78 @@ def test_submit_collect_equals_forward(backend):
     m.close()
 
 
+def test_collect_defaults_follow_the_ticket_and_read_outputs(backend):
+  """collect(t) returns what submit() asked for (collect's own defaults used to ask for the [M,C,7,7]
+  features of a pooled-only ticket and raised); odt_read_outputs returns the last asynchronous forward's outputs; a
+  decoder can write into the slot's pinned buffer and submit without a staging copy."""
+  import ctypes as C
+  from object_detection_tracking_amd._lib import ODT_DTYPE_U8
+  name, lib = backend
+  B, H, W = (1, 64, 96) if name == "emu" else (2, 256, 448)
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1], im_batch_size=B, rpn_test_post_nms_topk=16, max_size=448)
+  m = models.get_model(cfg, 0, weights=weights_for(cfg), lib=lib, is_multi=True)
+  try:
+    e = m.engine(B, H, W)
+    fr = synthetic_frames(B, H, W, seed=7)
+    want = e.forward(fr, want_feats=True, want_pooled=True)
+    r = e.collect(e.submit(fr, want_feats=False, want_pooled=True))        # defaults = as submitted
+    assert r[4] is None and np.array_equal(r[5], want[5]) and np.array_equal(r[0], want[0])
+    r = e.collect(e.submit(fr, want_feats=True, want_pooled=False))
+    assert r[5] is None and np.array_equal(r[4], want[4])
+    # frames written straight into the pinned ingest buffer, submit(None)
+    buf = e.ingest_buffer(np.uint8)
+    assert buf.shape == fr.shape and buf.dtype == np.uint8
+    np.copyto(buf, fr)
+    r = e.collect(e.submit(None, want_feats=False, want_pooled=True))
+    assert np.array_equal(r[0], want[0]) and np.array_equal(r[5], want[5])
+    # read_outputs after an asynchronous forward of another batch
+    fr2 = synthetic_frames(B, H, W, seed=8)
+    want2 = e.forward(fr2, want_feats=True, want_pooled=True)
+    e.forward(fr)                                                            # something else in between
+    if name == "hip":
+      import torch
+      d = torch.from_numpy(fr2).cuda(0)
+      e.forward_device_async(d.data_ptr(), ODT_DTYPE_U8)
+    else:
+      e.lib.check(e.lib.dll.odt_forward_async(e.h, fr2.ctypes.data_as(C.c_void_p), ODT_DTYPE_U8, 0, None))
+    got = e.read_outputs(want_feats=True, want_pooled=True)
+    for a, b in zip(got, want2):
+      assert np.array_equal(a, b)
+    # a fresh handle has nothing to read
+    e2 = m.engine(B, H + 32, W)
+    with pytest.raises(OdtError, match="no forward"):
+      e2.read_outputs()
+  finally:
+    m.close()
+
+
+def test_tail_overlap_off_is_bit_identical(backend, monkeypatch):
+  """ODT_TAIL_OVERLAP=0 (no test set it): the whole forward in stream order on the handle's stream, the
+  small D2H copies enqueued behind it -- same results as the default (tail on the side stream) bit for bit."""
+  name, lib = backend
+  B, H, W = (1, 64, 96) if name == "emu" else (2, 256, 448)
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1], im_batch_size=B, rpn_test_post_nms_topk=16, max_size=448)
+  batches = [synthetic_frames(B, H, W, seed=s) for s in (1, 2, 3)]
+  res = {}
+  for mode in ("1", "0"):
+    monkeypatch.setenv("ODT_TAIL_OVERLAP", mode)
+    m = models.get_model(cfg, 0, weights=weights_for(cfg), lib=lib, is_multi=True)
+    try:
+      e = m.engine(B, H, W)
+      blocking = [e.forward(b, want_feats=False, want_pooled=True) for b in batches]
+      streamed = list(e.forward_stream(batches * 2))                       # pooled only: the compute-stream D2H path
+      for g, w in zip(streamed, blocking + blocking):
+        for a, b in zip(g[:4], w[:4]):
+          assert np.array_equal(a, b)
+        assert np.array_equal(g[5], w[5])
+      res[mode] = blocking
+    finally:
+      m.close()
+  for a, b in zip(res["1"], res["0"]):
+    for x, y in zip(a, b):
+      assert (x is None and y is None) or np.array_equal(x, y)
+
+
 # ---- device-side frame resize (reference obj_detect_tracking.py:597-608: astype(float32) +
 # resizeImage on the host for every frame) ---------------------------------------------------------
 def _raw_vs_host_resize(lib, src_hw, dtype, short_edge, max_size):

@@ -7,39 +7,34 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 
-def main():
-  ap = argparse.ArgumentParser()
-  ap.add_argument("--model", default="efficientdet-d7")
-  ap.add_argument("--size", type=int, default=0, help="network input (square); 0 = the model's native size")
-  ap.add_argument("--frame", default="", help="HxW of the source frames (default: the network input size)")
-  ap.add_argument("--steps", type=int, default=20)
-  ap.add_argument("--warmup", type=int, default=3)
-  ap.add_argument("--no-cpu-baseline", action="store_true")
-  a = ap.parse_args()
+def measure(model="efficientdet-d7", size=0, frame="", steps=20, warmup=3, cpu_baseline=True, device=0, tmot_frames=30,
+            pmc_profile=None):
+  """One EfficientDet configuration on one GPU -> the dict bench.py prints under `extra.efficientdet_d7` and this tool
+  prints as its JSON line (metric / value / roofline / cpu_baseline / extra)."""
   import torch
   from object_detection_tracking_amd import models
   from object_detection_tracking_amd._lib import ODT_DTYPE_U8
   from object_detection_tracking_amd.config import make_config
   from object_detection_tracking_amd.efficientdet import arch
   from object_detection_tracking_amd.weights import synthetic_frames
-  S = a.size or arch.det_config(a.model)["image_size"]
-  fh, fw = (int(v) for v in a.frame.split("x")) if a.frame else (S, S)
-  cfg = make_config(is_efficientdet=True, efficientdet_modelname=a.model, efficientdet_max_detection_topk=5000,
+  S = size or arch.det_config(model)["image_size"]
+  fh, fw = (int(v) for v in frame.split("x")) if frame else (S, S)
+  cfg = make_config(is_efficientdet=True, efficientdet_modelname=model, efficientdet_max_detection_topk=5000,
                     short_edge_size=S, max_size=S)
   cfg.max_size = S
-  m = models.get_model(cfg, 0, weights=arch.synthetic_det_weights(a.model, 0, gain=arch.bench_gain(a.model)))
+  m = models.get_model(cfg, device, weights=arch.synthetic_det_weights(model, 0, gain=arch.bench_gain(model)))
   fr = synthetic_frames(1, fh, fw)[0]
   e = m.engine((fh, fw))
-  dev = torch.from_numpy(fr[None].copy()).cuda(0)              # HBM-resident uint8 frame
+  dev = torch.from_numpy(fr[None].copy()).cuda(device)              # HBM-resident uint8 frame
   step = lambda: e.lib.check(e.lib.dll.odt_forward_async(e.h, dev.data_ptr(), ODT_DTYPE_U8, 1, None))
-  for _ in range(a.warmup):
+  for _ in range(warmup):
     step()
   e.synchronize(); torch.cuda.synchronize()
   t0 = time.perf_counter()
-  for _ in range(a.steps):
+  for _ in range(steps):
     step()
   e.synchronize(); torch.cuda.synchronize()
-  dt = (time.perf_counter() - t0) / a.steps
+  dt = (time.perf_counter() - t0) / steps
   t1 = time.perf_counter()
   for _ in range(5):
     out = m.predict(fr)
@@ -52,11 +47,10 @@ def main():
   from object_detection_tracking_amd.tmot.multitracker import JDETracker
   id2class = {i: ("Person" if i % 2 else "Vehicle") for i in range(0, 1024)}
   jde = {c: JDETracker(0.0, frame_gap=1.0) for c in ("Person", "Vehicle")}
-  nfr, ntr, t_trk = 30, 0, 0.0
-  t2 = time.perf_counter()
-  for i in range(nfr):
-    boxes, labels, probs, feats = m.predict(fr)[:4]
-    t3 = time.perf_counter()
+  nfr, ntr, t_trk = tmot_frames, 0, 0.0
+
+  def track(boxes, labels, probs, feats):
+    n = 0
     for cname, trk in jde.items():
       tl, cf, ft = create_obj_arrays(boxes, probs, labels, feats, id2class, [cname], 0.0, 0, 1.0)
       keep = preprocessing.non_max_suppression_native(tl, 0.85, cf)
@@ -64,15 +58,44 @@ def main():
       # ratio / the L2 normalisation of such a detection is NaN in the reference's tracker as well; the bench drops them)
       keep = [k for k in keep if np.isfinite(tl[k]).all() and 1.0 <= tl[k, 2] < 1e6 and 1.0 <= tl[k, 3] < 1e6 and
               np.isfinite(ft[k]).all() and float(np.abs(ft[k]).max()) > 0.0]
-      ntr = len(trk.update([(tl[k], cf[k], ft[k]) for k in keep]))
+      n = len(trk.update([(tl[k], cf[k], ft[k]) for k in keep]))
+    return n
+
+  t2 = time.perf_counter()
+  for i in range(nfr):
+    boxes, labels, probs, feats = m.predict(fr)[:4]
+    t3 = time.perf_counter()
+    ntr = track(boxes, labels, probs, feats)
     t_trk += time.perf_counter() - t3
   tmot_dt = (time.perf_counter() - t2) / nfr
-  algo_bytes, algo_flops = arch.algorithmic_traffic_and_flops(a.model, S, S)
+  # the same loop with the tracker's host work of frame i under the detector's forward of frame i+1 (the forward is
+  # enqueued on the handle's stream before the previous frame's detections are tracked; odt_read_outputs collects it)
+  for trk in jde.values():
+    trk.reset() if hasattr(trk, "reset") else None
+  jde = {c: JDETracker(0.0, frame_gap=1.0) for c in ("Person", "Vehicle")}
+  piped_dt = None
+  if hasattr(m, "predict_async"):
+    t2 = time.perf_counter()
+    m.predict_async(fr)
+    for i in range(nfr):
+      res = m.predict_collect()
+      if i + 1 < nfr:
+        m.predict_async(fr)
+      track(*res[:4])
+    piped_dt = (time.perf_counter() - t2) / nfr
+  algo_bytes, algo_flops = arch.algorithmic_traffic_and_flops(model, S, S)
+  fused_bytes, _ = arch.algorithmic_traffic_and_flops(model, S, S, fused=True)
   res_extra = {"host_to_host_ms": host * 1e3, "detections": int(len(out[0])),
                "algorithmic_gflop_per_frame": algo_flops / 1e9, "effective_tflops": algo_flops / dt / 1e12,
                "detect_tmot_fps": 1.0 / tmot_dt, "tmot_host_ms_per_frame": 1e3 * t_trk / nfr, "tmot_tracks_last": int(ntr)}
+  if piped_dt is not None:
+    res_extra["detect_tmot_pipelined_fps"] = 1.0 / piped_dt
+  try:
+    res_extra["handle"] = e.describe()
+  except Exception:
+    pass
   cpu = None
-  if not a.no_cpu_baseline:
+  if cpu_baseline:
     # the oracle (torch-CPU fp32 restatement of the TF graph; NOT TensorFlow) on the same frame
     import torch as _t
     from oracle import effnet
@@ -80,28 +103,51 @@ def main():
     t2 = time.perf_counter()
     x, sc = effnet.preprocess_resized(fr, (S, S))
     redf = effnet.backbone_forward(m.cfg["backbone"], w, x)
-    fpn = effnet.feature_network(a.model, w, {l: _t.from_numpy(redf[l]) for l in (3, 4, 5)}, (S, S))
-    cb = effnet.class_box_nets(a.model, w, fpn)
-    effnet.detect(a.model, cb, (S, S), image_scale=sc)
+    fpn = effnet.feature_network(model, w, {l: _t.from_numpy(redf[l]) for l in (3, 4, 5)}, (S, S))
+    cb = effnet.class_box_nets(model, w, fpn)
+    effnet.detect(model, cb, (S, S), image_scale=sc)
     cdt = time.perf_counter() - t2
     cpu = {"value": 1.0 / cdt, "unit": "frames/s", "cores": int(_t.get_num_threads()), "kind": "port",
            "sample": "one frame through oracle.effnet (torch-CPU fp32 + numpy tail), one pass, %.1f s" % cdt}
   traffic = None
-  pmc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_pmc_summary_effdet_d7.json")
-  if a.model == "efficientdet-d7" and S == 1536 and os.path.exists(pmc):
-    # HBM bytes per forward from the committed rocprofv3 --pmc passes (tools/gpurun/r2_effdet_pmc.sh), FETCH_SIZE doubled
-    traffic = json.load(open(pmc))["hbm_GB_per_forward_fetch_x2"] * 1e9
-  print(json.dumps({"roofline": {"bound": "hbm", "kernel": "whole network (depthwise / SE / fusion kernels are HBM-bound, "
-                    "the 1x1 convs small-K MFMA)", "achieved": algo_bytes / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
-                    "frac": algo_bytes / dt / 1e9 / 8000.0, "traffic": traffic,
-                    "algorithmic_bytes_per_frame": algo_bytes},
-                    "cpu_baseline": cpu, "metric": "%s FPS @%dx%d input per MI355X" % (a.model, S, S), "value": 1.0 / dt, "unit": "frames/s",
-                    "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3, "dtype": "f32",
-                    "data": "synthetic", "config": {"workload": "%s (EfficientNet backbone + BiFPN + class/box nets + top-5000 / NMS / "
-                    "per-level ROI features), frame %dx%d scaled on the device, batch 1, 90 classes, random-init weights, frame "
-                    "resident in HBM (uint8)" % (a.model, fw, fh)},
-                    "extra": res_extra}), flush=True)
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  for name in ([pmc_profile] if pmc_profile else ["r03_pmc_summary_effdet_d7.json", "r02_pmc_summary_effdet_d7.json"]):
+    pmc = os.path.join(root, "profiles", name)
+    if model == "efficientdet-d7" and S == 1536 and os.path.exists(pmc):
+      # HBM bytes per forward from the committed rocprofv3 --pmc passes (tools/gpurun/r2_effdet_pmc.sh), FETCH_SIZE doubled
+      traffic = json.load(open(pmc))["hbm_GB_per_forward_fetch_x2"] * 1e9
+      break
+  res = {"roofline": {"bound": "hbm", "kernel": "whole network (depthwise / SE / fusion kernels are HBM-bound, "
+                      "the 1x1 convs small-K MFMA)", "achieved": algo_bytes / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
+                      "frac": algo_bytes / dt / 1e9 / 8000.0, "traffic": traffic,
+                      "algorithmic_bytes_per_frame": algo_bytes,
+                      "fused_graph_bytes_per_frame": fused_bytes, "frac_vs_fused_graph_bytes": fused_bytes / dt / 1e9 / 8000.0,
+                      "frac_measured_traffic": (traffic / dt / 1e9 / 8000.0) if traffic else None,
+                      "note": "achieved / frac: bytes of the UNFUSED graph (every operator reads its inputs and writes its "
+                              "output once) per second; frac_vs_fused_graph_bytes: against the byte count of the best fusion "
+                              "the graph allows (arch.algorithmic_traffic_and_flops(fused=True)); frac_measured_traffic: "
+                              "the kernels' own PMC-counted HBM bytes per second"},
+         "cpu_baseline": cpu, "metric": "%s FPS @%dx%d input per MI355X" % (model, S, S), "value": 1.0 / dt, "unit": "frames/s",
+         "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": dt * 1e3, "dtype": "f32",
+         "data": "synthetic", "config": {"workload": "%s (EfficientNet backbone + BiFPN + class/box nets + top-5000 / NMS / "
+         "per-level ROI features), frame %dx%d scaled on the device, batch 1, 90 classes, random-init weights, frame "
+         "resident in HBM (uint8)" % (model, fw, fh)},
+         "extra": res_extra}
   m.close()
+  return res
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--model", default="efficientdet-d7")
+  ap.add_argument("--size", type=int, default=0, help="network input (square); 0 = the model's native size")
+  ap.add_argument("--frame", default="", help="HxW of the source frames (default: the network input size)")
+  ap.add_argument("--steps", type=int, default=20)
+  ap.add_argument("--warmup", type=int, default=3)
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--device", type=int, default=0)
+  a = ap.parse_args()
+  print(json.dumps(measure(a.model, a.size, a.frame, a.steps, a.warmup, not a.no_cpu_baseline, device=a.device)), flush=True)
 
 
 if __name__ == "__main__":
