@@ -468,3 +468,39 @@ def test_checkpoint_index_values_by_the_protobuf_runtime(tmp_path):
   assert set(got) == set(names)
   for k in names:
     assert got[k].dtype == np.float32 and np.array_equal(got[k], w[k]), k
+
+
+@pytest.mark.gpu
+def test_frozen_pb_to_hip_forward_vs_oracle(hip_lib, tmp_path):
+  """The frozen route end to end on the product library (it ran on the simulator only): weights written
+  as a frozen GraphDef, read back by frozen_pb.py, architecture taken from the file, forward on the MI355X through the
+  named-tensor surface -- against the oracle on the ORIGINAL weights (so a reader that dropped or permuted a tensor
+  shows up as a parity failure, not as self-consistency)."""
+  from common import match_detections
+  from object_detection_tracking_amd.frozen_pb import write_frozen_pb
+  from oracle.graph import OracleModel
+  cfg = small_config(resnet_num_block=[1, 2, 2, 1], rpn_test_post_nms_topk=100, max_size=448, short_edge_size=256)
+  w = weights_for(cfg)
+  pb = str(tmp_path / "obj_v3_frozen.pb")
+  write_frozen_pb(pb, w)
+  fr = synthetic_frames(1, 256, 448, seed=11)[0]
+  ref = OracleModel(cfg, w).forward(fr)
+  m = models.Mask_RCNN_FPN_frozen(pb, 0, add_mask=False, is_multi=False, config=cfg, lib=hip_lib)
+  try:
+    boxes, labels, probs, feats = models.Session().run(
+        ["model_0/final_boxes:0", "model_0/final_labels:0", "model_0/final_probs:0", "model_0/fpn_box_feat:0"],
+        feed_dict=m.get_feed_dict_forward(fr))
+    e = m.engine(1, 256, 448)
+    c5 = e.tap("c5").transpose(0, 3, 1, 2)
+    assert float(np.abs(c5 - ref["c5"]).max() / np.abs(ref["c5"]).max()) < 2e-5
+    miss, extra = match_detections(boxes, labels, probs, ref["final_boxes"], ref["final_labels"], ref["final_probs"], 1e-3, 1e-4)
+    assert miss == 0 and extra == 0 and len(boxes) > 3, (miss, extra, len(boxes))
+    assert feats.shape == (len(boxes), 256, 7, 7)
+  finally:
+    m.close()
+  # and with the architecture read off the file (no config: the reference's Mask_RCNN_FPN_frozen takes none)
+  m2 = models.Mask_RCNN_FPN_frozen(pb, 0, lib=hip_lib)
+  try:
+    assert list(m2.config.resnet_num_block) == [1, 2, 2, 1]
+  finally:
+    m2.close()
