@@ -44,6 +44,7 @@ def main():
                   help="multi = Mask_RCNN_FPN_multi (batched graph, the headline); single = Mask_RCNN_FPN (BASELINE config #2: "
                        "the b=1 graph of obj_detect_tracking.py -- min-size filter, prob > 1e-4, per-class NMS; needs --batch 1)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--keep-taps", action="store_true", help="A/B: a dedicated buffer per stage tensor instead of the activation arena")
   ap.add_argument("--no-d7", action="store_true", help="skip the EfficientDet-D7 leg of `extra` (BASELINE config #5)")
   ap.add_argument("--no-affinity", action="store_true", help="N > 1: do not pin the ranks to the CPUs next to their GPU")
   ap.add_argument("--no-extras", action="store_true", help="skip the `extra` measurements (A/B runs)")
@@ -113,7 +114,7 @@ def main():
   if not multi and B != 1:
     raise SystemExit("bench.py: --graph single is the b=1 graph (obj_detect_tracking.py:241-242): pass --batch 1")
   cfg = make_config(rpn_test_post_nms_topk=args.topk, im_batch_size=B, max_size=max(H, W),
-                    short_edge_size=min(H, W))
+                    short_edge_size=min(H, W), keep_taps=bool(args.keep_taps))
   weights = synthetic_weights(cfg, seed=0)
   S = max(1, args.streams)
   all_models = [models.get_model(cfg, local_rank, weights=weights, is_multi=multi) for _ in range(S)]
@@ -437,11 +438,16 @@ def sustained_peak(lib, device):
       out[key + "bf16_tflops"] = tf.value
       out[key + "clock_ghz"] = ghz.value
       out[key + "measured_ms"] = ms.value
+    # the ceiling is the better of the two loops: on some boxes the bare register-operand stream is throttled harder
+    # (lower matrix-pipe duty at the same clock) than the one that pauses for its LDS fragment reads
+    out["registers_only_bf16_tflops"] = out["bf16_tflops"]
+    out["bf16_tflops"] = max(out["bf16_tflops"], out["with_lds_fragment_reads_bf16_tflops"])
     out["f32_work_tflops"] = out["bf16_tflops"] / SPLIT_PRODUCTS
     out["frac_of_datasheet_bf16_peak"] = out["bf16_tflops"] / BF16_MFMA_PEAK_TFLOPS
     out["what"] = ("v_mfma_f32_32x32x16_bf16 in the split kernels' mix (2 x 4 accumulator tiles per wave, 6 products per k16 "
-                   "step, one 8-wave workgroup per CU), random bf16 operands in registers, no memory traffic; "
-                   "back-to-back launches, 100 ms warm-up, >= 300 ms timed")
+                   "step, one 8-wave workgroup per CU), random bf16 operands, no global-memory traffic; operands held in "
+                   "registers / re-read from LDS per k16 step as the conv kernels do -- bf16_tflops is the better of the two; "
+                   "back-to-back launches, 100 ms warm-up, >= 300 ms timed each")
   except Exception as ex:
     out["failed"] = repr(ex)
   return out

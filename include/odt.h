@@ -72,6 +72,11 @@ typedef struct odt_config {
   float eff_image_scale;    /* image_scale_to_original applied to the output boxes (wrapper :57) */
   int32_t conv_arith;       /* ODT_ARITH_*: how the conv / FC products are evaluated (fixed per handle, see odt_describe) */
   int32_t conv_split_family;/* 0 library default; 1..3 newest bf16x3 kernel family allowed (A/B runs)                 */
+  int32_t keep_taps;        /* 0 (production): activations live in a liveness-planned arena -- a stage tensor's memory is
+                             * reused as soon as its last consumer has run, and odt_tap can only read the tensors that
+                             * outlive the forward (outputs, proposals, zero-bordered buffers); 1 (debug / parity runs):
+                             * every stage tensor keeps a dedicated buffer and odt_tap can read all of them after a
+                             * forward (b=8 @1080p: ~25 GB instead of ~5 GB of activations) */
 } odt_config;
 
 /* conv_arith: all modes keep f32 tensors and f32 accumulation.  ODT_ARITH_F32: every product on the exact-f32 MFMA
@@ -177,7 +182,8 @@ int odt_ingest_buffer(odt_handle h, int dtype, void** buffer, size_t* bytes);
 int odt_describe(odt_handle h, char* buf, int cap);
 
 /* Debug / parity taps: copy a named stage tensor (device layout: NHWC) to the
- * host.  shape_out receives up to 4 dims.  Names: "image_pad", "conv0",
+ * host (handles created with odt_config.keep_taps = 1; without it only the tensors that outlive a forward are
+ * readable and the others return an error).  shape_out receives up to 4 dims.  Names: "image_pad", "conv0",
  * "pool0", "c2".."c5", "p2".."p6", "rpn2".."rpn6" (16 ch: 3 logits + 12
  * deltas + 1 pad), "proposals", "nproposals", "roi_feat", "fc7", "head_out",
  * "decoded_boxes", "label_probs". */

@@ -62,6 +62,7 @@ def make_config(**overrides):
   c.nn_budget = 5
   c.tracking_objs = "Person,Vehicle"
   c.frame_gap = 8
+  c.keep_taps = False             # True: dedicated buffers for every stage tensor (engine.tap() of backbone stages; ~5x the activation memory)
   for k, v in overrides.items():
     setattr(c, k, v)
   return finalize_config(c)

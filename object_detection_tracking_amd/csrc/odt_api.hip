@@ -11,6 +11,8 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -153,6 +155,30 @@ struct odt_model {
   std::vector<double> prof_layer_ms;
   int prof_launches = 0;
 
+  // ---- activation arena (odt_config.keep_taps == 0): stage tensors get VIRTUAL addresses while the plan is built
+  // (kVirtBase + running offset: never dereferenced), plan_arena() assigns each the lowest arena offset that no tensor
+  // with an overlapping live range [first op, last op] occupies and rewrites every pointer of the plan.  Tensors that
+  // must keep their contents between forwards (zero borders, zero pad channels, outputs) stay dedicated allocations.
+  struct VTensor { size_t bytes = 0, voff = 0, off = 0; int first = 1 << 30, last = -1, region = 0; };
+  static constexpr uintptr_t kVirtBase = 0x400000000000ull;
+  bool arena_on = false;
+  std::set<std::string> transient_taps;     // stage names whose memory is reused within a forward (arena mode)
+  std::vector<VTensor> vt;
+  size_t vnext = 0;
+  float* arena[2] = {nullptr, nullptr};     // 0: trunk (live ranges end before the tail) | 1: read / written by the tail ops
+  size_t arena_bytes[2] = {0, 0};
+  size_t dedicated_tensor_bytes = 0, virtual_tensor_bytes = 0;
+  bool is_virtual(const void* p) const {
+    const uintptr_t a = (uintptr_t)p;
+    return a >= kVirtBase && a < kVirtBase + vnext;
+  }
+  int vt_index(const void* p) const {       // the virtual tensor an address falls into
+    const size_t o = (size_t)((uintptr_t)p - kVirtBase);
+    size_t lo = 0, hi = vt.size();
+    while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (vt[mid].voff <= o) lo = mid; else hi = mid; }
+    return (int)lo;
+  }
+
   float* alloc_f(size_t elems, bool zero) {
     bufs.emplace_back(new DevBuf());
     if (bufs.back()->alloc(elems * sizeof(float))) return nullptr;
@@ -168,8 +194,21 @@ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 int make_tensor(odt_model* m, const std::string& name, int B, int H, int W, int C, Tensor* t,
                 bool zero = false) {
   t->B = B; t->H = H; t->W = W; t->C = C; t->h = H; t->w = W; t->c = C;
+  if (m->arena_on && !zero) {
+    // (zero == true means "regions the kernels never write must read as zero": such a tensor cannot share memory)
+    odt_model::VTensor v;
+    v.bytes = (t->elems() * sizeof(float) + 255) & ~(size_t)255;
+    v.voff = m->vnext;
+    m->vnext += v.bytes;
+    m->vt.push_back(v);
+    m->virtual_tensor_bytes += v.bytes;
+    t->d = reinterpret_cast<float*>(odt_model::kVirtBase + v.voff);
+    if (!name.empty()) m->taps[name] = *t;
+    return 0;
+  }
   t->d = m->alloc_f(t->elems(), zero);
   ODT_CHECK(t->d != nullptr, "device allocation failed for " + name + ": " + g_err);
+  m->dedicated_tensor_bytes += t->elems() * sizeof(float);
   if (!name.empty()) m->taps[name] = *t;
   return 0;
 }
@@ -384,6 +423,115 @@ int attach_split_weights(odt_model* m) {
 }
 
 
+// ---- activation arena -----------------------------------------------------------------------------------------------
+// ops [op_tail, end) of forward i (selection / ROIAlign / box head / NMS / features) may run on the side stream under ops
+// [0, op_first_fpn) of forward i+1 (run_plan: tail overlap); 0 / 0 when the graph has no such split
+void find_overlap_points(odt_model* m) {
+  m->op_first_fpn = m->op_tail = 0;
+  if (m->cfg.graph == ODT_GRAPH_EFFNET) return;
+  for (size_t i = 0; i < m->ops.size(); ++i) {
+    if (m->ops[i].kind == OP_PROPOSALS) { m->op_tail = i; break; }
+    if (m->op_first_fpn == 0 && m->ops[i].kind == OP_CONV && m->convs[m->ops[i].conv].name.compare(0, 4, "fpn/") == 0)
+      m->op_first_fpn = i;
+  }
+  if (m->op_tail == 0 || m->op_first_fpn == 0 || m->op_first_fpn >= m->op_tail) m->op_first_fpn = m->op_tail = 0;
+}
+
+// every device pointer op `oi` reads or writes, as a mutable reference (plan_arena: liveness, then the rewrite)
+template <typename F>
+void visit_op_ptrs(odt_model* m, size_t oi, F&& f) {
+  Op& op = m->ops[oi];
+  auto roi = [&](RoiAlignParams& r) {
+    for (auto& p : r.feat) f(p);
+    f(r.boxes); f(r.out_nhwc); f(r.out_nchw); f(r.pooled);
+  };
+  f(op.in.d); f(op.out.d);
+  switch (op.kind) {
+    case OP_PRE: case OP_PRE_RGB: f(m->image_pad.d); break;
+    case OP_CONV: { ConvParams& c = m->convs[op.conv].p; f(c.in); f(c.res); f(c.out); f(c.in2); break; }
+    case OP_PROPOSALS: for (auto& l : m->prop.lvl) f(l.rpn); f(m->prop.props); break;
+    case OP_ROI_HEAD: roi(m->roi_head); break;
+    case OP_ROI_FINAL: roi(m->roi_final); break;
+    case OP_ROI_MASK: roi(m->roi_mask); break;
+    case OP_ROI_EFF: roi(m->roi_eff); break;
+    case OP_DETECT: f(m->det.head_out); f(m->det.props); break;
+    case OP_MASK_SELECT: f(m->mask_sel.logits); break;
+    case OP_DW: f(op.dw.in); f(op.dw.out); break;
+    case OP_FUSE: for (auto& p : op.fuse.in) f(p); f(op.fuse.out); break;
+    case OP_FUSE_DW: for (auto& p : op.fuse.in) f(p); f(op.dw.in); f(op.dw.out); break;
+    case OP_EFF_POST: for (auto& p : m->eff_post.cls) f(p); for (auto& p : m->eff_post.box) f(p); break;
+    case OP_CMEAN: case OP_CSCALE: case OP_SE_GATE: case OP_SE_GATE_MEAN: case OP_WSCALE: case OP_POOL: case OP_SUB2: break;
+  }
+}
+
+// Lay the virtual stage tensors out in (at most) two arenas by live range and rewrite the plan's pointers.
+// Region 1 holds what the tail ops touch (so that forward i's tail and forward i+1's early trunk never share memory);
+// within a region a tensor takes the lowest offset not occupied by a tensor whose [first, last] range intersects its own
+// (largest tensors first).  Called once, before the conv parameter records go to the device.
+int plan_arena(odt_model* m) {
+  if (!m->arena_on || m->vt.empty()) return 0;
+  find_overlap_points(m);
+  const int nops = (int)m->ops.size();
+  for (int oi = 0; oi < nops; ++oi)
+    visit_op_ptrs(m, (size_t)oi, [&](auto& p) {
+      if (p == nullptr || !m->is_virtual((const void*)p)) return;
+      odt_model::VTensor& v = m->vt[m->vt_index((const void*)p)];
+      v.first = std::min(v.first, oi); v.last = std::max(v.last, oi);
+    });
+  const bool split = m->op_tail > 0;
+  for (auto& v : m->vt) {
+    if (v.last < 0) { v.first = 0; v.last = nops - 1; }          // never referenced by an op (tap only): keep it apart
+    v.region = split && v.last >= (int)m->op_tail ? 1 : 0;
+    if (v.region == 1) v.last = nops - 1;                        // readable after the forward (appearance features / taps of the pyramid)
+  }
+  std::vector<int> order(m->vt.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+  std::sort(order.begin(), order.end(), [&](int a, int b) {
+    return m->vt[a].bytes != m->vt[b].bytes ? m->vt[a].bytes > m->vt[b].bytes : a < b;
+  });
+  std::vector<int> placed;
+  for (int id : order) {
+    odt_model::VTensor& v = m->vt[id];
+    // candidates: offset 0 and the end of every conflicting placed tensor; take the lowest that fits
+    std::vector<std::pair<size_t, size_t>> busy;     // [begin, end) of placed tensors of this region alive at the same time
+    for (int q : placed) {
+      const odt_model::VTensor& u = m->vt[q];
+      if (u.region == v.region && u.first <= v.last && v.first <= u.last) busy.emplace_back(u.off, u.off + u.bytes);
+    }
+    std::sort(busy.begin(), busy.end());
+    size_t off = 0;
+    for (const auto& b : busy) {
+      if (off + v.bytes <= b.first) break;
+      off = std::max(off, b.second);
+    }
+    v.off = off;
+    m->arena_bytes[v.region] = std::max(m->arena_bytes[v.region], off + v.bytes);
+    placed.push_back(id);
+  }
+  for (int r = 0; r < 2; ++r) {
+    if (m->arena_bytes[r] == 0) continue;
+    m->arena[r] = m->alloc_f(m->arena_bytes[r] / sizeof(float), false);
+    ODT_CHECK(m->arena[r] != nullptr, "device allocation failed (activation arena): " + g_err);
+  }
+  auto fix = [&](auto& p) {
+    if (p == nullptr || !m->is_virtual((const void*)p)) return;
+    const odt_model::VTensor& v = m->vt[m->vt_index((const void*)p)];
+    const size_t within = (size_t)((uintptr_t)p - odt_model::kVirtBase) - v.voff;
+    p = reinterpret_cast<std::remove_reference_t<decltype(p)>>(reinterpret_cast<char*>(m->arena[v.region]) + v.off + within);
+  };
+  // taps first (they still hold virtual addresses: remember which of them do not outlive a forward)
+  for (auto& kv : m->taps) {
+    if (kv.second.d != nullptr && m->is_virtual(kv.second.d)) {
+      const odt_model::VTensor& v = m->vt[m->vt_index(kv.second.d)];
+      if (v.region == 0 && !(v.first == 0 && v.last == nops - 1)) m->transient_taps.insert(kv.first);
+    }
+    fix(kv.second.d);
+  }
+  for (size_t oi = 0; oi < m->ops.size(); ++oi) visit_op_ptrs(m, oi, fix);
+  fix(m->image_pad.d);
+  return 0;
+}
+
 #include "effdet_plan.inc"
 
 }  // namespace
@@ -465,6 +613,7 @@ namespace {
 // Build the whole static plan (called from odt_finalize_weights).
 int build_plan(odt_model* m) {
   const odt_config& cfg = m->cfg;
+  m->arena_on = cfg.keep_taps == 0;
   if (cfg.graph == ODT_GRAPH_EFFNET) return build_plan_effnet(m);
   const int B = cfg.batch, H = cfg.height, W = cfg.width;
   const int FC = cfg.fpn_channels;
@@ -818,6 +967,7 @@ int build_plan(odt_model* m) {
     { Op op; op.kind = OP_MASK_SELECT; m->ops.push_back(op); }
   }
   if (attach_split_weights(m)) return 1;
+  if (plan_arena(m)) return 1;
   {   // conv parameter records in device memory
     std::vector<ConvParams> recs;
     for (const ConvOp& c : m->convs) recs.push_back(c.p);
@@ -994,13 +1144,8 @@ int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStre
   if (m->tail_overlap < 0) {
     const char* e = getenv("ODT_TAIL_OVERLAP");
     m->tail_overlap = (cfg.graph != ODT_GRAPH_EFFNET && !(e && e[0] == '0')) ? 1 : 0;
-    m->op_first_fpn = m->op_tail = 0;
-    for (size_t i = 0; i < m->ops.size(); ++i) {
-      if (m->ops[i].kind == OP_PROPOSALS) { m->op_tail = i; break; }
-      if (m->op_first_fpn == 0 && m->ops[i].kind == OP_CONV && m->convs[m->ops[i].conv].name.compare(0, 4, "fpn/") == 0)
-        m->op_first_fpn = i;
-    }
-    if (m->op_tail == 0 || m->op_first_fpn == 0 || m->op_first_fpn >= m->op_tail) m->tail_overlap = 0;
+    find_overlap_points(m);
+    if (m->op_tail == 0) m->tail_overlap = 0;
   }
   m->done_stream = st;
   ++m->forwards_enqueued;
@@ -1350,6 +1495,8 @@ int odt_tap(odt_handle h, const char* name, float* dst, size_t cap_elems, int64_
   }
   auto it = h->taps.find(name);
   ODT_CHECK(it != h->taps.end(), std::string("odt_tap: unknown stage ") + name);
+  ODT_CHECK(h->transient_taps.count(name) == 0, std::string("odt_tap: stage tensor ") + name + " is not kept after a forward "
+            "(its memory is reused inside the activation arena): create the handle with odt_config.keep_taps = 1");
   const Tensor& t = it->second;
   shape_out[0] = t.B; shape_out[1] = t.H; shape_out[2] = t.W; shape_out[3] = t.C; *rank_out = 4;
   if (dst) {
@@ -1391,15 +1538,23 @@ int odt_describe(odt_handle h, char* buf, int cap) {
     fam[c.p.wt_split != nullptr ? c.p.wt_split_kind : 0] += 1;
     if (c.p.wt_split != nullptr && c.p.splitk > 1) ++nsk;
   }
-  char tmp[640];
+  size_t dev_bytes = 0;
+  for (const auto& b : h->bufs) dev_bytes += b->bytes;
+  dev_bytes += h->frames_src.bytes;
+  for (const auto& sl : h->slot) dev_bytes += sl.dev_in_bytes;
+  char tmp[1024];
   std::snprintf(tmp, sizeof(tmp),
                 "{\"conv_arith\": \"%s\", \"conv_launches\": %d, \"exact_f32_mfma_launches\": %d, "
                 "\"bf16x3_split_launches\": %d, \"split_launches_by_family\": {\"split3_8wave_lds_dma\": %d, "
                 "\"two_stage_128x256\": %d, \"one_stage_bk32\": %d, \"of_split3_with_split_k\": %d}, \"policy\": {\"family\": %d, \"min_tiles\": %ld, "
-                "\"min_tiles3\": %ld, \"min_k\": %d}, \"env_overrides_applied\": %d, \"graph_replay\": %d}",
+                "\"min_tiles3\": %ld, \"min_k\": %d}, \"env_overrides_applied\": %d, \"graph_replay\": %d, "
+                "\"memory\": {\"device_bytes\": %zu, \"activation_arena_bytes\": [%zu, %zu], \"arena_tensors\": %zu, "
+                "\"arena_tensor_bytes_unshared\": %zu, \"dedicated_tensor_bytes\": %zu, \"keep_taps\": %d}}",
                 h->policy.arith != 0 && fam[1] + fam[2] + fam[3] > 0 ? "f32 through bf16x3 split products" : "exact f32 MFMA",
                 (int)h->convs.size(), fam[0], fam[1] + fam[2] + fam[3], fam[3], fam[2], fam[1], nsk, h->policy.family,
-                h->policy.min_tiles, h->policy.min_tiles3, h->policy.min_k, h->policy.env_overrides, h->graph_mode);
+                h->policy.min_tiles, h->policy.min_tiles3, h->policy.min_k, h->policy.env_overrides, h->graph_mode,
+                dev_bytes, h->arena_bytes[0], h->arena_bytes[1], h->vt.size(), h->virtual_tensor_bytes,
+                h->dedicated_tensor_bytes, h->cfg.keep_taps);
   std::strncpy(buf, tmp, cap - 1); buf[cap - 1] = 0;
   return 0;
 }

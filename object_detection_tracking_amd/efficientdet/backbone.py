@@ -14,7 +14,7 @@ from .arch import backbone_spec
 class EfficientNetBackbone(object):
 
   def __init__(self, name, weights, batch, height, width, device=0, lib=None, det=None, num_classes=90,
-               topk=5000, score_thresh=0.0, per_im=100, image_scale=1.0):
+               topk=5000, score_thresh=0.0, per_im=100, image_scale=1.0, keep_taps=True):
     self.lib = lib if lib is not None else _lib.get_lib()
     self.name, self.batch, self.height, self.width = name, batch, height, width
     self.src_height, self.src_width = height, width
@@ -25,6 +25,7 @@ class EfficientNetBackbone(object):
     c.eff_det = -1 if det is None else int(det[-1])      # "efficientdet-dN"
     c.num_class = num_classes; c.eff_topk = topk; c.result_score_thresh = score_thresh
     c.result_per_im = per_im; c.eff_image_scale = image_scale; c.head_nms_thresh = 0.5
+    c.keep_taps = int(bool(keep_taps))     # (features() / tap() read stage tensors: the stand-alone backbone keeps them by default)
     self.h = C.c_void_p()
     self.lib.check(self.lib.dll.odt_create(C.byref(c), device, C.byref(self.h)))
     try:

@@ -100,7 +100,8 @@ class EfficientDet(object):
           det=self.model_name, num_classes=self.num_classes,
           topk=int(getattr(self.config, "efficientdet_max_detection_topk", 5000)),
           score_thresh=float(getattr(self.config, "result_score_thres", 0.0)),
-          per_im=int(getattr(self.config, "result_per_im", 100)))
+          per_im=int(getattr(self.config, "result_per_im", 100)),
+          keep_taps=bool(getattr(self.config, "keep_taps", False)))
       if key != (self.height, self.width):
         e.set_source_size(*key)
       self._engines[key] = e

@@ -109,6 +109,9 @@ class _Engine(object):
     arith = getattr(config, "conv_arith", None)
     c.conv_arith = {None: 0, "default": 0, "f32": _lib.ODT_ARITH_F32, "bf16x3": _lib.ODT_ARITH_BF16X3}[arith]
     c.conv_split_family = int(getattr(config, "conv_split_family", 0) or 0)
+    # debug / parity runs: every stage tensor keeps its own buffer and tap() can read it after a forward; the production
+    # default plans the activations into an arena (a stage's memory is reused once its consumers have run)
+    c.keep_taps = int(bool(getattr(config, "keep_taps", False)))
     self.h = C.c_void_p()
     lib.check(lib.dll.odt_create(C.byref(c), device, C.byref(self.h)))
     try:
@@ -267,8 +270,8 @@ class _Engine(object):
   def describe(self):
     """What the handle runs (odt_describe): conv arithmetic mode, launches per kernel family, policy thresholds."""
     import json
-    buf = C.create_string_buffer(1024)
-    self.lib.check(self.lib.dll.odt_describe(self.h, buf, 1024))
+    buf = C.create_string_buffer(2048)
+    self.lib.check(self.lib.dll.odt_describe(self.h, buf, 2048))
     return json.loads(buf.value.decode())
 
   def profile(self, enable):

