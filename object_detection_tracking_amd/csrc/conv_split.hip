@@ -820,6 +820,67 @@ __device__ __forceinline__ void split3_epilogue(const ConvParams& p, f32x16 (&ac
     return;
   }
   const f32x4 bias4 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, col * 4, 0, 0);
+  if constexpr (BN == 256) {
+    if (p.head_wt != nullptr) {
+      // ---- fused 1x1 head (RPN class || box: 15 columns of a 16-wide GEMM over this tile's 256 channels).  Per pass:
+      // accumulators -> LDS, bias + activation in place, then wave w multiplies rows [16 w, 16 w + 16) of the pass by
+      // head_wt with v_mfma_f32_16x16x4_f32 (exact f32: an fmaf chain in k order).  k order of the chain: step
+      // (t, u) takes channels 16 t + 4 j + u, j = lane / 16 -- one ds_read_b128 per lane feeds four MFMAs; the lane's 64
+      // B-operand values (head_wt[16 t + 4 j + u][lane % 16]) are fetched once, up front.
+      const int lane = tid & 63, wave = tid >> 6;
+      const int hn = lane & 15, hj = lane >> 4;
+      float hb[64];
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) hb[t * 4 + u] = p.head_wt[(16 * t + 4 * hj + u) * 16 + hn];
+      const float hbias = p.head_bias[hn];
+      static_assert(RP % 16 == 0, "head tiles");
+      constexpr int RT = RP / 16;               // 16-row tiles per pass
+#pragma unroll 1
+      for (int pass = 0; pass < NPASS; ++pass) {
+        if (pass > 0) ODT_BARRIER_LDS();
+        if (wm / WPP == pass) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                Ct[((wm % WPP) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * CS + wn * TN * 32 + j * 32 + fr] = acc[i][j][r];
+        }
+        ODT_BARRIER_LDS();
+#pragma unroll
+        for (int s2 = 0; s2 < NCH; ++s2) {      // bias + activation in place (each thread its own 16-byte chunks)
+          f32x4* q = reinterpret_cast<f32x4*>(&Ct[(row0 + s2 * RSTEP) * CS + c4 * 4]);
+          f32x4 v = *q + bias4;
+          if (p.relu == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          *q = v;
+        }
+        ODT_BARRIER_LDS();
+        for (int rt = wave; rt < RT; rt += 8) {
+          f32x4 c = {0.f, 0.f, 0.f, 0.f};
+          const float* arow = &Ct[(rt * 16 + hn) * CS + 4 * hj];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * t);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], hb[t * 4 + u], c, 0, 0, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {          // C layout: row 4 j + i, column lane % 16
+            const int m = m0 + pass * RP + rt * 16 + 4 * hj + i;
+            if (m < M) p.head_out[(size_t)m * p.head_ldc + hn] = hn < 15 ? c[i] + hbias : 0.f;
+          }
+        }
+      }
+      ODT_STAMP(5);
+      return;
+    }
+  }
   // (no barrier needed here: the last stage's barrier sits behind every fragment read of the ring)
   auto run = [&](auto act_c, auto res_c) {
     constexpr int ACT = decltype(act_c)::value;

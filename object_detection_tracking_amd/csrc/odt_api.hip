@@ -75,6 +75,7 @@ struct Op {
   const float* wt0 = nullptr;   // OP_WSCALE: the conv's unscaled weights [Cout][K] (conv = index of the conv whose weights are rebuilt)
   float* aux2 = nullptr;   // OP_CMEAN: partial-sum scratch
   int pad_t = 0, pad_l = 0;   // OP_PRE_RGB
+  bool skip = false;          // OP_CONV folded into its producer's epilogue (fuse_rpn_heads): not launched
 };
 
 }  // namespace
@@ -91,6 +92,7 @@ struct odt_model {
   std::vector<std::unique_ptr<DevBuf>> bufs;
   std::map<std::string, Tensor> taps;
   std::vector<ConvOp> convs;
+  std::vector<char> conv_fused;      // convs[i] is evaluated inside another conv's epilogue (no launch of its own)
   ConvParams* convs_dev = nullptr;   // device copies of convs[i].p
   std::vector<Op> ops;
   // geometry
@@ -423,6 +425,48 @@ int attach_split_weights(odt_model* m) {
 }
 
 
+// ---- RPN head folded into the RPN conv's epilogue --------------------------------------------------------------------
+// rpn/conv0@pL (3x3, 256 -> 256, ReLU) is followed by rpn/head@pL (1x1, 256 -> 3 logits || 12 deltas) and nothing else
+// reads its output (models.py:979-1009).  Where the 3x3 conv runs on a conv_split3 kernel whose n-tile is the whole
+// Cout (256) and has no split-K, the head is evaluated on the staged C tile in that kernel's epilogue (exact-f32 MFMA):
+// the [M,256] tensor is neither written nor read back (2.1 GB at P2, b = 8) and the N = 15 launch disappears.
+// ODT_FUSE_RPN_HEAD=0 keeps the two launches (A/B).  Called after attach_split_weights, before plan_arena.
+int fuse_rpn_heads(odt_model* m) {
+  m->conv_fused.assign(m->convs.size(), 0);
+  const char* e = getenv("ODT_FUSE_RPN_HEAD");
+  if (e != nullptr && e[0] == '0') return 0;
+  const HostTensor* W = find_w(m, "__rpnhead/W");
+  const HostTensor* Bv = find_w(m, "__rpnhead/b");
+  if (W == nullptr || Bv == nullptr) return 0;
+  const float *hw = nullptr, *hb = nullptr;
+  for (size_t oi = 0; oi + 1 < m->ops.size(); ++oi) {
+    Op& oa = m->ops[oi]; Op& ob = m->ops[oi + 1];
+    if (oa.kind != OP_CONV || ob.kind != OP_CONV) continue;
+    ConvOp& a = m->convs[oa.conv]; ConvOp& b = m->convs[ob.conv];
+    if (a.name.compare(0, 10, "rpn/conv0@") != 0 || b.name.compare(0, 9, "rpn/head@") != 0) continue;
+    const ConvParams& bp = b.p;
+    ConvParams& ap = a.p;
+    const bool ok = ap.wt_split != nullptr && ap.wt_split_kind == 3 && ap.wt_split_bn == 256 && ap.Cout == 256 && ap.splitk <= 1 &&
+                    ap.res_mode == 0 && ap.in2 == nullptr && ap.relu <= 1 && bp.in == ap.out && bp.kh == 1 && bp.kw == 1 &&
+                    bp.Cin == 256 && bp.Cout == 15 && bp.out_ldc == 16 && bp.stride == 1 && bp.res_mode == 0 && bp.relu == 0 &&
+                    bp.out_oy == 0 && bp.out_ox == 0 && bp.out_H == bp.Ho && bp.out_W == bp.Wo && bp.Ho == ap.Ho && bp.Wo == ap.Wo &&
+                    ap.out_oy == 0 && ap.out_ox == 0 && ap.out_H == ap.Ho && ap.out_W == ap.Wo && (int)W->data.size() == 256 * 15;
+    if (!ok) continue;
+    if (hw == nullptr) {
+      std::vector<float> v((size_t)256 * 16, 0.f), vb(16, 0.f);
+      for (int c = 0; c < 256; ++c)
+        for (int j = 0; j < 15; ++j) v[(size_t)c * 16 + j] = W->data[(size_t)c * 15 + j];
+      for (int j = 0; j < 15; ++j) vb[j] = Bv->data[j];
+      if (upload_raw(m, v, &hw) || upload_raw(m, vb, &hb)) return 1;
+    }
+    ap.head_wt = hw; ap.head_bias = hb; ap.head_out = bp.out; ap.head_ldc = bp.out_ldc;
+    ap.out = nullptr;                      // nothing else reads the 256-channel tensor
+    ob.skip = true;
+    m->conv_fused[ob.conv] = 1;
+  }
+  return 0;
+}
+
 // ---- activation arena -----------------------------------------------------------------------------------------------
 // ops [op_tail, end) of forward i (selection / ROIAlign / box head / NMS / features) may run on the side stream under ops
 // [0, op_first_fpn) of forward i+1 (run_plan: tail overlap); 0 / 0 when the graph has no such split
@@ -441,6 +485,7 @@ void find_overlap_points(odt_model* m) {
 template <typename F>
 void visit_op_ptrs(odt_model* m, size_t oi, F&& f) {
   Op& op = m->ops[oi];
+  if (op.skip) return;
   auto roi = [&](RoiAlignParams& r) {
     for (auto& p : r.feat) f(p);
     f(r.boxes); f(r.out_nhwc); f(r.out_nchw); f(r.pooled);
@@ -479,7 +524,12 @@ int plan_arena(odt_model* m) {
       v.first = std::min(v.first, oi); v.last = std::max(v.last, oi);
     });
   const bool split = m->op_tail > 0;
-  for (auto& v : m->vt) {
+  std::vector<char> tapped(m->vt.size(), 0);
+  for (const auto& kv : m->taps)
+    if (kv.second.d != nullptr && m->is_virtual(kv.second.d)) tapped[m->vt_index(kv.second.d)] = 1;
+  for (size_t i = 0; i < m->vt.size(); ++i) {
+    auto& v = m->vt[i];
+    if (v.last < 0 && !tapped[i]) { v.bytes = 0; v.first = v.last = 0; }     // no op touches it (its producer was fused away)
     if (v.last < 0) { v.first = 0; v.last = nops - 1; }          // never referenced by an op (tap only): keep it apart
     v.region = split && v.last >= (int)m->op_tail ? 1 : 0;
     if (v.region == 1) v.last = nops - 1;                        // readable after the forward (appearance features / taps of the pyramid)
@@ -967,6 +1017,7 @@ int build_plan(odt_model* m) {
     { Op op; op.kind = OP_MASK_SELECT; m->ops.push_back(op); }
   }
   if (attach_split_weights(m)) return 1;
+  if (fuse_rpn_heads(m)) return 1;
   if (plan_arena(m)) return 1;
   {   // conv parameter records in device memory
     std::vector<ConvParams> recs;
@@ -996,10 +1047,11 @@ static int run_ops(odt_model* m, const void* src, int dtype, hipStream_t st, siz
         }
         break;
       case OP_CONV: {
+        if (op.skip) break;
         const ConvOp& c = m->convs[op.conv];
-        if (m->profile) ODT_HIP(hipEventRecord(m->ev[ev_i++], st));
+        if (m->profile) ODT_HIP(hipEventRecord(m->ev[2 * op.conv], st));
         if (launch_conv(c.p, st, m->convs_dev + op.conv)) { g_err = c.name + ": " + g_err; return 1; }
-        if (m->profile) ODT_HIP(hipEventRecord(m->ev[ev_i++], st));
+        if (m->profile) ODT_HIP(hipEventRecord(m->ev[2 * op.conv + 1], st));
         break;
       }
       case OP_POOL:
@@ -1107,16 +1159,19 @@ static int finish_profile(odt_model* m, hipStream_t st) {
   ODT_HIP(hipEventRecord(m->ev_total[1], st));
   ODT_HIP(hipStreamSynchronize(st));
   double ms = 0, fl = 0;
+  int launched = 0;
   for (size_t i = 0; i < m->convs.size(); ++i) {
+    if (m->conv_fused[i]) continue;          // evaluated inside its producer's epilogue (its FLOPs are counted there)
     float t = 0;
     ODT_HIP(hipEventElapsedTime(&t, m->ev[2 * i], m->ev[2 * i + 1]));
     ms += t; fl += conv_flops(m->convs[i].p);
     if (m->prof_layer_ms.size() < m->convs.size()) m->prof_layer_ms.resize(m->convs.size(), 0.0);
     m->prof_layer_ms[i] += t;
+    ++launched;
   }
   float tt = 0;
   ODT_HIP(hipEventElapsedTime(&tt, m->ev_total[0], m->ev_total[1]));
-  m->prof_conv_ms += ms; m->prof_conv_flops += fl; m->prof_launches += (int)m->convs.size();
+  m->prof_conv_ms += ms; m->prof_conv_flops += fl; m->prof_launches += launched;
   m->prof_total_ms += tt;
   return 0;
 }
@@ -1247,6 +1302,7 @@ int odt_finalize_weights(odt_handle h) {
   ODT_CHECK(!h->finalized, "weights already finalized");
   ODT_HIP(hipSetDevice(h->device));
   if (build_plan(h)) return 1;
+  h->conv_fused.resize(h->convs.size(), 0);
   ODT_HIP(hipDeviceSynchronize());
   h->finalized = true;
   h->host_w.clear();
@@ -1522,10 +1578,12 @@ int odt_profile_layer(odt_handle h, int index, char* name, int name_cap, double*
   if (index < 0 || index >= (int)h->convs.size()) return 0;
   const ConvOp& c = h->convs[index];
   if (name && name_cap > 0) {    // layers on the bf16x3 split kernel are tagged (bench.py / profile_layers.py group by it)
-    const std::string nm = c.name + (c.p.wt_split != nullptr ? "[bf16x3]" : "");
+    const bool fused = index < (int)h->conv_fused.size() && h->conv_fused[index];
+    const std::string nm = c.name + (fused ? "[fused into the producer's epilogue]" : (c.p.head_wt != nullptr ? "+head" : "")) +
+                           (!fused && c.p.wt_split != nullptr ? "[bf16x3]" : "");
     std::strncpy(name, nm.c_str(), name_cap - 1); name[name_cap - 1] = 0;
   }
-  if (flops) *flops = conv_flops(c.p);
+  if (flops) *flops = (index < (int)h->conv_fused.size() && h->conv_fused[index]) ? 0.0 : conv_flops(c.p);
   if (ms) *ms = index < (int)h->prof_layer_ms.size() ? h->prof_layer_ms[index] : 0.0;
   if (mnk) { mnk[0] = (int64_t)c.p.B * c.p.Ho * c.p.Wo; mnk[1] = c.p.Cout; mnk[2] = (int64_t)c.p.kh * c.p.kw * c.p.Cin; }
   return 0;
@@ -1533,8 +1591,10 @@ int odt_profile_layer(odt_handle h, int index, char* name, int name_cap, double*
 
 int odt_describe(odt_handle h, char* buf, int cap) {
   ODT_CHECK(h != nullptr && buf != nullptr && cap > 0, "odt_describe: null argument");
-  int fam[4] = {0, 0, 0, 0}, nsk = 0;
-  for (const ConvOp& c : h->convs) {
+  int fam[4] = {0, 0, 0, 0}, nsk = 0, nfused = 0;
+  for (size_t i = 0; i < h->convs.size(); ++i) {
+    const ConvOp& c = h->convs[i];
+    if (i < h->conv_fused.size() && h->conv_fused[i]) { ++nfused; continue; }
     fam[c.p.wt_split != nullptr ? c.p.wt_split_kind : 0] += 1;
     if (c.p.wt_split != nullptr && c.p.splitk > 1) ++nsk;
   }
@@ -1544,14 +1604,14 @@ int odt_describe(odt_handle h, char* buf, int cap) {
   for (const auto& sl : h->slot) dev_bytes += sl.dev_in_bytes;
   char tmp[1024];
   std::snprintf(tmp, sizeof(tmp),
-                "{\"conv_arith\": \"%s\", \"conv_launches\": %d, \"exact_f32_mfma_launches\": %d, "
+                "{\"conv_arith\": \"%s\", \"conv_launches\": %d, \"convs_fused_into_epilogues\": %d, \"exact_f32_mfma_launches\": %d, "
                 "\"bf16x3_split_launches\": %d, \"split_launches_by_family\": {\"split3_8wave_lds_dma\": %d, "
                 "\"two_stage_128x256\": %d, \"one_stage_bk32\": %d, \"of_split3_with_split_k\": %d}, \"policy\": {\"family\": %d, \"min_tiles\": %ld, "
                 "\"min_tiles3\": %ld, \"min_k\": %d}, \"env_overrides_applied\": %d, \"graph_replay\": %d, "
                 "\"memory\": {\"device_bytes\": %zu, \"activation_arena_bytes\": [%zu, %zu], \"arena_tensors\": %zu, "
                 "\"arena_tensor_bytes_unshared\": %zu, \"dedicated_tensor_bytes\": %zu, \"keep_taps\": %d}}",
                 h->policy.arith != 0 && fam[1] + fam[2] + fam[3] > 0 ? "f32 through bf16x3 split products" : "exact f32 MFMA",
-                (int)h->convs.size(), fam[0], fam[1] + fam[2] + fam[3], fam[3], fam[2], fam[1], nsk, h->policy.family,
+                (int)h->convs.size() - nfused, nfused, fam[0], fam[1] + fam[2] + fam[3], fam[3], fam[2], fam[1], nsk, h->policy.family,
                 h->policy.min_tiles, h->policy.min_tiles3, h->policy.min_k, h->policy.env_overrides, h->graph_mode,
                 dev_bytes, h->arena_bytes[0], h->arena_bytes[1], h->vt.size(), h->virtual_tensor_bytes,
                 h->dedicated_tensor_bytes, h->cfg.keep_taps);

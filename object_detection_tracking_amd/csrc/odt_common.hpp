@@ -76,6 +76,14 @@ struct ConvParams {
   int wt_split_kwr;    // kind 3: 1 = conv_split3k_kernel (the three kw taps of a (slice, kh) group share one staged run of pixels)
   int splitk;          // 0 / 1: off
   float* partial;      // scratch [splitk][M][Cout] (plan-owned, shared by the plan's split-K layers)
+  // optional fused 1x1 head behind this conv (conv_split3 kernels whose n-tile is the whole Cout = 256: the RPN 3x3 conv +
+  // ReLU, models.py:979-1009): head_out[m][j] = sum_c act(conv)[m][c] * head_wt[c][j] + head_bias[j], j < 16, evaluated on
+  // the staged C tile in the epilogue with exact-f32 MFMA (v_mfma_f32_16x16x4_f32) -- the 256-channel tensor is never
+  // written (out == nullptr) or read back, and the separate N = 15 launch disappears
+  const float* head_wt;    // [Cout][16] (k-major, column 15 zero) or nullptr
+  const float* head_bias;  // [16]
+  float* head_out;         // [M][head_ldc] dense rows (m = (n, ho, wo))
+  int head_ldc;
 };
 // fills the derived fields (multiply-shift divisors); call before copying a record to the device
 void conv_prepare(ConvParams& p);

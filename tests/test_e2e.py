@@ -354,3 +354,37 @@ def test_arena_four_coresident_handles_b8_1080p(hip_lib):
   finally:
     for m in ms:
       m.close()
+
+
+def test_rpn_head_fused_into_conv_epilogue(backend, monkeypatch):
+  """rpn/head@pL (1x1, 256 -> 3 logits || 12 deltas) evaluated inside the epilogue of rpn/conv0@pL where that conv runs on
+  a conv_split3 kernel with the whole Cout in one n-tile (at 1080p: P2, P3, P4; here forced by the tile thresholds):
+  the RPN outputs agree with the two-launch form at f32 rounding level, the whole forward with the oracle, and the
+  handle reports the folded launches."""
+  name, lib = backend
+  monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1"); monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "1")
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1])
+  w = weights_for(cfg)
+  H, W = (64, 96) if name == "emu" else (160, 224)
+  fr = synthetic_frames(1, H, W, seed=5)
+  out = {}
+  for mode in ("0", "1"):
+    monkeypatch.setenv("ODT_FUSE_RPN_HEAD", mode)
+    m = models.get_model(_with_taps(cfg), 0, weights=w, lib=lib)
+    try:
+      det = m.predict(fr[0])
+      e = m.engine(1, H, W)
+      out[mode] = (det, {l: e.tap("rpn%d" % l) for l in range(2, 7)}, e.describe())
+    finally:
+      m.close()
+  assert out["0"][2]["convs_fused_into_epilogues"] == 0 and out["1"][2]["convs_fused_into_epilogues"] >= 2, out["1"][2]
+  assert out["1"][2]["conv_launches"] + out["1"][2]["convs_fused_into_epilogues"] == out["0"][2]["conv_launches"]
+  for l in range(2, 7):
+    a, b = out["1"][1][l], out["0"][1][l]
+    assert np.all(a[..., 15] == 0)
+    assert _rel(a, b) < 1e-5, l
+  miss, extra = match_detections(out["1"][0][0], out["1"][0][1], out["1"][0][2], out["0"][0][0], out["0"][0][1], out["0"][0][2], 1e-3, 1e-4)
+  assert miss + extra == 0
+  monkeypatch.setenv("ODT_FUSE_RPN_HEAD", "1")
+  miss, extra = _run_single(lib, cfg, H, W)           # fused form against the oracle, arena + taps handles
+  assert miss == 0 and extra == 0

@@ -66,6 +66,9 @@ def _set_diff(b1, l1, p1, b2, l2, p2, tol_box, tol_prob):
 def _measure(lib, cfg, B, H, W, ref, multi):
   w = weights_for(cfg)
   fr = synthetic_frames(B, H, W)
+  import copy
+  cfg = copy.copy(cfg)
+  cfg.keep_taps = True                    # stage errors are read through the taps (the arena handle is compared bit for bit in test_e2e.py)
   m = models.get_model(cfg, 0, weights=w, lib=lib, is_multi=multi)
   try:
     side = max(H, W)
