@@ -22,7 +22,7 @@
  * convolutions as six exact bf16 x bf16 matrix-core products of a 3-way bf16 split
  * of both float32 operands (error at the level of an f32 dot product in another
  * summation order); ODT_CONV_SPLIT=0 uses the exact-f32 matrix instruction for
- * every layer.  ODT_GRAPH=0 disables hipGraph replay of the launch sequence.
+ * every layer.
  */
 #ifndef ODT_H_
 #define ODT_H_
@@ -71,7 +71,7 @@ typedef struct odt_config {
   int32_t eff_topk;         /* efficientdet_max_detection_topk (5000)         */
   float eff_image_scale;    /* image_scale_to_original applied to the output boxes (wrapper :57) */
   int32_t conv_arith;       /* ODT_ARITH_*: how the conv / FC products are evaluated (fixed per handle, see odt_describe) */
-  int32_t conv_split_family;/* 0 library default; 1..3 newest bf16x3 kernel family allowed (A/B runs)                 */
+  int32_t conv_split_family;/* 0 library default (3); 1: one-stage bf16x3 kernel only; 3: conv_split3 kernels where they fit (A/B runs) */
   int32_t keep_taps;        /* 0 (production): activations live in a liveness-planned arena -- a stage tensor's memory is
                              * reused as soon as its last consumer has run, and odt_tap can only read the tensors that
                              * outlive the forward (outputs, proposals, zero-bordered buffers); 1 (debug / parity runs):
@@ -166,8 +166,10 @@ int odt_set_source_size(odt_handle h, int src_height, int src_width);
  * odt_submit_ex: the same with a choice of what crosses PCIe on the way back (ODT_WANT_* bits).  The
  * only consumer of fpn_box_feat on this path averages it to [M,C] (deep_sort/utils.py:27-28), so the
  * tracking loop asks for ODT_WANT_POOLED only: 0.8 MB per 8-frame batch instead of the 40 MB of
- * [M,256,7,7]; with nothing large to copy the D2H rides on the compute stream and the forward is a
- * hipGraph replay (one cached graph per slot).  odt_submit == odt_submit_ex(..., ODT_WANT_ALL, ...). */
+ * [M,256,7,7]; with nothing large to copy the D2H is enqueued right behind the forward on the stream its tail runs on
+ * (the handle's side stream when the tail of forward i overlaps the trunk of forward i+1 -- the default -- or the compute
+ * stream with ODT_TAIL_OVERLAP=0); tickets that do ask for the features use the copy stream.
+ * odt_submit == odt_submit_ex(..., ODT_WANT_ALL, ...). */
 #define ODT_WANT_FEATS  1   /* fpn_box_feat [M,C,7,7] */
 #define ODT_WANT_POOLED 2   /* its 7x7 mean [M,C] */
 #define ODT_WANT_MASKS  4   /* final_masks (add_mask models) */

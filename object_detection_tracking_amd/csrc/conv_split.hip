@@ -394,345 +394,6 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
   stamp(5);
 }
 
-// ---- experimental second loop structure (ODT_CONV_SPLIT_PIPE=2, 128 x 256 tile only; not the default:
-// written at the end of round 1: simulator-verified and bit-identical to the default kernel on the
-// GPU for two shapes, but not timed yet).  BK = 16 per stage, TWO LDS
-// stages (2 x 36.4 KB), one barrier per slice, no MFMA-free phase: the registers -> LDS move of
-// slice c+1 (split arithmetic + stores) rides behind the MFMAs of groups 1-2 of slice c, the global
-// prefetch of slice c+2 is issued right after it, and the first fragments of slice c+1 are read
-// behind the last group (after the barrier).  Prefetch registers halve (A 8 + B 24).
-__global__ void __launch_bounds__(256, 2) conv_split2_kernel(const ConvParams* __restrict__ pp) {
-  constexpr int SBM = 128, SBN = 256, TN = 4;
-  constexpr int AKG = SBM * 16 + 32, APL = 2 * AKG;      // two k-groups of 8 per stage
-  constexpr int BKG = SBN * 16 + 32, BPL = 2 * BKG;
-  constexpr int STAGE = 3 * APL + 3 * BPL;               // 37,248 B
-  constexpr int STAGE_B_BYTES = 3 * 2 * SBN * 16;        // 24,576 B of pre-imaged weights per stage
-  constexpr int NB = STAGE_B_BYTES / 4096;               // 6 chunks of 16 B per thread
-  const ConvParams p = *pp;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int ntn = cout_padded(p.Cout) / SBN;
-  int wg = (int)blockIdx.x;
-  {
-    const int nwg = (int)gridDim.x, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
-  }
-  const int mt = wg / ntn, nt = wg - mt * ntn;
-  const int m0 = mt * SBM, n0 = nt * SBN;
-  const int HoWo = p.Ho * p.Wo;
-  const int M = p.B * HoWo;
-  const int cpt = p.Cin >> 4;                              // 16-channel slices per tap
-  const int cpt2 = p.in2 != nullptr ? p.Cin2 >> 4 : 0;
-  const int nslices = p.kh * p.kw * cpt + cpt2;
-
-  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.in, 0, (int)((unsigned)p.B * p.in_Ha * p.in_Wa * p.in_ldc * 4u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.in2 != nullptr ? p.in2 : p.in), 0,
-      (int)(p.in2 != nullptr ? (unsigned)p.B * p.in2_Ha * p.in2_Wa * p.in2_ldc * 4u : 0u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.wt_split, 0, (int)((unsigned)ntn * nslices * (unsigned)STAGE_B_BYTES), 0x00020000);
-
-  // ---- A loader: thread -> (row lr + 64*j, 16-byte column lc): 4 lanes x 16 B = the 16 channels of a slice
-  const int lc = tid & 3, lr = tid >> 2;
-  int a_hw0[2];
-  unsigned a_img[2];
-  const bool dense_in = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 &&
-                        p.H == p.in_Ha && p.W == p.in_Wa && p.Ho == p.H && p.Wo == p.W;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int m = m0 + lr + 64 * j;
-    const bool ok = m < M;
-    if (dense_in) {
-      a_hw0[j] = 0;
-      a_img[j] = ok ? (unsigned)m * p.in_ldc * 4u + lc * 16u : kOOB;
-    } else {
-      const int mm = ok ? m : 0;
-      const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), r = mm - n * HoWo;
-      const int ho = sfast_div(r, p.div_wo_mul, p.div_wo_sh), wo = r - ho * p.Wo;
-      a_hw0[j] = (int)(((unsigned)(ho * p.stride - p.pad_t) << 16) | ((unsigned)(wo * p.stride - p.pad_l) & 0xffffu));
-      a_img[j] = ok ? (unsigned)n * p.in_Ha * p.in_Wa * p.in_ldc * 4u + lc * 16u : kOOB;
-    }
-  }
-  const unsigned pix_bytes = (unsigned)p.in_ldc * 4u;
-  int l_cc = 0, l_kh = 0, l_kw = 0;
-  unsigned a_row[2];
-  auto set_tap = [&](int khh, int kww) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int hi = (a_hw0[j] >> 16) + khh * p.dil, wi = (int)(short)(a_hw0[j] & 0xffff) + kww * p.dil;
-      const bool v = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W && a_img[j] != kOOB;
-      a_row[j] = v ? a_img[j] + (unsigned)(hi * p.in_Wa + wi) * pix_bytes : kOOB;
-    }
-  };
-  set_tap(0, 0);
-  bool l_src2 = false;
-  int l_cpt = cpt;
-  auto set_src2 = [&]() {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int m = m0 + lr + 64 * j;
-      const bool ok = m < M;
-      const int mm = ok ? m : 0;
-      const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), r = mm - n * HoWo;
-      const int ho = sfast_div(r, p.div_wo_mul, p.div_wo_sh), wo = r - ho * p.Wo;
-      const unsigned pix = ((unsigned)n * p.in2_Ha + (unsigned)(ho * p.in2_stride)) * p.in2_Wa + (unsigned)(wo * p.in2_stride);
-      a_row[j] = ok ? pix * (unsigned)p.in2_ldc * 4u + lc * 16u : kOOB;
-    }
-  };
-  unsigned l_b = (unsigned)nt * (unsigned)nslices * (unsigned)STAGE_B_BYTES;
-
-  f32x4 ga[2];
-  u32x4 gb[NB];
-  auto load_a = [&](int j) {
-    ga[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(l_src2 ? rs_in2 : rs_in, (int)a_row[j], l_cc * 64, 0);
-  };
-  auto load_b = [&](int i) {
-    gb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, tid * 16 + i * 4096, (int)l_b, 0);
-  };
-  auto advance_b = [&]() { l_b += (unsigned)STAGE_B_BYTES; };
-  auto advance_a = [&]() {
-    if (++l_cc == l_cpt) {
-      l_cc = 0;
-      if (!l_src2) {
-        if (++l_kw == p.kw) { l_kw = 0; ++l_kh; }
-        if (l_kh == p.kh && cpt2 > 0) {
-          l_src2 = true; l_cpt = cpt2;
-          set_src2();
-        } else {
-          set_tap(l_kh, l_kw);
-        }
-      }
-    }
-  };
-  auto store_a = [&](int buf, int j) {
-    unsigned h0, m0_, l0, h1, m1, l1;
-    split2(ga[j][0], ga[j][1], h0, m0_, l0);
-    split2(ga[j][2], ga[j][3], h1, m1, l1);
-    unsigned char* st = lds + buf * STAGE + (lc >> 1) * AKG + (lr + 64 * j) * 16 + (lc & 1) * 8;
-    *reinterpret_cast<u32x2*>(st + 0 * APL) = u32x2{h0, h1};
-    *reinterpret_cast<u32x2*>(st + 1 * APL) = u32x2{m0_, m1};
-    *reinterpret_cast<u32x2*>(st + 2 * APL) = u32x2{l0, l1};
-  };
-  auto store_b = [&](int buf, int i) {       // chunk tid + 256 i of the stage image [piece][k-group][n]
-    *reinterpret_cast<u32x4*>(lds + buf * STAGE + 3 * APL + (i >> 1) * BPL + (i & 1) * BKG + tid * 16) = gb[i];
-  };
-
-  f32x16 acc[2][TN];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int fr = lane & 31, fg = lane >> 5;
-  // slice 0 -> registers
-#pragma unroll
-  for (int j = 0; j < 2; ++j) load_a(j);
-#pragma unroll
-  for (int i = 0; i < NB; ++i) load_b(i);
-  advance_a(); advance_b();
-  if (p.res_mode != 0) {
-    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)p.res, 0, (int)((unsigned)p.B * p.res_H * p.res_W * p.res_ldc * 4u), 0x00020000);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
-        unsigned rpix = (unsigned)row;
-        if (p.res_mode == 2) {
-          const int mm = row < M ? row : 0;
-          const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), rr = mm - n * HoWo;
-          const int ho = sfast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
-          rpix = ((unsigned)n * p.res_H + (unsigned)(ho >> 1)) * p.res_W + (unsigned)(wo >> 1);
-        }
-        const unsigned roff = row < M ? rpix * (unsigned)p.res_ldc * 4u + (unsigned)(n0 + wn * TN * 32 + fr) * 4u : kOOB;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, (int)roff, j * 128, 0));
-      }
-  }
-  // slice 0 -> LDS stage 0; slice 1 -> registers
-#pragma unroll
-  for (int j = 0; j < 2; ++j) store_a(0, j);
-#pragma unroll
-  for (int i = 0; i < NB; ++i) store_b(0, i);
-  if (nslices > 1) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) load_a(j);
-#pragma unroll
-    for (int i = 0; i < NB; ++i) load_b(i);
-    advance_a(); advance_b();
-  }
-  __syncthreads();
-
-  bf16x8 fa[3][2], fb[3];
-  auto rdA = [&](int buf, int q) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-      fa[q][t] = *reinterpret_cast<const bf16x8*>(lds + buf * STAGE + q * APL + fg * AKG + (wm * 64 + t * 32 + fr) * 16);
-  };
-  auto rdB = [&](int buf, int q, int j) {
-    fb[q] = *reinterpret_cast<const bf16x8*>(lds + buf * STAGE + 3 * APL + q * BPL + fg * BKG + (wn * TN * 32 + j * 32 + fr) * 16);
-  };
-#pragma unroll
-  for (int q = 0; q < 3; ++q) rdA(0, q);
-#pragma unroll
-  for (int q = 0; q < 3; ++q) rdB(0, q, 0);
-
-#define ODT_MF(qa, qb, j) { acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][0], fb[qb], acc[0][j], 0, 0, 0); \
-                            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][1], fb[qb], acc[1][j], 0, 0, 0); }
-#define ODT_FENCE() __builtin_amdgcn_sched_barrier(0)
-  // One slice.  NEXT: slice c+1 exists (registers -> other stage, read its first fragments);
-  // PRE: slice c+2 exists (fetch it).  The K loop is peeled so that no MFMA sits in a conditional arm.
-  auto slice = [&](int c, auto NEXT, auto PRE) {
-    constexpr bool next = decltype(NEXT)::value, pre = decltype(PRE)::value;
-    const int cur = c & 1, nxt = cur ^ 1;
-    ODT_FENCE();
-    // group 0: fragments of group 1 behind it
-    ODT_MF(2, 0, 0); ODT_FENCE();
-    ODT_MF(1, 0, 0); ODT_MF(0, 0, 0); ODT_FENCE();
-    rdB(cur, 0, 1); ODT_FENCE();
-    ODT_MF(1, 1, 0); ODT_MF(0, 1, 0); ODT_FENCE();
-    rdB(cur, 1, 1); ODT_FENCE();
-    ODT_MF(0, 2, 0); ODT_FENCE();
-    rdB(cur, 2, 1); ODT_FENCE();
-    // group 1: A of slice c+1 -> LDS
-    ODT_MF(2, 0, 1); ODT_FENCE();
-    if constexpr (next) store_a(nxt, 0);
-    ODT_FENCE();
-    ODT_MF(1, 0, 1); ODT_MF(0, 0, 1); ODT_FENCE();
-    rdB(cur, 0, 2); ODT_FENCE();
-    ODT_MF(1, 1, 1); ODT_FENCE();
-    if constexpr (next) store_a(nxt, 1);
-    ODT_FENCE();
-    ODT_MF(0, 1, 1); ODT_FENCE();
-    rdB(cur, 1, 2);
-    // the A registers are free again: fetch the activations of slice c+2 right away (they come from
-    // HBM; the lead over their use in group 1 of the next slice is what covers the round trip)
-    if constexpr (pre) { load_a(0); load_a(1); advance_a(); }
-    ODT_FENCE();
-    ODT_MF(0, 2, 1); ODT_FENCE();
-    rdB(cur, 2, 2); ODT_FENCE();
-    // group 2: weights of slice c+1 -> LDS, then the weight prefetch of slice c+2 (L2 hits)
-    ODT_MF(2, 0, 2); ODT_FENCE();
-    if constexpr (next) { store_b(nxt, 0); store_b(nxt, 1); }
-    ODT_FENCE();
-    ODT_MF(1, 0, 2); ODT_FENCE();
-    if constexpr (next) { store_b(nxt, 2); store_b(nxt, 3); }
-    ODT_FENCE();
-    ODT_MF(0, 0, 2); ODT_FENCE();
-    rdB(cur, 0, 3);
-    if constexpr (next) { store_b(nxt, 4); store_b(nxt, 5); }
-    ODT_FENCE();
-    ODT_MF(1, 1, 2); ODT_FENCE();
-    if constexpr (pre) { load_b(0); load_b(1); }
-    ODT_FENCE();
-    ODT_MF(0, 1, 2); ODT_FENCE();
-    rdB(cur, 1, 3);
-    if constexpr (pre) { load_b(2); load_b(3); }
-    ODT_FENCE();
-    ODT_MF(0, 2, 2); ODT_FENCE();
-    rdB(cur, 2, 3);
-    if constexpr (pre) { load_b(4); load_b(5); advance_b(); }
-    ODT_FENCE();
-    __syncthreads();          // stage nxt is complete; nobody reads stage cur any more
-    ODT_FENCE();
-    // group 3 (operands in registers): first fragments of slice c+1 behind it
-    ODT_MF(2, 0, 3); ODT_FENCE();
-    if constexpr (next) rdA(nxt, 2);
-    ODT_FENCE();
-    ODT_MF(1, 0, 3); ODT_MF(0, 0, 3); ODT_FENCE();
-    if constexpr (next) rdB(nxt, 0, 0);
-    ODT_FENCE();
-    ODT_MF(1, 1, 3); ODT_FENCE();
-    if constexpr (next) rdA(nxt, 1);
-    ODT_FENCE();
-    ODT_MF(0, 1, 3); ODT_FENCE();
-    if constexpr (next) rdB(nxt, 1, 0);
-    ODT_FENCE();
-    ODT_MF(0, 2, 3); ODT_FENCE();
-    if constexpr (next) { rdA(nxt, 0); rdB(nxt, 2, 0); }
-    ODT_FENCE();
-  };
-  {
-    int c = 0;
-    for (; c + 2 < nslices; ++c) slice(c, std::true_type{}, std::true_type{});
-    if (c + 1 < nslices) { slice(c, std::true_type{}, std::false_type{}); ++c; }
-    slice(c, std::false_type{}, std::false_type{});
-  }
-#undef ODT_MF
-#undef ODT_FENCE
-  __syncthreads();
-
-  // ---- epilogue: as conv_split_kernel<2,2,4>
-  constexpr int CS = SBN + 4, RP = 64, NCH = 16;
-  static_assert(RP * CS * 4 <= 2 * STAGE, "C tile pass must fit");
-  float* Ct = reinterpret_cast<float*>(lds);
-  const bool dense_io = p.out_oy == 0 && p.out_ox == 0 && p.out_H == p.Ho && p.out_W == p.Wo;
-  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.out, 0, (int)((unsigned)p.B * p.out_H * p.out_W * p.out_ldc * 4u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_bias =
-      __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (int)((unsigned)p.Cout * 4u), 0x00020000);
-  const int c4 = tid & 63, row0 = tid >> 6;
-  const int col = n0 + c4 * 4;
-  const f32x4 bias4 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, col * 4, 0, 0);
-  auto run = [&](auto act_c) {
-    constexpr int ACT = decltype(act_c)::value;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      if (pass > 0) __syncthreads();
-      if (wm == pass) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              Ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * CS + wn * 128 + j * 32 + fr] = acc[i][j][r];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int s2 = 0; s2 < NCH; ++s2) {
-        const int rl = row0 + s2 * 4;
-        const int m = m0 + pass * RP + rl;
-        const bool ok = m < M;
-        unsigned opix;
-        if (dense_io) {
-          opix = (unsigned)m;
-        } else {
-          const int mm = ok ? m : 0;
-          const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), rr = mm - n * HoWo;
-          const int ho = sfast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
-          opix = ((unsigned)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
-        }
-        const unsigned ooff = ok ? (opix * p.out_ldc + col) * 4u : kOOB;
-        f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[rl * CS + c4 * 4]);
-        v += bias4;
-        if (ACT == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (ACT == 2) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f / (1.0f + expf(-v[e])));
-        } else if (ACT == 3) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
-        }
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)ooff, 0, 0);
-      }
-    }
-  };
-  if (p.relu == 1) run(std::integral_constant<int, 1>{});
-  else if (p.relu == 2) run(std::integral_constant<int, 2>{});
-  else if (p.relu == 3) run(std::integral_constant<int, 3>{});
-  else run(std::integral_constant<int, 0>{});
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // conv_split3_kernel: the round-2 loop structure.  Same arithmetic (bf16x3, six piece products), but
 //   * 8 waves / 512 threads, ONE workgroup per CU, 256-row tiles: a weight stage is fetched once per 256
@@ -1254,7 +915,7 @@ struct Split3kCfg {
   static_assert(LDS <= 160 * 1024, "LDS");
 };
 
-template <int TN, bool TRACE = false, bool KWR_LATE = true>
+template <int TN, bool TRACE = false>
 __global__ void __launch_bounds__(512, 2) conv_split3k_kernel(const ConvParams* __restrict__ pp) {
   using G = Split3kCfg<TN>;
   constexpr int WM = 4, WN = 2, KW = 3;
@@ -1471,16 +1132,11 @@ __global__ void __launch_bounds__(512, 2) conv_split3k_kernel(const ConvParams* 
       ODT_MF(2, 0, j); ODT_FENCE();
       if (last) { if constexpr (next) rdA(2); }
       else if constexpr (gn) {
-        // the next group's run: registers -> LDS.  LATE (default): all of it in the group's third stage, two stages
-        // behind the fetch (the P2-level runs come from HBM / MALL: one stage of lead left the split waiting)
-        if constexpr (KWR_LATE) {
-          if constexpr (KWI == 2) {
-            if (TN > 2) { if (j < 3) store_slot(a_nxt, j); }
-            else if (first) { store_slot(a_nxt, 0); store_slot(a_nxt, 1); store_slot(a_nxt, 2); }
-          }
-        } else if (first) {
-          if constexpr (KWI == 1) { store_slot(a_nxt, 0); store_slot(a_nxt, 1); }
-          if constexpr (KWI == 2) store_slot(a_nxt, 2);
+        // the next group's run: registers -> LDS, all of it in the group's third stage, two stages behind the fetch
+        // (the P2-level runs come from HBM / MALL: one stage of lead left the split waiting)
+        if constexpr (KWI == 2) {
+          if (TN > 2) { if (j < 3) store_slot(a_nxt, j); }
+          else if (first) { store_slot(a_nxt, 0); store_slot(a_nxt, 1); store_slot(a_nxt, 2); }
         }
       }
       ODT_FENCE();
@@ -1633,7 +1289,7 @@ ConvPolicy conv_policy_default() {
   q.min_tiles = 256;      // one- / two-stage kernels: A/B at b=8 and b=1: 256 > 384 > 128 >> 64
   q.min_tiles3 = 200;
   q.min_k = 64;           // A/B at b=8: K >= 256: 155.0, >= 128: 156.2, >= 64: 156.6 FPS
-  q.min_bn = 0; q.force_bm3 = 0; q.short_k = 0; q.short_k2 = 0; q.splitk_max = 8; q.force_splitk = 0; q.kw_reuse = true; q.kwr_n64 = true; q.src2 = true; q.res2 = true; q.env_overrides = 0;
+  q.min_bn = 0; q.force_bm3 = 0; q.splitk_max = 8; q.force_splitk = 0; q.kw_reuse = true; q.kwr_n64 = true; q.src2 = true; q.res2 = true; q.env_overrides = 0;
   return q;
 }
 
@@ -1644,14 +1300,12 @@ ConvPolicy conv_policy_from_env(ConvPolicy q) {
   };
   long v;
   v = q.arith; geti("ODT_CONV_SPLIT", &v); q.arith = v != 0 ? 1 : 0;
-  v = q.family; geti("ODT_CONV_SPLIT_PIPE", &v); q.family = v < 1 ? 1 : (v > 3 ? 3 : (int)v);
+  v = q.family; geti("ODT_CONV_SPLIT_PIPE", &v); q.family = v >= 3 ? 3 : 1;
   geti("ODT_CONV_SPLIT_MINTILES", &q.min_tiles);
   geti("ODT_CONV_SPLIT3_MINTILES", &q.min_tiles3);
   v = q.min_k; geti("ODT_CONV_SPLIT_MINK", &v); q.min_k = (int)v;
   v = q.min_bn; geti("ODT_CONV_SPLIT_MINBN", &v); q.min_bn = (int)v;
   v = q.force_bm3; geti("ODT_CONV_SPLIT3_BM", &v); q.force_bm3 = (int)v;
-  v = q.short_k; geti("ODT_CONV_SPLIT3_SHORTK", &v); q.short_k = (int)v;
-  v = q.short_k2; geti("ODT_CONV_SPLIT2_SHORTK", &v); q.short_k2 = (int)v;
   v = q.splitk_max; geti("ODT_CONV_SPLIT3_SPLITK", &v); q.splitk_max = v < 1 ? 1 : (v > 16 ? 16 : (int)v);
   v = 1; geti("ODT_CONV_SPLIT3_KWR", &v); q.kw_reuse = v != 0;
   v = q.kwr_n64; geti("ODT_CONV_SPLIT3_KWR_N64", &v); q.kwr_n64 = v != 0;
@@ -1711,23 +1365,12 @@ bool conv_split_wanted(const ConvParams& p, const ConvPolicy& q) {
 }
 
 // which kernel family takes a conv that conv_split_wanted() accepted: family 1 = one-stage BK = 32 kernel everywhere,
-// 2 = two-stage 128 x 256 kernel where it exists, 3 (default) = conv_split3_kernel where its tiles fill the chip
+// 3 (default) = conv_split3_kernel where its tiles fill the chip (the one-stage kernel keeps the 64-wide layers)
 void conv_split_choose(ConvParams& p, const ConvPolicy& q) {
   const int bn = conv_split_bn(p.Cout);
   const long M = (long)p.B * p.Ho * p.Wo;
   p.wt_split_kind = 1; p.wt_split_bm = conv_split_bm(p.Cout); p.wt_split_bn = bn; p.splitk = 1; p.wt_split_kwr = 0;
   const int K = p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0);
-  if (q.family >= 3 && q.short_k > 0 && K <= q.short_k && p.Cout % 128 == 0 && p.Cout >= 512 && p.kh * p.kw <= 32 &&
-      ((M + 127) / 128) * (p.Cout / 128) >= 2 * q.min_tiles3) {
-    p.wt_split_kind = 3; p.wt_split_bm = 128; p.wt_split_bn = 128;
-    return;
-  }
-  // A/B knob (off): short reductions on 256-wide tiles through the two-stage 128 x 256 kernel, two workgroups per CU.
-  // Same-box result (profiles/r02_shortk_persistent_stagger_ab.txt): res4 conv3 5.17 -> 4.94 ms, res2 conv3 slower, +-0 overall.
-  if (q.family >= 2 && q.short_k2 > 0 && K <= q.short_k2 && bn == 256 && ((M + 127) / 128) * (cout_padded(p.Cout) / 256) >= 2 * q.min_tiles3) {
-    p.wt_split_kind = 2; p.wt_split_bm = 128;
-    return;
-  }
   int b3, n3, k3;
   if (split3_fit(p, q, &b3, &n3, &k3)) {
     p.wt_split_kind = 3; p.wt_split_bm = b3; p.wt_split_bn = n3; p.splitk = k3;
@@ -1736,7 +1379,6 @@ void conv_split_choose(ConvParams& p, const ConvPolicy& q) {
                       p.in2 == nullptr && 2 * p.dil <= 4 && p.Ho * p.Wo >= 256 && p.kh * 3 <= 30) ? 1 : 0;
     return;
   }
-  if (q.family >= 2 && bn == 256) { p.wt_split_kind = 2; p.wt_split_bm = 128; }
 }
 
 size_t conv_split_partial_bytes(const ConvParams& p) {
@@ -1762,7 +1404,7 @@ int conv_make_split_weights(const ConvParams& p, void* img_dev, hipStream_t stre
   ODT_CHECK(kscale == nullptr || (p.kh == 1 && p.kw == 1 && p.in2 == nullptr), "conv_make_split_weights: a folded gate belongs to a single-source 1x1 conv");
   const int bn = p.wt_split_bn != 0 ? p.wt_split_bn : conv_split_bn(p.Cout);
   const int K = p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0);
-  ODT_CHECK(bn != 0 && K % 32 == 0 && p.wt_split_kind >= 1 && p.wt_split_kind <= 3,
+  ODT_CHECK(bn != 0 && K % 32 == 0 && (p.wt_split_kind == 1 || p.wt_split_kind == 3),
             "conv_make_split_weights: Cout % 64 == 0, K % 32 == 0 and a chosen kernel family required");
   if (p.wt_split_kind == 3) {
     const long total = (long)cout_padded(p.Cout) * (K >> 4) * 2;
@@ -1771,7 +1413,7 @@ int conv_make_split_weights(const ConvParams& p, void* img_dev, hipStream_t stre
   } else {
     const long total = (long)cout_padded(p.Cout) * (K >> 3);
     hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, p.Cout, K,
-                       bn, p.wt_split_kind == 2 ? 16 : 32, (unsigned short*)img_dev, kscale);
+                       bn, 32, (unsigned short*)img_dev, kscale);
   }
   ODT_HIP(hipGetLastError());
   return 0;
@@ -1796,14 +1438,11 @@ int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t st
     if (p.wt_split_kwr) {
       ODT_CHECK(bm == 256 && sk == 1 && p.kw == 3 && p.stride == 1 && p.in_Wa == p.Wo && p.in2 == nullptr,
                 "conv split3k: unsupported shape");
-      static const bool early = getenv("ODT_CONV_SPLIT3_KWR_EARLY") != nullptr;     // A/B knob: split + store one stage behind the fetch
       if (bn == 256) {
         if (p.trace != nullptr) hipLaunchKernelGGL((conv_split3k_kernel<4, true>), dim3(grid), dim3(512), 0, stream, dev);
-        else if (early) hipLaunchKernelGGL((conv_split3k_kernel<4, false, false>), dim3(grid), dim3(512), 0, stream, dev);
         else hipLaunchKernelGGL((conv_split3k_kernel<4, false>), dim3(grid), dim3(512), 0, stream, dev);
       } else if (bn == 128) {
         if (p.trace != nullptr) hipLaunchKernelGGL((conv_split3k_kernel<2, true>), dim3(grid), dim3(512), 0, stream, dev);
-        else if (early) hipLaunchKernelGGL((conv_split3k_kernel<2, false, false>), dim3(grid), dim3(512), 0, stream, dev);
         else hipLaunchKernelGGL((conv_split3k_kernel<2, false>), dim3(grid), dim3(512), 0, stream, dev);
       } else {
         hipLaunchKernelGGL((conv_split3k_kernel<1, false>), dim3(grid), dim3(512), 0, stream, dev);
@@ -1825,10 +1464,7 @@ int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t st
   }
   const int bm = conv_split_bm(p.Cout);
   const unsigned grid = (unsigned)(((M + bm - 1) / bm) * (cout_padded(p.Cout) / bn));
-  if (p.wt_split_kind == 2) {
-    ODT_CHECK(bn == 256, "conv split: the 16-wide stage image belongs to the 128 x 256 tile");
-    hipLaunchKernelGGL(conv_split2_kernel, dim3(grid), dim3(256), 0, stream, dev);
-  } else if (p.trace != nullptr) {        // tuning: the stamped instantiations
+  if (p.trace != nullptr) {        // tuning: the stamped instantiations
     if (bn == 256) hipLaunchKernelGGL((conv_split_kernel<2, 2, 4, true>), dim3(grid), dim3(256), 0, stream, dev);
     else if (bn == 128) hipLaunchKernelGGL((conv_split_kernel<4, 1, 4, true>), dim3(grid), dim3(256), 0, stream, dev);
     else hipLaunchKernelGGL((conv_split_kernel<4, 1, 2, true>), dim3(grid), dim3(256), 0, stream, dev);

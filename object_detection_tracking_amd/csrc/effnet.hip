@@ -345,54 +345,6 @@ __global__ void __launch_bounds__(256) bifpn_fuse_kernel(FuseParams p) {
   }
 }
 
-// BiFPN node without the fused tensor: dwconv_kernel<3, 1, PX>'s walk (same thread mapping, same summation order per
-// output), its column loads replaced by the fused value at that pixel (zero outside the image, as the 'SAME' padding of
-// the fused tensor).  A fused value is evaluated once per kernel row that uses it (3 (PX + 2) / PX per output).
-template <int PX>
-__global__ void __launch_bounds__(256) bifpn_fuse_dw_kernel(FuseParams p, const float* __restrict__ dwt, const float* __restrict__ dbias,
-                                                            float* __restrict__ out, int nsplit) {
-  constexpr int K = 3, NC = PX - 1 + K;
-  const int tid = threadIdx.x;
-  const int cq = tid & 15, pg = tid >> 4;
-  const int c4 = blockIdx.x * 16 + cq, c4n = p.ldc >> 2;
-  if (c4 >= c4n) return;
-  const int sp = blockIdx.y, b = blockIdx.z;
-  const int nxb = (p.w + PX - 1) / PX, units = nxb * p.h;
-  const int per = (units + nsplit - 1) / nsplit;
-  const int lo = sp * per, hi = lo + per < units ? lo + per : units;
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  const f32x4 bias = *reinterpret_cast<const f32x4*>(dbias + c4 * 4);
-  for (int u = lo + pg; u < hi; u += 16) {
-    const int yo = u / nxb, xb = u - yo * nxb;
-    const int xo0 = xb * PX, x0 = xo0 - 1;
-    f32x4 acc[PX];
-#pragma unroll
-    for (int q = 0; q < PX; ++q) acc[q] = zero;
-#pragma unroll
-    for (int ky = 0; ky < K; ++ky) {
-      const int y = yo + ky - 1;
-      if ((unsigned)y >= (unsigned)p.h) continue;
-      f32x4 col[NC];
-#pragma unroll
-      for (int cidx = 0; cidx < NC; ++cidx) {
-        const int x = x0 + cidx;
-        col[cidx] = (unsigned)x < (unsigned)p.w ? bifpn_fuse_at(p, b, y, x, c4) : zero;
-      }
-#pragma unroll
-      for (int kx = 0; kx < K; ++kx) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(dwt + (long)(ky * K + kx) * p.ldc + c4 * 4);
-#pragma unroll
-        for (int q = 0; q < PX; ++q) acc[q] += col[q + kx] * w;
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < PX; ++q) {
-      const int xo = xo0 + q;
-      if (xo >= p.w) break;
-      *reinterpret_cast<f32x4*>(out + (((long)b * p.h + yo) * p.w + xo) * p.ldc + c4 * 4) = acc[q] + bias;
-    }
-  }
-}
 
 }  // namespace
 
@@ -418,17 +370,6 @@ int launch_bifpn_fuse(const FuseParams& p, hipStream_t stream) {
   return 0;
 }
 
-int launch_bifpn_fuse_dw(const FuseParams& p, const float* dwt, const float* dbias, float* out, hipStream_t stream) {
-  ODT_CHECK(p.n >= 1 && p.n <= 3 && p.ldc % 4 == 0 && dwt && dbias && out, "bifpn_fuse_dw: bad arguments");
-  constexpr int PX = 4;
-  const long units = (long)((p.w + PX - 1) / PX) * p.h;
-  const int cblocks = ((p.ldc >> 2) + 15) / 16;
-  const long cap = std::max<long>(1, 4096 / ((long)cblocks * p.B));
-  const int nsplit = (int)std::max<long>(1, std::min(cap, (units + 15) / 16));
-  hipLaunchKernelGGL((bifpn_fuse_dw_kernel<PX>), dim3(cblocks, nsplit, p.B), dim3(256), 0, stream, p, dwt, dbias, out, nsplit);
-  ODT_HIP(hipGetLastError());
-  return 0;
-}
 
 int launch_preprocess_rgb_resize(const void* frames, int dtype, int B, int Hs, int Ws, int Hr, int Wr, int pad_t,
                                  int pad_l, int Hp, int Wp, float* out, hipStream_t stream) {

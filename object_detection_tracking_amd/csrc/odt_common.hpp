@@ -66,8 +66,8 @@ struct ConvParams {
   // optional bf16-piece image of `wt` (conv_make_split_weights): the layer runs on the bf16x3
   // split kernel (conv_split.hip: f32 result through six exact bf16 MFMA products per MAC)
   const void* wt_split;
-  int wt_split_kind;   // which kernel family the image was laid out for: 1 one-stage BK = 32 (conv_split_kernel) |
-                       // 2 two-stage BK = 16, 128 x 256 (conv_split2_kernel) | 3 conv_split3_kernel (8 waves, LDS-DMA)
+  int wt_split_kind;   // which kernel family the image was laid out for: 1 one-stage BK = 32 (conv_split_kernel, the 64-wide
+                       // layers) | 3 conv_split3_kernel / conv_split3k_kernel (8 waves, LDS-DMA weight stages)
   int wt_split_bm;     // kind 3: rows of the block tile (256, or 128 when 256-row tiles would not fill the chip)
   int wt_split_bn;     // n-tile width the image was laid out for (kind 3 may use 128 on wider layers; 0: conv_split_bn(Cout))
   // split-K (conv_split3_kernel only): the reduction is cut into `splitk` contiguous ranges of stages, one workgroup per
@@ -95,7 +95,7 @@ double conv_flops(const ConvParams& p);   // algorithmic 2*M*N*K
 // resolve it per call.
 struct ConvPolicy {
   int arith;            // 0 exact-f32 MFMA everywhere | 1 bf16x3 split kernels where they pay
-  int family;           // newest split kernel family allowed: 1 one-stage | 2 two-stage 128 x 256 | 3 conv_split3_kernel
+  int family;           // newest split kernel family allowed: 1 one-stage only | 3 conv_split3_kernel where it fits (default)
   long min_tiles;       // tiles a layer must offer the one- / two-stage kernels (256)
   long min_tiles3;      // ... conv_split3_kernel's 256- / 128-row tiles (200)
   int min_k, min_bn;    // shortest reduction / narrowest n-tile taken
@@ -104,9 +104,6 @@ struct ConvPolicy {
   bool kw_reuse;        // conv_split3k_kernel for the stride-1 KH x 3 layers it fits (ODT_CONV_SPLIT3_KWR=0: off)
   bool kwr_n64;         // ... also for 64-wide layers (256 x 64 tile, wave tile 64 x 32)
   int force_splitk;     // 0 auto | k: force that split-K factor wherever conv_split3_kernel runs (tests)
-  int short_k2;         // reductions up to this length on 256-wide layers run the two-stage 128 x 256 kernel (two workgroups per CU)
-  int short_k;          // conv_split3_kernel: reductions up to this length on >= 512-wide layers run 128 x 128 tiles, two
-                        // workgroups per CU (one's prologue / store tail under the other's main loop); 0 = off
   bool src2, res2;      // take the K-concatenated stage-entry convs / the 2x-upsampled-residual FPN laterals
   int env_overrides;    // how many ODT_CONV_* variables were applied (recorded by odt_describe)
 };
@@ -164,9 +161,6 @@ struct FuseParams {
   float* out;
 };
 int launch_bifpn_fuse(const FuseParams& p, hipStream_t stream);
-// BiFPN node in one kernel: the fused value (FuseParams, `out` unused) is evaluated where the 3x3 stride-1 'SAME'
-// depthwise conv behind it needs it -- no fused tensor in memory.  dwt [9][ldc], dbias [ldc], out [B,h,w,ldc]
-int launch_bifpn_fuse_dw(const FuseParams& p, const float* dwt, const float* dbias, float* out, hipStream_t stream);
 int launch_preprocess_rgb(const void* frames, int dtype, int B, int H, int W, int pad_t, int pad_l, int Hp, int Wp,
                           float* out, hipStream_t stream);
 int channel_mean_splits(int HW, int ldc, int B);

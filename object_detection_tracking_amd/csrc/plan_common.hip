@@ -1,0 +1,383 @@
+// Plan-building helpers shared by the FPN detector plan (plan_fpn.hip) and the EfficientDet plan (plan_effdet.hip):
+// tensors (dedicated or arena-planned), weight upload with BN folding, conv ops, bf16x3 weight images, the RPN-head
+// fusion and the activation arena.
+#include "odt_model.hpp"
+
+#define g_err (::odt::last_error())
+
+namespace odt {
+
+int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+int make_tensor(odt_model* m, const std::string& name, int B, int H, int W, int C, Tensor* t, bool zero) {
+  t->B = B; t->H = H; t->W = W; t->C = C; t->h = H; t->w = W; t->c = C;
+  if (m->arena_on && !zero) {
+    // (zero == true means "regions the kernels never write must read as zero": such a tensor cannot share memory)
+    odt_model::VTensor v;
+    v.bytes = (t->elems() * sizeof(float) + 255) & ~(size_t)255;
+    v.voff = m->vnext;
+    m->vnext += v.bytes;
+    m->vt.push_back(v);
+    m->virtual_tensor_bytes += v.bytes;
+    t->d = reinterpret_cast<float*>(odt_model::kVirtBase + v.voff);
+    if (!name.empty()) m->taps[name] = *t;
+    return 0;
+  }
+  t->d = m->alloc_f(t->elems(), zero);
+  ODT_CHECK(t->d != nullptr, "device allocation failed for " + name + ": " + g_err);
+  m->dedicated_tensor_bytes += t->elems() * sizeof(float);
+  if (!name.empty()) m->taps[name] = *t;
+  return 0;
+}
+
+const HostTensor* find_w(odt_model* m, const std::string& name) {
+  auto it = m->host_w.find(name);
+  return it == m->host_w.end() ? nullptr : &it->second;
+}
+
+// Upload conv weights in [Cout][kh][kw][Cin] with optional folded BN; returns device ptrs.
+int upload_conv(odt_model* m, const std::string& scope, int kh, int kw, int cin, int cout,
+                bool has_bn, const float** wt_out, const float** bias_out) {
+  const HostTensor* W = find_w(m, scope + "/W");
+  ODT_CHECK(W != nullptr, "missing weight " + scope + "/W");
+  ODT_CHECK(W->data.size() == (size_t)kh * kw * cin * cout,
+            "bad shape for " + scope + "/W");
+  std::vector<double> scale(cout, 1.0), shift(cout, 0.0);
+  if (has_bn) {
+    const HostTensor* g = find_w(m, scope + "/bn/gamma");
+    const HostTensor* b = find_w(m, scope + "/bn/beta");
+    const HostTensor* mu = find_w(m, scope + "/bn/mean/EMA");
+    const HostTensor* var = find_w(m, scope + "/bn/variance/EMA");
+    ODT_CHECK(g && b && mu && var, "missing BN variables for " + scope);
+    for (int o = 0; o < cout; ++o) {   // tf.nn.batch_normalization, eps 1e-5 (nn.py:1771-1774)
+      const double inv = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
+      scale[o] = inv;
+      shift[o] = (double)b->data[o] - (double)mu->data[o] * inv;
+    }
+  } else {
+    const HostTensor* b = find_w(m, scope + "/b");
+    ODT_CHECK(b != nullptr, "missing bias " + scope + "/b");
+    for (int o = 0; o < cout; ++o) shift[o] = b->data[o];
+  }
+  std::vector<float> wt((size_t)cout * kh * kw * cin), bias(cout);
+  for (int y = 0; y < kh; ++y)
+    for (int x = 0; x < kw; ++x)
+      for (int i = 0; i < cin; ++i)
+        for (int o = 0; o < cout; ++o)
+          wt[(((size_t)o * kh + y) * kw + x) * cin + i] =
+              (float)((double)W->data[(((size_t)y * kw + x) * cin + i) * cout + o] * scale[o]);
+  for (int o = 0; o < cout; ++o) bias[o] = (float)shift[o];
+  float* dw = m->alloc_f(wt.size(), false);
+  float* db = m->alloc_f(bias.size(), false);
+  ODT_CHECK(dw && db, "device allocation failed for weights of " + scope);
+  ODT_HIP(hipMemcpy(dw, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+  ODT_HIP(hipMemcpy(db, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+  *wt_out = dw; *bias_out = db;
+  return 0;
+}
+
+// conv3 + convshortcut of a stage-entry bottleneck as ONE 1x1 conv over the K-concatenated input
+// [t2 | x]: weights [cout][cin_a + cin_b] with each part's BN folded in, bias = shift_a + shift_b
+// (reference nn.py:503-521: conv3 -> BN, shortcut conv -> BN, add, ReLU).
+int upload_conv_cat(odt_model* m, const std::string& sa, int cin_a, const std::string& sb, int cin_b, int cout,
+                    const float** wt_out, const float** bias_out) {
+  std::vector<float> wt((size_t)cout * (cin_a + cin_b));
+  std::vector<double> shift(cout, 0.0);
+  const std::string scopes[2] = {sa, sb};
+  const int cins[2] = {cin_a, cin_b};
+  int koff = 0;
+  for (int part = 0; part < 2; ++part) {
+    const std::string& scope = scopes[part];
+    const int cin = cins[part];
+    const HostTensor* W = find_w(m, scope + "/W");
+    const HostTensor* g = find_w(m, scope + "/bn/gamma");
+    const HostTensor* b = find_w(m, scope + "/bn/beta");
+    const HostTensor* mu = find_w(m, scope + "/bn/mean/EMA");
+    const HostTensor* var = find_w(m, scope + "/bn/variance/EMA");
+    ODT_CHECK(W && g && b && mu && var, "missing variables for " + scope);
+    ODT_CHECK(W->data.size() == (size_t)cin * cout, "bad shape for " + scope + "/W");
+    for (int o = 0; o < cout; ++o) {
+      const double inv = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
+      shift[o] += (double)b->data[o] - (double)mu->data[o] * inv;
+      for (int i = 0; i < cin; ++i)
+        wt[(size_t)o * (cin_a + cin_b) + koff + i] = (float)((double)W->data[(size_t)i * cout + o] * inv);
+    }
+    koff += cin;
+  }
+  std::vector<float> bias(cout);
+  for (int o = 0; o < cout; ++o) bias[o] = (float)shift[o];
+  float* dw = m->alloc_f(wt.size(), false);
+  float* db = m->alloc_f(bias.size(), false);
+  ODT_CHECK(dw && db, "device allocation failed for weights of " + sa);
+  ODT_HIP(hipMemcpy(dw, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+  ODT_HIP(hipMemcpy(db, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+  *wt_out = dw; *bias_out = db;
+  return 0;
+}
+
+int upload_raw(odt_model* m, const std::vector<float>& v, const float** out) {
+  float* d = m->alloc_f(v.size(), false);
+  ODT_CHECK(d != nullptr, "device allocation failed");
+  ODT_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+  *out = d;
+  return 0;
+}
+
+// Append a conv op.  `in` logical dims (h,w) bound the reads; output tensor is created here
+// unless `out_existing` is given.
+int add_conv(odt_model* m, const std::string& name, const Tensor& in, int cin, const float* wt,
+             const float* bias, int kh, int kw, int cout, int stride, int dil, int pad_t, int pad_l,
+             int Ho, int Wo, int oy, int ox, const Tensor* res, int res_mode, bool relu,
+             int out_ldc, Tensor* out, const std::string& tap) {
+  ConvOp c;
+  c.name = name;
+  ConvParams& p = c.p;
+  std::memset(&p, 0, sizeof(p));
+  if (out->d == nullptr) {
+    if (make_tensor(m, tap, in.B, Ho + oy, Wo + ox, out_ldc, out, oy != 0 || ox != 0 || out_ldc != cout))
+      return 1;
+    out->c = cout;
+  }
+  p.in = in.d; p.wt = wt; p.bias = bias; p.out = out->d;
+  p.res = res ? res->d : nullptr;
+  p.B = in.B; p.H = in.h; p.W = in.w; p.Cin = cin; p.in_ldc = in.C;
+  p.in_Ha = in.H; p.in_Wa = in.W;   // sliced views keep the allocation pitch
+  p.Ho = Ho; p.Wo = Wo; p.Cout = cout;
+  p.kh = kh; p.kw = kw; p.stride = stride; p.dil = dil; p.pad_t = pad_t; p.pad_l = pad_l;
+  p.out_H = out->H; p.out_W = out->W; p.out_oy = oy; p.out_ox = ox; p.out_ldc = out->C;
+  p.res_mode = res ? res_mode : 0;
+  if (res) { p.res_H = res->H; p.res_W = res->W; p.res_ldc = res->C; }
+  p.relu = relu ? 1 : 0;
+  conv_prepare(p);
+  m->convs.push_back(c);
+  Op op;
+  op.kind = OP_CONV;
+  op.conv = (int)m->convs.size() - 1;
+  m->ops.push_back(op);
+  return 0;
+}
+
+
+// A handle's side streams (tail, H2D, D2H) are created with the highest stream priority.  Not for the arbitration: the
+// runtime multiplexes all streams of ONE priority onto a few hardware queues in creation order, and a side stream that
+// lands on the main stream's queue is serialised behind the forward it is meant to overlap (seen with the tracker's
+// stream: tools/experiments/track_stream_collision.py); streams of another priority get queues of their own.
+// ODT_SIDE_STREAM_PRIORITY=0: plain streams (A/B).
+int create_side_stream(hipStream_t* s) {
+  static const bool flat = getenv("ODT_SIDE_STREAM_PRIORITY") != nullptr && getenv("ODT_SIDE_STREAM_PRIORITY")[0] == '0';
+  if (flat) { ODT_HIP(hipStreamCreate(s)); return 0; }
+  int least = 0, greatest = 0;
+  ODT_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  ODT_HIP(hipStreamCreateWithPriority(s, hipStreamDefault, greatest));
+  return 0;
+}
+
+// bf16-piece weight images (conv_split.hip) for the plan's convs that the split kernel takes
+int attach_split_weights(odt_model* m) {
+  // the handle's conv policy: odt_config first, ODT_CONV_* debug overrides on top (read once, here)
+  ConvPolicy pol = conv_policy_default();
+  if (m->cfg.conv_arith == ODT_ARITH_F32) pol.arith = 0;
+  else if (m->cfg.conv_arith == ODT_ARITH_BF16X3) pol.arith = 1;
+  if (m->cfg.conv_split_family >= 1 && m->cfg.conv_split_family <= 3) pol.family = m->cfg.conv_split_family >= 3 ? 3 : 1;
+  pol = conv_policy_from_env(pol);
+  m->policy = pol;
+  if (pol.arith == 0) return 0;
+  std::map<const float*, const void*> made;      // the RPN conv is shared by the five levels
+  std::map<const float*, int> made_kind;
+  size_t need_partial = 0;                        // split-K scratch: one buffer, the plan's layers run one after another
+  for (ConvOp& c : m->convs) {
+    if (!conv_split_wanted(c.p, pol)) continue;
+    auto it = made.find(c.p.wt);
+    if (it == made.end()) {
+      const int K = c.p.kh * c.p.kw * c.p.Cin + (c.p.in2 != nullptr ? c.p.Cin2 : 0);
+      float* img = m->alloc_f((conv_split_weight_bytes(c.p.Cout, K) + 3) / 4, false);
+      ODT_CHECK(img != nullptr, "device allocation failed (split weights of " + c.name + ")");
+      conv_split_choose(c.p, pol);
+      if (conv_make_split_weights(c.p, img, 0)) return 1;
+      it = made.emplace(c.p.wt, img).first;
+      made_kind[c.p.wt] = c.p.wt_split_kind + 16 * c.p.wt_split_bn;
+    }
+    conv_split_choose(c.p, pol);
+    // shared weights (the RPN conv over five levels): one image, so one kernel family -- the first (largest) level's
+    if (c.p.wt_split_kind + 16 * c.p.wt_split_bn != made_kind[c.p.wt]) {
+      // (the image depends on the kernel family and the n-tile width only: tile height and split-K stay this level's)
+      const int kind = made_kind[c.p.wt] % 16, bn = made_kind[c.p.wt] / 16;
+      ODT_CHECK(kind != 3 || c.p.Cin % 16 == 0, "split weights: shared image of an unsupported layout");
+      if (c.p.wt_split_kind != kind) {
+        c.p.splitk = 1;
+        if (kind == 3) c.p.wt_split_bm = bn >= 128 ? 128 : 256;
+        else c.p.wt_split_bm = conv_split_bm(c.p.Cout);
+      }
+      c.p.wt_split_kind = kind; c.p.wt_split_bn = bn;
+    }
+    need_partial = std::max(need_partial, conv_split_partial_bytes(c.p));
+    c.p.wt_split = it->second;
+  }
+  if (need_partial > 0) {
+    // split-K scratch: the layers of one stream run one after another and share a buffer -- but the tail ops (box-head
+    // FCs ...) of forward i run on the side stream UNDER the trunk of forward i+1 (tail overlap), so the two groups get
+    // a buffer each
+    std::vector<char> in_tail(m->convs.size(), 0);
+    bool tail = false;
+    for (const Op& op : m->ops) {
+      if (op.kind == OP_PROPOSALS) tail = true;
+      if (op.kind == OP_CONV && tail) in_tail[op.conv] = 1;
+    }
+    size_t need[2] = {0, 0};
+    for (size_t i = 0; i < m->convs.size(); ++i)
+      need[in_tail[i]] = std::max(need[in_tail[i]], conv_split_partial_bytes(m->convs[i].p));
+    float* part[2] = {nullptr, nullptr};
+    for (int g = 0; g < 2; ++g) {
+      if (need[g] == 0) continue;
+      part[g] = m->alloc_f((need[g] + 3) / 4, false);
+      ODT_CHECK(part[g] != nullptr, "device allocation failed (split-K partial sums)");
+    }
+    for (size_t i = 0; i < m->convs.size(); ++i)
+      if (conv_split_partial_bytes(m->convs[i].p) > 0) m->convs[i].p.partial = part[in_tail[i]];
+  }
+  ODT_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
+
+// ---- RPN head folded into the RPN conv's epilogue --------------------------------------------------------------------
+// rpn/conv0@pL (3x3, 256 -> 256, ReLU) is followed by rpn/head@pL (1x1, 256 -> 3 logits || 12 deltas) and nothing else
+// reads its output (models.py:979-1009).  Where the 3x3 conv runs on a conv_split3 kernel whose n-tile is the whole
+// Cout (256) and has no split-K, the head is evaluated on the staged C tile in that kernel's epilogue (exact-f32 MFMA):
+// the [M,256] tensor is neither written nor read back (2.1 GB at P2, b = 8) and the N = 15 launch disappears.
+// ODT_FUSE_RPN_HEAD=0 keeps the two launches (A/B).  Called after attach_split_weights, before plan_arena.
+int fuse_rpn_heads(odt_model* m) {
+  m->conv_fused.assign(m->convs.size(), 0);
+  const char* e = getenv("ODT_FUSE_RPN_HEAD");
+  if (e != nullptr && e[0] == '0') return 0;
+  const HostTensor* W = find_w(m, "__rpnhead/W");
+  const HostTensor* Bv = find_w(m, "__rpnhead/b");
+  if (W == nullptr || Bv == nullptr) return 0;
+  const float *hw = nullptr, *hb = nullptr;
+  for (size_t oi = 0; oi + 1 < m->ops.size(); ++oi) {
+    Op& oa = m->ops[oi]; Op& ob = m->ops[oi + 1];
+    if (oa.kind != OP_CONV || ob.kind != OP_CONV) continue;
+    ConvOp& a = m->convs[oa.conv]; ConvOp& b = m->convs[ob.conv];
+    if (a.name.compare(0, 10, "rpn/conv0@") != 0 || b.name.compare(0, 9, "rpn/head@") != 0) continue;
+    const ConvParams& bp = b.p;
+    ConvParams& ap = a.p;
+    const bool ok = ap.wt_split != nullptr && ap.wt_split_kind == 3 && ap.wt_split_bn == 256 && ap.Cout == 256 && ap.splitk <= 1 &&
+                    ap.res_mode == 0 && ap.in2 == nullptr && ap.relu <= 1 && bp.in == ap.out && bp.kh == 1 && bp.kw == 1 &&
+                    bp.Cin == 256 && bp.Cout == 15 && bp.out_ldc == 16 && bp.stride == 1 && bp.res_mode == 0 && bp.relu == 0 &&
+                    bp.out_oy == 0 && bp.out_ox == 0 && bp.out_H == bp.Ho && bp.out_W == bp.Wo && bp.Ho == ap.Ho && bp.Wo == ap.Wo &&
+                    ap.out_oy == 0 && ap.out_ox == 0 && ap.out_H == ap.Ho && ap.out_W == ap.Wo && (int)W->data.size() == 256 * 15;
+    if (!ok) continue;
+    if (hw == nullptr) {
+      std::vector<float> v((size_t)256 * 16, 0.f), vb(16, 0.f);
+      for (int c = 0; c < 256; ++c)
+        for (int j = 0; j < 15; ++j) v[(size_t)c * 16 + j] = W->data[(size_t)c * 15 + j];
+      for (int j = 0; j < 15; ++j) vb[j] = Bv->data[j];
+      if (upload_raw(m, v, &hw) || upload_raw(m, vb, &hb)) return 1;
+    }
+    ap.head_wt = hw; ap.head_bias = hb; ap.head_out = bp.out; ap.head_ldc = bp.out_ldc;
+    ap.out = nullptr;                      // nothing else reads the 256-channel tensor
+    ob.skip = true;
+    m->conv_fused[ob.conv] = 1;
+  }
+  return 0;
+}
+
+// ---- activation arena -----------------------------------------------------------------------------------------------
+// ops [op_tail, end) of forward i (selection / ROIAlign / box head / NMS / features) may run on the side stream under ops
+// [0, op_first_fpn) of forward i+1 (run_plan: tail overlap); 0 / 0 when the graph has no such split
+void find_overlap_points(odt_model* m) {
+  m->op_first_fpn = m->op_tail = 0;
+  if (m->cfg.graph == ODT_GRAPH_EFFNET) return;
+  for (size_t i = 0; i < m->ops.size(); ++i) {
+    if (m->ops[i].kind == OP_PROPOSALS) { m->op_tail = i; break; }
+    if (m->op_first_fpn == 0 && m->ops[i].kind == OP_CONV && m->convs[m->ops[i].conv].name.compare(0, 4, "fpn/") == 0)
+      m->op_first_fpn = i;
+  }
+  if (m->op_tail == 0 || m->op_first_fpn == 0 || m->op_first_fpn >= m->op_tail) m->op_first_fpn = m->op_tail = 0;
+}
+
+// Lay the virtual stage tensors out in (at most) two arenas by live range and rewrite the plan's pointers.
+// Region 1 holds what the tail ops touch (so that forward i's tail and forward i+1's early trunk never share memory);
+// within a region a tensor takes the lowest offset not occupied by a tensor whose [first, last] range intersects its own
+// (largest tensors first).  Called once, before the conv parameter records go to the device.
+int plan_arena(odt_model* m) {
+  if (!m->arena_on || m->vt.empty()) return 0;
+  find_overlap_points(m);
+  const int nops = (int)m->ops.size();
+  for (int oi = 0; oi < nops; ++oi)
+    visit_op_ptrs(m, (size_t)oi, [&](auto& p) {
+      if (p == nullptr || !m->is_virtual((const void*)p)) return;
+      odt_model::VTensor& v = m->vt[m->vt_index((const void*)p)];
+      v.first = std::min(v.first, oi); v.last = std::max(v.last, oi);
+    });
+  const bool split = m->op_tail > 0;
+  std::vector<char> tapped(m->vt.size(), 0);
+  for (const auto& kv : m->taps)
+    if (kv.second.d != nullptr && m->is_virtual(kv.second.d)) tapped[m->vt_index(kv.second.d)] = 1;
+  for (size_t i = 0; i < m->vt.size(); ++i) {
+    auto& v = m->vt[i];
+    if (v.last < 0 && !tapped[i]) { v.bytes = 0; v.first = v.last = 0; }     // no op touches it (its producer was fused away)
+    if (v.last < 0) { v.first = 0; v.last = nops - 1; }          // never referenced by an op (tap only): keep it apart
+    v.region = split && v.last >= (int)m->op_tail ? 1 : 0;
+    if (v.region == 1) v.last = nops - 1;                        // readable after the forward (appearance features / taps of the pyramid)
+  }
+  std::vector<int> order(m->vt.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+  std::sort(order.begin(), order.end(), [&](int a, int b) {
+    return m->vt[a].bytes != m->vt[b].bytes ? m->vt[a].bytes > m->vt[b].bytes : a < b;
+  });
+  std::vector<int> placed;
+  for (int id : order) {
+    odt_model::VTensor& v = m->vt[id];
+    // candidates: offset 0 and the end of every conflicting placed tensor; take the lowest that fits
+    std::vector<std::pair<size_t, size_t>> busy;     // [begin, end) of placed tensors of this region alive at the same time
+    for (int q : placed) {
+      const odt_model::VTensor& u = m->vt[q];
+      if (u.region == v.region && u.first <= v.last && v.first <= u.last) busy.emplace_back(u.off, u.off + u.bytes);
+    }
+    std::sort(busy.begin(), busy.end());
+    size_t off = 0;
+    for (const auto& b : busy) {
+      if (off + v.bytes <= b.first) break;
+      off = std::max(off, b.second);
+    }
+    v.off = off;
+    m->arena_bytes[v.region] = std::max(m->arena_bytes[v.region], off + v.bytes);
+    placed.push_back(id);
+  }
+  for (int r = 0; r < 2; ++r) {
+    if (m->arena_bytes[r] == 0) continue;
+    m->arena[r] = m->alloc_f(m->arena_bytes[r] / sizeof(float), false);
+    ODT_CHECK(m->arena[r] != nullptr, "device allocation failed (activation arena): " + g_err);
+  }
+  auto fix = [&](auto& p) {
+    if (p == nullptr || !m->is_virtual((const void*)p)) return;
+    const odt_model::VTensor& v = m->vt[m->vt_index((const void*)p)];
+    const size_t within = (size_t)((uintptr_t)p - odt_model::kVirtBase) - v.voff;
+    p = reinterpret_cast<std::remove_reference_t<decltype(p)>>(reinterpret_cast<char*>(m->arena[v.region]) + v.off + within);
+  };
+  // taps first (they still hold virtual addresses: remember which of them do not outlive a forward)
+  for (auto& kv : m->taps) {
+    if (kv.second.d != nullptr && m->is_virtual(kv.second.d)) {
+      const odt_model::VTensor& v = m->vt[m->vt_index(kv.second.d)];
+      if (v.region == 0 && !(v.first == 0 && v.last == nops - 1)) m->transient_taps.insert(kv.first);
+    }
+    fix(kv.second.d);
+  }
+  for (size_t oi = 0; oi < m->ops.size(); ++oi) visit_op_ptrs(m, oi, fix);
+  fix(m->image_pad.d);
+  return 0;
+}
+
+// conv parameter records in device memory (the kernels read their ConvParams from there)
+int upload_conv_records(odt_model* m) {
+  std::vector<ConvParams> recs;
+  for (const ConvOp& c : m->convs) recs.push_back(c.p);
+  m->bufs.emplace_back(new DevBuf());
+  if (m->bufs.back()->alloc(recs.size() * sizeof(ConvParams))) return 1;
+  m->convs_dev = (ConvParams*)m->bufs.back()->p;
+  ODT_HIP(hipMemcpy(m->convs_dev, recs.data(), recs.size() * sizeof(ConvParams), hipMemcpyHostToDevice));
+  return 0;
+}
+
+}  // namespace odt

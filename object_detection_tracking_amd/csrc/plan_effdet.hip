@@ -1,5 +1,11 @@
-// EfficientDet plan builder: included by odt_api.hip inside its anonymous namespace (uses the plan
-// helpers defined there: Tensor, Op, odt_model, make_tensor, find_w, upload_raw, add_conv).
+// EfficientDet plan builder (plan helpers: plan_common.hip -- Tensor, Op, odt_model, make_tensor, find_w, upload_raw,
+// add_conv).
+#include "odt_model.hpp"
+
+#define g_err (::odt::last_error())
+
+namespace odt {
+
 // ------------------------------------------------------------------------------------------------
 // EfficientNet backbone plan (EfficientDet path, SURVEY.md 8f rank 3 -- detector half in progress).
 // reference efficientdet/backbone/efficientnet_builder.py:37-53,162-168, efficientnet_model.py:137-159,
@@ -12,14 +18,6 @@ static bool eff_split_on() {        // (read per plan build: tests and A/B runs 
   return !(e != nullptr && e[0] == '0');
 }
 int r32(int c) { return eff_split_on() ? (c + 63) / 64 * 64 : (c + 31) / 32 * 32; }
-// BiFPN nodes: ODT_EFFDET_FUSE_DW=1 evaluates the fusion inside the depthwise kernel (no fused tensor, one launch less).
-// Off: re-evaluating a fused value for each of the 3.75 taps that use it (index arithmetic, weights, swish) costs more than
-// the tensor round trip it saves -- D7 same-box A/B 68.7 -> 51.4 FPS; a version that stages the fused tile in LDS once
-// would be the way.
-static bool eff_fuse_dw_on() {
-  const char* e = getenv("ODT_EFFDET_FUSE_DW");
-  return e != nullptr && e[0] == '1';
-}
 // squeeze-excite gate folded into the projection's weights at batch 1 (ODT_EFFDET_WSCALE=0: a pass over the activations)
 static bool eff_wscale_on() {
   const char* e = getenv("ODT_EFFDET_WSCALE");
@@ -112,9 +110,8 @@ int eff_same(int n, int k, int s, int* before) {
 }
 
 // depthwise 3x3 'same' (no BN, no activation) + pointwise 1x1 (+bias, optional BN fold, activation)
-// (fuse != nullptr: the input is a BiFPN fusion evaluated inside the depthwise kernel; `in` then only carries the shape)
 int eff_sepconv(odt_model* m, const std::string& scope, const std::string& bn_scope, const Tensor& in, int cin,
-                int cout, int act, const std::string& tap, Tensor* out, const FuseParams* fuse = nullptr) {
+                int cout, int act, const std::string& tap, Tensor* out) {
   const int B = in.B, ldc = in.C;
   const HostTensor* Wd = find_w(m, scope + "/depthwise_kernel");
   ODT_CHECK(Wd && Wd->data.size() == (size_t)9 * cin, "missing / bad " + scope + "/depthwise_kernel");
@@ -123,13 +120,12 @@ int eff_sepconv(odt_model* m, const std::string& scope, const std::string& bn_sc
   const float *dwt, *dbias;
   if (upload_raw(m, v, &dwt) || upload_raw(m, bv, &dbias)) return 1;
   Tensor t1{};
-  if (make_tensor(m, "", B, in.h, in.w, ldc, &t1, true)) return 1;
+  if (make_tensor(m, "", B, in.h, in.w, ldc, &t1, false)) return 1;     // (the depthwise kernel writes every channel of the stride)
   {
-    Op op; op.kind = fuse != nullptr ? OP_FUSE_DW : OP_DW;
+    Op op; op.kind = OP_DW;
     op.dw.in = in.d; op.dw.wt = dwt; op.dw.bias = dbias; op.dw.out = t1.d;
     op.dw.B = B; op.dw.H = in.h; op.dw.W = in.w; op.dw.Ho = in.h; op.dw.Wo = in.w; op.dw.ldc = ldc;
     op.dw.k = 3; op.dw.stride = 1; op.dw.pad_t = 1; op.dw.pad_l = 1; op.dw.act = 0;
-    if (fuse != nullptr) op.fuse = *fuse;
     m->ops.push_back(op);
   }
   const float *wt, *bias;
@@ -222,17 +218,11 @@ int build_effdet_heads(odt_model* m, const Tensor* red, const int* red_ch) {
       op.fuse.n = n; op.fuse.act = 2; op.fuse.B = B; op.fuse.h = th; op.fuse.w = tw; op.fuse.ldc = LF;
       const std::string q = p + "op_after_combine" + std::to_string(feats.size()) + "/";
       Tensor node{};
-      if (eff_fuse_dw_on()) {      // the fusion is evaluated inside the depthwise kernel: no fused tensor, one launch less
-        Tensor shape{}; shape.B = B; shape.h = th; shape.w = tw; shape.H = th; shape.W = tw; shape.C = LF; shape.c = F;
-        op.fuse.out = nullptr;
-        if (eff_sepconv(m, q + "conv", q + "bn", shape, F, F, 0, "cell" + std::to_string(rep) + "_fnode" + std::to_string(i), &node, &op.fuse)) return 1;
-      } else {
-        Tensor fused{};
-        if (make_tensor(m, "", B, th, tw, LF, &fused, true)) return 1;
-        op.fuse.out = fused.d;
-        m->ops.push_back(op);
-        if (eff_sepconv(m, q + "conv", q + "bn", fused, F, F, 0, "cell" + std::to_string(rep) + "_fnode" + std::to_string(i), &node)) return 1;
-      }
+      Tensor fused{};
+      if (make_tensor(m, "", B, th, tw, LF, &fused, false)) return 1;     // (the fusion kernel writes every channel of the stride)
+      op.fuse.out = fused.d;
+      m->ops.push_back(op);
+      if (eff_sepconv(m, q + "conv", q + "bn", fused, F, F, 0, "cell" + std::to_string(rep) + "_fnode" + std::to_string(i), &node)) return 1;
       feats.push_back(Feat{node, F});
     }
     // next cell's inputs: the last node of every level (efficientdet_arch.py:676-682)
@@ -467,3 +457,4 @@ int build_plan_effnet(odt_model* m) {
   return 0;
 }
 
+}  // namespace odt

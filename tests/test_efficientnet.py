@@ -195,7 +195,7 @@ def test_efficientdet_d0_end_to_end(backend):
   _det_e2e(lib, "efficientdet-d0", 136, 152 if name == "emu" else 200, topk=300 if name == "emu" else 1000)
 
 
-@pytest.mark.parametrize("mode", ["split_forced", "f32_32ch", "fuse_dw", "gate_pass"])
+@pytest.mark.parametrize("mode", ["split_forced", "f32_32ch", "gate_pass"])
 def test_efficientdet_d0_arithmetic_and_stride_modes(backend, mode, monkeypatch):
   """The two ways the EfficientDet plan can run its 1x1 convs: every one of them forced onto the bf16x3 split kernels
   (channel counts that are not multiples of 64 -- 40, 72, 144, 240, 432 ... -- go through the padded n-tile: zero weight
@@ -203,8 +203,6 @@ def test_efficientdet_d0_arithmetic_and_stride_modes(backend, mode, monkeypatch)
   name, lib = backend
   if mode == "split_forced":
     monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1"); monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "1")
-  elif mode == "fuse_dw":           # BiFPN fusion evaluated inside the depthwise kernel (A/B variant, off by default)
-    monkeypatch.setenv("ODT_EFFDET_FUSE_DW", "1")
   elif mode == "gate_pass":         # squeeze-excite gate as a pass over the activations instead of folded into the weights
     monkeypatch.setenv("ODT_EFFDET_WSCALE", "0")
   else:

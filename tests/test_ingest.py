@@ -36,7 +36,7 @@ def test_submit_collect_equals_forward(backend):
     with pytest.raises(OdtError, match="ticket"):
       e.collect(t0)
     # the tracking loop's default: pooled features only (0.8 MB instead of 40 MB per 8-frame batch) -- the copies ride
-    # behind the forward on the compute stream and the whole batch replays as one cached hipGraph per slot
+    # right behind the forward's tail (side stream by default; compute stream with ODT_TAIL_OVERLAP=0, tested below)
     many = batches + batches
     got = list(e.forward_stream(many))
     assert len(got) == len(many)

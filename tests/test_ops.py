@@ -508,11 +508,10 @@ SPLIT_CASES = [
 
 
 # kernel families of the split path (conv_split_choose): "3/256", "3/128": conv_split3_kernel (8 waves, LDS-DMA weight
-# stages, three-stage ring; the default) with 256- / 128-row tiles; "2": the two-stage 128 x 256 loop; "1": the
-# one-stage BK = 32 loop of round 1
+# stages, three-stage ring; the default) with 256- / 128-row tiles; "1": the one-stage BK = 32 loop (the 64-wide layers)
 # "3/128/k3": the same with the reduction cut into three split-K ranges + split_reduce_kernel
 # "3/256/nokwr": 256-row tiles with the kw-reuse kernel (conv_split3k_kernel, the default for stride-1 KH x 3 convs) off
-SPLIT_PIPES = ["3/256", "3/256/nokwr", "3/128", "3/128/k3", "2", "1"]
+SPLIT_PIPES = ["3/256", "3/256/nokwr", "3/128", "3/128/k3", "1"]
 
 
 def _split_env(monkeypatch, pipe="3/256"):
@@ -648,7 +647,7 @@ def test_conv_fuzz_split(backend, pipe, monkeypatch):
     _fuzz_case(rng, lib, big=name == "hip", couts=[64, 128, 192, 256, 384])
 
 
-@pytest.mark.parametrize("pipe", ["3/256", "3/128", "3/128/k3", "2"])
+@pytest.mark.parametrize("pipe", ["3/256", "3/128", "3/128/k3"])
 def test_conv2d_split_16wide_stage_extras(backend, pipe, monkeypatch):
   """BK = 16 stage kernels: 96- and 160-channel sources (odd numbers of 16-channel slices), residual, second
   source at stride 2."""
