@@ -480,52 +480,6 @@ __device__ __forceinline__ void split3_epilogue(const ConvParams& p, f32x16 (&ac
     ODT_STAMP(5);
     return;
   }
-  if (p.out_planes != 0) {
-    // ---- planes output: the tile as bf16x3 pieces [piece][k-group][pixel][8 bf16].  Thread -> (row r of the pass, k-group
-    // g of the n-tile), lanes along r: a wave writes 64 consecutive pixels of one k-group = 1 KB contiguous per piece.
-    constexpr int KG = BN / 8, UNITS = RP * KG, UPT = UNITS / 512;
-    static_assert(UNITS % 512 == 0 && RP % 64 == 0, "planes epilogue mapping");
-    const unsigned P = (unsigned)p.B * p.out_H * p.out_W;
-    const unsigned plane = (unsigned)(cout_padded(p.Cout) / 8) * P * 16u;
-    const __amdgpu_buffer_rsrc_t rs_pl = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)(3u * plane), 0x00020000);
-#pragma unroll 1
-    for (int pass = 0; pass < NPASS; ++pass) {
-      if (pass > 0) ODT_BARRIER_LDS();
-      if (wm / WPP == pass) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              Ct[((wm % WPP) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * CS + wn * TN * 32 + j * 32 + fr] = acc[i][j][r];
-      }
-      ODT_BARRIER_LDS();
-#pragma unroll
-      for (int u = 0; u < UPT; ++u) {
-        const int unit = u * 512 + tid, g = unit / RP, r = unit - g * RP;
-        const int m = m0 + pass * RP + r;
-        const float* src = &Ct[r * CS + g * 8];
-        f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
-        v0 += (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, (n0 + g * 8) * 4, 0, 0);
-        v1 += (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, (n0 + g * 8 + 4) * 4, 0, 0);
-        if (p.relu == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
-        }
-        unsigned h0, h1, h2, h3, d0, d1, d2, d3, l0, l1, l2, l3;
-        split2(v0[0], v0[1], h0, d0, l0); split2(v0[2], v0[3], h1, d1, l1);
-        split2(v1[0], v1[1], h2, d2, l2); split2(v1[2], v1[3], h3, d3, l3);
-        const u32x4 h = {h0, h1, h2, h3}, md = {d0, d1, d2, d3}, lo = {l0, l1, l2, l3};
-        const unsigned off = m < M ? ((unsigned)(n0 / 8 + g) * P + (unsigned)m) * 16u : kOOB;
-        __builtin_amdgcn_raw_buffer_store_b128(h, rs_pl, (int)off, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(md, rs_pl, (int)off, (int)plane, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(lo, rs_pl, (int)off, (int)(2u * plane), 0);
-      }
-    }
-    ODT_STAMP(5);
-    return;
-  }
   const f32x4 bias4 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, col * 4, 0, 0);
   if constexpr (BN == 256) {
     if (p.head_wt != nullptr) {
@@ -671,9 +625,7 @@ struct Split3Cfg {
   static_assert(LDS <= 160 * 1024, "LDS ring");
 };
 
-// AP: the A operand comes in planes form (ConvParams::in_planes: dense single-source 1x1 convs) and is streamed into the
-// stage ring by LDS-DMA like the weights -- no A registers, no split arithmetic, no ds_write in the main loop.
-template <int WM, int WN, int TN, bool TRACE = false, bool AP = false>
+template <int WM, int WN, int TN, bool TRACE = false>
 __global__ void __launch_bounds__(512, 2) conv_split3_kernel(const ConvParams* __restrict__ pp) {
   using G = Split3Cfg<WM, WN, TN>;
   constexpr int BM = G::BM, BN = G::BN, AKG = G::AKG, APL = G::APL, BKG = G::BKG, BPL = G::BPL;
@@ -738,44 +690,21 @@ __global__ void __launch_bounds__(512, 2) conv_split3_kernel(const ConvParams* _
     }
     l_b += (unsigned)STAGE_B;
   };
-  // ---- activations in planes form (AP): piece (q, k-group kg, 64-row block rb) of a stage = one 1-KB DMA instruction:
-  // lanes = 64 consecutive output rows (= pixels: dense 1x1), source plane q, k-group 2 * slice + kg
-  constexpr int RB = BM / 64, NPA = 6 * RB, NWA = AP ? NPA / 8 : 0;
-  static_assert(!AP || (NPA % 8 == 0 && NCHUNK % 8 == 0), "planes input: uniform DMA counts per wave");
-  const unsigned ap_P = (unsigned)p.B * p.in_Ha * p.in_Wa;
-  const unsigned ap_plane = (unsigned)(p.Cin >> 3) * ap_P * 16u;
-  const __amdgpu_buffer_rsrc_t rs_pl = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)(AP ? 3u * ap_plane : 0u), 0x00020000);
-  int ap_cs = s_begin;                       // next 16-channel slice of the A stream (single source, one tap)
-  auto dma_a = [&](int st) {
-    if constexpr (AP) {
-#pragma unroll
-      for (int i = 0; i < NWA; ++i) {
-        const int pi = i * 8 + wave, q = pi / (2 * RB), rem = pi - q * (2 * RB), kg = rem / RB, rb = rem - kg * RB;   // wave-uniform
-        const int m = m0 + rb * 64 + lane;
-        const unsigned vo = m < M ? (unsigned)m * 16u : kOOB;
-        const unsigned so = (unsigned)q * ap_plane + (unsigned)(ap_cs * 2 + kg) * ap_P * 16u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_pl, ODT_LDS_PTR(lds + st + q * APL + kg * AKG + rb * 1024), 16, (int)vo, (int)so, 0, 0);
-      }
-      ++ap_cs;
-    }
-  };
   // this wave's DMA instructions per stage: NW or NW - 1 (the counted wait in front of a barrier needs the exact
   // number).  wait_stage: this wave's share of the stage that the barrier publishes has landed -- its DMA (issued
   // one stage earlier) and its LDS stores; YOUNGER: one stage's worth of A fetches + DMA was issued behind that
   // DMA and may stay in flight.
-  constexpr int NW = (NCHUNK + 7) / 8 + NWA;
-  constexpr int RAW = AP ? 0 : RA;           // A fetches in flight as register loads
+  constexpr int NW = (NCHUNK + 7) / 8;
   const bool dma_full = (NCHUNK % 8) == 0 || wave < (NCHUNK % 8);
   auto wait_stage = [&](auto YOUNGER) {
     if constexpr (decltype(YOUNGER)::value) {
-      if (dma_full) ODT_WAIT_VM_LGKM0(RAW + NW); else ODT_WAIT_VM_LGKM0(RAW + NW - 1);
+      if (dma_full) ODT_WAIT_VM_LGKM0(RA + NW); else ODT_WAIT_VM_LGKM0(RA + NW - 1);
     } else {
       ODT_WAIT_VM_LGKM0(0);
     }
   };
-  dma_a(0);
   dma_b(0);
-  if (nsteps > 1) { dma_a(STAGE); dma_b(STAGE); }
+  if (nsteps > 1) dma_b(STAGE);
 
   // ---- activations: thread -> (row (t >> 2) + 128 j, 16-byte column t & 3): four lanes cover the 64 contiguous
   // bytes (16 channels) of a row's stage.  Per row: the byte offset of the tap-(0,0) input pixel and a bit per tap
@@ -871,13 +800,11 @@ __global__ void __launch_bounds__(512, 2) conv_split3_kernel(const ConvParams* _
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int fr = lane & 31, fg = lane >> 5;
-  // ---- prologue: stage 0 complete, stage 1's weights in flight, A of stage 1 in registers (AP: in flight as DMA)
-  if constexpr (!AP) {
-    load_a();
-    stamp(6);
-    store_a(0);
-    if (nsteps > 1) load_a();
-  }
+  // ---- prologue: stage 0 complete, stage 1's weights in flight, A of stage 1 in registers
+  load_a();
+  stamp(6);
+  store_a(0);
+  if (nsteps > 1) load_a();
   if (nsteps > 1) wait_stage(std::true_type{}); else wait_stage(std::false_type{});
   __builtin_amdgcn_s_barrier();
   stamp(7); stamp(1);
@@ -916,8 +843,8 @@ __global__ void __launch_bounds__(512, 2) conv_split3_kernel(const ConvParams* _
       if (last) {
         if (TN == 1) {
           // single column group: the side work precedes the barrier
-          if constexpr (next && !AP) store_a(st_nxt);
-          if constexpr (pre) { if constexpr (!AP) load_a(); dma_a(st_nn); dma_b(st_nn); }
+          if constexpr (next) store_a(st_nxt);
+          if constexpr (pre) { load_a(); dma_b(st_nn); }
         }
         // stage nxt must be complete before its first fragment reads below: own LDS stores, own DMA of stage c+1
         // (issued one stage ago; this stage's A fetch and DMA may stay in flight), then the barrier
@@ -927,19 +854,18 @@ __global__ void __launch_bounds__(512, 2) conv_split3_kernel(const ConvParams* _
       }
       ODT_MF(2, 0, j); ODT_FENCE();
       if (last) { if constexpr (next) rdA(st_nxt, 2); }
-      else if (first) { if constexpr (next && !AP) store_a(st_nxt); }
+      else if (first) { if constexpr (next) store_a(st_nxt); }
       ODT_FENCE();
       ODT_MF(1, 0, j); ODT_MF(0, 0, j); ODT_FENCE();
       if (!last) rdB(st_cur, 0, j + 1); else if constexpr (next) rdB(st_nxt, 0, 0);
       ODT_FENCE();
       ODT_MF(1, 1, j); ODT_FENCE();
       if (last) { if constexpr (next) rdA(st_nxt, 1); }
-      else if (first) { if constexpr (pre && !AP) load_a(); }
+      else if (first) { if constexpr (pre) load_a(); }
       ODT_FENCE();
       ODT_MF(0, 1, j); ODT_FENCE();
       if (!last) rdB(st_cur, 1, j + 1); else if constexpr (next) rdB(st_nxt, 1, 0);
-      if (!last && j == 0) { if constexpr (pre && AP && TN > 2) dma_a(st_nn); }
-      if (!last && j == (TN > 2 ? 1 : 0)) { if constexpr (pre) { if constexpr (AP && TN <= 2) dma_a(st_nn); dma_b(st_nn); } }
+      if (!last && j == (TN > 2 ? 1 : 0)) { if constexpr (pre) dma_b(st_nn); }
       ODT_FENCE();
       ODT_MF(0, 2, j); ODT_FENCE();
       if (!last) rdB(st_cur, 2, j + 1); else if constexpr (next) { rdA(st_nxt, 0); rdB(st_nxt, 2, 0); }
@@ -1495,12 +1421,6 @@ int conv_make_split_weights(const ConvParams& p, void* img_dev, hipStream_t stre
 
 template <int WM, int WN, int TN>
 static void launch_split3(const ConvParams& p, const ConvParams* dev, unsigned grid, hipStream_t stream) {
-  if constexpr (WM == 4 && WN == 2 && TN == 4) {
-    if (p.in_planes != 0) {      // A operand in planes form: streamed by LDS-DMA
-      hipLaunchKernelGGL((conv_split3_kernel<WM, WN, TN, false, true>), dim3(grid), dim3(512), 0, stream, dev);
-      return;
-    }
-  }
   if (p.trace != nullptr) hipLaunchKernelGGL((conv_split3_kernel<WM, WN, TN, true>), dim3(grid), dim3(512), 0, stream, dev);
   else hipLaunchKernelGGL((conv_split3_kernel<WM, WN, TN, false>), dim3(grid), dim3(512), 0, stream, dev);
 }

@@ -80,13 +80,6 @@ struct ConvParams {
   // ReLU, models.py:979-1009): head_out[m][j] = sum_c act(conv)[m][c] * head_wt[c][j] + head_bias[j], j < 16, evaluated on
   // the staged C tile in the epilogue with exact-f32 MFMA (v_mfma_f32_16x16x4_f32) -- the 256-channel tensor is never
   // written (out == nullptr) or read back, and the separate N = 15 launch disappears
-  // bf16x3 "planes" form of a tensor (conv_split3 kernels only): the three bf16 pieces hi / mid / lo of every f32 value
-  // (x = hi + mid + lo exactly, conv_split.hip) as three planes [piece][C / 8 k-groups][P pixels][8 bf16].  A consumer
-  // streams its A operand from it by LDS-DMA exactly as it streams the weight image -- no f32 fetch, no split arithmetic,
-  // no ds_write in its main loop -- and gets bit for bit the pieces it would have made itself.  Used for the narrow tensors
-  // between the convs of a bottleneck (the producer's epilogue writes planes INSTEAD of f32: nothing else reads them).
-  int in_planes;       // 1: `in` is the planes form of the [B,H,W,Cin] input (dense 1x1 / kw-reuse 3x3 consumers)
-  int out_planes;      // 1: `out` receives the planes form of the output (dense, no offset), P = B * out_H * out_W
   const float* head_wt;    // [Cout][16] (k-major, column 15 zero) or nullptr
   const float* head_bias;  // [16]
   float* head_out;         // [M][head_ldc] dense rows (m = (n, ho, wo))

@@ -159,7 +159,6 @@ struct odt_model {
   float* arena[2] = {nullptr, nullptr};     // 0: trunk (live ranges end before the tail) | 1: read / written by the tail ops
   size_t arena_bytes[2] = {0, 0};
   size_t dedicated_tensor_bytes = 0, virtual_tensor_bytes = 0;
-  int planes_tensors = 0;                   // stage tensors kept as bf16x3 planes (plan_planes)
   bool is_virtual(const void* p) const {
     const uintptr_t a = (uintptr_t)p;
     return a >= kVirtBase && a < kVirtBase + vnext;
@@ -196,7 +195,6 @@ int add_conv(odt_model* m, const std::string& name, const Tensor& in, int cin, c
 int create_side_stream(hipStream_t* s);
 int attach_split_weights(odt_model* m);
 int fuse_rpn_heads(odt_model* m);
-int plan_planes(odt_model* m);
 void find_overlap_points(odt_model* m);
 int plan_arena(odt_model* m);
 int upload_conv_records(odt_model* m);

@@ -296,53 +296,6 @@ void find_overlap_points(odt_model* m) {
   if (m->op_tail == 0 || m->op_first_fpn == 0 || m->op_first_fpn >= m->op_tail) m->op_first_fpn = m->op_tail = 0;
 }
 
-// ---- narrow bottleneck tensors in bf16x3 planes form ---------------------------------------------------------------------
-// t2 of a bottleneck (conv2's output) is read by conv3 and by nothing else, and conv3 re-splits it once per n-tile (4x for
-// N = 1024).  Where both convs run on conv_split3 kernels, the producer's epilogue writes the three bf16 pieces as planes
-// (ConvParams::out_planes) and the consumer streams them by LDS-DMA (in_planes) -- the pieces are exactly the ones the
-// consumer would have made, so results do not change by a bit.  Arena handles only (a keep_taps handle keeps every stage
-// tensor in f32 for the taps); ODT_CONV_PLANES=0 turns it off (A/B).  Called after attach_split_weights, before plan_arena.
-int plan_planes(odt_model* m) {
-  if (!m->arena_on) return 0;
-  const char* e = getenv("ODT_CONV_PLANES");
-  if (e != nullptr && e[0] == '0') return 0;
-  std::vector<char> tapped(m->vt.size(), 0);
-  for (const auto& kv : m->taps)
-    if (kv.second.d != nullptr && m->is_virtual(kv.second.d)) tapped[m->vt_index(kv.second.d)] = 1;
-  // ops that touch each virtual tensor
-  std::vector<std::vector<int>> users(m->vt.size());
-  for (size_t oi = 0; oi < m->ops.size(); ++oi)
-    visit_op_ptrs(m, oi, [&](auto& p) {
-      if (p == nullptr || !m->is_virtual((const void*)p)) return;
-      auto& u = users[m->vt_index((const void*)p)];
-      if (u.empty() || u.back() != (int)oi) u.push_back((int)oi);
-    });
-  for (size_t oi = 0; oi < m->ops.size(); ++oi) {
-    if (m->ops[oi].kind != OP_CONV || m->ops[oi].skip) continue;
-    ConvParams& a = m->convs[m->ops[oi].conv].p;
-    if (a.out == nullptr || !m->is_virtual(a.out)) continue;
-    const int ti = m->vt_index(a.out);
-    if (tapped[ti] || users[ti].size() != 2 || users[ti][0] != (int)oi) continue;
-    const Op& oc = m->ops[users[ti][1]];
-    if (oc.kind != OP_CONV) continue;
-    ConvParams& c = m->convs[oc.conv].p;
-    const bool producer_ok = a.wt_split != nullptr && a.wt_split_kind == 3 && a.splitk <= 1 && a.res_mode == 0 && a.relu <= 1 &&
-                             a.head_wt == nullptr && a.out_oy == 0 && a.out_ox == 0 && a.out_H == a.Ho && a.out_W == a.Wo &&
-                             a.Cout % 64 == 0 && a.out_ldc == a.Cout;
-    const bool consumer_ok = c.in == a.out && c.res != a.out && c.in2 == nullptr && c.wt_split != nullptr && c.wt_split_kind == 3 &&
-                             c.wt_split_bm == 256 && c.wt_split_bn == 256 && c.wt_split_kwr == 0 && c.splitk <= 1 && c.kh == 1 &&
-                             c.kw == 1 && c.stride == 1 && c.pad_t == 0 && c.pad_l == 0 && c.H == c.in_Ha && c.W == c.in_Wa &&
-                             c.Ho == c.H && c.Wo == c.W && c.Cin == a.Cout && c.in_ldc == a.Cout && c.in_Ha == a.out_H &&
-                             c.in_Wa == a.out_W && c.B == a.B;
-    const double bytes = 6.0 * (double)a.Cout * a.B * a.out_H * a.out_W;
-    if (!producer_ok || !consumer_ok || bytes >= 2147483648.0) continue;
-    a.out_planes = 1; c.in_planes = 1;
-    m->vt[ti].bytes = ((size_t)bytes + 255) & ~(size_t)255;      // three bf16 planes instead of one f32 tensor
-    ++m->planes_tensors;
-  }
-  return 0;
-}
-
 // Lay the virtual stage tensors out in (at most) two arenas by live range and rewrite the plan's pointers.
 // Region 1 holds what the tail ops touch (so that forward i's tail and forward i+1's early trunk never share memory);
 // within a region a tensor takes the lowest offset not occupied by a tensor whose [first, last] range intersects its own

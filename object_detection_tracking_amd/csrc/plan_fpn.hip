@@ -365,7 +365,6 @@ int build_plan(odt_model* m) {
   }
   if (attach_split_weights(m)) return 1;
   if (fuse_rpn_heads(m)) return 1;
-  if (plan_planes(m)) return 1;
   if (plan_arena(m)) return 1;
   {   // conv parameter records in device memory
     std::vector<ConvParams> recs;

@@ -383,29 +383,3 @@ def test_rpn_head_fused_into_conv_epilogue(backend, monkeypatch):
   miss, extra = _run_single(lib, cfg, H, W)           # fused form against the oracle, arena + taps handles
   assert miss == 0 and extra == 0
 
-
-def test_bottleneck_tensors_as_bf16x3_planes(backend, monkeypatch):
-  """conv2 -> conv3 tensors of the bottlenecks in planes form (the producer's epilogue writes the three bf16 pieces, the
-  consumer streams them by LDS-DMA): an arena handle with planes, an arena handle without (ODT_CONV_PLANES=0) and a
-  keep_taps handle (always f32) must agree BIT FOR BIT -- the pieces are exactly what the consumer would have split."""
-  name, lib = backend
-  monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1"); monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "1")
-  cfg = small_config(resnet_num_block=[1, 2, 1, 1] if name == "emu" else [2, 2, 3, 2])
-  w = weights_for(cfg)
-  H, W = (64, 96) if name == "emu" else (224, 320)
-  fr = synthetic_frames(1, H, W, seed=9)
-  outs = []
-  for planes, taps in (("1", False), ("0", False), ("1", True)):
-    monkeypatch.setenv("ODT_CONV_PLANES", planes)
-    m = models.get_model(_with_taps(cfg) if taps else cfg, 0, weights=w, lib=lib)
-    try:
-      det = m.predict(fr[0])
-      mem = m.engine(1, H, W).describe()["memory"]
-      outs.append((det, mem))
-    finally:
-      m.close()
-  # (stage-entry blocks feed conv3 a K-concatenated second source: their t2 stays f32)
-  assert outs[0][1]["bf16x3_plane_tensors"] >= (1 if name == "emu" else 5) and outs[1][1]["bf16x3_plane_tensors"] == 0 and outs[2][1]["bf16x3_plane_tensors"] == 0, [o[1] for o in outs]
-  for other in (outs[1], outs[2]):
-    for a, b in zip(outs[0][0], other[0]):
-      assert np.array_equal(a, b)
