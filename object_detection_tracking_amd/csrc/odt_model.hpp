@@ -89,7 +89,10 @@ struct odt_model {
   std::map<std::string, Tensor> taps;
   std::vector<ConvOp> convs;
   std::vector<char> conv_fused;      // convs[i] is evaluated inside another conv's epilogue (no launch of its own)
-  ConvParams* convs_dev = nullptr;   // device copies of convs[i].p
+  ConvParams* convs_dev = nullptr;   // device copies of conv_recs
+  std::vector<ConvParams> conv_recs; // launch records: convs[i] runs as records [conv_rec0[i], + conv_nrec[i]) (batch ranges,
+  std::vector<int> conv_rec0, conv_nrec;   // more than one only where a tensor would reach 2 GiB: upload_conv_records)
+  int chunked_convs = 0;
   std::vector<Op> ops;
   // geometry
   int Hp = 0, Wp = 0;

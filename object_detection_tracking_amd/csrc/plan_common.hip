@@ -369,14 +369,49 @@ int plan_arena(odt_model* m) {
   return 0;
 }
 
-// conv parameter records in device memory (the kernels read their ConvParams from there)
+// conv parameter records in device memory (the kernels read their ConvParams from there).  The conv kernels address
+// their tensors through buffer descriptors with 32-bit offsets: a launch whose input / output / residual tensor would
+// reach 2 GiB (b = 16 @1080p: conv0's output, the res2 tensors, P2) is cut into equal batch ranges, each with its own
+// record whose pointers start at that range's first image -- every image's arithmetic is unchanged.
+// (ODT_CONV_CHUNK_BYTES: test knob that lowers the limit so that small plans exercise the chunked path.)
+static int conv_batch_chunks(const ConvParams& p, double limit) {
+  auto fits = [&](int n) {
+    const double b = (double)(p.B / n);
+    return b * p.in_Ha * p.in_Wa * p.in_ldc * 4.0 < limit && b * p.out_H * p.out_W * p.out_ldc * 4.0 < limit &&
+           (p.res_mode == 0 || b * p.res_H * p.res_W * p.res_ldc * 4.0 < limit) &&
+           (p.in2 == nullptr || b * p.in2_Ha * p.in2_Wa * p.in2_ldc * 4.0 < limit);
+  };
+  for (int n = 1; n <= p.B; ++n)
+    if (p.B % n == 0 && fits(n)) return n;
+  return p.B;           // (one image per launch; launch_conv reports it if even that is too large)
+}
+
 int upload_conv_records(odt_model* m) {
-  std::vector<ConvParams> recs;
-  for (const ConvOp& c : m->convs) recs.push_back(c.p);
+  double limit = 2147483648.0;
+  if (const char* e = getenv("ODT_CONV_CHUNK_BYTES")) { if (atof(e) > 0) limit = atof(e); }
+  m->conv_recs.clear(); m->conv_rec0.clear(); m->conv_nrec.clear();
+  for (const ConvOp& c : m->convs) {
+    const ConvParams& p = c.p;
+    const int n = conv_batch_chunks(p, limit), bc = p.B / n;
+    m->conv_rec0.push_back((int)m->conv_recs.size());
+    m->conv_nrec.push_back(n);
+    for (int k = 0; k < n; ++k) {
+      ConvParams q = p;
+      const size_t b0 = (size_t)k * bc;
+      q.B = bc;
+      q.in = p.in + b0 * p.in_Ha * p.in_Wa * p.in_ldc;
+      if (p.out != nullptr) q.out = p.out + b0 * p.out_H * p.out_W * p.out_ldc;
+      if (p.res != nullptr) q.res = p.res + b0 * p.res_H * p.res_W * p.res_ldc;
+      if (p.in2 != nullptr) q.in2 = p.in2 + b0 * p.in2_Ha * p.in2_Wa * p.in2_ldc;
+      if (p.head_out != nullptr) q.head_out = p.head_out + b0 * p.Ho * p.Wo * p.head_ldc;
+      m->conv_recs.push_back(q);
+    }
+    if (n > 1) ++m->chunked_convs;
+  }
   m->bufs.emplace_back(new DevBuf());
-  if (m->bufs.back()->alloc(recs.size() * sizeof(ConvParams))) return 1;
+  if (m->bufs.back()->alloc(m->conv_recs.size() * sizeof(ConvParams))) return 1;
   m->convs_dev = (ConvParams*)m->bufs.back()->p;
-  ODT_HIP(hipMemcpy(m->convs_dev, recs.data(), recs.size() * sizeof(ConvParams), hipMemcpyHostToDevice));
+  ODT_HIP(hipMemcpy(m->convs_dev, m->conv_recs.data(), m->conv_recs.size() * sizeof(ConvParams), hipMemcpyHostToDevice));
   return 0;
 }
 

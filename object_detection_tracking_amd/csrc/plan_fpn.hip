@@ -366,14 +366,7 @@ int build_plan(odt_model* m) {
   if (attach_split_weights(m)) return 1;
   if (fuse_rpn_heads(m)) return 1;
   if (plan_arena(m)) return 1;
-  {   // conv parameter records in device memory
-    std::vector<ConvParams> recs;
-    for (const ConvOp& c : m->convs) recs.push_back(c.p);
-    m->bufs.emplace_back(new DevBuf());
-    if (m->bufs.back()->alloc(recs.size() * sizeof(ConvParams))) return 1;
-    m->convs_dev = (ConvParams*)m->bufs.back()->p;
-    ODT_HIP(hipMemcpy(m->convs_dev, recs.data(), recs.size() * sizeof(ConvParams), hipMemcpyHostToDevice));
-  }
+  if (upload_conv_records(m)) return 1;
   return 0;
 }
 
