@@ -632,6 +632,8 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
   ODT_CHECK((double)p.B * p.out_H * p.out_W * p.out_ldc * 4.0 < 2147483648.0 &&
             (p.res_mode == 0 || (double)p.B * p.res_H * p.res_W * p.res_ldc * 4.0 < 2147483648.0),
             "conv: output / residual tensors must be smaller than 2 GiB (32-bit buffer offsets)");
+  ODT_CHECK(p.nlvl <= 1 || (p.wt_split != nullptr && p.wt_split_kind == 3 && p.splitk <= 1 && p.nlvl <= 5 && p.head_wt == nullptr),
+            "conv: per-row-range epilogue constants need a conv_split3 kernel without split-K");
   const long M = (long)p.B * p.Ho * p.Wo;
   const long tiles128 = ((M + 127) / 128) * ((p.Cout + 127) / 128);
   int tile = 0;   // 0 auto | 1: 128x64 | 2: 64x64 | 3: 128x128  (ODT_CONV_TILE: tuning / test knob)

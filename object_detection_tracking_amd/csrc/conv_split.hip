@@ -445,8 +445,17 @@ __device__ __forceinline__ void split3_epilogue(const ConvParams& p, f32x16 (&ac
                         (p.res_mode == 0 || (p.res_mode == 1 && p.res_H == p.Ho && p.res_W == p.Wo));
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.out, 0, (int)((unsigned)p.B * p.out_H * p.out_W * p.out_ldc * 4u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_bias =
-      __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (int)((unsigned)p.Cout * 4u), 0x00020000);
+  // per-row-range constants (ConvParams::nlvl): every tile lies inside one range (ranges start on multiples of 256 rows)
+  int lvl_off = 0;
+  if (p.nlvl > 1) {
+    int lvl = 0;
+    for (int i = 1; i < p.nlvl; ++i) lvl += m0 >= p.lvl_start[i] ? 1 : 0;
+    lvl_off = lvl * p.lvl_stride;
+  }
+  const unsigned nbias = p.nlvl > 1 ? (unsigned)(p.nlvl * p.lvl_stride) : (unsigned)p.Cout;
+  const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (int)(nbias * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_scale = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.lvl_scale != nullptr ? p.lvl_scale : p.bias), 0, (int)(p.lvl_scale != nullptr ? nbias * 4u : 0u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.res_mode != 0 ? p.res : p.bias), 0,
       (int)(p.res_mode != 0 ? (unsigned)p.B * p.res_H * p.res_W * p.res_ldc * 4u : 0u), 0x00020000);
@@ -480,7 +489,10 @@ __device__ __forceinline__ void split3_epilogue(const ConvParams& p, f32x16 (&ac
     ODT_STAMP(5);
     return;
   }
-  const f32x4 bias4 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, col * 4, 0, 0);
+  const f32x4 bias4 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, (lvl_off + col) * 4, 0, 0);
+  const bool has_scale = p.lvl_scale != nullptr;
+  f32x4 scale4 = {1.f, 1.f, 1.f, 1.f};
+  if (has_scale) scale4 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_scale, (lvl_off + col) * 4, 0, 0);
   if constexpr (BN == 256) {
     if (p.head_wt != nullptr) {
       // ---- fused 1x1 head (RPN class || box: 15 columns of a 16-wide GEMM over this tile's 256 channels).  Per pass:
@@ -582,6 +594,7 @@ __device__ __forceinline__ void split3_epilogue(const ConvParams& p, f32x16 (&ac
 #pragma unroll
       for (int s2 = 0; s2 < NCH; ++s2) {
         f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[(row0 + s2 * RSTEP) * CS + c4 * 4]);
+        if (has_scale) v = v * scale4;
         v += bias4;
         if constexpr (RES) v += rres[s2];
         if (ACT == 1) {

@@ -121,9 +121,14 @@ __global__ void __launch_bounds__(256) dwconv_kernel(DwConvParams p) {
     const unsigned rem = nl - (unsigned)b * nb;
     sp = (int)(rem / gridDim.x); cb = (int)(rem - (unsigned)sp * gridDim.x);
   }
+  // several maps in one launch (nlvl > 0, batch 1): the grid's image index selects the map
+  const float* pin = p.in;
+  float* pout = p.out;
+  int pH = p.H, pW = p.W, pHo = p.Ho, pWo = p.Wo;
+  if (p.nlvl > 0) { pin = p.lin[b]; pout = p.lout[b]; pH = pHo = p.lH[b]; pW = pWo = p.lW[b]; b = 0; }
   const int c4 = cb * 16 + cq, c4n = p.ldc >> 2;
   const bool cok = c4 < c4n;
-  const int nxb = (p.Wo + PX - 1) / PX, units = nxb * p.Ho;
+  const int nxb = (pWo + PX - 1) / PX, units = nxb * pHo;
   const int per = (units + p.nsplit - 1) / p.nsplit;
   const int lo = sp * per, hi = lo + per < units ? lo + per : units;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -139,13 +144,13 @@ __global__ void __launch_bounds__(256) dwconv_kernel(DwConvParams p) {
 #pragma unroll
       for (int ky = 0; ky < K; ++ky) {
         const int y = yo * S + ky - p.pad_t;
-        if ((unsigned)y >= (unsigned)p.H) continue;
-        const float* row = p.in + (((long)b * p.H + y) * p.W) * p.ldc + c4 * 4;
+        if ((unsigned)y >= (unsigned)pH) continue;
+        const float* row = pin + (((long)b * pH + y) * pW) * p.ldc + c4 * 4;
         f32x4 col[NC];
 #pragma unroll
         for (int cidx = 0; cidx < NC; ++cidx) {
           const int x = x0 + cidx;
-          col[cidx] = (unsigned)x < (unsigned)p.W ? *reinterpret_cast<const f32x4*>(row + (long)x * p.ldc) : zero;
+          col[cidx] = (unsigned)x < (unsigned)pW ? *reinterpret_cast<const f32x4*>(row + (long)x * p.ldc) : zero;
         }
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
@@ -157,13 +162,13 @@ __global__ void __launch_bounds__(256) dwconv_kernel(DwConvParams p) {
 #pragma unroll
       for (int q = 0; q < PX; ++q) {
         const int xo = xo0 + q;
-        if (xo >= p.Wo) break;
+        if (xo >= pWo) break;
         f32x4 v = acc[q] + bias;
         if (p.act == 2) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = swishf(v[e]);
         }
-        *reinterpret_cast<f32x4*>(p.out + (((long)b * p.Ho + yo) * p.Wo + xo) * p.ldc + c4 * 4) = v;
+        *reinterpret_cast<f32x4*>(pout + (((long)b * pHo + yo) * pWo + xo) * p.ldc + c4 * 4) = v;
         sum += v;
       }
     }
@@ -410,10 +415,17 @@ int dwconv_splits(const DwConvParams& p) {
 int launch_dwconv(const DwConvParams& p0, hipStream_t stream) {
   ODT_CHECK(p0.ldc % 4 == 0 && (p0.k == 3 || p0.k == 5) && (p0.stride == 1 || p0.stride == 2), "dwconv: bad geometry");
   DwConvParams p = p0;
+  if (p.nlvl > 0) {
+    // several maps in one launch: splits sized for the largest map (the others' surplus workgroups find nothing to do)
+    ODT_CHECK(p.nlvl <= 5 && p.B == 1 && p.stride == 1 && p.sum_part == nullptr, "dwconv: multi-map launches are batch 1, stride 1");
+    int big = 0;
+    for (int i = 1; i < p.nlvl; ++i) if ((long)p.lH[i] * p.lW[i] > (long)p.lH[big] * p.lW[big]) big = i;
+    p.H = p.Ho = p.lH[big]; p.W = p.Wo = p.lW[big];
+  }
   p.cqn = 16; p.nsplit = dwconv_splits(p);
   static const bool bands = !(getenv("ODT_DW_XCD") != nullptr && getenv("ODT_DW_XCD")[0] == '0');     // A/B knob
   p.xcd_bands = bands ? 1 : 0;
-  const dim3 g(dwconv_cblocks(p), p.nsplit, p.B), t(256);
+  const dim3 g(dwconv_cblocks(p), p.nsplit, p.nlvl > 0 ? p.nlvl : p.B), t(256);
   const bool wide = dw_px1() == 8;
   if (p.k == 3 && p.stride == 1) {
     if (wide) hipLaunchKernelGGL((dwconv_kernel<3, 1, 8>), g, t, 0, stream, p);

@@ -80,6 +80,15 @@ struct ConvParams {
   // ReLU, models.py:979-1009): head_out[m][j] = sum_c act(conv)[m][c] * head_wt[c][j] + head_bias[j], j < 16, evaluated on
   // the staged C tile in the epilogue with exact-f32 MFMA (v_mfma_f32_16x16x4_f32) -- the 256-channel tensor is never
   // written (out == nullptr) or read back, and the separate N = 15 launch disappears
+  // optional per-row-range epilogue constants (conv_split3 kernels without split-K): rows [lvl_start[i], lvl_start[i+1])
+  // of the GEMM take bias[i * lvl_stride + c] and, if given, the factor lvl_scale[i * lvl_stride + c] in front of it
+  // (out = act(acc * scale + bias)).  The EfficientDet class / box nets share their conv weights between the five pyramid
+  // levels but carry one BatchNorm per level (efficientdet_arch.py:227-393): with the levels' pixels concatenated (each
+  // padded to whole 256-row tiles) a layer is ONE launch instead of five.
+  int nlvl;            // 0 / 1: off
+  int lvl_start[5];
+  int lvl_stride;
+  const float* lvl_scale;
   const float* head_wt;    // [Cout][16] (k-major, column 15 zero) or nullptr
   const float* head_bias;  // [16]
   float* head_out;         // [M][head_ldc] dense rows (m = (n, ho, wo))
@@ -147,6 +156,12 @@ struct DwConvParams {
   float* sum_part;     // [B][dwconv_splits()][ldc] or nullptr
   int cqn, nsplit;     // filled by launch_dwconv: channel quads per workgroup (16), pixel splits
   int xcd_bands;       // filled by launch_dwconv: 1 = contiguous band of workgroups per XCD (halo rows shared in its L2)
+  // optional: several independent [H,W] maps in one launch (batch 1, stride 1 'SAME': the five pyramid levels of a class /
+  // box net layer): map i reads lin[i] and writes lout[i], both [lH[i], lW[i], ldc]; grid z = map
+  int nlvl;            // 0: off
+  const float* lin[5];
+  float* lout[5];
+  int lH[5], lW[5];
 };
 int launch_dwconv(const DwConvParams& p, hipStream_t stream);
 int dwconv_splits(const DwConvParams& p);       // pixel splits launch_dwconv will use (sizes sum_part)

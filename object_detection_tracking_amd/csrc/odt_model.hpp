@@ -196,6 +196,7 @@ int add_conv(odt_model* m, const std::string& name, const Tensor& in, int cin, c
              int kw, int cout, int stride, int dil, int pad_t, int pad_l, int Ho, int Wo, int oy, int ox, const Tensor* res,
              int res_mode, bool relu, int out_ldc, Tensor* out, const std::string& tap);
 int create_side_stream(hipStream_t* s);
+ConvPolicy resolve_conv_policy(const odt_model* m);
 int attach_split_weights(odt_model* m);
 int fuse_rpn_heads(odt_model* m);
 void find_overlap_points(odt_model* m);
@@ -227,7 +228,7 @@ void visit_op_ptrs(odt_model* m, size_t oi, F&& f) {
     case OP_ROI_EFF: roi(m->roi_eff); break;
     case OP_DETECT: f(m->det.head_out); f(m->det.props); break;
     case OP_MASK_SELECT: f(m->mask_sel.logits); break;
-    case OP_DW: f(op.dw.in); f(op.dw.out); break;
+    case OP_DW: f(op.dw.in); f(op.dw.out); for (auto& p : op.dw.lin) f(p); for (auto& p : op.dw.lout) f(p); break;
     case OP_FUSE: for (auto& p : op.fuse.in) f(p); f(op.fuse.out); break;
     case OP_EFF_POST: for (auto& p : m->eff_post.cls) f(p); for (auto& p : m->eff_post.box) f(p); break;
     case OP_CMEAN: case OP_CSCALE: case OP_SE_GATE: case OP_SE_GATE_MEAN: case OP_WSCALE: case OP_POOL: case OP_SUB2: break;

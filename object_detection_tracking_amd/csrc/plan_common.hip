@@ -173,13 +173,17 @@ int create_side_stream(hipStream_t* s) {
 }
 
 // bf16-piece weight images (conv_split.hip) for the plan's convs that the split kernel takes
-int attach_split_weights(odt_model* m) {
-  // the handle's conv policy: odt_config first, ODT_CONV_* debug overrides on top (read once, here)
+// the handle's conv policy: odt_config first, ODT_CONV_* debug overrides on top
+ConvPolicy resolve_conv_policy(const odt_model* m) {
   ConvPolicy pol = conv_policy_default();
   if (m->cfg.conv_arith == ODT_ARITH_F32) pol.arith = 0;
   else if (m->cfg.conv_arith == ODT_ARITH_BF16X3) pol.arith = 1;
   if (m->cfg.conv_split_family >= 1 && m->cfg.conv_split_family <= 3) pol.family = m->cfg.conv_split_family >= 3 ? 3 : 1;
-  pol = conv_policy_from_env(pol);
+  return conv_policy_from_env(pol);
+}
+
+int attach_split_weights(odt_model* m) {
+  const ConvPolicy pol = resolve_conv_policy(m);
   m->policy = pol;
   if (pol.arith == 0) return 0;
   std::map<const float*, const void*> made;      // the RPN conv is shared by the five levels

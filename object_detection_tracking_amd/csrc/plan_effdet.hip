@@ -235,6 +235,102 @@ int build_effdet_heads(odt_model* m, const Tensor* red, const int* red_ch) {
   for (int l = 3; l <= 7; ++l) m->taps["fpn_" + std::to_string(l)] = feats[l - 3].t;
   // class / box nets: shared separable convs, per-level BN, swish (efficientdet_arch.py:227-393)
   Tensor cls_out[5], box_out[5];
+  // Batch 1 and layers wide enough for the conv_split3 kernels: the five levels of a layer run as ONE depthwise launch and
+  // ONE pointwise launch over the levels' pixels concatenated (each level padded to whole 256-row tiles so that a tile never
+  // straddles two levels; the per-level BatchNorm becomes per-row-range scale / bias in the epilogue).  D7: 120 launches
+  // instead of 600 for the two nets.  ODT_EFFDET_MERGE_LEVELS=0: one launch per level and layer (A/B; smaller models and
+  // batch > 1 always).
+  int off[6] = {0, 0, 0, 0, 0, 0};
+  for (int l = 0; l < 5; ++l) off[l + 1] = off[l] + (fh[l + 3] * fw[l + 3] + 255) / 256 * 256;
+  const int Mtot = off[5];
+  bool merge = B == 1 && eff_split_on();
+  if (const char* e = getenv("ODT_EFFDET_MERGE_LEVELS")) merge = merge && e[0] != '0';
+  if (merge) {      // would the merged pointwise conv run on a conv_split3 kernel without split-K?
+    ConvParams q; std::memset(&q, 0, sizeof(q));
+    q.B = 1; q.H = 1; q.W = Mtot; q.in_Ha = 1; q.in_Wa = Mtot; q.Cin = LF; q.in_ldc = LF; q.Ho = 1; q.Wo = Mtot; q.Cout = F;
+    q.kh = q.kw = 1; q.stride = 1; q.dil = 1; q.out_H = 1; q.out_W = Mtot; q.out_ldc = LF;
+    const ConvPolicy pol = resolve_conv_policy(m);
+    merge = conv_split_wanted(q, pol);
+    if (merge) { conv_split_choose(q, pol); merge = q.wt_split_kind == 3 && q.splitk <= 1; }
+  }
+  if (merge) {
+    auto level_view = [&](const Tensor& cat, int l) {
+      Tensor v = cat;
+      v.d = cat.d + (size_t)off[l] * cat.C; v.B = 1; v.H = v.h = fh[l + 3]; v.W = v.w = fw[l + 3];
+      return v;
+    };
+    // one separable layer over all levels: depthwise (levels as maps of one launch) -> pointwise over Mtot rows
+    auto merged_sepconv = [&](const std::string& scope, const std::string& bn_prefix, const Tensor* lvl_in, const Tensor* cat_in,
+                              int cout, int act, Tensor* out) {
+      const HostTensor* Wd = find_w(m, scope + "/depthwise_kernel");
+      ODT_CHECK(Wd && Wd->data.size() == (size_t)9 * F, "missing / bad " + scope + "/depthwise_kernel");
+      std::vector<float> v((size_t)9 * LF, 0.f), bv(LF, 0.f);
+      for (int t = 0; t < 9; ++t) for (int c = 0; c < F; ++c) v[(size_t)t * LF + c] = Wd->data[(size_t)t * F + c];
+      const float *dwt, *dbias;
+      if (upload_raw(m, v, &dwt) || upload_raw(m, bv, &dbias)) return 1;
+      Tensor t1{};
+      if (make_tensor(m, "", 1, 1, Mtot, LF, &t1, false)) return 1;
+      {
+        Op op; op.kind = OP_DW;
+        op.dw.wt = dwt; op.dw.bias = dbias; op.dw.B = 1; op.dw.ldc = LF; op.dw.k = 3; op.dw.stride = 1; op.dw.pad_t = 1; op.dw.pad_l = 1;
+        op.dw.act = 0; op.dw.nlvl = 5;
+        for (int l = 0; l < 5; ++l) {
+          op.dw.lin[l] = lvl_in != nullptr ? lvl_in[l].d : cat_in->d + (size_t)off[l] * LF;
+          op.dw.lout[l] = t1.d + (size_t)off[l] * LF;
+          op.dw.lH[l] = fh[l + 3]; op.dw.lW[l] = fw[l + 3];
+        }
+        op.dw.in = op.dw.lin[0]; op.dw.out = op.dw.lout[0];
+        op.dw.H = op.dw.Ho = fh[3]; op.dw.W = op.dw.Wo = fw[3];
+        m->ops.push_back(op);
+      }
+      const float *wt, *bias;
+      if (eff_upload_pw(m, scope, "", true, F, LF, cout, &wt, &bias, "pointwise_kernel")) return 1;
+      const int lco = r32(cout);
+      Tensor view = t1;                      // [1, 1, Mtot, LF]
+      if (add_conv(m, scope, view, LF, wt, bias, 1, 1, cout, 1, 1, 0, 0, 1, Mtot, 0, 0, nullptr, 0, false, lco, out, "")) return 1;
+      ConvParams& cp = m->convs.back().p;
+      cp.relu = act;
+      if (!bn_prefix.empty()) {
+        // per-level BatchNorm in the epilogue: out = (W x) * inv_l + (beta_l - mean_l * inv_l + b * inv_l)
+        const HostTensor* pb = find_w(m, scope + "/bias");
+        ODT_CHECK(pb != nullptr && (int)pb->data.size() == cout, "missing / bad " + scope + "/bias");
+        std::vector<float> sc((size_t)5 * lco, 1.f), sh((size_t)5 * lco, 0.f);
+        for (int l = 0; l < 5; ++l) {
+          std::vector<double> scale, shift;
+          if (eff_bn(m, bn_prefix + std::to_string(l + 3), cout, &scale, &shift)) return 1;
+          for (int o = 0; o < cout; ++o) {
+            sc[(size_t)l * lco + o] = (float)scale[o];
+            sh[(size_t)l * lco + o] = (float)(shift[o] + (double)pb->data[o] * scale[o]);
+          }
+        }
+        const float *dsc, *dsh;
+        if (upload_raw(m, sc, &dsc) || upload_raw(m, sh, &dsh)) return 1;
+        cp.bias = dsh; cp.lvl_scale = dsc; cp.nlvl = 5; cp.lvl_stride = lco;
+        for (int l = 0; l < 5; ++l) cp.lvl_start[l] = off[l];
+      }
+      return 0;
+    };
+    Tensor lvl_feats[5];
+    for (int l = 0; l < 5; ++l) lvl_feats[l] = feats[l].t;
+    for (int net = 0; net < 2; ++net) {
+      const std::string nn = net == 0 ? "class" : "box";
+      Tensor x{};
+      for (int r = 0; r < dc.repeats; ++r) {
+        Tensor y{};
+        if (merged_sepconv(nn + "_net/" + nn + "-" + std::to_string(r), nn + "_net/" + nn + "-" + std::to_string(r) + "-bn-",
+                           r == 0 ? lvl_feats : nullptr, r == 0 ? nullptr : &x, F, 2, &y)) return 1;
+        x = y;
+      }
+      Tensor o{};
+      const int nout = net == 0 ? ncls * 9 : 36;
+      if (merged_sepconv(nn + "_net/" + nn + "-predict", "", dc.repeats == 0 ? lvl_feats : nullptr, dc.repeats == 0 ? nullptr : &x, nout, 0, &o))
+        return 1;
+      for (int l = 0; l < 5; ++l) {
+        (net == 0 ? cls_out : box_out)[l] = level_view(o, l);
+        m->taps[nn + "_" + std::to_string(l + 3)] = (net == 0 ? cls_out : box_out)[l];
+      }
+    }
+  } else {
   for (int l = 3; l <= 7; ++l) {
     for (int net = 0; net < 2; ++net) {
       const std::string nn = net == 0 ? "class" : "box";
@@ -250,6 +346,7 @@ int build_effdet_heads(odt_model* m, const Tensor* red, const int* red_ch) {
       if (eff_sepconv(m, nn + "_net/" + nn + "-predict", "", x, F, nout, 0, nn + "_" + std::to_string(l), &o)) return 1;
       (net == 0 ? cls_out : box_out)[l - 3] = o;
     }
+  }
   }
   // ---- detection tail (efficientdet_wrapper.py:363-480, anchors.py:369-489) + per-level ROIAlign mean
   EffPostParams& ep = m->eff_post;

@@ -342,3 +342,37 @@ def test_efficientdet_d7_1536_parity(hip_lib):
   nodes, 5-layer heads) at 1536 x 1536, the reference's top-k of 5000, on the weights bench.py runs (VERDICT round 2:
   the tests stopped at D2 / B6-512)."""
   _det_full_parity(hip_lib, "efficientdet-d7", 1536, 1536, topk=5000, thr=0.02, gain=arch.bench_gain("efficientdet-d7"))
+
+
+def test_efficientdet_levels_merged_into_one_launch(backend, monkeypatch):
+  """Class / box nets with the five pyramid levels of a layer in ONE depthwise and ONE pointwise launch (batch 1, layers
+  on the conv_split3 kernels: D7 by itself, here D1 -- 88 filters padded to 128 -- with the tile threshold lowered): the
+  per-level BatchNorm is applied as per-row-range scale / bias in the conv epilogue.  Against the oracle (stage taps +
+  detections) and against the one-launch-per-level plan."""
+  name, lib = backend
+  monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1"); monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "1")
+  H, W = (136, 152) if name == "emu" else (264, 328)
+  _det_full_parity(lib, "efficientdet-d1", H, W, topk=300 if name == "emu" else 1000, thr=0.02, gain=1.0)
+  # launch counts: merged vs per level
+  from object_detection_tracking_amd import models
+  from object_detection_tracking_amd.config import make_config
+  from object_detection_tracking_amd.weights import synthetic_frames
+  w = arch.synthetic_det_weights("efficientdet-d1", 0)
+  fr = synthetic_frames(1, H, W, seed=13)[0]
+  res = {}
+  for mode in ("1", "0"):
+    monkeypatch.setenv("ODT_EFFDET_MERGE_LEVELS", mode)
+    cfg = make_config(is_efficientdet=True, efficientdet_modelname="efficientdet-d1", efficientdet_max_detection_topk=300,
+                      short_edge_size=H, max_size=W, threshold_conf=0.02)
+    cfg.max_size = W; cfg.result_score_thres = 0.02
+    m = models.get_model(cfg, 0, weights=w, lib=lib)
+    try:
+      det = m.predict(fr)
+      from object_detection_tracking_amd.models import _Engine
+      res[mode] = (det, _Engine.describe(m.engine((H, W)))["conv_launches"])
+    finally:
+      m.close()
+  assert res["0"][1] - res["1"][1] == 4 * 2 * (3 + 1), (res["0"][1], res["1"][1])     # 5 -> 1 launches per layer: 3 repeats + predict, two nets
+  from common import match_detections
+  miss, extra = match_detections(res["1"][0][0], res["1"][0][1], res["1"][0][2], res["0"][0][0], res["0"][0][1], res["0"][0][2], 5e-2, 5e-5)
+  assert miss + extra <= 2, (miss, extra)
