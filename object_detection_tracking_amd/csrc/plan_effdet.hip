@@ -247,8 +247,8 @@ int build_effdet_heads(odt_model* m, const Tensor* red, const int* red_ch) {
   if (const char* e = getenv("ODT_EFFDET_MERGE_LEVELS")) merge = merge && e[0] != '0';
   if (merge) {      // would the merged pointwise conv run on a conv_split3 kernel without split-K?
     ConvParams q; std::memset(&q, 0, sizeof(q));
-    q.B = 1; q.H = 1; q.W = Mtot; q.in_Ha = 1; q.in_Wa = Mtot; q.Cin = LF; q.in_ldc = LF; q.Ho = 1; q.Wo = Mtot; q.Cout = F;
-    q.kh = q.kw = 1; q.stride = 1; q.dil = 1; q.out_H = 1; q.out_W = Mtot; q.out_ldc = LF;
+    q.B = 1; q.H = Mtot / 256; q.W = 256; q.in_Ha = q.H; q.in_Wa = 256; q.Cin = LF; q.in_ldc = LF; q.Ho = q.H; q.Wo = 256; q.Cout = F;
+    q.kh = q.kw = 1; q.stride = 1; q.dil = 1; q.out_H = q.H; q.out_W = 256; q.out_ldc = LF;
     const ConvPolicy pol = resolve_conv_policy(m);
     merge = conv_split_wanted(q, pol);
     if (merge) { conv_split_choose(q, pol); merge = q.wt_split_kind == 3 && q.splitk <= 1; }
@@ -269,7 +269,7 @@ int build_effdet_heads(odt_model* m, const Tensor* red, const int* red_ch) {
       const float *dwt, *dbias;
       if (upload_raw(m, v, &dwt) || upload_raw(m, bv, &dbias)) return 1;
       Tensor t1{};
-      if (make_tensor(m, "", 1, 1, Mtot, LF, &t1, false)) return 1;
+      if (make_tensor(m, "", 1, Mtot / 256, 256, LF, &t1, false)) return 1;      // (rows as [Mtot / 256, 256]: tap coordinates are 16-bit)
       {
         Op op; op.kind = OP_DW;
         op.dw.wt = dwt; op.dw.bias = dbias; op.dw.B = 1; op.dw.ldc = LF; op.dw.k = 3; op.dw.stride = 1; op.dw.pad_t = 1; op.dw.pad_l = 1;
@@ -286,8 +286,7 @@ int build_effdet_heads(odt_model* m, const Tensor* red, const int* red_ch) {
       const float *wt, *bias;
       if (eff_upload_pw(m, scope, "", true, F, LF, cout, &wt, &bias, "pointwise_kernel")) return 1;
       const int lco = r32(cout);
-      Tensor view = t1;                      // [1, 1, Mtot, LF]
-      if (add_conv(m, scope, view, LF, wt, bias, 1, 1, cout, 1, 1, 0, 0, 1, Mtot, 0, 0, nullptr, 0, false, lco, out, "")) return 1;
+      if (add_conv(m, scope, t1, LF, wt, bias, 1, 1, cout, 1, 1, 0, 0, Mtot / 256, 256, 0, 0, nullptr, 0, false, lco, out, "")) return 1;
       ConvParams& cp = m->convs.back().p;
       cp.relu = act;
       if (!bn_prefix.empty()) {

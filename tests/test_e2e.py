@@ -410,31 +410,30 @@ def test_convs_cut_into_batch_ranges_are_bit_identical(backend, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_forward_multi_b16_1080p(hip_lib):
-  """b = 16 @1080p: conv0's output, the res2 tensors and the P2-level tensors pass 2 GiB -- the plan cuts those convs into
-  two batch ranges (round 2 refused the size).  Frames 0..7 give the detections of the b = 8 plan (the box head's split-K
-  choice differs with the row count, so compared as matched sets within the e2e tolerance)."""
-  cfg16 = make_config(rpn_test_post_nms_topk=300, im_batch_size=16)
+def test_forward_multi_b24_1080p(hip_lib):
+  """b = 24 @1080p: conv0's output, the res2 tensors and the P2-level tensors pass 2 GiB (b = 16 is just below it) -- the
+  plan cuts those convs into two batch ranges.  Frames 0..7 give the detections of the b = 8 plan (the box head's
+  split-K choice differs with the row count, so compared as matched sets within the e2e tolerance)."""
+  cfgb = make_config(rpn_test_post_nms_topk=300, im_batch_size=24)
   cfg8 = make_config(rpn_test_post_nms_topk=300, im_batch_size=8)
-  w = weights_for(cfg16)
-  fr = synthetic_frames(16, 1080, 1920, seed=3)
+  w = weights_for(cfgb)
+  fr8 = synthetic_frames(8, 1080, 1920, seed=3)
+  fr = np.concatenate([fr8, fr8[::-1], fr8], 0)
   m8 = models.get_model(cfg8, 0, weights=w, lib=hip_lib, is_multi=True)
   try:
-    ref = m8.predict_batch(fr[:8])
+    ref = m8.predict_batch(fr8)
   finally:
     m8.close()
-  m = models.get_model(cfg16, 0, weights=w, lib=hip_lib, is_multi=True)
+  m = models.get_model(cfgb, 0, weights=w, lib=hip_lib, is_multi=True)
   try:
     boxes, labels, probs, valid, feats = m.predict_batch(fr)
-    d = m.engine(16, 1080, 1920).describe()
-    assert d["convs_cut_into_batch_ranges"] >= 10 and d["memory"]["device_bytes"] < 12e9, d
-    assert np.array_equal(valid[:8], ref[3]) and np.all(valid > 0)
-    tot = 0
-    for b in range(8):
+    d = m.engine(24, 1080, 1920).describe()
+    assert d["convs_cut_into_batch_ranges"] >= 10 and d["memory"]["device_bytes"] < 16e9, d
+    assert np.all(valid > 0) and np.isfinite(feats).all()
+    for b, rb in [(i, i) for i in range(8)] + [(8 + i, 7 - i) for i in range(8)] + [(16 + i, i) for i in range(8)]:
       v = valid[b]
-      miss, extra = match_detections(boxes[b, :v], labels[b, :v], probs[b, :v], ref[0][b, :v], ref[1][b, :v], ref[2][b, :v], 1e-2, 1e-4)
-      tot += miss + extra
-    assert tot == 0, tot
-    assert np.isfinite(feats).all()
+      assert v == ref[3][rb], (b, v, ref[3][rb])
+      miss, extra = match_detections(boxes[b, :v], labels[b, :v], probs[b, :v], ref[0][rb, :v], ref[1][rb, :v], ref[2][rb, :v], 1e-2, 1e-4)
+      assert miss + extra == 0, (b, miss, extra)
   finally:
     m.close()
