@@ -382,13 +382,15 @@ def main():
 def pmc_traffic(mode):
   """HBM bytes per conv launch from the separate rocprofv3 --pmc passes of this same command
   (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; tools/pmc_summary.py), or None."""
-  path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json" if mode == "f32" else "r02_pmc_summary_split.json")
-  try:
-    with open(path) as fh:
-      return float(json.load(fh)["conv_hbm_bytes_per_launch_fetch_x2" if mode == "f32" else
-                                 "split_hbm_bytes_per_launch_fetch_x2"])
-  except Exception:
-    return None
+  names = ["r03_pmc_summary.json", "r02_pmc_summary.json"] if mode == "f32" else ["r03_pmc_summary_split.json", "r02_pmc_summary_split.json"]
+  for name in names:         # the newest committed summary
+    try:
+      with open(os.path.join(ROOT, "profiles", name)) as fh:
+        return float(json.load(fh)["conv_hbm_bytes_per_launch_fetch_x2" if mode == "f32" else
+                                   "split_hbm_bytes_per_launch_fetch_x2"])
+    except Exception:
+      continue
+  return None
 
 
 def cpu_model_name():
