@@ -512,8 +512,10 @@ __device__ __forceinline__ void split3_epilogue(const ConvParams& p, f32x16 (&ac
   // per-row-range constants (ConvParams::nlvl): every tile lies inside one range (ranges start on multiples of 256 rows)
   int lvl_off = 0;
   if (p.nlvl > 1) {
-    int lvl = 0;
-    for (int i = 1; i < p.nlvl; ++i) lvl += m0 >= p.lvl_start[i] ? 1 : 0;
+    // (constant indices: a runtime-indexed field would send the whole parameter record to scratch memory; unused entries
+    // are INT_MAX)
+    const int lvl = (m0 >= p.lvl_start[1] ? 1 : 0) + (m0 >= p.lvl_start[2] ? 1 : 0) + (m0 >= p.lvl_start[3] ? 1 : 0) +
+                    (m0 >= p.lvl_start[4] ? 1 : 0);
     lvl_off = lvl * p.lvl_stride;
   }
   const unsigned nbias = p.nlvl > 1 ? (unsigned)(p.nlvl * p.lvl_stride) : (unsigned)p.Cout;

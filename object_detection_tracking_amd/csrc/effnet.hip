@@ -125,7 +125,13 @@ __global__ void __launch_bounds__(256) dwconv_kernel(DwConvParams p) {
   const float* pin = p.in;
   float* pout = p.out;
   int pH = p.H, pW = p.W, pHo = p.Ho, pWo = p.Wo;
-  if (p.nlvl > 0) { pin = p.lin[b]; pout = p.lout[b]; pH = pHo = p.lH[b]; pW = pWo = p.lW[b]; b = 0; }
+  if (p.nlvl > 0) {
+    // (selected with constant indices: a runtime-indexed kernel-argument field would be copied to scratch memory)
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      if (i == b) { pin = p.lin[i]; pout = p.lout[i]; pH = pHo = p.lH[i]; pW = pWo = p.lW[i]; }
+    b = 0;
+  }
   const int c4 = cb * 16 + cq, c4n = p.ldc >> 2;
   const bool cok = c4 < c4n;
   const int nxb = (pWo + PX - 1) / PX, units = nxb * pHo;

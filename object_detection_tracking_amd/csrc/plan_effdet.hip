@@ -305,7 +305,7 @@ int build_effdet_heads(odt_model* m, const Tensor* red, const int* red_ch) {
         const float *dsc, *dsh;
         if (upload_raw(m, sc, &dsc) || upload_raw(m, sh, &dsh)) return 1;
         cp.bias = dsh; cp.lvl_scale = dsc; cp.nlvl = 5; cp.lvl_stride = lco;
-        for (int l = 0; l < 5; ++l) cp.lvl_start[l] = off[l];
+        for (int l = 0; l < 5; ++l) cp.lvl_start[l] = off[l];      // (all five in use; fewer ranges: fill the rest with INT_MAX)
       }
       return 0;
     };

@@ -1,0 +1,45 @@
+"""Build-time guard: the hot kernels must not use scratch (private) memory.
+
+Round 3 lost 25 % of the step for a few sessions to ONE runtime-indexed field of the by-value parameter record
+(`p.lvl_start[i]` in a loop): the compiler answered by placing the whole 344-byte record in scratch memory for every
+conv_split3 kernel.  hipcc reports the per-kernel resource usage at compile time (no GPU needed)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "object_detection_tracking_amd", "csrc")
+
+
+def _resources(src):
+  hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+  r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", CSRC, "-c",
+                      "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull,
+                      os.path.join(CSRC, src)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+  assert r.returncode == 0, r.stderr[-2000:]
+  out, cur = {}, None
+  for line in r.stderr.splitlines():
+    m = re.search(r"Function Name: (\S+)", line)
+    if m:
+      cur = m.group(1); out[cur] = {}
+    for key, short in (("VGPRs", "vgprs"), (r"ScratchSize \[bytes/lane\]", "scratch"), (r"Occupancy \[waves/SIMD\]", "occupancy")):
+      m = re.search(r"remark:\s+" + key + r": (\d+)", line)
+      if m and cur:
+        out[cur][short] = int(m.group(1))
+  return out
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") and "HIPCC" not in os.environ, reason="hipcc not installed")
+def test_hot_kernels_use_no_scratch_memory():
+  res = _resources("conv_split.hip")
+  hot = {k: v for k, v in res.items() if "conv_split3" in k or "conv_split_kernelILi4ELi1ELi2E" in k}      # (the 256 x 64 one-stage tile is the one the plans use)
+  assert len(hot) >= 12, sorted(res)
+  for k, v in hot.items():
+    assert v.get("scratch", 0) == 0, (k, v)
+    assert v.get("occupancy", 0) >= 2, (k, v)          # two waves per SIMD: one 8-wave workgroup per CU (or two 4-wave ones)
+  res = _resources("effnet.hip")
+  for k, v in res.items():
+    if "dwconv_kernel" in k or "bifpn_fuse" in k:
+      assert v.get("scratch", 0) == 0, (k, v)
