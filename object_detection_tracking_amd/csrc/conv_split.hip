@@ -91,17 +91,12 @@ __device__ __forceinline__ void split2(float a0, float a1, unsigned& hi, unsigne
 // TRACE: tuning builds only (ODT_CONV_TRACE through odt_op_conv2d): wall-clock stamps per workgroup in
 // the slots of conv_igemm.hip (0 start, 6 first loads issued, 7 first stage stored, 1 main loop, 2 epilogue,
 // 3/4 first pass staged / stored, 5 end; 8/9 HW_ID / XCC_ID).  Compiled out of the production kernels.
-// POOL (256 x 64 tile only): ConvParams::pool_out -- the tile's 256 rows are a 9 x 27 patch of conv outputs (13 rows idle)
-// and the epilogue writes the 3x3 / stride-2 max-pool of it (4 x 13 pooled pixels) instead of the conv output.
-constexpr int kPoolTH = 9, kPoolTW = 27, kPoolPY = 4, kPoolPX = 13;
-template <int WM, int WN, int TN, bool TRACE = false, bool POOL = false>
+template <int WM, int WN, int TN, bool TRACE = false>
 __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __restrict__ pp) {
   using Cfg = SplitCfg<WM, WN, TN>;
   constexpr int SBM = Cfg::BM, SBN = Cfg::BN, AKG = Cfg::AKG, APL = Cfg::APL, BKG = Cfg::BKG, BPL = Cfg::BPL;
-  constexpr int STAGE_B_BYTES = Cfg::STAGE_B, RA = Cfg::RA, NB = Cfg::NB;
-  constexpr int LDS_SPLIT = POOL ? (Cfg::LDS > SBM * (SBN + 4) * 4 ? Cfg::LDS : SBM * (SBN + 4) * 4) : Cfg::LDS;   // POOL: the whole C tile at once
+  constexpr int LDS_SPLIT = Cfg::LDS, STAGE_B_BYTES = Cfg::STAGE_B, RA = Cfg::RA, NB = Cfg::NB;
   static_assert(WM * WN == 4, "4 waves");
-  static_assert(!POOL || (SBM == 256 && SBN == 64), "fused max-pool: 256 x 64 tile");
   const ConvParams p = *pp;
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_SPLIT];
   unsigned char* const ldsB = lds + 3 * APL;
@@ -134,14 +129,6 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
   const int cpt = p.Cin >> 5;
   const int cpt2 = p.in2 != nullptr ? p.Cin2 >> 5 : 0;    // slices of the second A source (1x1 only)
   const int nslices = p.kh * p.kw * cpt + cpt2;
-  // POOL: tile mt = (image, pooled-row block, pooled-column block); its conv patch starts at (2 py0 - 1, 2 px0 - 1)
-  int pool_n = 0, pool_y0 = 0, pool_x0 = 0;
-  if constexpr (POOL) {
-    const int tpx = (p.pool_W + kPoolPX - 1) / kPoolPX, tpy = (p.pool_H + kPoolPY - 1) / kPoolPY;
-    pool_n = mt / (tpy * tpx);
-    const int rem = mt - pool_n * (tpy * tpx), by = rem / tpx;
-    pool_y0 = by * kPoolPY; pool_x0 = (rem - by * tpx) * kPoolPX;
-  }
 
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.in, 0, (int)((unsigned)p.B * p.in_Ha * p.in_Wa * p.in_ldc * 4u), 0x00020000);
@@ -161,13 +148,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
   for (int j = 0; j < RA; ++j) {
     const int m = m0 + lr + 32 * j;
     const bool ok = m < M;
-    if constexpr (POOL) {
-      const int r = lr + 32 * j, ty = (r * 19419) >> 19, tx = r - kPoolTW * ty;      // r / 27 (exact for r < 256)
-      const int ho = 2 * pool_y0 - 1 + ty, wo = 2 * pool_x0 - 1 + tx;
-      const bool v = r < kPoolTH * kPoolTW && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo;
-      a_hw0[j] = (int)(((unsigned)(ho * p.stride - p.pad_t) << 16) | ((unsigned)(wo * p.stride - p.pad_l) & 0xffffu));
-      a_img[j] = v ? (unsigned)pool_n * p.in_Ha * p.in_Wa * p.in_ldc * 4u + lc * 16u : kOOB;
-    } else if (dense_in) {
+    if (dense_in) {
       a_hw0[j] = 0;
       a_img[j] = ok ? (unsigned)m * p.in_ldc * 4u + lc * 16u : kOOB;
     } else {
@@ -342,51 +323,6 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
   }
 
   stamp(2);
-  if constexpr (POOL) {
-    // ---- fused max-pool epilogue: the whole 9 x 27 patch into LDS, then thread -> (pooled pixel, 16-byte channel chunk):
-    // max over the 3 x 3 window (positions outside the conv output are the pool's zero padding -- conv + ReLU is >= 0, so
-    // they simply do not take part), + bias, ReLU (both commute with the max), one 16-byte store.
-    constexpr int PCS = SBN + 4;
-    float* Pt = reinterpret_cast<float*>(lds);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          Pt[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * PCS + wn * TN * 32 + j * 32 + fr] = acc[i][j][r];
-    __syncthreads();
-    constexpr int PC4 = SBN / 4, UNITS = kPoolPY * kPoolPX * PC4;
-    for (int u = tid; u < UNITS; u += 256) {
-      const int c4 = u % PC4, pp2 = u / PC4, py = pp2 / kPoolPX, px = pp2 - py * kPoolPX;
-      const int yo = pool_y0 + py, xo = pool_x0 + px;
-      if (yo >= p.pool_H || xo >= p.pool_W) continue;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      bool any = false;
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const int ty = 2 * py + dy, ho = 2 * pool_y0 - 1 + ty;
-        if ((unsigned)ho >= (unsigned)p.Ho) continue;
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int tx = 2 * px + dx, wo = 2 * pool_x0 - 1 + tx;
-          if ((unsigned)wo >= (unsigned)p.Wo) continue;
-          const f32x4 q = *reinterpret_cast<const f32x4*>(&Pt[(ty * kPoolTW + tx) * PCS + c4 * 4]);
-          if (!any) { v = q; any = true; }
-          else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], q[e]);
-          }
-        }
-      }
-      v += *reinterpret_cast<const f32x4*>(p.bias + n0 + c4 * 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-      *reinterpret_cast<f32x4*>(p.pool_out + (((size_t)pool_n * p.pool_H + yo) * p.pool_W + xo) * p.pool_ldc + n0 + c4 * 4) = v;
-    }
-    stamp(5);
-    return;
-  }
   // ---- epilogue (the fast path of conv_igemm.hip without a residual): stage the tile through
   // LDS in two passes of RP rows, bias + activation, whole 16-byte-per-lane row segments.
   constexpr int CS = SBN + 4;
@@ -1542,14 +1478,6 @@ int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t st
     return 0;
   }
   const int bm = conv_split_bm(p.Cout);
-  if (p.pool_out != nullptr) {
-    ODT_CHECK(bn == 64 && cout_padded(p.Cout) == 64 && p.relu == 1 && p.res_mode == 0 && p.in2 == nullptr && p.splitk <= 1 &&
-              2 * p.pool_H <= p.Ho + 1 && 2 * p.pool_W <= p.Wo + 1, "conv split: fused max-pool needs a 64-channel conv + ReLU");
-    const unsigned tiles = (unsigned)p.B * ((p.pool_H + kPoolPY - 1) / kPoolPY) * ((p.pool_W + kPoolPX - 1) / kPoolPX);
-    hipLaunchKernelGGL((conv_split_kernel<4, 1, 2, false, true>), dim3(tiles), dim3(256), 0, stream, dev);
-    ODT_HIP(hipGetLastError());
-    return 0;
-  }
   const unsigned grid = (unsigned)(((M + bm - 1) / bm) * (cout_padded(p.Cout) / bn));
   if (p.trace != nullptr) {        // tuning: the stamped instantiations
     if (bn == 256) hipLaunchKernelGGL((conv_split_kernel<2, 2, 4, true>), dim3(grid), dim3(256), 0, stream, dev);

@@ -89,12 +89,6 @@ struct ConvParams {
   int lvl_start[5];
   int lvl_stride;
   const float* lvl_scale;
-  // optional fused 3x3 / stride-2 max-pool with zero pad 1 at the top / left behind the conv + ReLU (conv0 -> pool0 of the
-  // backbone, nn.py:886-896; one-stage 256 x 64 split kernel): a tile is a 9 x 27 patch of conv outputs (rows and columns
-  // 2 y0 - 1 ..., the windows of 4 x 13 pooled pixels), the max is taken over the staged C tile and only the pooled tensor
-  // is written -- conv0's [B,544,960,64] output (1.07 GB at b = 8) is neither written nor read back, the pool launch goes.
-  float* pool_out;     // [B, pool_H, pool_W, pool_ldc] or nullptr
-  int pool_H, pool_W, pool_ldc;
   const float* head_wt;    // [Cout][16] (k-major, column 15 zero) or nullptr
   const float* head_bias;  // [16]
   float* head_out;         // [M][head_ldc] dense rows (m = (n, ho, wo))

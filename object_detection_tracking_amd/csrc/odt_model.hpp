@@ -93,7 +93,6 @@ struct odt_model {
   std::vector<ConvParams> conv_recs; // launch records: convs[i] runs as records [conv_rec0[i], + conv_nrec[i]) (batch ranges,
   std::vector<int> conv_rec0, conv_nrec;   // more than one only where a tensor would reach 2 GiB: upload_conv_records)
   int chunked_convs = 0;
-  int pool_fused = 0;                // pool0 evaluated in conv0's epilogue (fuse_conv0_pool)
   std::vector<Op> ops;
   // geometry
   int Hp = 0, Wp = 0;
@@ -200,7 +199,6 @@ int create_side_stream(hipStream_t* s);
 ConvPolicy resolve_conv_policy(const odt_model* m);
 int attach_split_weights(odt_model* m);
 int fuse_rpn_heads(odt_model* m);
-int fuse_conv0_pool(odt_model* m);
 void find_overlap_points(odt_model* m);
 int plan_arena(odt_model* m);
 int upload_conv_records(odt_model* m);
@@ -222,7 +220,7 @@ void visit_op_ptrs(odt_model* m, size_t oi, F&& f) {
   f(op.in.d); f(op.out.d);
   switch (op.kind) {
     case OP_PRE: case OP_PRE_RGB: f(m->image_pad.d); break;
-    case OP_CONV: { ConvParams& c = m->convs[op.conv].p; f(c.in); f(c.res); f(c.out); f(c.in2); f(c.pool_out); break; }
+    case OP_CONV: { ConvParams& c = m->convs[op.conv].p; f(c.in); f(c.res); f(c.out); f(c.in2); break; }
     case OP_PROPOSALS: for (auto& l : m->prop.lvl) f(l.rpn); f(m->prop.props); break;
     case OP_ROI_HEAD: roi(m->roi_head); break;
     case OP_ROI_FINAL: roi(m->roi_final); break;

@@ -286,34 +286,6 @@ int fuse_rpn_heads(odt_model* m) {
   return 0;
 }
 
-// ---- pool0 folded into conv0's epilogue -------------------------------------------------------------------------------
-// conv0 (7x7 s2 + BN + ReLU) is followed by the 3x3 / stride-2 max-pool and nothing else reads its output (nn.py:886-896).
-// On the one-stage 256 x 64 split kernel the pool is taken over the staged C tile (conv_split_kernel<..., POOL>): the
-// [B,544,960,64] tensor (1.07 GB at b = 8) is neither written nor read back and the pool launch disappears; same bits
-// (max commutes with + bias and ReLU).  Arena handles only (a keep_taps handle keeps "conv0" readable);
-// ODT_FUSE_POOL=0: two launches (A/B).  Called after attach_split_weights, before plan_arena.
-int fuse_conv0_pool(odt_model* m) {
-  if (!m->arena_on) return 0;
-  const char* e = getenv("ODT_FUSE_POOL");
-  if (e != nullptr && e[0] == '0') return 0;
-  for (size_t oi = 0; oi + 1 < m->ops.size(); ++oi) {
-    Op& oa = m->ops[oi]; Op& ob = m->ops[oi + 1];
-    if (oa.kind != OP_CONV || ob.kind != OP_POOL || oa.skip) continue;
-    ConvOp& a = m->convs[oa.conv];
-    ConvParams& ap = a.p;
-    const bool ok = a.name == "conv0" && ap.wt_split != nullptr && ap.wt_split_kind == 1 && ap.Cout == 64 && ap.relu == 1 &&
-                    ap.res_mode == 0 && ap.in2 == nullptr && ob.in.d == ap.out && ap.out_oy == 0 && ap.out_ox == 0 &&
-                    ap.out_H == ap.Ho && ap.out_W == ap.Wo && ob.out.C == 64 && 2 * ob.out.H <= ap.Ho + 1 && 2 * ob.out.W <= ap.Wo + 1;
-    if (!ok) continue;
-    ap.pool_out = ob.out.d; ap.pool_H = ob.out.H; ap.pool_W = ob.out.W; ap.pool_ldc = ob.out.C;
-    ap.out = nullptr;
-    ob.skip = true;
-    m->taps.erase("conv0");
-    m->pool_fused = 1;
-  }
-  return 0;
-}
-
 // ---- activation arena -----------------------------------------------------------------------------------------------
 // ops [op_tail, end) of forward i (selection / ROIAlign / box head / NMS / features) may run on the side stream under ops
 // [0, op_first_fpn) of forward i+1 (run_plan: tail overlap); 0 / 0 when the graph has no such split
@@ -436,7 +408,6 @@ int upload_conv_records(odt_model* m) {
       if (p.res != nullptr) q.res = p.res + b0 * p.res_H * p.res_W * p.res_ldc;
       if (p.in2 != nullptr) q.in2 = p.in2 + b0 * p.in2_Ha * p.in2_Wa * p.in2_ldc;
       if (p.head_out != nullptr) q.head_out = p.head_out + b0 * p.Ho * p.Wo * p.head_ldc;
-      if (p.pool_out != nullptr) q.pool_out = p.pool_out + b0 * p.pool_H * p.pool_W * p.pool_ldc;
       m->conv_recs.push_back(q);
     }
     if (n > 1) ++m->chunked_convs;

@@ -45,7 +45,6 @@ static int run_ops(odt_model* m, const void* src, int dtype, hipStream_t st, siz
         break;
       }
       case OP_POOL:
-        if (op.skip) break;          // folded into conv0's epilogue
         if (launch_maxpool3x3s2(op.in.d, op.in.B, op.in.h, op.in.w, op.in.C, op.out.d, op.out.H, op.out.W, st)) return 1;
         break;
       case OP_SUB2:
@@ -603,12 +602,12 @@ int odt_describe(odt_handle h, char* buf, int cap) {
                 "\"one_stage_bk32\": %d, \"of_split3_with_split_k\": %d}, \"policy\": {\"family\": %d, \"min_tiles\": %ld, "
                 "\"min_tiles3\": %ld, \"min_k\": %d}, \"env_overrides_applied\": %d, "
                 "\"memory\": {\"device_bytes\": %zu, \"activation_arena_bytes\": [%zu, %zu], \"arena_tensors\": %zu, "
-                "\"arena_tensor_bytes_unshared\": %zu, \"dedicated_tensor_bytes\": %zu, \"keep_taps\": %d}, \"convs_cut_into_batch_ranges\": %d, \"pool0_in_conv0_epilogue\": %d}",
+                "\"arena_tensor_bytes_unshared\": %zu, \"dedicated_tensor_bytes\": %zu, \"keep_taps\": %d}, \"convs_cut_into_batch_ranges\": %d}",
                 h->policy.arith != 0 && fam[1] + fam[3] > 0 ? "f32 through bf16x3 split products" : "exact f32 MFMA",
                 (int)h->convs.size() - nfused, nfused, fam[0], fam[1] + fam[3], fam[3], fam[1], nsk, h->policy.family,
                 h->policy.min_tiles, h->policy.min_tiles3, h->policy.min_k, h->policy.env_overrides,
                 dev_bytes, h->arena_bytes[0], h->arena_bytes[1], h->vt.size(), h->virtual_tensor_bytes,
-                h->dedicated_tensor_bytes, h->cfg.keep_taps, h->chunked_convs, h->pool_fused);
+                h->dedicated_tensor_bytes, h->cfg.keep_taps, h->chunked_convs);
   std::strncpy(buf, tmp, cap - 1); buf[cap - 1] = 0;
   return 0;
 }

@@ -437,28 +437,3 @@ def test_forward_multi_b24_1080p(hip_lib):
       assert miss + extra == 0, (b, miss, extra)
   finally:
     m.close()
-
-
-def test_pool0_fused_into_conv0_epilogue(backend, monkeypatch):
-  """pool0 (3x3 / stride-2 max over conv0 + ReLU, zero pad 1 top / left; nn.py:886-896) taken over the staged C tile of
-  conv0 on the one-stage split kernel: odd and even sizes (partial pooled tiles at the right / bottom), batch 2; bit for
-  bit the result of the two-launch form (max commutes with + bias and ReLU), which the keep_taps handle still runs."""
-  name, lib = backend
-  monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1"); monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "1")
-  for B, H, W in (((2, 70, 110),) if name == "emu" else ((2, 230, 394), (1, 256, 448))):
-    cfg = small_config(resnet_num_block=[1, 1, 1, 1], im_batch_size=B, rpn_test_post_nms_topk=32, max_size=max(256, W), short_edge_size=H)
-    w = weights_for(cfg)
-    fr = synthetic_frames(B, H, W, seed=6)
-    outs = []
-    for fuse, taps in (("1", False), ("0", False), ("1", True)):
-      monkeypatch.setenv("ODT_FUSE_POOL", fuse)
-      m = models.get_model(_with_taps(cfg) if taps else cfg, 0, weights=w, lib=lib, is_multi=True)
-      try:
-        det = m.predict_batch(fr)
-        outs.append((det, m.engine(B, H, W).describe()["pool0_in_conv0_epilogue"]))
-      finally:
-        m.close()
-    assert [o[1] for o in outs] == [1, 0, 0], [o[1] for o in outs]
-    for other in (outs[1], outs[2]):
-      for a, b in zip(outs[0][0], other[0]):
-        assert np.array_equal(a, b), (B, H, W)
