@@ -66,6 +66,13 @@ class EfficientNetBackbone(object):
   def synchronize(self):
     self.lib.check(self.lib.dll.odt_synchronize(self.h))
 
+  def describe(self):
+    """What the handle runs (odt_describe): kernel families, launches, memory."""
+    import json
+    buf = C.create_string_buffer(2048)
+    self.lib.check(self.lib.dll.odt_describe(self.h, buf, 2048))
+    return json.loads(buf.value.decode())
+
   def tap(self, name):
     """Stage tensor in the device layout (NHWC, channel stride padded to 32), as numpy."""
     shape = (C.c_int64 * 4)(); rank = C.c_int()
