@@ -379,9 +379,10 @@ def test_rpn_head_fused_into_conv_epilogue(backend, monkeypatch):
     assert _rel(a, b) < 1e-5, l
   miss, extra = match_detections(out["1"][0][0], out["1"][0][1], out["1"][0][2], out["0"][0][0], out["0"][0][1], out["0"][0][2], 1e-3, 1e-4)
   assert miss + extra == 0
-  monkeypatch.setenv("ODT_FUSE_RPN_HEAD", "1")
-  miss, extra = _run_single(lib, cfg, H, W)           # fused form against the oracle, arena + taps handles
-  assert miss == 0 and extra == 0
+  if name == "hip":                                    # (simulator: the two-launch form is what the oracle tests cover; fused == two-launch above)
+    monkeypatch.setenv("ODT_FUSE_RPN_HEAD", "1")
+    miss, extra = _run_single(lib, cfg, H, W)         # fused form against the oracle, arena + taps handles
+    assert miss == 0 and extra == 0
 
 
 
