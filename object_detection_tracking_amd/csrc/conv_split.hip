@@ -1,1195 +1,16 @@
-// f32 implicit-GEMM convolution on the bf16 matrix pipe of gfx950 ("bf16x3 split"), for the
-// Cout % 64 == 0 layers of the ResNet-101-FPN frame with at least one tile per CU (97 of the 121
-// conv launches at b=8, 87 % of the conv time; same reference ops as conv_igemm.hip:
-// nn.py:337-381 conv2d + :1771-1774 folded BN + ReLU, :503-521 residual, :949-1014 FPN lateral).
-//
-// Arithmetic.  Every f32 operand is cut into three bf16 pieces by round-to-nearest,
-//     x = hi + mid + lo   exactly   (3 x 8 significand bits = the 24 bits of an f32),
-// |mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|, so a*b is the sum of nine piece products.  The six largest
-// are evaluated on v_mfma_f32_32x32x16_bf16 (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid); the
-// three dropped ones (mid*lo, lo*mid, lo*lo) are bounded by (2^-23 + 2^-32) |a||b|: two f32
-// roundings of the product, unbiased (the pieces carry either sign).  Each piece product is exact
-// in f32 (8 x 8 bits) and the accumulation is f32 inside the MFMA unit: the result carries the
-// error of an f32 dot product with a different summation order (measured ~1e-7 of sum|a||b| on
-// K = 2304, the same as a sequential f32 loop; tools/experiments/split_gemm.hip; the bound is
-// asserted in tests/test_ops.py).  |x| above 3.39e38 (bf16 rounds to inf) is outside the domain;
-// below ~1e-33 the lo piece is a bf16 subnormal (absolute effect < 1e-38 per product).
-// bf16 MFMA runs at 16x the f32 MFMA rate, so six products cost 6/16 of the f32 instruction time:
-// the ceiling is 2.67x the f32 MFMA peak.
-//
-// Tiling.  128 x 256 block tile for the Cout % 256 layers (the whole Cout of a 256-channel layer:
-// A is fetched from HBM and split once), 256 x 128 / 256 x 64 for Cout % 128 / % 64; 4 waves, wave
-// tile 64 x 128 (64 x 64), BK = 32, one LDS stage (72 KB: 3 A planes + 3 B planes) + register
-// prefetch of the next slice, 2 workgroups per CU.
-// A: f32 NHWC activations, gathered per tap exactly as in conv_igemm.hip, split on the way into
-// LDS.  B: weights split ONCE at plan-build time (conv_make_split_weights) into the per-stage LDS
-// image [n-tile][k-slice][piece][k-group][BN n][8 k] so that a stage is one linear copy.
-// LDS planes are [k-group][row][8 bf16]: a wave's ds_read_b128 of an MFMA operand is one
-// contiguous 512-byte run per 32 lanes.
-//
-// Scope: no residual, a same-shape residual or a nearest-2x upsampled one (both become the
-// accumulators' start value), an optional K-concatenated second A source (1x1), Cout % 64 == 0, Cin % 32 == 0, 16-byte-aligned
-// output rows; everything else stays on the exact-f32 MFMA kernel (launch_conv decides).
-#include <cstdlib>
-#include <type_traits>
-
-#include "odt_common.hpp"
+// f32 implicit-GEMM convolution on the bf16 matrix pipe of gfx950 ("bf16x3 split"): weight images, the per-handle policy
+// (which convs take the split kernels and which family) and the dispatch.  Kernels: conv_split3.hip (conv_split3_kernel /
+// conv_split3k_kernel: 8 waves, LDS-DMA weight stages, three-stage ring; the default), conv_split1.hip (one-stage 4-wave
+// loop: the 64-wide layers).  Same reference ops as conv_igemm.hip: nn.py:337-381 conv2d + :1771-1774 folded BN + ReLU,
+// :503-521 residual, :949-1014 FPN lateral.  The arithmetic is described in conv_split_common.hpp.
+// Scope: no residual, a same-shape residual or a nearest-2x upsampled one, an optional K-concatenated second A source
+// (1x1), Cout % 64 == 0 (padded), Cin % 32 == 0, 16-byte-aligned output rows; everything else stays on the exact-f32 MFMA
+// kernel (launch_conv decides).
+#include "conv_split_common.hpp"
 
 namespace odt {
 
 namespace {
-
-typedef unsigned int u32x4 __attribute__((vector_size(16)));
-typedef unsigned int u32x2 __attribute__((vector_size(8)));
-typedef short bf16x8 __attribute__((vector_size(16)));
-
-constexpr unsigned kOOB = 0x80000000u;
-// Tile configurations <WM, WN, TN>: 4 waves as WM x WN, wave tile 64 x (32*TN):
-//   <2,2,4> 128 x 256  (Cout % 256 == 0)     <4,1,4> 256 x 128  (Cout % 128 == 0: res3)
-//   <4,1,2> 256 x 64   (Cout % 64 == 0: res2)
-template <int WM, int WN, int TN>
-struct SplitCfg {
-  static constexpr int BM = WM * 64, BN = WN * TN * 32;
-  static constexpr int AKG = BM * 16 + 32, APL = 4 * AKG;     // bytes: one k-group / one piece plane of A
-  static constexpr int BKG = BN * 16 + 32, BPL = 4 * BKG;
-  static constexpr int LDS = 3 * APL + 3 * BPL;               // 74,496 B (62,208 for 256 x 64)
-  static constexpr int STAGE_B = 3 * 4 * BN * 16;             // bytes of pre-imaged weights per stage
-  static constexpr int RA = BM / 32;                          // A rows (16-B loads) per thread and slice
-  static constexpr int NB = STAGE_B / 4096;                   // B 16-B chunks per thread and slice
-};
-
-// Cout rounded up to the 64-wide n-tile granule: layers whose channel count is not a multiple of 64 (EfficientNet's
-// 240, 432, 864 ...) run with zero weight rows and a zero bias in the padding; their tensors' pixel stride covers it
-__host__ __device__ __forceinline__ int cout_padded(int cout) { return (cout + 63) & ~63; }
-__device__ __forceinline__ int sfast_div(int n, unsigned mul, unsigned sh) {
-  return mul ? (int)(__umulhi((unsigned)n, mul) >> sh) : n;
-}
-// Two f32 -> two bf16 (round to nearest even) in one dword: v_cvt_pk_bf16_f32.  (The CPU simulator
-// of the test suite supplies its own ODT_CVT_PK_BF16.)
-#ifndef ODT_CVT_PK_BF16
-typedef __bf16 odt_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float odt_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a0, float a1) {
-  const odt_f32x2 v = {a0, a1};
-  const odt_bf16x2 r = __builtin_convertvector(v, odt_bf16x2);
-  return *reinterpret_cast<const unsigned*>(&r);
-}
-#define ODT_CVT_PK_BF16(a0, a1) cvt_pk_bf16(a0, a1)
-#endif
-// x = hi + mid + lo exactly: hi = RN8(x); x - hi has <= 16 significant bits and is exact in f32;
-// mid = RN8(x - hi); the rest has <= 8 bits, so lo is exact.  |mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|.
-__device__ __forceinline__ void split2(float a0, float a1, unsigned& hi, unsigned& mid, unsigned& lo) {
-  hi = ODT_CVT_PK_BF16(a0, a1);
-  const float r0 = a0 - __uint_as_float(hi << 16);
-  const float r1 = a1 - __uint_as_float(hi & 0xffff0000u);
-  mid = ODT_CVT_PK_BF16(r0, r1);
-  const float s0 = r0 - __uint_as_float(mid << 16);
-  const float s1 = r1 - __uint_as_float(mid & 0xffff0000u);
-  lo = ODT_CVT_PK_BF16(s0, s1);
-}
-
-// TRACE: tuning builds only (ODT_CONV_TRACE through odt_op_conv2d): wall-clock stamps per workgroup in
-// the slots of conv_igemm.hip (0 start, 6 first loads issued, 7 first stage stored, 1 main loop, 2 epilogue,
-// 3/4 first pass staged / stored, 5 end; 8/9 HW_ID / XCC_ID).  Compiled out of the production kernels.
-template <int WM, int WN, int TN, bool TRACE = false>
-__global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __restrict__ pp) {
-  using Cfg = SplitCfg<WM, WN, TN>;
-  constexpr int SBM = Cfg::BM, SBN = Cfg::BN, AKG = Cfg::AKG, APL = Cfg::APL, BKG = Cfg::BKG, BPL = Cfg::BPL;
-  constexpr int LDS_SPLIT = Cfg::LDS, STAGE_B_BYTES = Cfg::STAGE_B, RA = Cfg::RA, NB = Cfg::NB;
-  static_assert(WM * WN == 4, "4 waves");
-  const ConvParams p = *pp;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_SPLIT];
-  unsigned char* const ldsB = lds + 3 * APL;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  auto stamp = [&](int i) {
-    if constexpr (TRACE) {
-      if (tid == 0) p.trace[(size_t)blockIdx.x * 16 + i] = wall_clock64();
-    }
-  };
-  stamp(0);
-  if constexpr (TRACE) {
-    if (tid == 0) {
-      p.trace[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-      p.trace[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-    }
-  }
-  const int ntn = cout_padded(p.Cout) / SBN;
-  // XCD-aware tile order (see conv_igemm.hip): one contiguous run of tiles per XCD
-  int wg = (int)blockIdx.x;
-  {
-    const int nwg = (int)gridDim.x, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
-  }
-  const int mt = wg / ntn, nt = wg - mt * ntn;
-  const int m0 = mt * SBM, n0 = nt * SBN;
-  const int HoWo = p.Ho * p.Wo;
-  const int M = p.B * HoWo;
-  const int cpt = p.Cin >> 5;
-  const int cpt2 = p.in2 != nullptr ? p.Cin2 >> 5 : 0;    // slices of the second A source (1x1 only)
-  const int nslices = p.kh * p.kw * cpt + cpt2;
-
-  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.in, 0, (int)((unsigned)p.B * p.in_Ha * p.in_Wa * p.in_ldc * 4u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.in2 != nullptr ? p.in2 : p.in), 0,
-      (int)(p.in2 != nullptr ? (unsigned)p.B * p.in2_Ha * p.in2_Wa * p.in2_ldc * 4u : 0u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.wt_split, 0, (int)((unsigned)ntn * nslices * (unsigned)STAGE_B_BYTES), 0x00020000);
-
-  // ---- A loader: thread -> (row lr + 32*j, 16-byte column lc), as in conv_igemm.hip
-  const int lc = tid & 7, lr = tid >> 3;
-  int a_hw0[RA];
-  unsigned a_img[RA];
-  const bool dense_in = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 &&
-                        p.H == p.in_Ha && p.W == p.in_Wa && p.Ho == p.H && p.Wo == p.W;
-#pragma unroll
-  for (int j = 0; j < RA; ++j) {
-    const int m = m0 + lr + 32 * j;
-    const bool ok = m < M;
-    if (dense_in) {
-      a_hw0[j] = 0;
-      a_img[j] = ok ? (unsigned)m * p.in_ldc * 4u + lc * 16u : kOOB;
-    } else {
-      const int mm = ok ? m : 0;
-      const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), r = mm - n * HoWo;
-      const int ho = sfast_div(r, p.div_wo_mul, p.div_wo_sh), wo = r - ho * p.Wo;
-      a_hw0[j] = (int)(((unsigned)(ho * p.stride - p.pad_t) << 16) | ((unsigned)(wo * p.stride - p.pad_l) & 0xffffu));
-      a_img[j] = ok ? (unsigned)n * p.in_Ha * p.in_Wa * p.in_ldc * 4u + lc * 16u : kOOB;
-    }
-  }
-  const unsigned pix_bytes = (unsigned)p.in_ldc * 4u;
-  int l_cc = 0, l_kh = 0, l_kw = 0;
-  unsigned a_row[RA];
-  auto set_tap = [&](int khh, int kww) {
-#pragma unroll
-    for (int j = 0; j < RA; ++j) {
-      const int hi = (a_hw0[j] >> 16) + khh * p.dil, wi = (int)(short)(a_hw0[j] & 0xffff) + kww * p.dil;
-      const bool v = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W && a_img[j] != kOOB;
-      a_row[j] = v ? a_img[j] + (unsigned)(hi * p.in_Wa + wi) * pix_bytes : kOOB;
-    }
-  };
-  set_tap(0, 0);
-  // second source (stage-entry bottleneck: conv3(t2) + convshortcut(x) as one K-concatenated GEMM):
-  // output row m reads pixel (n, ho * in2_stride, wo * in2_stride) of in2
-  bool l_src2 = false;
-  int l_cpt = cpt;
-  auto set_src2 = [&]() {
-#pragma unroll
-    for (int j = 0; j < RA; ++j) {
-      const int m = m0 + lr + 32 * j;
-      const bool ok = m < M;
-      const int mm = ok ? m : 0;
-      const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), r = mm - n * HoWo;
-      const int ho = sfast_div(r, p.div_wo_mul, p.div_wo_sh), wo = r - ho * p.Wo;
-      const unsigned pix = ((unsigned)n * p.in2_Ha + (unsigned)(ho * p.in2_stride)) * p.in2_Wa + (unsigned)(wo * p.in2_stride);
-      a_row[j] = ok ? pix * (unsigned)p.in2_ldc * 4u + lc * 16u : kOOB;
-    }
-  };
-  unsigned l_b = (unsigned)nt * (unsigned)nslices * (unsigned)STAGE_B_BYTES;   // weight-image offset of the load stream
-
-  f32x4 ga[RA];
-  u32x4 gb[NB];
-  const int b_st = (tid / SBN) * BKG + (tid % SBN) * 16;   // this thread's place inside a 256-chunk run
-  auto load_slice = [&]() {
-#pragma unroll
-    for (int j = 0; j < RA; ++j)
-      ga[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(l_src2 ? rs_in2 : rs_in, (int)a_row[j], l_cc * 128, 0);
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-      gb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, tid * 16 + i * 4096, (int)l_b, 0);
-    l_b += (unsigned)STAGE_B_BYTES;
-    if (++l_cc == l_cpt) {
-      l_cc = 0;
-      if (!l_src2) {
-        if (++l_kw == p.kw) { l_kw = 0; ++l_kh; }
-        if (l_kh == p.kh && cpt2 > 0) {
-          l_src2 = true; l_cpt = cpt2;
-          set_src2();
-        } else {
-          set_tap(l_kh, l_kw);      // harmless past the last tap (never loaded)
-        }
-      }
-    }
-  };
-  auto store_slice = [&]() {
-#pragma unroll
-    for (int j = 0; j < RA; ++j) {
-      unsigned h0, m0_, l0, h1, m1, l1;
-      split2(ga[j][0], ga[j][1], h0, m0_, l0);
-      split2(ga[j][2], ga[j][3], h1, m1, l1);
-      const int off = (lc >> 1) * AKG + (lr + 32 * j) * 16 + (lc & 1) * 8;
-      *reinterpret_cast<u32x2*>(lds + 0 * APL + off) = u32x2{h0, h1};
-      *reinterpret_cast<u32x2*>(lds + 1 * APL + off) = u32x2{m0_, m1};
-      *reinterpret_cast<u32x2*>(lds + 2 * APL + off) = u32x2{l0, l1};
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {        // chunk tid + 256 i of the stage image [piece][k-group][n]
-      constexpr int per = 4 * SBN / 256;  // chunks-of-256 per piece
-      *reinterpret_cast<u32x4*>(ldsB + (i / per) * BPL + (((i % per) * 256) / SBN) * BKG + b_st) = gb[i];
-    }
-  };
-
-  f32x16 acc[2][TN];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int fr = lane & 31, fg = lane >> 5;
-  load_slice();
-  stamp(6);
-  if (p.res_mode != 0) {
-    // residual of the same shape (bottleneck conv3) or the nearest-2x upsampled coarser level (FPN
-    // lateral, res_mode 2): the accumulators START at the residual, read in the MFMA C layout (a
-    // 32-lane group covers one 128-byte row segment) while the first slice is in flight -- no
-    // residual traffic in the epilogue.
-    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)p.res, 0, (int)((unsigned)p.B * p.res_H * p.res_W * p.res_ldc * 4u), 0x00020000);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
-        unsigned rpix = (unsigned)row;
-        if (p.res_mode == 2) {
-          const int mm = row < M ? row : 0;
-          const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), rr = mm - n * HoWo;
-          const int ho = sfast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
-          rpix = ((unsigned)n * p.res_H + (unsigned)(ho >> 1)) * p.res_W + (unsigned)(wo >> 1);
-        }
-        const unsigned roff = row < M ? rpix * (unsigned)p.res_ldc * 4u + (unsigned)(n0 + wn * TN * 32 + fr) * 4u : kOOB;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, (int)roff, j * 128, 0));
-      }
-  }
-  for (int c = 0; c < nslices; ++c) {
-    store_slice();
-    __syncthreads();
-    if constexpr (TRACE) { if (c == 0) { stamp(7); stamp(1); } }
-    if (c + 1 < nslices) load_slice();
-    {
-      // Two k16 steps x TN 32-column groups.  Within a group the b0 (hi) products run first,
-      // then b1, then b2; each piece's fragment of the NEXT group is re-read right after its last
-      // use, behind the remaining MFMAs of this group (sched_barrier fences pin the order: left
-      // alone the scheduler issues a group's three reads and waits for them in front of its MFMAs).
-      bf16x8 fa[3][2], fb[3];
-      auto rdA = [&](int q, int ks) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-          fa[q][t] = *reinterpret_cast<const bf16x8*>(lds + q * APL + (ks * 2 + fg) * AKG + (wm * 64 + t * 32 + fr) * 16);
-      };
-      auto rdB = [&](int q, int ks, int j) {
-        fb[q] = *reinterpret_cast<const bf16x8*>(ldsB + q * BPL + (ks * 2 + fg) * BKG + (wn * TN * 32 + j * 32 + fr) * 16);
-      };
-#define ODT_MF(qa, qb, j) { acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][0], fb[qb], acc[0][j], 0, 0, 0); \
-                            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][1], fb[qb], acc[1][j], 0, 0, 0); }
-#define ODT_FENCE() __builtin_amdgcn_sched_barrier(0)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) rdA(q, 0);
-#pragma unroll
-      for (int q = 0; q < 3; ++q) rdB(q, 0, 0);
-      ODT_FENCE();
-#pragma unroll
-      for (int g = 0; g < 2 * TN; ++g) {
-        const int j = g % TN;
-        const int nks = (g + 1) / TN, nj = (g + 1) % TN;
-        const bool has_next = g < 2 * TN - 1, a_next = has_next && nj == 0;
-        ODT_MF(2, 0, j); ODT_FENCE();          // lo * hi
-        if (a_next) rdA(2, nks);
-        ODT_FENCE();
-        ODT_MF(1, 0, j); ODT_MF(0, 0, j); ODT_FENCE();   // mid * hi, hi * hi
-        if (has_next) rdB(0, nks, nj);
-        ODT_FENCE();
-        ODT_MF(1, 1, j); ODT_FENCE();          // mid * mid
-        if (a_next) rdA(1, nks);
-        ODT_FENCE();
-        ODT_MF(0, 1, j); ODT_FENCE();          // hi * mid
-        if (has_next) rdB(1, nks, nj);
-        ODT_FENCE();
-        ODT_MF(0, 2, j); ODT_FENCE();          // hi * lo
-        if (a_next) rdA(0, nks);
-        if (has_next) rdB(2, nks, nj);
-        ODT_FENCE();
-      }
-#undef ODT_MF
-#undef ODT_FENCE
-    }
-    __syncthreads();
-  }
-
-  stamp(2);
-  // ---- epilogue (the fast path of conv_igemm.hip without a residual): stage the tile through
-  // LDS in two passes of RP rows, bias + activation, whole 16-byte-per-lane row segments.
-  constexpr int CS = SBN + 4;
-  constexpr int RP = SBM / 2, WPP = RP / 64;               // rows / wave-rows per pass
-  constexpr int C4 = SBN / 4, RSTEP = 256 / C4;            // 16-byte chunks per row; rows per sweep of the block
-  constexpr int NCH = RP / RSTEP;                          // chunks per thread and pass
-  static_assert(RP * CS * 4 <= LDS_SPLIT, "C tile pass must fit");
-  float* Ct = reinterpret_cast<float*>(lds);
-  const bool dense_io = p.out_oy == 0 && p.out_ox == 0 && p.out_H == p.Ho && p.out_W == p.Wo;
-  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.out, 0, (int)((unsigned)p.B * p.out_H * p.out_W * p.out_ldc * 4u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_bias =
-      __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (int)((unsigned)p.Cout * 4u), 0x00020000);
-  const int c4 = tid % C4, row0 = tid / C4;
-  const int col = n0 + c4 * 4;
-  const f32x4 bias4 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, col * 4, 0, 0);
-  auto run = [&](auto act_c) {
-    constexpr int ACT = decltype(act_c)::value;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      if (pass > 0) __syncthreads();
-      if (wm / WPP == pass) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              Ct[((wm % WPP) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * CS + wn * TN * 32 + j * 32 + fr] = acc[i][j][r];
-      }
-      __syncthreads();
-      if (pass == 0) stamp(3);
-#pragma unroll
-      for (int s2 = 0; s2 < NCH; ++s2) {
-        const int rl = row0 + s2 * RSTEP;
-        const int m = m0 + pass * RP + rl;
-        const bool ok = m < M;
-        unsigned opix;
-        if (dense_io) {
-          opix = (unsigned)m;
-        } else {
-          const int mm = ok ? m : 0;
-          const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), rr = mm - n * HoWo;
-          const int ho = sfast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
-          opix = ((unsigned)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
-        }
-        const unsigned ooff = ok ? (opix * p.out_ldc + col) * 4u : kOOB;
-        f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[rl * CS + c4 * 4]);
-        v += bias4;
-        if (ACT == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (ACT == 2) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f / (1.0f + expf(-v[e])));
-        } else if (ACT == 3) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
-        }
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)ooff, 0, 0);
-      }
-      if (pass == 0) stamp(4);
-    }
-  };
-  if (p.relu == 1) run(std::integral_constant<int, 1>{});
-  else if (p.relu == 2) run(std::integral_constant<int, 2>{});
-  else if (p.relu == 3) run(std::integral_constant<int, 3>{});
-  else run(std::integral_constant<int, 0>{});
-  stamp(5);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// conv_split3_kernel: the round-2 loop structure.  Same arithmetic (bf16x3, six piece products), but
-//   * 8 waves / 512 threads, ONE workgroup per CU, 256-row tiles: a weight stage is fetched once per 256
-//     output rows (half the L2 -> LDS weight traffic of the 128-row tiles);
-//   * BK = 16 per LDS stage, a ring of THREE stages, ONE barrier per stage;
-//   * weights: the pre-split image goes global -> LDS by LDS-DMA (buffer_load ... lds), two stages ahead --
-//     no prefetch registers, no ds_write; the pipeline never drains (counted vmcnt, raw s_barrier);
-//   * activations: f32 -> registers (one stage ahead) -> split -> LDS behind the MFMAs of the first
-//     column group; the last column group's operands are read before the barrier and its MFMAs cover
-//     the first fragment reads of the next stage;
-//   * K order = (16-channel slice, kh, kw): the nine taps of a channel slice are consecutive stages, so
-//     a 3x3 conv re-reads its activation lines from L1 / L2 instead of the fabric (tap-major order
-//     streamed the whole tile's input through L2 once per tap);
-//   * residual (same shape / nearest-2x) added in the epilogue from 16-byte row chunks that are fetched
-//     while the C tile is staged through LDS (the MFMA-layout accumulator preload of the one-stage
-//     kernel cost 128 four-byte loads per lane: 9 us of a 63 us res4 conv3 tile).
-// Tile configurations <WM, WN, TN> (WM x WN = 8 waves, wave tile 64 x 32 TN):
-//   <4,2,4> 256 x 256 (Cout % 256 == 0)   <4,2,2> 256 x 128 (Cout % 128 == 0)   <4,2,1> 256 x 64 (Cout % 64 == 0)
-#ifdef ODT_HIP_EMULATOR
-#define ODT_WAIT_VM_LGKM0(n) do { } while (0)
-#define ODT_BARRIER_LDS() __syncthreads()
-#define ODT_LDS_PTR(p) ((void*)(p))
-#else
-// counted wait: at most n vector-memory operations (A fetches / DMA of younger stages) stay in flight; all LDS done
-#define ODT_WAIT_VM_LGKM0(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(n) : "memory")
-// workgroup barrier that orders LDS traffic only (__syncthreads() would also drain the global stores in flight)
-#define ODT_BARRIER_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
-#define ODT_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-#endif
-
-#define ODT_STAMP(i) do { if constexpr (TRACE) { if (tid == 0) p.trace[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } } while (0)
-// Epilogue shared by the conv_split3 kernels: accumulators of the 8 waves (wave tile 64 x 32 TN at (wm, wn)) -> LDS ->
-// rows of 16-byte chunks -> bias (+ residual) + activation -> global, or the raw partial tile of a split-K range.
-template <int WM, int WN, int TN, int LDSB, bool TRACE>
-__device__ __forceinline__ void split3_epilogue(const ConvParams& p, f32x16 (&acc)[2][TN], unsigned char* lds, int m0, int n0,
-                                                int M, int HoWo, int ks, int splitk, int tid, int wm, int wn, int fr, int fg) {
-  constexpr int BM = 64 * WM, BN = 32 * TN * WN;
-  // ---- epilogue: the C tile goes through LDS in passes of RP rows; per 16-byte row chunk: bias (+ residual)
-  // + activation, 16-byte stores (a wave writes whole row segments).  The residual chunks of a pass are fetched
-  // before the pass is staged, so their latency hides behind the LDS round trip.
-  constexpr int CS = BN + 4;
-  constexpr int FIT = LDSB / (CS * 4);                    // rows of the C tile the ring's LDS holds
-  constexpr int RP = FIT >= BM ? BM : (FIT >= BM / 2 ? BM / 2 : (FIT >= BM / 4 ? BM / 4 : 64));   // rows per pass
-  constexpr int NPASS = BM / RP, WPP = RP / 64;
-  constexpr int C4 = BN / 4, RSTEP = 512 / C4, NCH = RP / RSTEP;
-  static_assert(RP >= 64 && BM % RP == 0 && RP % RSTEP == 0, "epilogue passes");
-  float* Ct = reinterpret_cast<float*>(lds);
-  const bool dense_io = p.out_oy == 0 && p.out_ox == 0 && p.out_H == p.Ho && p.out_W == p.Wo &&
-                        (p.res_mode == 0 || (p.res_mode == 1 && p.res_H == p.Ho && p.res_W == p.Wo));
-  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.out, 0, (int)((unsigned)p.B * p.out_H * p.out_W * p.out_ldc * 4u), 0x00020000);
-  // per-row-range constants (ConvParams::nlvl): every tile lies inside one range (ranges start on multiples of 256 rows)
-  int lvl_off = 0;
-  if (p.nlvl > 1) {
-    // (constant indices: a runtime-indexed field would send the whole parameter record to scratch memory; unused entries
-    // are INT_MAX)
-    const int lvl = (m0 >= p.lvl_start[1] ? 1 : 0) + (m0 >= p.lvl_start[2] ? 1 : 0) + (m0 >= p.lvl_start[3] ? 1 : 0) +
-                    (m0 >= p.lvl_start[4] ? 1 : 0);
-    lvl_off = lvl * p.lvl_stride;
-  }
-  const unsigned nbias = p.nlvl > 1 ? (unsigned)(p.nlvl * p.lvl_stride) : (unsigned)p.Cout;
-  const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (int)(nbias * 4u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_scale = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.lvl_scale != nullptr ? p.lvl_scale : p.bias), 0, (int)(p.lvl_scale != nullptr ? nbias * 4u : 0u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.res_mode != 0 ? p.res : p.bias), 0,
-      (int)(p.res_mode != 0 ? (unsigned)p.B * p.res_H * p.res_W * p.res_ldc * 4u : 0u), 0x00020000);
-  const int c4 = tid % C4, row0 = tid / C4;
-  const int col = n0 + c4 * 4;
-  if (splitk > 1) {
-    // split-K: the raw partial tile, dense [M][Cout] rows of this range's slab (bias / residual / activation happen in
-    // split_reduce_kernel once all ranges are in)
-    const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.partial + (size_t)ks * M * cout_padded(p.Cout)), 0, (int)((unsigned)M * cout_padded(p.Cout) * 4u), 0x00020000);
-#pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-      if (pass > 0) ODT_BARRIER_LDS();
-      if (wm / WPP == pass) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              Ct[((wm % WPP) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * CS + wn * TN * 32 + j * 32 + fr] = acc[i][j][r];
-      }
-      ODT_BARRIER_LDS();
-#pragma unroll
-      for (int s2 = 0; s2 < NCH; ++s2) {
-        const int m = m0 + pass * RP + row0 + s2 * RSTEP;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[(row0 + s2 * RSTEP) * CS + c4 * 4]);
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_part, m < M ? (int)(((unsigned)m * cout_padded(p.Cout) + col) * 4u) : (int)kOOB, 0, 0);
-      }
-    }
-    ODT_STAMP(5);
-    return;
-  }
-  const f32x4 bias4 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, (lvl_off + col) * 4, 0, 0);
-  const bool has_scale = p.lvl_scale != nullptr;
-  f32x4 scale4 = {1.f, 1.f, 1.f, 1.f};
-  if (has_scale) scale4 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_scale, (lvl_off + col) * 4, 0, 0);
-  if constexpr (BN == 256) {
-    if (p.head_wt != nullptr) {
-      // ---- fused 1x1 head (RPN class || box: 15 columns of a 16-wide GEMM over this tile's 256 channels).  Per pass:
-      // accumulators -> LDS, bias + activation in place, then wave w multiplies rows [16 w, 16 w + 16) of the pass by
-      // head_wt with v_mfma_f32_16x16x4_f32 (exact f32: an fmaf chain in k order).  k order of the chain: step
-      // (t, u) takes channels 16 t + 4 j + u, j = lane / 16 -- one ds_read_b128 per lane feeds four MFMAs; the lane's 64
-      // B-operand values (head_wt[16 t + 4 j + u][lane % 16]) are fetched once, up front.
-      const int lane = tid & 63, wave = tid >> 6;
-      const int hn = lane & 15, hj = lane >> 4;
-      float hb[64];
-#pragma unroll
-      for (int t = 0; t < 16; ++t)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) hb[t * 4 + u] = p.head_wt[(16 * t + 4 * hj + u) * 16 + hn];
-      const float hbias = p.head_bias[hn];
-      static_assert(RP % 16 == 0, "head tiles");
-      constexpr int RT = RP / 16;               // 16-row tiles per pass
-#pragma unroll 1
-      for (int pass = 0; pass < NPASS; ++pass) {
-        if (pass > 0) ODT_BARRIER_LDS();
-        if (wm / WPP == pass) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-              for (int r = 0; r < 16; ++r)
-                Ct[((wm % WPP) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * CS + wn * TN * 32 + j * 32 + fr] = acc[i][j][r];
-        }
-        ODT_BARRIER_LDS();
-#pragma unroll
-        for (int s2 = 0; s2 < NCH; ++s2) {      // bias + activation in place (each thread its own 16-byte chunks)
-          f32x4* q = reinterpret_cast<f32x4*>(&Ct[(row0 + s2 * RSTEP) * CS + c4 * 4]);
-          f32x4 v = *q + bias4;
-          if (p.relu == 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-          *q = v;
-        }
-        ODT_BARRIER_LDS();
-        for (int rt = wave; rt < RT; rt += 8) {
-          f32x4 c = {0.f, 0.f, 0.f, 0.f};
-          const float* arow = &Ct[(rt * 16 + hn) * CS + 4 * hj];
-#pragma unroll
-          for (int t = 0; t < 16; ++t) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * t);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], hb[t * 4 + u], c, 0, 0, 0);
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {          // C layout: row 4 j + i, column lane % 16
-            const int m = m0 + pass * RP + rt * 16 + 4 * hj + i;
-            if (m < M) p.head_out[(size_t)m * p.head_ldc + hn] = hn < 15 ? c[i] + hbias : 0.f;
-          }
-        }
-      }
-      ODT_STAMP(5);
-      return;
-    }
-  }
-  // (no barrier needed here: the last stage's barrier sits behind every fragment read of the ring)
-  auto run = [&](auto act_c, auto res_c) {
-    constexpr int ACT = decltype(act_c)::value;
-    constexpr bool RES = decltype(res_c)::value;
-#pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-      unsigned ooff[NCH];
-      f32x4 rres[RES ? NCH : 1];
-#pragma unroll
-      for (int s2 = 0; s2 < NCH; ++s2) {
-        const int m = m0 + pass * RP + row0 + s2 * RSTEP;
-        const bool ok = m < M;
-        unsigned opix = (unsigned)m, rpix = (unsigned)m;
-        if (!dense_io) {
-          const int mm = ok ? m : 0;
-          const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), rr = mm - n * HoWo;
-          const int ho = sfast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
-          opix = ((unsigned)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
-          rpix = p.res_mode == 2 ? ((unsigned)n * p.res_H + (unsigned)(ho >> 1)) * p.res_W + (unsigned)(wo >> 1)
-                                 : ((unsigned)n * p.res_H + (unsigned)ho) * p.res_W + (unsigned)wo;
-        }
-        ooff[s2] = ok ? (opix * p.out_ldc + col) * 4u : kOOB;
-        if constexpr (RES)
-          rres[s2] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_res, ok ? (int)((rpix * p.res_ldc + col) * 4u) : (int)kOOB, 0, 0);
-      }
-      if (pass > 0) ODT_BARRIER_LDS();        // the previous pass has been read
-      if (wm / WPP == pass) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              Ct[((wm % WPP) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * CS + wn * TN * 32 + j * 32 + fr] = acc[i][j][r];
-      }
-      ODT_BARRIER_LDS();
-      if (pass == 0) ODT_STAMP(3);
-#pragma unroll
-      for (int s2 = 0; s2 < NCH; ++s2) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[(row0 + s2 * RSTEP) * CS + c4 * 4]);
-        if (has_scale) v = v * scale4;
-        v += bias4;
-        if constexpr (RES) v += rres[s2];
-        if (ACT == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (ACT == 2) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f / (1.0f + expf(-v[e])));
-        } else if (ACT == 3) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
-        }
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)ooff[s2], 0, 0);
-      }
-      if (pass == 0) ODT_STAMP(4);
-    }
-  };
-  if (p.res_mode != 0) {
-    if (p.relu == 1) run(std::integral_constant<int, 1>{}, std::true_type{});
-    else if (p.relu == 0) run(std::integral_constant<int, 0>{}, std::true_type{});
-    else if (p.relu == 2) run(std::integral_constant<int, 2>{}, std::true_type{});
-    else run(std::integral_constant<int, 3>{}, std::true_type{});
-  } else {
-    if (p.relu == 1) run(std::integral_constant<int, 1>{}, std::false_type{});
-    else if (p.relu == 0) run(std::integral_constant<int, 0>{}, std::false_type{});
-    else if (p.relu == 2) run(std::integral_constant<int, 2>{}, std::false_type{});
-    else run(std::integral_constant<int, 3>{}, std::false_type{});
-  }
-}
-
-template <int WM, int WN, int TN>
-struct Split3Cfg {
-  static constexpr int BM = 64 * WM, BN = 32 * TN * WN;
-  static constexpr int AKG = BM * 16 + 64, APL = 2 * AKG;   // A piece plane: [k-group 2][row][8 bf16], 64-B pad per k-group
-  static constexpr int BKG = BN * 16, BPL = 2 * BKG;        // B: the linear image the DMA writes
-  static constexpr int STAGE_B = 3 * BPL;                   // bytes of weight image per stage
-  static constexpr int STAGE = 3 * APL + STAGE_B;
-  static constexpr int LDS = 3 * STAGE;
-  static constexpr int NCHUNK = STAGE_B / 1024;             // 1-KB DMA pieces (one wave instruction each) per stage
-  static constexpr int RA = BM / 128;                       // A rows (16-byte loads) per thread and stage
-  static_assert(LDS <= 160 * 1024, "LDS ring");
-};
-
-template <int WM, int WN, int TN, bool TRACE = false>
-__global__ void __launch_bounds__(512, 2) conv_split3_kernel(const ConvParams* __restrict__ pp) {
-  using G = Split3Cfg<WM, WN, TN>;
-  constexpr int BM = G::BM, BN = G::BN, AKG = G::AKG, APL = G::APL, BKG = G::BKG, BPL = G::BPL;
-  constexpr int STAGE = G::STAGE, STAGE_B = G::STAGE_B, NCHUNK = G::NCHUNK, RA = G::RA;
-  static_assert(WM * WN == 8, "8 waves");
-  const ConvParams p = *pp;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  auto stamp = [&](int i) {
-    if constexpr (TRACE) {
-      if (tid == 0) p.trace[(size_t)blockIdx.x * 16 + i] = wall_clock64();
-    }
-  };
-  stamp(0);
-  if constexpr (TRACE) {
-    if (tid == 0) {
-      p.trace[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-      p.trace[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-    }
-  }
-  const int ntn = cout_padded(p.Cout) / BN;
-  int wg = (int)blockIdx.x;
-  {
-    const int nwg = (int)gridDim.x, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
-  }
-  // split-K: consecutive workgroups are the K ranges of one tile (they share its activation rows in L2)
-  const int splitk = p.splitk > 1 ? p.splitk : 1;
-  const int ks = wg % splitk;
-  wg /= splitk;
-  const int mt = wg / ntn, nt = wg - mt * ntn;
-  const int m0 = mt * BM, n0 = nt * BN;
-  const int HoWo = p.Ho * p.Wo;
-  const int M = p.B * HoWo;
-  const int ntaps = p.kh * p.kw;
-  const int cpt = p.Cin >> 4;                                // 16-channel slices of the first source
-  const int cpt2 = p.in2 != nullptr ? p.Cin2 >> 4 : 0;       // ... of the K-concatenated second source (1x1 only)
-  const int nsteps1 = ntaps * cpt, nsteps_all = nsteps1 + cpt2;
-  // this workgroup's stages [s_begin, s_begin + nsteps): split-K ranges are balanced to within one stage
-  const int s_begin = (int)(((long)nsteps_all * ks) / splitk);
-  const int nsteps = (int)(((long)nsteps_all * (ks + 1)) / splitk) - s_begin;
-
-  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.in, 0, (int)((unsigned)p.B * p.in_Ha * p.in_Wa * p.in_ldc * 4u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.in2 != nullptr ? p.in2 : p.in), 0,
-      (int)(p.in2 != nullptr ? (unsigned)p.B * p.in2_Ha * p.in2_Wa * p.in2_ldc * 4u : 0u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.wt_split, 0, (int)((unsigned)ntn * nsteps_all * (unsigned)STAGE_B), 0x00020000);
-
-  // ---- weights: wave w, instruction i copies the 1-KB piece i * 8 + w of the stage image
-  unsigned l_b = ((unsigned)nt * (unsigned)nsteps_all + (unsigned)s_begin) * (unsigned)STAGE_B;
-  auto dma_b = [&](int st) {
-#pragma unroll
-    for (int i = 0; i < (NCHUNK + 7) / 8; ++i) {
-      if ((i + 1) * 8 <= NCHUNK || i * 8 + wave < NCHUNK)    // wave-uniform
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, ODT_LDS_PTR(lds + st + 3 * APL + (i * 8 + wave) * 1024), 16,
-                                                 lane * 16 + (i * 8 + wave) * 1024, (int)l_b, 0, 0);
-    }
-    l_b += (unsigned)STAGE_B;
-  };
-  // this wave's DMA instructions per stage: NW or NW - 1 (the counted wait in front of a barrier needs the exact
-  // number).  wait_stage: this wave's share of the stage that the barrier publishes has landed -- its DMA (issued
-  // one stage earlier) and its LDS stores; YOUNGER: one stage's worth of A fetches + DMA was issued behind that
-  // DMA and may stay in flight.
-  constexpr int NW = (NCHUNK + 7) / 8;
-  const bool dma_full = (NCHUNK % 8) == 0 || wave < (NCHUNK % 8);
-  auto wait_stage = [&](auto YOUNGER) {
-    if constexpr (decltype(YOUNGER)::value) {
-      if (dma_full) ODT_WAIT_VM_LGKM0(RA + NW); else ODT_WAIT_VM_LGKM0(RA + NW - 1);
-    } else {
-      ODT_WAIT_VM_LGKM0(0);
-    }
-  };
-  dma_b(0);
-  if (nsteps > 1) dma_b(STAGE);
-
-  // ---- activations: thread -> (row (t >> 2) + 128 j, 16-byte column t & 3): four lanes cover the 64 contiguous
-  // bytes (16 channels) of a row's stage.  Per row: the byte offset of the tap-(0,0) input pixel and a bit per tap
-  // (inside the image and m < M); a stage's offset is base + tap offset, or out of range (the load returns zeros).
-  const int a_c = tid & 3, a_r = tid >> 2;
-  const unsigned pix_bytes = (unsigned)p.in_ldc * 4u;
-  int a_base[RA];
-  unsigned a_mask[RA];
-  const bool dense_in = ntaps == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 &&
-                        p.H == p.in_Ha && p.W == p.in_Wa && p.Ho == p.H && p.Wo == p.W;
-#pragma unroll
-  for (int j = 0; j < RA; ++j) {
-    const int m = m0 + a_r + 128 * j;
-    const bool ok = m < M;
-    if (dense_in) {
-      a_base[j] = (int)((unsigned)m * pix_bytes + a_c * 16u);
-      a_mask[j] = ok ? 1u : 0u;
-    } else {
-      const int mm = ok ? m : 0;
-      const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), r = mm - n * HoWo;
-      const int ho = sfast_div(r, p.div_wo_mul, p.div_wo_sh), wo = r - ho * p.Wo;
-      const int hi0 = ho * p.stride - p.pad_t, wi0 = wo * p.stride - p.pad_l;
-      a_base[j] = (int)(((unsigned)n * p.in_Ha * p.in_Wa + (unsigned)(hi0 * p.in_Wa + wi0)) * pix_bytes + a_c * 16u);
-      unsigned mk = 0;
-      for (int t = 0, khh = 0, kww = 0; t < ntaps; ++t) {
-        const int hi = hi0 + khh * p.dil, wi = wi0 + kww * p.dil;
-        if (ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) mk |= 1u << t;
-        if (++kww == p.kw) { kww = 0; ++khh; }
-      }
-      a_mask[j] = mk;
-    }
-  }
-  // load stream position: (16-channel slice, tap) with the tap innermost; then the second source's slices
-  // (a split-K range starts inside the first source: launch_conv_split keeps split-K off for second-source convs)
-  int l_cs = s_begin / ntaps, l_tap = s_begin - l_cs * ntaps;
-  int l_kh = l_tap / p.kw, l_kw = l_tap - l_kh * p.kw;
-  bool l_src2 = false;
-  unsigned a_row[RA];
-  auto set_rows = [&]() {
-    const unsigned tapoff = (unsigned)(l_kh * p.dil * p.in_Wa + l_kw * p.dil) * pix_bytes;
-#pragma unroll
-    for (int j = 0; j < RA; ++j) a_row[j] = ((a_mask[j] >> l_tap) & 1u) ? (unsigned)a_base[j] + tapoff : kOOB;
-  };
-  auto set_src2 = [&]() {
-#pragma unroll
-    for (int j = 0; j < RA; ++j) {
-      const int m = m0 + a_r + 128 * j;
-      const bool ok = m < M;
-      const int mm = ok ? m : 0;
-      const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), r = mm - n * HoWo;
-      const int ho = sfast_div(r, p.div_wo_mul, p.div_wo_sh), wo = r - ho * p.Wo;
-      const unsigned pix = ((unsigned)n * p.in2_Ha + (unsigned)(ho * p.in2_stride)) * p.in2_Wa + (unsigned)(wo * p.in2_stride);
-      a_row[j] = ok ? pix * (unsigned)p.in2_ldc * 4u + a_c * 16u : kOOB;
-    }
-  };
-  set_rows();
-  f32x4 ga[RA];
-  auto load_a = [&]() {
-#pragma unroll
-    for (int j = 0; j < RA; ++j)
-      ga[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(l_src2 ? rs_in2 : rs_in, (int)a_row[j], l_cs * 64, 0);
-    // advance
-    if (l_src2) {
-      ++l_cs;
-    } else if (ntaps == 1) {
-      if (++l_cs == cpt && cpt2 > 0) { l_cs = 0; l_src2 = true; set_src2(); }
-    } else {
-      ++l_tap;
-      if (++l_kw == p.kw) { l_kw = 0; ++l_kh; }
-      if (l_tap == ntaps) { l_tap = 0; l_kh = 0; l_kw = 0; ++l_cs; }
-      set_rows();            // (harmless past the last stage: never loaded)
-    }
-  };
-  auto store_a = [&](int st) {
-#pragma unroll
-    for (int j = 0; j < RA; ++j) {
-      unsigned h0, m0_, l0, h1, m1, l1;
-      split2(ga[j][0], ga[j][1], h0, m0_, l0);
-      split2(ga[j][2], ga[j][3], h1, m1, l1);
-      unsigned char* d = lds + st + (a_c >> 1) * AKG + (a_r + 128 * j) * 16 + (a_c & 1) * 8;
-      *reinterpret_cast<u32x2*>(d + 0 * APL) = u32x2{h0, h1};
-      *reinterpret_cast<u32x2*>(d + 1 * APL) = u32x2{m0_, m1};
-      *reinterpret_cast<u32x2*>(d + 2 * APL) = u32x2{l0, l1};
-    }
-  };
-
-  f32x16 acc[2][TN];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int fr = lane & 31, fg = lane >> 5;
-  // ---- prologue: stage 0 complete, stage 1's weights in flight, A of stage 1 in registers
-  load_a();
-  stamp(6);
-  store_a(0);
-  if (nsteps > 1) load_a();
-  if (nsteps > 1) wait_stage(std::true_type{}); else wait_stage(std::false_type{});
-  __builtin_amdgcn_s_barrier();
-  stamp(7); stamp(1);
-
-  bf16x8 fa[3][2], fb[3];
-  const int a_rd = fg * AKG + (wm * 64 + fr) * 16;
-  const int b_rd = 3 * APL + fg * BKG + (wn * TN * 32 + fr) * 16;
-  auto rdA = [&](int st, int q) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) fa[q][t] = *reinterpret_cast<const bf16x8*>(lds + st + q * APL + a_rd + t * 512);
-  };
-  auto rdB = [&](int st, int q, int j) {
-    fb[q] = *reinterpret_cast<const bf16x8*>(lds + st + q * BPL + b_rd + j * 512);
-  };
-#pragma unroll
-  for (int q = 0; q < 3; ++q) rdA(0, q);
-#pragma unroll
-  for (int q = 0; q < 3; ++q) rdB(0, q, 0);
-
-#define ODT_MF(qa, qb, j) { acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][0], fb[qb], acc[0][j], 0, 0, 0); \
-                            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][1], fb[qb], acc[1][j], 0, 0, 0); }
-#define ODT_FENCE() __builtin_amdgcn_sched_barrier(0)
-  int st_cur = 0, st_nxt = STAGE, st_nn = 2 * STAGE;
-  // One stage.  NEXT: stage c+1 exists (its A: registers -> LDS; read its first fragments behind the last column
-  // group); PRE: stage c+2 exists (fetch its A, start its weight DMA).  The K loop is peeled so that no MFMA sits
-  // in a conditional arm.
-  auto step = [&](auto NEXT, auto PRE) {
-    constexpr bool next = decltype(NEXT)::value, pre = decltype(PRE)::value;
-    ODT_FENCE();
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const bool last = j == TN - 1, first = j == 0;
-      // where the side work of a stage rides: A store behind the first product of the first group, the A fetch
-      // behind its fourth, the DMA issue behind the fifth product of the second group (TN = 1: all in the one
-      // group, in front of the barrier)
-      if (last) {
-        if (TN == 1) {
-          // single column group: the side work precedes the barrier
-          if constexpr (next) store_a(st_nxt);
-          if constexpr (pre) { load_a(); dma_b(st_nn); }
-        }
-        // stage nxt must be complete before its first fragment reads below: own LDS stores, own DMA of stage c+1
-        // (issued one stage ago; this stage's A fetch and DMA may stay in flight), then the barrier
-        wait_stage(std::integral_constant<bool, pre>{});
-        __builtin_amdgcn_s_barrier();
-        ODT_FENCE();
-      }
-      ODT_MF(2, 0, j); ODT_FENCE();
-      if (last) { if constexpr (next) rdA(st_nxt, 2); }
-      else if (first) { if constexpr (next) store_a(st_nxt); }
-      ODT_FENCE();
-      ODT_MF(1, 0, j); ODT_MF(0, 0, j); ODT_FENCE();
-      if (!last) rdB(st_cur, 0, j + 1); else if constexpr (next) rdB(st_nxt, 0, 0);
-      ODT_FENCE();
-      ODT_MF(1, 1, j); ODT_FENCE();
-      if (last) { if constexpr (next) rdA(st_nxt, 1); }
-      else if (first) { if constexpr (pre) load_a(); }
-      ODT_FENCE();
-      ODT_MF(0, 1, j); ODT_FENCE();
-      if (!last) rdB(st_cur, 1, j + 1); else if constexpr (next) rdB(st_nxt, 1, 0);
-      if (!last && j == (TN > 2 ? 1 : 0)) { if constexpr (pre) dma_b(st_nn); }
-      ODT_FENCE();
-      ODT_MF(0, 2, j); ODT_FENCE();
-      if (!last) rdB(st_cur, 2, j + 1); else if constexpr (next) { rdA(st_nxt, 0); rdB(st_nxt, 2, 0); }
-      ODT_FENCE();
-    }
-    const int t = st_cur; st_cur = st_nxt; st_nxt = st_nn; st_nn = t;
-  };
-  {
-    int c = 0;
-    for (; c + 2 < nsteps; ++c) step(std::true_type{}, std::true_type{});
-    if (c + 1 < nsteps) { step(std::true_type{}, std::false_type{}); ++c; }
-    step(std::false_type{}, std::false_type{});
-  }
-#undef ODT_MF
-#undef ODT_FENCE
-  stamp(2);
-  split3_epilogue<WM, WN, TN, G::LDS, TRACE>(p, acc, lds, m0, n0, M, HoWo, ks, splitk, tid, wm, wn, fr, fg);
-  stamp(5);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// conv_split3k_kernel: conv_split3_kernel for stride-1 KH x 3 convs whose input rows have the output's pitch
-// (in_Wa == Wo: the 3x3 layers of res3 / res4, the FPN post-hoc and RPN convs) -- the three kw taps of a
-// (16-channel slice, kh) group read ONE staged, once-split run of input pixels at row offsets 0, dil, 2 dil instead
-// of fetching and splitting the activations per tap.  Ablation on the MI355X (A work on every third stage only,
-// profiles/r02_ablate_a_third.txt): P2-level 3x3 229 -> 296 TF, res4 conv2 227 -> 253, all conv launches -7 %.
-//   * the 256 output pixels of a tile are consecutive in (n, ho, wo); within an image their tap-(kh, 0) input pixels are
-//     consecutive too (stride 1, equal pitch), so a group's stage is the run [first - pad_l, last - pad_l + 2 dil];
-//     a tile that crosses an image boundary stages two runs back to back (capacity 256 + 2 x 2 dil rows);
-//   * taps that fall outside the image (left / right / top / bottom border, rows past M) read a zero row of the
-//     stage instead: a per-lane 9-bit validity mask picks the fragment address -- no masking of data;
-//   * A stages: two buffers (this group / next group), B stages: the three-deep DMA ring as before; the group's
-//     fetch (3 x 16 B per thread) is issued in its first stage, split + stored in the second and third.
-// Same arithmetic, same K order, same weight image and epilogue as conv_split3_kernel: results are bit-identical.
-template <int TN>
-struct Split3kCfg {
-  static constexpr int BM = 256, BN = 64 * TN;
-  static constexpr int PR = 272;                             // stage rows: 256 + 2 runs x 2 dil (dil <= 2) + the zero row, padded
-  static constexpr int ZR = PR - 1;                          // the zero row
-  static constexpr int AKG = PR * 16 + 64, APL = 2 * AKG, ABUF = 3 * APL;
-  static constexpr int BKG = BN * 16, BPL = 2 * BKG, STAGE_B = 3 * BPL;
-  static constexpr int BOFF = 2 * ABUF;
-  static constexpr int RING = BOFF + 3 * STAGE_B;
-  static constexpr int CTILE = 128 * (BN + 4) * 4;            // two 128-row epilogue passes
-  static constexpr int LDS = RING > CTILE ? RING : CTILE;
-  static constexpr int NCHUNK = STAGE_B / 1024;
-  static_assert(LDS <= 160 * 1024, "LDS");
-};
-
-template <int TN, bool TRACE = false>
-__global__ void __launch_bounds__(512, 2) conv_split3k_kernel(const ConvParams* __restrict__ pp) {
-  using G = Split3kCfg<TN>;
-  constexpr int WM = 4, WN = 2, KW = 3;
-  constexpr int BM = G::BM, BN = G::BN, AKG = G::AKG, APL = G::APL, ABUF = G::ABUF, BKG = G::BKG, BPL = G::BPL;
-  constexpr int STAGE_B = G::STAGE_B, BOFF = G::BOFF, NCHUNK = G::NCHUNK, ZR = G::ZR;
-  const ConvParams p = *pp;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  auto stamp = [&](int i) {
-    if constexpr (TRACE) {
-      if (tid == 0) p.trace[(size_t)blockIdx.x * 16 + i] = wall_clock64();
-    }
-  };
-  stamp(0);
-  if constexpr (TRACE) {
-    if (tid == 0) {
-      p.trace[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-      p.trace[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-    }
-  }
-  const int ntn = cout_padded(p.Cout) / BN;
-  int wg = (int)blockIdx.x;
-  {
-    const int nwg = (int)gridDim.x, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
-  }
-  const int mt = wg / ntn, nt = wg - mt * ntn;
-  const int m0 = mt * BM, n0 = nt * BN;
-  const int HoWo = p.Ho * p.Wo;
-  const int M = p.B * HoWo;
-  const int cpt = p.Cin >> 4;
-  const int nsteps = p.kh * KW * cpt, ngroups = p.kh * cpt;
-  const int halo = (KW - 1) * p.dil;
-
-  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.in, 0, (int)((unsigned)p.B * p.in_Ha * p.in_Wa * p.in_ldc * 4u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.wt_split, 0, (int)((unsigned)ntn * nsteps * (unsigned)STAGE_B), 0x00020000);
-
-  // ---- weights: as conv_split3_kernel
-  unsigned l_b = (unsigned)nt * (unsigned)nsteps * (unsigned)STAGE_B;
-  auto dma_b = [&](int boff) {
-#pragma unroll
-    for (int i = 0; i < (NCHUNK + 7) / 8; ++i) {
-      if ((i + 1) * 8 <= NCHUNK || i * 8 + wave < NCHUNK)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, ODT_LDS_PTR(lds + boff + (i * 8 + wave) * 1024), 16,
-                                                 lane * 16 + (i * 8 + wave) * 1024, (int)l_b, 0, 0);
-    }
-    l_b += (unsigned)STAGE_B;
-  };
-  constexpr int NW = (NCHUNK + 7) / 8;
-  const bool dma_full = (NCHUNK % 8) == 0 || wave < (NCHUNK % 8);
-  constexpr int RA = 3;                      // A fetch instructions per thread and group
-  // wait_stage<A, Y>: this wave's DMA of the stage the barrier publishes has landed (+ all its LDS stores); Y: this
-  // stage's DMA was issued behind it and may stay in flight; A: so may the group fetch (RA loads) issued in this stage
-  auto wait_stage = [&](auto AF, auto YF) {
-    constexpr bool a = decltype(AF)::value, y = decltype(YF)::value;
-    if constexpr (!y) {
-      ODT_WAIT_VM_LGKM0(0);
-    } else if constexpr (a) {
-      if (dma_full) ODT_WAIT_VM_LGKM0(RA + NW); else ODT_WAIT_VM_LGKM0(RA + NW - 1);
-    } else {
-      if (dma_full) ODT_WAIT_VM_LGKM0(NW); else ODT_WAIT_VM_LGKM0(NW - 1 > 0 ? NW - 1 : 0);
-    }
-  };
-  dma_b(BOFF);
-  if (nsteps > 1) dma_b(BOFF + STAGE_B);
-
-  // ---- the tile's two runs of input pixels (tap (kh, 0) of row r: run0 for r < len0, run1 behind it)
-  const int pix_bytes = p.in_ldc * 4;
-  const int n_first = sfast_div(m0, p.div_howo_mul, p.div_howo_sh), r_img = m0 - n_first * HoWo;
-  const int len0 = HoWo - r_img < BM ? HoWo - r_img : BM;
-  const int pix0 = (n_first * p.in_Ha - p.pad_t) * p.in_Wa + r_img - p.pad_l;          // (pitch == Wo: r_img = ho * Wo + wo)
-  const int pix1 = ((n_first + 1) * p.in_Ha - p.pad_t) * p.in_Wa - p.pad_l;
-  // loader: thread -> stage row (t >> 2) + 128 j, 16-byte column t & 3
-  const int a_c = tid & 3, a_r = tid >> 2;
-  int a_base[RA];
-#pragma unroll
-  for (int j = 0; j < RA; ++j) {
-    const int pr = a_r + 128 * j;
-    const int pix = pr < len0 + halo ? pix0 + pr : pix1 + (pr - len0 - halo);
-    a_base[j] = pr < BM + 2 * halo ? pix * pix_bytes + a_c * 16 : (int)kOOB;
-  }
-  int l_cs = 0, l_kh = 0;                    // next group to fetch
-  f32x4 ga[RA];
-  auto load_group = [&]() {
-    const int khoff = l_kh * p.dil * p.in_Wa * pix_bytes;
-#pragma unroll
-    for (int j = 0; j < RA; ++j) {
-      const unsigned v = (unsigned)a_base[j] == kOOB ? kOOB : (unsigned)(a_base[j] + khoff);
-      ga[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)v, l_cs * 64, 0);
-    }
-    if (++l_kh == p.kh) { l_kh = 0; ++l_cs; }
-  };
-  auto store_slot = [&](int abuf, int j) {
-    const int pr = a_r + 128 * j;
-    if (pr < BM + 2 * halo) {
-      unsigned h0, m0_, l0, h1, m1, l1;
-      split2(ga[j][0], ga[j][1], h0, m0_, l0);
-      split2(ga[j][2], ga[j][3], h1, m1, l1);
-      unsigned char* d = lds + abuf + (a_c >> 1) * AKG + pr * 16 + (a_c & 1) * 8;
-      *reinterpret_cast<u32x2*>(d + 0 * APL) = u32x2{h0, h1};
-      *reinterpret_cast<u32x2*>(d + 1 * APL) = u32x2{m0_, m1};
-      *reinterpret_cast<u32x2*>(d + 2 * APL) = u32x2{l0, l1};
-    }
-  };
-  // the zero rows of both A buffers (never overwritten: stage rows stop at 256 + 2 halo <= ZR)
-  if (tid < 12) {
-    const int b = tid / 6, q = (tid % 6) >> 1, kg = tid & 1;
-    *reinterpret_cast<u32x4*>(lds + b * ABUF + q * APL + kg * AKG + ZR * 16) = u32x4{0u, 0u, 0u, 0u};
-  }
-
-  // ---- fragment rows of this lane: stage row of (row, tap kw = 0) and the 9-bit tap validity
-  const int fr = lane & 31, fg = lane >> 5;
-  int fa_base[2];
-  unsigned fa_mask[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int row = wm * 64 + t * 32 + fr, m = m0 + row;
-    const bool ok = m < M;
-    const int mm = ok ? m : 0;
-    const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), r = mm - n * HoWo;
-    const int ho = sfast_div(r, p.div_wo_mul, p.div_wo_sh), wo = r - ho * p.Wo;
-    unsigned mk = 0;
-    for (int khh = 0; khh < p.kh; ++khh)
-      for (int kww = 0; kww < KW; ++kww) {
-        const int hi = ho - p.pad_t + khh * p.dil, wi = wo - p.pad_l + kww * p.dil;
-        if (ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) mk |= 1u << (khh * KW + kww);
-      }
-    fa_mask[t] = mk;
-    fa_base[t] = fg * AKG + (row < len0 ? row : row + halo) * 16;
-  }
-  const int fa_zero = fg * AKG + ZR * 16;
-  const int b_rd = fg * BKG + (wn * TN * 32 + fr) * 16;
-
-  f32x16 acc[2][TN];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // ---- prologue: group 0 staged, B stages 0 / 1 in flight
-  load_group();
-  stamp(6);
-#pragma unroll
-  for (int j = 0; j < RA; ++j) store_slot(0, j);
-  if (nsteps > 1) {
-    if (dma_full) ODT_WAIT_VM_LGKM0(NW); else ODT_WAIT_VM_LGKM0(NW - 1 > 0 ? NW - 1 : 0);
-  } else {
-    ODT_WAIT_VM_LGKM0(0);
-  }
-  __builtin_amdgcn_s_barrier();
-  stamp(7); stamp(1);
-
-  bf16x8 fa[3][2], fb[3];
-  int fa_addr[2];                            // this stage's fragment addresses (A buffer + row + tap, or the zero row)
-  int c_kh = 0;                              // kh of the group being computed
-  auto tap_addr = [&](int abuf, int khh, int kww) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-      fa_addr[t] = abuf + (((fa_mask[t] >> (khh * KW + kww)) & 1u) ? fa_base[t] + kww * p.dil * 16 : fa_zero);
-  };
-  auto rdA = [&](int q) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) fa[q][t] = *reinterpret_cast<const bf16x8*>(lds + q * APL + fa_addr[t]);
-  };
-  auto rdB = [&](int boff, int q, int j) {
-    fb[q] = *reinterpret_cast<const bf16x8*>(lds + boff + q * BPL + b_rd + j * 512);
-  };
-  int a_cur = 0, a_nxt = ABUF;
-  int b_cur = BOFF, b_nxt = BOFF + STAGE_B, b_nn = BOFF + 2 * STAGE_B;
-  tap_addr(a_cur, 0, 0);
-#pragma unroll
-  for (int q = 0; q < 3; ++q) rdA(q);
-#pragma unroll
-  for (int q = 0; q < 3; ++q) rdB(b_cur, q, 0);
-
-#define ODT_MF(qa, qb, j) { acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][0], fb[qb], acc[0][j], 0, 0, 0); \
-                            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][1], fb[qb], acc[1][j], 0, 0, 0); }
-#define ODT_FENCE() __builtin_amdgcn_sched_barrier(0)
-  // One stage = tap kw = KWI of the current group.  NEXT / PRE as in conv_split3_kernel (stage c+1 / c+2 exist);
-  // GN: a next group exists (fetch it in the first stage, split + store it in the second and third)
-  auto step = [&](auto KWIC, auto NEXT, auto PRE, auto GNC) {
-    constexpr int KWI = decltype(KWIC)::value;
-    constexpr bool next = decltype(NEXT)::value, pre = decltype(PRE)::value, gn = decltype(GNC)::value;
-    ODT_FENCE();
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const bool last = j == TN - 1, first = j == 0;
-      if (last) {
-        if (TN == 1) {
-          // single column group: the stage's side work precedes the barrier (fetch before the DMA: the counted wait
-          // assumes that issue order)
-          if constexpr (gn) {
-            if constexpr (KWI == 0) load_group();
-            if constexpr (KWI == 2) { store_slot(a_nxt, 0); store_slot(a_nxt, 1); store_slot(a_nxt, 2); }
-          }
-          if constexpr (pre) dma_b(b_nn);
-        }
-        wait_stage(std::integral_constant<bool, (KWI == 0 && gn)>{}, std::integral_constant<bool, pre>{});
-        __builtin_amdgcn_s_barrier();
-        // fragment addresses of the next stage: next tap of this group, or tap 0 of the next group's buffer
-        if constexpr (next) {
-          if constexpr (KWI + 1 < KW) tap_addr(a_cur, c_kh, KWI + 1);
-          else tap_addr(a_nxt, c_kh + 1 == p.kh ? 0 : c_kh + 1, 0);
-        }
-        ODT_FENCE();
-      }
-      ODT_MF(2, 0, j); ODT_FENCE();
-      if (last) { if constexpr (next) rdA(2); }
-      else if constexpr (gn) {
-        // the next group's run: registers -> LDS, all of it in the group's third stage, two stages behind the fetch
-        // (the P2-level runs come from HBM / MALL: one stage of lead left the split waiting)
-        if constexpr (KWI == 2) {
-          if (TN > 2) { if (j < 3) store_slot(a_nxt, j); }
-          else if (first) { store_slot(a_nxt, 0); store_slot(a_nxt, 1); store_slot(a_nxt, 2); }
-        }
-      }
-      ODT_FENCE();
-      ODT_MF(1, 0, j); ODT_MF(0, 0, j); ODT_FENCE();
-      if (!last) rdB(b_cur, 0, j + 1); else if constexpr (next) rdB(b_nxt, 0, 0);
-      ODT_FENCE();
-      ODT_MF(1, 1, j); ODT_FENCE();
-      if (last) { if constexpr (next) rdA(1); }
-      else if (first) { if constexpr (gn && KWI == 0) load_group(); }
-      ODT_FENCE();
-      ODT_MF(0, 1, j); ODT_FENCE();
-      if (!last) rdB(b_cur, 1, j + 1); else if constexpr (next) rdB(b_nxt, 1, 0);
-      if (!last && j == (TN > 2 ? 1 : 0)) { if constexpr (pre) dma_b(b_nn); }
-      ODT_FENCE();
-      ODT_MF(0, 2, j); ODT_FENCE();
-      if (!last) rdB(b_cur, 2, j + 1); else if constexpr (next) { rdA(0); rdB(b_nxt, 2, 0); }
-      ODT_FENCE();
-    }
-    const int t = b_cur; b_cur = b_nxt; b_nxt = b_nn; b_nn = t;
-    if constexpr (KWI == KW - 1) {
-      const int u = a_cur; a_cur = a_nxt; a_nxt = u;
-      if (++c_kh == p.kh) c_kh = 0;
-    }
-  };
-  {
-    using T = std::true_type; using F = std::false_type;
-    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
-    for (int g = 0; g + 1 < ngroups; ++g) { step(K0{}, T{}, T{}, T{}); step(K1{}, T{}, T{}, T{}); step(K2{}, T{}, T{}, T{}); }
-    step(K0{}, T{}, T{}, F{});
-    step(K1{}, T{}, F{}, F{});
-    step(K2{}, F{}, F{}, F{});
-  }
-#undef ODT_MF
-#undef ODT_FENCE
-  stamp(2);
-  split3_epilogue<WM, WN, TN, G::LDS, TRACE>(p, acc, lds, m0, n0, M, HoWo, 0, 1, tid, wm, wn, fr, fg);
-  stamp(5);
-}
 
 // f32 weights [Cout][K] -> per-stage image of bf16 pieces (one thread per 8 consecutive k of a row)
 // (kscale != nullptr: the row is multiplied by kscale[k] first -- a per-input-channel gate folded into a 1x1 conv's weights)
@@ -1212,38 +33,6 @@ __global__ void split_weights_kernel(const float* __restrict__ wt, int Cout, int
       img[at + 1] = (unsigned short)(piece[q] >> 16);
     }
   }
-}
-
-// split-K combine: out = act(sum over ranges (in range order: deterministic) + bias (+ residual)); one thread per
-// 16-byte chunk of an output row
-__global__ void __launch_bounds__(256) split_reduce_kernel(const ConvParams* __restrict__ pp) {
-  const ConvParams p = *pp;
-  const int Np = cout_padded(p.Cout), C4 = Np >> 2;
-  const long M = (long)p.B * p.Ho * p.Wo;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= M * C4) return;
-  const int m = (int)(idx / C4), col = (int)(idx - (long)m * C4) * 4;
-  const size_t slab = (size_t)M * Np;
-  f32x4 v = *reinterpret_cast<const f32x4*>(p.partial + (size_t)m * Np + col);
-  for (int k = 1; k < p.splitk; ++k) v += *reinterpret_cast<const f32x4*>(p.partial + (size_t)k * slab + (size_t)m * Np + col);
-  for (int e = 0; e < 4; ++e) v[e] += col + e < p.Cout ? p.bias[col + e] : 0.f;
-  const int HoWo = p.Ho * p.Wo;
-  const int n = sfast_div(m, p.div_howo_mul, p.div_howo_sh), rr = m - n * HoWo;
-  const int ho = sfast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
-  if (p.res_mode != 0) {
-    const size_t rpix = p.res_mode == 2 ? ((size_t)n * p.res_H + (size_t)(ho >> 1)) * p.res_W + (size_t)(wo >> 1)
-                                        : ((size_t)n * p.res_H + (size_t)ho) * p.res_W + (size_t)wo;
-    v += *reinterpret_cast<const f32x4*>(p.res + rpix * p.res_ldc + col);
-  }
-  if (p.relu == 1) {
-    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-  } else if (p.relu == 2) {
-    for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f / (1.0f + expf(-v[e])));
-  } else if (p.relu == 3) {
-    for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
-  }
-  const size_t opix = ((size_t)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
-  *reinterpret_cast<f32x4*>(p.out + opix * p.out_ldc + col) = v;
 }
 
 // conv_split3_kernel's image: [n-tile][stage][piece][k-group 2][BN n][8 k], stage order = (16-channel slice, tap)
@@ -1434,60 +223,8 @@ int conv_make_split_weights(const ConvParams& p, void* img_dev, hipStream_t stre
   return 0;
 }
 
-template <int WM, int WN, int TN>
-static void launch_split3(const ConvParams& p, const ConvParams* dev, unsigned grid, hipStream_t stream) {
-  if (p.trace != nullptr) hipLaunchKernelGGL((conv_split3_kernel<WM, WN, TN, true>), dim3(grid), dim3(512), 0, stream, dev);
-  else hipLaunchKernelGGL((conv_split3_kernel<WM, WN, TN, false>), dim3(grid), dim3(512), 0, stream, dev);
-}
-
 int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t stream) {
-  const long M = (long)p.B * p.Ho * p.Wo;
-  const int bn = p.wt_split_bn != 0 ? p.wt_split_bn : conv_split_bn(p.Cout);
-  if (p.wt_split_kind == 3) {
-    const int bm = p.wt_split_bm;
-    ODT_CHECK((bm == 256 || (bm == 128 && bn >= 128)) && p.Cin % 16 == 0 && p.kh * p.kw <= 32, "conv split3: unsupported tile / shape");
-    const int sk = p.splitk > 1 ? p.splitk : 1;
-    ODT_CHECK(sk == 1 || (p.partial != nullptr && p.in2 == nullptr && (p.kh * p.kw * p.Cin >> 4) >= sk),
-              "conv split3: split-K needs a partial buffer, a single source and at least one stage per range");
-    const unsigned grid = (unsigned)(((M + bm - 1) / bm) * (cout_padded(p.Cout) / bn) * sk);
-    if (p.wt_split_kwr) {
-      ODT_CHECK(bm == 256 && sk == 1 && p.kw == 3 && p.stride == 1 && p.in_Wa == p.Wo && p.in2 == nullptr,
-                "conv split3k: unsupported shape");
-      if (bn == 256) {
-        if (p.trace != nullptr) hipLaunchKernelGGL((conv_split3k_kernel<4, true>), dim3(grid), dim3(512), 0, stream, dev);
-        else hipLaunchKernelGGL((conv_split3k_kernel<4, false>), dim3(grid), dim3(512), 0, stream, dev);
-      } else if (bn == 128) {
-        if (p.trace != nullptr) hipLaunchKernelGGL((conv_split3k_kernel<2, true>), dim3(grid), dim3(512), 0, stream, dev);
-        else hipLaunchKernelGGL((conv_split3k_kernel<2, false>), dim3(grid), dim3(512), 0, stream, dev);
-      } else {
-        hipLaunchKernelGGL((conv_split3k_kernel<1, false>), dim3(grid), dim3(512), 0, stream, dev);
-      }
-    } else if (bm == 256) {
-      if (bn == 256) launch_split3<4, 2, 4>(p, dev, grid, stream);
-      else if (bn == 128) launch_split3<4, 2, 2>(p, dev, grid, stream);
-      else launch_split3<4, 2, 1>(p, dev, grid, stream);
-    } else {
-      if (bn == 256) launch_split3<2, 4, 2>(p, dev, grid, stream);
-      else launch_split3<2, 4, 1>(p, dev, grid, stream);
-    }
-    if (sk > 1) {
-      const long chunks = M * (cout_padded(p.Cout) / 4);
-      hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, dev);
-    }
-    ODT_HIP(hipGetLastError());
-    return 0;
-  }
-  const int bm = conv_split_bm(p.Cout);
-  const unsigned grid = (unsigned)(((M + bm - 1) / bm) * (cout_padded(p.Cout) / bn));
-  if (p.trace != nullptr) {        // tuning: the stamped instantiations
-    if (bn == 256) hipLaunchKernelGGL((conv_split_kernel<2, 2, 4, true>), dim3(grid), dim3(256), 0, stream, dev);
-    else if (bn == 128) hipLaunchKernelGGL((conv_split_kernel<4, 1, 4, true>), dim3(grid), dim3(256), 0, stream, dev);
-    else hipLaunchKernelGGL((conv_split_kernel<4, 1, 2, true>), dim3(grid), dim3(256), 0, stream, dev);
-  } else if (bn == 256) hipLaunchKernelGGL((conv_split_kernel<2, 2, 4>), dim3(grid), dim3(256), 0, stream, dev);
-  else if (bn == 128) hipLaunchKernelGGL((conv_split_kernel<4, 1, 4>), dim3(grid), dim3(256), 0, stream, dev);
-  else hipLaunchKernelGGL((conv_split_kernel<4, 1, 2>), dim3(grid), dim3(256), 0, stream, dev);
-  ODT_HIP(hipGetLastError());
-  return 0;
+  return p.wt_split_kind == 3 ? launch_conv_split3(p, dev, stream) : launch_conv_split1(p, dev, stream);
 }
 
 }  // namespace odt

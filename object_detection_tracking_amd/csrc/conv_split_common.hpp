@@ -1,0 +1,83 @@
+// Shared pieces of the bf16x3 split convolution kernels (conv_split1.hip: one-stage 4-wave loop; conv_split3.hip: 8-wave
+// LDS-DMA kernels; conv_split.hip: weight images, policy, dispatch).
+//
+// Arithmetic.  Every f32 operand is cut into three bf16 pieces by round-to-nearest,
+//     x = hi + mid + lo   exactly   (3 x 8 significand bits = the 24 bits of an f32),
+// |mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|, so a*b is the sum of nine piece products.  The six largest
+// are evaluated on v_mfma_f32_32x32x16_bf16 (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid); the
+// three dropped ones (mid*lo, lo*mid, lo*lo) are bounded by (2^-23 + 2^-32) |a||b|: two f32
+// roundings of the product, unbiased (the pieces carry either sign).  Each piece product is exact
+// in f32 (8 x 8 bits) and the accumulation is f32 inside the MFMA unit: the result carries the
+// error of an f32 dot product with a different summation order (measured ~1e-7 of sum|a||b| on
+// K = 2304, the same as a sequential f32 loop; tools/experiments/split_gemm.hip; the bound is
+// asserted in tests/test_ops.py).  |x| above 3.39e38 (bf16 rounds to inf) is outside the domain;
+// below ~1e-33 the lo piece is a bf16 subnormal (absolute effect < 1e-38 per product).
+// bf16 MFMA runs at 16x the f32 MFMA rate, so six products cost 6/16 of the f32 instruction time:
+// the ceiling is 2.67x the f32 MFMA peak.
+#pragma once
+#include <cstdlib>
+#include <type_traits>
+
+#include "odt_common.hpp"
+
+namespace odt {
+namespace {
+
+typedef unsigned int u32x4 __attribute__((vector_size(16)));
+typedef unsigned int u32x2 __attribute__((vector_size(8)));
+typedef short bf16x8 __attribute__((vector_size(16)));
+
+constexpr unsigned kOOB = 0x80000000u;   // buffer offset that is out of range for every tensor (< 2 GiB)
+
+// Cout rounded up to the 64-wide n-tile granule: layers whose channel count is not a multiple of 64 (EfficientNet's
+// 240, 432, 864 ...) run with zero weight rows and a zero bias in the padding; their tensors' pixel stride covers it
+__host__ __device__ __forceinline__ int cout_padded(int cout) { return (cout + 63) & ~63; }
+__device__ __forceinline__ int sfast_div(int n, unsigned mul, unsigned sh) {
+  return mul ? (int)(__umulhi((unsigned)n, mul) >> sh) : n;
+}
+// Two f32 -> two bf16 (round to nearest even) in one dword: v_cvt_pk_bf16_f32.  (The CPU simulator
+// of the test suite supplies its own ODT_CVT_PK_BF16.)
+#ifndef ODT_CVT_PK_BF16
+typedef __bf16 odt_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float odt_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a0, float a1) {
+  const odt_f32x2 v = {a0, a1};
+  const odt_bf16x2 r = __builtin_convertvector(v, odt_bf16x2);
+  return *reinterpret_cast<const unsigned*>(&r);
+}
+#define ODT_CVT_PK_BF16(a0, a1) cvt_pk_bf16(a0, a1)
+#endif
+// x = hi + mid + lo exactly: hi = RN8(x); x - hi has <= 16 significant bits and is exact in f32;
+// mid = RN8(x - hi); the rest has <= 8 bits, so lo is exact.  |mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|.
+__device__ __forceinline__ void split2(float a0, float a1, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = ODT_CVT_PK_BF16(a0, a1);
+  const float r0 = a0 - __uint_as_float(hi << 16);
+  const float r1 = a1 - __uint_as_float(hi & 0xffff0000u);
+  mid = ODT_CVT_PK_BF16(r0, r1);
+  const float s0 = r0 - __uint_as_float(mid << 16);
+  const float s1 = r1 - __uint_as_float(mid & 0xffff0000u);
+  lo = ODT_CVT_PK_BF16(s0, s1);
+}
+
+// counted waits / LDS-only barrier / LDS pointer type of the LDS-DMA kernels (the simulator runs the DMA synchronously)
+#ifdef ODT_HIP_EMULATOR
+#define ODT_WAIT_VM_LGKM0(n) do { } while (0)
+#define ODT_BARRIER_LDS() __syncthreads()
+#define ODT_LDS_PTR(p) ((void*)(p))
+#else
+// counted wait: at most n vector-memory operations (A fetches / DMA of younger stages) stay in flight; all LDS done
+#define ODT_WAIT_VM_LGKM0(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(n) : "memory")
+// workgroup barrier that orders LDS traffic only (__syncthreads() would also drain the global stores in flight)
+#define ODT_BARRIER_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+#define ODT_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#endif
+
+#define ODT_STAMP(i) do { if constexpr (TRACE) { if (tid == 0) p.trace[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } } while (0)
+
+}  // namespace
+
+// per-family launchers (conv_split.hip dispatches on ConvParams::wt_split_kind)
+int launch_conv_split1(const ConvParams& p, const ConvParams* dev, hipStream_t stream);
+int launch_conv_split3(const ConvParams& p, const ConvParams* dev, hipStream_t stream);
+
+}  // namespace odt

@@ -33,7 +33,8 @@ def _resources(src):
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") and "HIPCC" not in os.environ, reason="hipcc not installed")
 def test_hot_kernels_use_no_scratch_memory():
-  res = _resources("conv_split.hip")
+  res = dict(_resources("conv_split3.hip"))
+  res.update(_resources("conv_split1.hip"))
   hot = {k: v for k, v in res.items() if "conv_split3" in k or "conv_split_kernelILi4ELi1ELi2E" in k}      # (the 256 x 64 one-stage tile is the one the plans use)
   assert len(hot) >= 12, sorted(res)
   for k, v in hot.items():
