@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
-SPLIT_PRODUCTS = 6              # bf16 MFMA products per f32 MAC in conv_split_kernel (csrc/conv_split.hip)
+SPLIT_PRODUCTS = 6              # bf16 MFMA products per f32 MAC in the conv_split kernels (csrc/conv_split3.hip, conv_split1.hip)
 
 
 def main():

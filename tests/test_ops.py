@@ -488,7 +488,7 @@ def test_conv_two_sources(backend, monkeypatch):
       np.testing.assert_allclose(got, np.maximum(want, 0), rtol=2e-4, atol=2e-4)
 
 
-# ---- bf16x3 split path (csrc/conv_split.hip): f32 results through six exact bf16 products ----
+# ---- bf16x3 split path (csrc/conv_split{,1,3}.hip): f32 results through six exact bf16 products ----
 SPLIT_CASES = [
     # B, H, W, Cin, Cout, k, stride, dil, pad_t, pad_l, Ho, Wo, relu
     (1, 9, 11, 64, 256, 3, 1, 1, 1, 1, 9, 11, True),         # 3x3 SAME, M = 99 (ragged tile)
