@@ -654,11 +654,23 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
   ConvPolicy pol{};
   if (q.wt_split == nullptr && dev_params == nullptr) pol = conv_policy_from_env(conv_policy_default());
   const bool split = q.wt_split != nullptr ? true : (dev_params == nullptr && conv_split_wanted(q, pol));
+  unsigned* tmp_amax = nullptr;
   if (split && q.wt_split == nullptr) {
     const int Ksp = q.kh * q.kw * q.Cin + (q.in2 != nullptr ? q.Cin2 : 0);
     ODT_HIP(hipMalloc(&tmp_img, conv_split_weight_bytes(q.Cout, Ksp)));
+    if (pol.family == 2 && q.in_amax == nullptr) {      // fp16x2 pieces need the sources' |max|: nobody recorded it for a stand-alone call
+      ODT_HIP(hipMalloc((void**)&tmp_amax, 2 * sizeof(unsigned)));
+      ODT_HIP(hipMemsetAsync(tmp_amax, 0, 2 * sizeof(unsigned), stream));
+      if (launch_tensor_amax(q.in, (size_t)q.B * q.in_Ha * q.in_Wa * q.in_ldc, tmp_amax, stream)) return 1;
+      q.in_amax = tmp_amax;
+      if (q.in2 != nullptr) {
+        if (launch_tensor_amax(q.in2, (size_t)q.B * q.in2_Ha * q.in2_Wa * q.in2_ldc, tmp_amax + 1, stream)) return 1;
+        q.in2_amax = tmp_amax + 1;
+      }
+    }
     conv_split_choose(q, pol);
     if (conv_make_split_weights(q, tmp_img, stream)) { (void)hipFree(tmp_img); return 1; }
+    if (q.wt_split_kind == 2) q.h2_chinv = conv_h2_chinv(tmp_img, q.Cout, Ksp);
     q.wt_split = tmp_img; modified = true;
     if (conv_split_partial_bytes(q) > 0) ODT_HIP(hipMalloc((void**)&tmp_partial, conv_split_partial_bytes(q)));
     q.partial = tmp_partial;
@@ -677,6 +689,7 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
       if (tmp != nullptr) ODT_HIP(hipFree(tmp));
       if (tmp_img != nullptr) ODT_HIP(hipFree(tmp_img));
       if (tmp_partial != nullptr) ODT_HIP(hipFree(tmp_partial));
+      if (tmp_amax != nullptr) ODT_HIP(hipFree(tmp_amax));
     }
     return 0;
   }

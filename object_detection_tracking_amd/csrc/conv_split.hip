@@ -104,7 +104,7 @@ ConvPolicy conv_policy_from_env(ConvPolicy q) {
   };
   long v;
   v = q.arith; geti("ODT_CONV_SPLIT", &v); q.arith = v != 0 ? 1 : 0;
-  v = q.family; geti("ODT_CONV_SPLIT_PIPE", &v); q.family = v >= 3 ? 3 : 1;
+  v = q.family; geti("ODT_CONV_SPLIT_PIPE", &v); q.family = v >= 3 ? 3 : (v == 2 ? 2 : 1);
   geti("ODT_CONV_SPLIT_MINTILES", &q.min_tiles);
   geti("ODT_CONV_SPLIT3_MINTILES", &q.min_tiles3);
   v = q.min_k; geti("ODT_CONV_SPLIT_MINK", &v); q.min_k = (int)v;
@@ -125,7 +125,7 @@ ConvPolicy conv_policy_from_env(ConvPolicy q) {
 static bool split3_fit(const ConvParams& p, const ConvPolicy& q, int* bm, int* bn, int* sk) {
   const int bn0 = conv_split_bn(p.Cout);
   const int K = p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0);
-  if (q.family < 3 || bn0 == 0 || p.kh * p.kw > 32 || K < 32 || p.Cin % 16 != 0) return false;
+  if (q.family < 2 || bn0 == 0 || p.kh * p.kw > 32 || K < 32 || p.Cin % 16 != 0) return false;
   const long M = (long)p.B * p.Ho * p.Wo;
   const int nsteps = K >> 4;
   *bn = bn0; *sk = 1;
@@ -181,12 +181,16 @@ void conv_split_choose(ConvParams& p, const ConvPolicy& q) {
     // stride-1 KH x 3 convs over rows of the output's pitch: the kw taps share a staged run of pixels
     p.wt_split_kwr = (q.kw_reuse && b3 == 256 && k3 == 1 && (n3 >= 128 || q.kwr_n64) && p.kw == 3 && p.stride == 1 && p.in_Wa == p.Wo &&
                       p.in2 == nullptr && 2 * p.dil <= 4 && p.Ho * p.Wo >= 256 && p.kh * 3 <= 30) ? 1 : 0;
+    // fp16x2 pieces: 256-row tiles at least 128 wide whose source tensor(s) come with a recorded |max|
+    if (q.family == 2 && b3 == 256 && n3 >= 128 && p.in_amax != nullptr && (p.in2 == nullptr || (p.in2_amax != nullptr && p.Cin2 % 32 == 0)) &&
+        p.Cin % 32 == 0 && p.nlvl <= 1 && p.lvl_scale == nullptr && (K >> 5) >= k3)
+      p.wt_split_kind = 2;
     return;
   }
 }
 
 size_t conv_split_partial_bytes(const ConvParams& p) {
-  return p.wt_split_kind == 3 && p.splitk > 1 ? (size_t)p.splitk * p.B * p.Ho * p.Wo * cout_padded(p.Cout) * sizeof(float) : 0;
+  return (p.wt_split_kind == 3 || p.wt_split_kind == 2) && p.splitk > 1 ? (size_t)p.splitk * p.B * p.Ho * p.Wo * cout_padded(p.Cout) * sizeof(float) : 0;
 }
 
 // f32 weights [Cout][K] times a per-k gate (the exact-f32 kernel's form of the folded gate)
@@ -208,8 +212,12 @@ int conv_make_split_weights(const ConvParams& p, void* img_dev, hipStream_t stre
   ODT_CHECK(kscale == nullptr || (p.kh == 1 && p.kw == 1 && p.in2 == nullptr), "conv_make_split_weights: a folded gate belongs to a single-source 1x1 conv");
   const int bn = p.wt_split_bn != 0 ? p.wt_split_bn : conv_split_bn(p.Cout);
   const int K = p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0);
-  ODT_CHECK(bn != 0 && K % 32 == 0 && (p.wt_split_kind == 1 || p.wt_split_kind == 3),
+  ODT_CHECK(bn != 0 && K % 32 == 0 && (p.wt_split_kind >= 1 && p.wt_split_kind <= 3),
             "conv_make_split_weights: Cout % 64 == 0, K % 32 == 0 and a chosen kernel family required");
+  if (p.wt_split_kind == 2) {
+    ODT_CHECK(kscale == nullptr && wt_src == nullptr, "conv_make_split_weights: the fp16x2 image takes the conv's own weights");
+    return conv_make_h2_weights(p, img_dev, stream);
+  }
   if (p.wt_split_kind == 3) {
     const long total = (long)cout_padded(p.Cout) * (K >> 4) * 2;
     hipLaunchKernelGGL(split_weights3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, p.Cout, K,
@@ -224,6 +232,7 @@ int conv_make_split_weights(const ConvParams& p, void* img_dev, hipStream_t stre
 }
 
 int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t stream) {
+  if (p.wt_split_kind == 2) return launch_conv_h2(p, dev, stream);
   return p.wt_split_kind == 3 ? launch_conv_split3(p, dev, stream) : launch_conv_split1(p, dev, stream);
 }
 

@@ -6,7 +6,7 @@
 // weight image [n-tile][k-slice][piece][k-group][BN n][8 k] (conv_make_split_weights), one linear copy per stage.
 // LDS planes are [k-group][row][8 bf16]: a wave's ds_read_b128 of an MFMA operand is one contiguous 512-byte run per 32
 // lanes.  Residuals (same shape / nearest-2x) become the accumulators' start value; optional K-concatenated second A source.
-#include "conv_split_common.hpp"
+#include "conv_split_epilogue.hpp"
 
 namespace odt {
 
@@ -277,6 +277,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
   const int c4 = tid % C4, row0 = tid / C4;
   const int col = n0 + c4 * 4;
   const f32x4 bias4 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, col * 4, 0, 0);
+  float vmax = 0.f;                          // |max| of what this thread stores (ConvParams::out_amax)
   auto run = [&](auto act_c) {
     constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
@@ -321,6 +322,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
           for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
         }
         __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)ooff, 0, 0);
+        if (ok) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
       }
       if (pass == 0) stamp(4);
     }
@@ -329,6 +331,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
   else if (p.relu == 2) run(std::integral_constant<int, 2>{});
   else if (p.relu == 3) run(std::integral_constant<int, 3>{});
   else run(std::integral_constant<int, 0>{});
+  publish_amax(p.out_amax, vmax, tid);
   stamp(5);
 }
 

@@ -16,213 +16,11 @@
 //     kernel cost 128 four-byte loads per lane: 9 us of a 63 us res4 conv3 tile).
 // Tile configurations <WM, WN, TN> (WM x WN = 8 waves, wave tile 64 x 32 TN):
 //   <4,2,4> 256 x 256 (Cout % 256 == 0)   <4,2,2> 256 x 128 (Cout % 128 == 0)   <4,2,1> 256 x 64 (Cout % 64 == 0)
-#include "conv_split_common.hpp"
+#include "conv_split_epilogue.hpp"
 
 namespace odt {
 
 namespace {
-
-// Epilogue shared by the conv_split3 kernels: accumulators of the 8 waves (wave tile 64 x 32 TN at (wm, wn)) -> LDS ->
-// rows of 16-byte chunks -> bias (+ residual) + activation -> global, or the raw partial tile of a split-K range.
-template <int WM, int WN, int TN, int LDSB, bool TRACE>
-__device__ __forceinline__ void split3_epilogue(const ConvParams& p, f32x16 (&acc)[2][TN], unsigned char* lds, int m0, int n0,
-                                                int M, int HoWo, int ks, int splitk, int tid, int wm, int wn, int fr, int fg) {
-  constexpr int BM = 64 * WM, BN = 32 * TN * WN;
-  // ---- epilogue: the C tile goes through LDS in passes of RP rows; per 16-byte row chunk: bias (+ residual)
-  // + activation, 16-byte stores (a wave writes whole row segments).  The residual chunks of a pass are fetched
-  // before the pass is staged, so their latency hides behind the LDS round trip.
-  constexpr int CS = BN + 4;
-  constexpr int FIT = LDSB / (CS * 4);                    // rows of the C tile the ring's LDS holds
-  constexpr int RP = FIT >= BM ? BM : (FIT >= BM / 2 ? BM / 2 : (FIT >= BM / 4 ? BM / 4 : 64));   // rows per pass
-  constexpr int NPASS = BM / RP, WPP = RP / 64;
-  constexpr int C4 = BN / 4, RSTEP = 512 / C4, NCH = RP / RSTEP;
-  static_assert(RP >= 64 && BM % RP == 0 && RP % RSTEP == 0, "epilogue passes");
-  float* Ct = reinterpret_cast<float*>(lds);
-  const bool dense_io = p.out_oy == 0 && p.out_ox == 0 && p.out_H == p.Ho && p.out_W == p.Wo &&
-                        (p.res_mode == 0 || (p.res_mode == 1 && p.res_H == p.Ho && p.res_W == p.Wo));
-  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.out, 0, (int)((unsigned)p.B * p.out_H * p.out_W * p.out_ldc * 4u), 0x00020000);
-  // per-row-range constants (ConvParams::nlvl): every tile lies inside one range (ranges start on multiples of 256 rows)
-  int lvl_off = 0;
-  if (p.nlvl > 1) {
-    // (constant indices: a runtime-indexed field would send the whole parameter record to scratch memory; unused entries
-    // are INT_MAX)
-    const int lvl = (m0 >= p.lvl_start[1] ? 1 : 0) + (m0 >= p.lvl_start[2] ? 1 : 0) + (m0 >= p.lvl_start[3] ? 1 : 0) +
-                    (m0 >= p.lvl_start[4] ? 1 : 0);
-    lvl_off = lvl * p.lvl_stride;
-  }
-  const unsigned nbias = p.nlvl > 1 ? (unsigned)(p.nlvl * p.lvl_stride) : (unsigned)p.Cout;
-  const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (int)(nbias * 4u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_scale = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.lvl_scale != nullptr ? p.lvl_scale : p.bias), 0, (int)(p.lvl_scale != nullptr ? nbias * 4u : 0u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.res_mode != 0 ? p.res : p.bias), 0,
-      (int)(p.res_mode != 0 ? (unsigned)p.B * p.res_H * p.res_W * p.res_ldc * 4u : 0u), 0x00020000);
-  const int c4 = tid % C4, row0 = tid / C4;
-  const int col = n0 + c4 * 4;
-  if (splitk > 1) {
-    // split-K: the raw partial tile, dense [M][Cout] rows of this range's slab (bias / residual / activation happen in
-    // split_reduce_kernel once all ranges are in)
-    const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.partial + (size_t)ks * M * cout_padded(p.Cout)), 0, (int)((unsigned)M * cout_padded(p.Cout) * 4u), 0x00020000);
-#pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-      if (pass > 0) ODT_BARRIER_LDS();
-      if (wm / WPP == pass) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              Ct[((wm % WPP) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * CS + wn * TN * 32 + j * 32 + fr] = acc[i][j][r];
-      }
-      ODT_BARRIER_LDS();
-#pragma unroll
-      for (int s2 = 0; s2 < NCH; ++s2) {
-        const int m = m0 + pass * RP + row0 + s2 * RSTEP;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[(row0 + s2 * RSTEP) * CS + c4 * 4]);
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_part, m < M ? (int)(((unsigned)m * cout_padded(p.Cout) + col) * 4u) : (int)kOOB, 0, 0);
-      }
-    }
-    ODT_STAMP(5);
-    return;
-  }
-  const f32x4 bias4 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, (lvl_off + col) * 4, 0, 0);
-  const bool has_scale = p.lvl_scale != nullptr;
-  f32x4 scale4 = {1.f, 1.f, 1.f, 1.f};
-  if (has_scale) scale4 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_scale, (lvl_off + col) * 4, 0, 0);
-  if constexpr (BN == 256) {
-    if (p.head_wt != nullptr) {
-      // ---- fused 1x1 head (RPN class || box: 15 columns of a 16-wide GEMM over this tile's 256 channels).  Per pass:
-      // accumulators -> LDS, bias + activation in place, then wave w multiplies rows [16 w, 16 w + 16) of the pass by
-      // head_wt with v_mfma_f32_16x16x4_f32 (exact f32: an fmaf chain in k order).  k order of the chain: step
-      // (t, u) takes channels 16 t + 4 j + u, j = lane / 16 -- one ds_read_b128 per lane feeds four MFMAs; the lane's 64
-      // B-operand values (head_wt[16 t + 4 j + u][lane % 16]) are fetched once, up front.
-      const int lane = tid & 63, wave = tid >> 6;
-      const int hn = lane & 15, hj = lane >> 4;
-      float hb[64];
-#pragma unroll
-      for (int t = 0; t < 16; ++t)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) hb[t * 4 + u] = p.head_wt[(16 * t + 4 * hj + u) * 16 + hn];
-      const float hbias = p.head_bias[hn];
-      static_assert(RP % 16 == 0, "head tiles");
-      constexpr int RT = RP / 16;               // 16-row tiles per pass
-#pragma unroll 1
-      for (int pass = 0; pass < NPASS; ++pass) {
-        if (pass > 0) ODT_BARRIER_LDS();
-        if (wm / WPP == pass) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-              for (int r = 0; r < 16; ++r)
-                Ct[((wm % WPP) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * CS + wn * TN * 32 + j * 32 + fr] = acc[i][j][r];
-        }
-        ODT_BARRIER_LDS();
-#pragma unroll
-        for (int s2 = 0; s2 < NCH; ++s2) {      // bias + activation in place (each thread its own 16-byte chunks)
-          f32x4* q = reinterpret_cast<f32x4*>(&Ct[(row0 + s2 * RSTEP) * CS + c4 * 4]);
-          f32x4 v = *q + bias4;
-          if (p.relu == 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-          *q = v;
-        }
-        ODT_BARRIER_LDS();
-        for (int rt = wave; rt < RT; rt += 8) {
-          f32x4 c = {0.f, 0.f, 0.f, 0.f};
-          const float* arow = &Ct[(rt * 16 + hn) * CS + 4 * hj];
-#pragma unroll
-          for (int t = 0; t < 16; ++t) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * t);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], hb[t * 4 + u], c, 0, 0, 0);
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {          // C layout: row 4 j + i, column lane % 16
-            const int m = m0 + pass * RP + rt * 16 + 4 * hj + i;
-            if (m < M) p.head_out[(size_t)m * p.head_ldc + hn] = hn < 15 ? c[i] + hbias : 0.f;
-          }
-        }
-      }
-      ODT_STAMP(5);
-      return;
-    }
-  }
-  // (no barrier needed here: the last stage's barrier sits behind every fragment read of the ring)
-  auto run = [&](auto act_c, auto res_c) {
-    constexpr int ACT = decltype(act_c)::value;
-    constexpr bool RES = decltype(res_c)::value;
-#pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-      unsigned ooff[NCH];
-      f32x4 rres[RES ? NCH : 1];
-#pragma unroll
-      for (int s2 = 0; s2 < NCH; ++s2) {
-        const int m = m0 + pass * RP + row0 + s2 * RSTEP;
-        const bool ok = m < M;
-        unsigned opix = (unsigned)m, rpix = (unsigned)m;
-        if (!dense_io) {
-          const int mm = ok ? m : 0;
-          const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), rr = mm - n * HoWo;
-          const int ho = sfast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
-          opix = ((unsigned)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
-          rpix = p.res_mode == 2 ? ((unsigned)n * p.res_H + (unsigned)(ho >> 1)) * p.res_W + (unsigned)(wo >> 1)
-                                 : ((unsigned)n * p.res_H + (unsigned)ho) * p.res_W + (unsigned)wo;
-        }
-        ooff[s2] = ok ? (opix * p.out_ldc + col) * 4u : kOOB;
-        if constexpr (RES)
-          rres[s2] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_res, ok ? (int)((rpix * p.res_ldc + col) * 4u) : (int)kOOB, 0, 0);
-      }
-      if (pass > 0) ODT_BARRIER_LDS();        // the previous pass has been read
-      if (wm / WPP == pass) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              Ct[((wm % WPP) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * CS + wn * TN * 32 + j * 32 + fr] = acc[i][j][r];
-      }
-      ODT_BARRIER_LDS();
-      if (pass == 0) ODT_STAMP(3);
-#pragma unroll
-      for (int s2 = 0; s2 < NCH; ++s2) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[(row0 + s2 * RSTEP) * CS + c4 * 4]);
-        if (has_scale) v = v * scale4;
-        v += bias4;
-        if constexpr (RES) v += rres[s2];
-        if (ACT == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (ACT == 2) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f / (1.0f + expf(-v[e])));
-        } else if (ACT == 3) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
-        }
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)ooff[s2], 0, 0);
-      }
-      if (pass == 0) ODT_STAMP(4);
-    }
-  };
-  if (p.res_mode != 0) {
-    if (p.relu == 1) run(std::integral_constant<int, 1>{}, std::true_type{});
-    else if (p.relu == 0) run(std::integral_constant<int, 0>{}, std::true_type{});
-    else if (p.relu == 2) run(std::integral_constant<int, 2>{}, std::true_type{});
-    else run(std::integral_constant<int, 3>{}, std::true_type{});
-  } else {
-    if (p.relu == 1) run(std::integral_constant<int, 1>{}, std::false_type{});
-    else if (p.relu == 0) run(std::integral_constant<int, 0>{}, std::false_type{});
-    else if (p.relu == 2) run(std::integral_constant<int, 2>{}, std::false_type{});
-    else run(std::integral_constant<int, 3>{}, std::false_type{});
-  }
-}
 
 template <int WM, int WN, int TN>
 struct Split3Cfg {
@@ -795,11 +593,15 @@ __global__ void __launch_bounds__(256) split_reduce_kernel(const ConvParams* __r
   const int Np = cout_padded(p.Cout), C4 = Np >> 2;
   const long M = (long)p.B * p.Ho * p.Wo;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= M * C4) return;
+  if (idx >= M * C4) { publish_amax(p.out_amax, 0.f, (int)threadIdx.x); return; }
   const int m = (int)(idx / C4), col = (int)(idx - (long)m * C4) * 4;
   const size_t slab = (size_t)M * Np;
   f32x4 v = *reinterpret_cast<const f32x4*>(p.partial + (size_t)m * Np + col);
   for (int k = 1; k < p.splitk; ++k) v += *reinterpret_cast<const f32x4*>(p.partial + (size_t)k * slab + (size_t)m * Np + col);
+  if (p.h2_chinv != nullptr) {          // fp16x2 pieces: undo the powers of two of the weight columns and of the A operand
+    const float inv = pow2f(-h2_in_scale_exp(p));
+    for (int e = 0; e < 4; ++e) v[e] *= p.h2_chinv[col + e] * inv;
+  }
   for (int e = 0; e < 4; ++e) v[e] += col + e < p.Cout ? p.bias[col + e] : 0.f;
   const int HoWo = p.Ho * p.Wo;
   const int n = sfast_div(m, p.div_howo_mul, p.div_howo_sh), rr = m - n * HoWo;
@@ -818,6 +620,7 @@ __global__ void __launch_bounds__(256) split_reduce_kernel(const ConvParams* __r
   }
   const size_t opix = ((size_t)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
   *reinterpret_cast<f32x4*>(p.out + opix * p.out_ldc + col) = v;
+  publish_amax(p.out_amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), (int)threadIdx.x);
 }
 
 }  // namespace
@@ -828,6 +631,11 @@ static void launch_split3(const ConvParams& p, const ConvParams* dev, unsigned g
   else hipLaunchKernelGGL((conv_split3_kernel<WM, WN, TN, false>), dim3(grid), dim3(512), 0, stream, dev);
 }
 
+
+void launch_split_reduce(const ConvParams& p, const ConvParams* dev, hipStream_t stream) {
+  const long chunks = (long)p.B * p.Ho * p.Wo * (cout_padded(p.Cout) / 4);
+  hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, dev);
+}
 
 int launch_conv_split3(const ConvParams& p, const ConvParams* dev, hipStream_t stream) {
   const long M = (long)p.B * p.Ho * p.Wo;
@@ -858,10 +666,7 @@ int launch_conv_split3(const ConvParams& p, const ConvParams* dev, hipStream_t s
     if (bn == 256) launch_split3<2, 4, 2>(p, dev, grid, stream);
     else launch_split3<2, 4, 1>(p, dev, grid, stream);
   }
-  if (sk > 1) {
-    const long chunks = M * (cout_padded(p.Cout) / 4);
-    hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, dev);
-  }
+  if (sk > 1) launch_split_reduce(p, dev, stream);
   ODT_HIP(hipGetLastError());
   return 0;
 }

@@ -59,6 +59,61 @@ __device__ __forceinline__ void split2(float a0, float a1, unsigned& hi, unsigne
   lo = ODT_CVT_PK_BF16(s0, s1);
 }
 
+// ---- fp16x2 pieces (conv_h2.hip) ------------------------------------------------------------------------------------
+// x 2^s = hi + lo + e with hi = RN11(x 2^s), lo = RN11(x 2^s - hi): |lo| <= 2^-11 |x 2^s|, |e| <= 2^-22 |x 2^s| (two f16
+// significands of 11 bits and a sign), provided hi is finite (|x| 2^s < 65520) and lo is not lost to the f16 exponent
+// range.  The power of two comes from the tensor's recorded |max| (h2_scale_exp): max |x| 2^s lies in [2^14, 2^15), so
+// hi never overflows, lo is a NORMAL f16 for every element down to 2^-17 of the tensor maximum and a subnormal below
+// (absolute error <= 2^-25 in scaled units = 2^-39 of the maximum -- the gfx950 matrix pipe takes f16 subnormals at full
+// precision, tools/experiments/mfma_f16_denorm_probe.hip).  a*b is evaluated as hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_32x32x16_f16 (each piece product is exact in f32: 11 x 11 bits), f32 accumulation; the dropped lo*lo and the
+// two representation errors are each <= 2^-22 |a||b|.
+#ifdef ODT_HIP_EMULATOR
+typedef short f16x8 __attribute__((vector_size(16)));
+#else
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#endif
+#ifndef ODT_CVT_PK_F16
+typedef _Float16 odt_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_f16(float a0, float a1) {      // v_cvt_pk_f16_f32 (round to nearest even)
+  const odt_f32x2 v = {a0, a1};
+  const odt_f16x2 r = __builtin_convertvector(v, odt_f16x2);
+  return *reinterpret_cast<const unsigned*>(&r);
+}
+__device__ __forceinline__ float f16_lo_f32(unsigned u) { return (float)(*reinterpret_cast<const odt_f16x2*>(&u))[0]; }
+__device__ __forceinline__ float f16_hi_f32(unsigned u) { return (float)(*reinterpret_cast<const odt_f16x2*>(&u))[1]; }
+#define ODT_CVT_PK_F16(a0, a1) cvt_pk_f16(a0, a1)
+#define ODT_F16_LO_F32(u) f16_lo_f32(u)
+#define ODT_F16_HI_F32(u) f16_hi_f32(u)
+#endif
+__device__ __forceinline__ void split2h(float a0, float a1, float s, unsigned& hi, unsigned& lo) {
+  const float x0 = a0 * s, x1 = a1 * s;
+  hi = ODT_CVT_PK_F16(x0, x1);
+  const float r0 = x0 - ODT_F16_LO_F32(hi), r1 = x1 - ODT_F16_HI_F32(hi);
+  lo = ODT_CVT_PK_F16(r0, r1);
+}
+// 2^e as a float (e in [-126, 127])
+__host__ __device__ __forceinline__ float pow2f(int e) {
+  const unsigned u = (unsigned)(e + 127) << 23;
+  float f;
+  __builtin_memcpy(&f, &u, 4);
+  return f;
+}
+// the power of two that takes a tensor whose |max| has the f32 bit pattern `amax_bits` into [2^14, 2^15): 14 - exponent,
+// kept inside the exponents a float scale (and its inverse) can carry; 0 for an all-zero / non-finite maximum
+__host__ __device__ __forceinline__ int h2_scale_exp(unsigned amax_bits) {
+  const int be = (int)((amax_bits >> 23) & 0xffu);
+  if (be == 0 || be == 255) return 0;
+  const int s = 14 - (be - 127);
+  return s > 100 ? 100 : (s < -100 ? -100 : s);
+}
+// the A-side scale exponent of a conv: from the recorded |max| of its source tensor(s)
+__device__ __forceinline__ int h2_in_scale_exp(const ConvParams& p) {
+  unsigned a = p.in_amax != nullptr ? *p.in_amax : 0u;
+  if (p.in2_amax != nullptr) { const unsigned b = *p.in2_amax; a = b > a ? b : a; }
+  return h2_scale_exp(a);
+}
+
 // counted waits / LDS-only barrier / LDS pointer type of the LDS-DMA kernels (the simulator runs the DMA synchronously)
 #ifdef ODT_HIP_EMULATOR
 #define ODT_WAIT_VM_LGKM0(n) do { } while (0)
@@ -79,5 +134,7 @@ __device__ __forceinline__ void split2(float a0, float a1, unsigned& hi, unsigne
 // per-family launchers (conv_split.hip dispatches on ConvParams::wt_split_kind)
 int launch_conv_split1(const ConvParams& p, const ConvParams* dev, hipStream_t stream);
 int launch_conv_split3(const ConvParams& p, const ConvParams* dev, hipStream_t stream);
+int launch_conv_h2(const ConvParams& p, const ConvParams* dev, hipStream_t stream);
+void launch_split_reduce(const ConvParams& p, const ConvParams* dev, hipStream_t stream);   // split-K combine (conv_split3.hip)
 
 }  // namespace odt

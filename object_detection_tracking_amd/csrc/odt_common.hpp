@@ -67,7 +67,8 @@ struct ConvParams {
   // split kernel (conv_split.hip: f32 result through six exact bf16 MFMA products per MAC)
   const void* wt_split;
   int wt_split_kind;   // which kernel family the image was laid out for: 1 one-stage BK = 32 (conv_split_kernel, the 64-wide
-                       // layers) | 3 conv_split3_kernel / conv_split3k_kernel (8 waves, LDS-DMA weight stages)
+                       // layers) | 3 conv_split3_kernel / conv_split3k_kernel (8 waves, LDS-DMA weight stages) | 2 conv_h2_kernel /
+                       // conv_h2k_kernel (fp16x2 pieces)
   int wt_split_bm;     // kind 3: rows of the block tile (256, or 128 when 256-row tiles would not fill the chip)
   int wt_split_bn;     // n-tile width the image was laid out for (kind 3 may use 128 on wider layers; 0: conv_split_bn(Cout))
   // split-K (conv_split3_kernel only): the reduction is cut into `splitk` contiguous ranges of stages, one workgroup per
@@ -89,6 +90,14 @@ struct ConvParams {
   int lvl_start[5];
   int lvl_stride;
   const float* lvl_scale;
+  // fp16x2 pieces (wt_split_kind == 2, conv_h2.hip): the A operand is scaled by a power of two taken from the recorded |max|
+  // of the source tensor(s) -- a u32 holding the f32 bit pattern, written by the producers' epilogues (out_amax: atomic max
+  // over the stored values; the plan clears the slots at the start of a forward) -- and the weight image's column n by
+  // 2^t_n; the epilogue multiplies the accumulators by h2_chinv[n] = 2^-t_n and by the inverse of the A scale.
+  const unsigned* in_amax;   // |max| of `in` (required for kind 2)
+  const unsigned* in2_amax;  // ... of `in2`
+  unsigned* out_amax;        // where this conv records the |max| of what it stores (any split kernel), or nullptr
+  const float* h2_chinv;     // [cout_padded(Cout)] (kind 2)
   const float* head_wt;    // [Cout][16] (k-major, column 15 zero) or nullptr
   const float* head_bias;  // [16]
   float* head_out;         // [M][head_ldc] dense rows (m = (n, ho, wo))
@@ -104,7 +113,8 @@ double conv_flops(const ConvParams& p);   // algorithmic 2*M*N*K
 // resolve it per call.
 struct ConvPolicy {
   int arith;            // 0 exact-f32 MFMA everywhere | 1 bf16x3 split kernels where they pay
-  int family;           // newest split kernel family allowed: 1 one-stage only | 3 conv_split3_kernel where it fits (default)
+  int family;           // split kernel families allowed: 1 one-stage only | 3 + conv_split3_kernel where it fits | 2 + the
+                        // fp16x2 kernels (conv_h2.hip) where a layer has 256-row tiles and a recorded input range
   long min_tiles;       // tiles a layer must offer the one- / two-stage kernels (256)
   long min_tiles3;      // ... conv_split3_kernel's 256- / 128-row tiles (200)
   int min_k, min_bn;    // shortest reduction / narrowest n-tile taken
@@ -133,6 +143,12 @@ int conv_make_split_weights(const ConvParams& p, void* img_dev, hipStream_t stre
                             const float* kscale = nullptr);
 int conv_scale_weights(const float* wt, const float* kscale, int Cout, int K, float* out, hipStream_t stream);
 int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t stream);
+// fp16x2 pieces (conv_h2.hip; wt_split_kind == 2): the image (conv_make_split_weights builds it) carries the per-column
+// inverse scales behind the pieces -- ConvParams::h2_chinv must point there; launch_tensor_amax records the |max| of a dense
+// array for a source tensor no producer recorded one for (stand-alone calls)
+const float* conv_h2_chinv(const void* img, int Cout, int K);
+int conv_make_h2_weights(const ConvParams& p, void* img_dev, hipStream_t stream);
+int launch_tensor_amax(const float* x, size_t n, unsigned* slot, hipStream_t stream);
 size_t conv_split_partial_bytes(const ConvParams& p);   // scratch a split-K conv needs (0: none)
 
 // ------------------------------------------------------------ elementwise (K1,K4)

@@ -93,6 +93,13 @@ struct odt_model {
   std::vector<ConvParams> conv_recs; // launch records: convs[i] runs as records [conv_rec0[i], + conv_nrec[i]) (batch ranges,
   std::vector<int> conv_rec0, conv_nrec;   // more than one only where a tensor would reach 2 GiB: upload_conv_records)
   int chunked_convs = 0;
+  // |max| slots of the tensors the split conv kernels produce (ConvParams::out_amax / in_amax: the fp16x2 kernels scale
+  // their A operand by them).  Two groups, cleared at the start of the ops that fill them: [0, kAmaxSlots) for producers in
+  // the trunk, [kAmaxSlots, 2 kAmaxSlots) for producers in the tail ops (which may run under the next forward's trunk).
+  static constexpr int kAmaxSlots = 512;
+  unsigned* amax_dev = nullptr;
+  int amax_used[2] = {0, 0};
+  int convs_h2 = 0;                  // convs on the fp16x2 kernels
   std::vector<Op> ops;
   // geometry
   int Hp = 0, Wp = 0;

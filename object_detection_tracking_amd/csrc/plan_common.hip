@@ -178,44 +178,71 @@ ConvPolicy resolve_conv_policy(const odt_model* m) {
   ConvPolicy pol = conv_policy_default();
   if (m->cfg.conv_arith == ODT_ARITH_F32) pol.arith = 0;
   else if (m->cfg.conv_arith == ODT_ARITH_BF16X3) pol.arith = 1;
-  if (m->cfg.conv_split_family >= 1 && m->cfg.conv_split_family <= 3) pol.family = m->cfg.conv_split_family >= 3 ? 3 : 1;
-  return conv_policy_from_env(pol);
+  if (m->cfg.conv_split_family >= 1 && m->cfg.conv_split_family <= 3) pol.family = m->cfg.conv_split_family;
+  pol = conv_policy_from_env(pol);
+  // (the EfficientDet graph keeps the bf16x3 kernels: its convs mostly lack 256-row x 128-column tiles, and its in-place
+  // gates would need their own range bookkeeping)
+  if (m->cfg.graph == ODT_GRAPH_EFFNET && pol.family == 2) pol.family = 3;
+  return pol;
 }
 
 int attach_split_weights(odt_model* m) {
   const ConvPolicy pol = resolve_conv_policy(m);
   m->policy = pol;
   if (pol.arith == 0) return 0;
-  std::map<const float*, const void*> made;      // the RPN conv is shared by the five levels
-  std::map<const float*, int> made_kind;
-  size_t need_partial = 0;                        // split-K scratch: one buffer, the plan's layers run one after another
-  for (ConvOp& c : m->convs) {
-    if (!conv_split_wanted(c.p, pol)) continue;
-    auto it = made.find(c.p.wt);
+  find_overlap_points(m);
+  m->amax_dev = reinterpret_cast<unsigned*>(m->alloc_f(2 * odt_model::kAmaxSlots, true));
+  ODT_CHECK(m->amax_dev != nullptr, "device allocation failed (range slots)");
+  // |max| slots: a tensor written by a split conv kernel gets one; a pooled / subsampled tensor shares its source's (its
+  // values are a subset); anything else has none, and a conv reading it stays off the fp16x2 kernels.  Tail convs only
+  // see slots filled in the tail (the trunk group is cleared by the next forward while the tail may still be running).
+  std::map<const float*, int> slot_of;
+  auto slot_ptr = [&](const float* t, bool tail_reader) -> const unsigned* {
+    auto it = t != nullptr ? slot_of.find(t) : slot_of.end();
+    if (it == slot_of.end()) return nullptr;
+    if (tail_reader != (it->second >= odt_model::kAmaxSlots)) return nullptr;
+    return m->amax_dev + it->second;
+  };
+  std::map<std::pair<const float*, int>, const void*> made;      // the RPN conv is shared by the five levels: one image per layout
+  size_t need_partial = 0;
+  for (size_t oi = 0; oi < m->ops.size(); ++oi) {
+    const Op& op = m->ops[oi];
+    const bool tail = m->op_tail > 0 && oi >= m->op_tail;
+    if (op.kind == OP_POOL || op.kind == OP_SUB2) {
+      auto it = slot_of.find(op.in.d);
+      if (it != slot_of.end()) slot_of[op.out.d] = it->second; else slot_of.erase(op.out.d);
+      continue;
+    }
+    if (op.kind != OP_CONV) continue;
+    ConvOp& c = m->convs[op.conv];
+    c.p.in_amax = slot_ptr(c.p.in, tail);
+    c.p.in2_amax = slot_ptr(c.p.in2, tail);
+    if (!conv_split_wanted(c.p, pol)) { slot_of.erase(c.p.out); continue; }      // exact-f32 kernel: records no range
+    conv_split_choose(c.p, pol);
+    const int K = c.p.kh * c.p.kw * c.p.Cin + (c.p.in2 != nullptr ? c.p.Cin2 : 0);
+    const auto key = std::make_pair(c.p.wt, c.p.wt_split_kind * 1024 + c.p.wt_split_bn);
+    auto it = made.find(key);
     if (it == made.end()) {
-      const int K = c.p.kh * c.p.kw * c.p.Cin + (c.p.in2 != nullptr ? c.p.Cin2 : 0);
       float* img = m->alloc_f((conv_split_weight_bytes(c.p.Cout, K) + 3) / 4, false);
       ODT_CHECK(img != nullptr, "device allocation failed (split weights of " + c.name + ")");
-      conv_split_choose(c.p, pol);
       if (conv_make_split_weights(c.p, img, 0)) return 1;
-      it = made.emplace(c.p.wt, img).first;
-      made_kind[c.p.wt] = c.p.wt_split_kind + 16 * c.p.wt_split_bn;
+      it = made.emplace(key, img).first;
     }
-    conv_split_choose(c.p, pol);
-    // shared weights (the RPN conv over five levels): one image, so one kernel family -- the first (largest) level's
-    if (c.p.wt_split_kind + 16 * c.p.wt_split_bn != made_kind[c.p.wt]) {
-      // (the image depends on the kernel family and the n-tile width only: tile height and split-K stay this level's)
-      const int kind = made_kind[c.p.wt] % 16, bn = made_kind[c.p.wt] / 16;
-      ODT_CHECK(kind != 3 || c.p.Cin % 16 == 0, "split weights: shared image of an unsupported layout");
-      if (c.p.wt_split_kind != kind) {
-        c.p.splitk = 1;
-        if (kind == 3) c.p.wt_split_bm = bn >= 128 ? 128 : 256;
-        else c.p.wt_split_bm = conv_split_bm(c.p.Cout);
-      }
-      c.p.wt_split_kind = kind; c.p.wt_split_bn = bn;
-    }
-    need_partial = std::max(need_partial, conv_split_partial_bytes(c.p));
     c.p.wt_split = it->second;
+    if (c.p.wt_split_kind == 2) { c.p.h2_chinv = conv_h2_chinv(c.p.wt_split, c.p.Cout, K); ++m->convs_h2; }
+    need_partial = std::max(need_partial, conv_split_partial_bytes(c.p));
+    // the output's slot
+    if (c.p.out != nullptr) {
+      auto so = slot_of.find(c.p.out);
+      int slot;
+      if (so != slot_of.end() && (so->second >= odt_model::kAmaxSlots) == tail) slot = so->second;
+      else {
+        ODT_CHECK(m->amax_used[tail] < odt_model::kAmaxSlots, "too many conv outputs for the range slots");
+        slot = (tail ? odt_model::kAmaxSlots : 0) + m->amax_used[tail]++;
+        slot_of[c.p.out] = slot;
+      }
+      c.p.out_amax = m->amax_dev + slot;
+    }
   }
   if (need_partial > 0) {
     // split-K scratch: the layers of one stream run one after another and share a buffer -- but the tail ops (box-head
@@ -265,7 +292,7 @@ int fuse_rpn_heads(odt_model* m) {
     if (a.name.compare(0, 10, "rpn/conv0@") != 0 || b.name.compare(0, 9, "rpn/head@") != 0) continue;
     const ConvParams& bp = b.p;
     ConvParams& ap = a.p;
-    const bool ok = ap.wt_split != nullptr && ap.wt_split_kind == 3 && ap.wt_split_bn == 256 && ap.Cout == 256 && ap.splitk <= 1 &&
+    const bool ok = ap.wt_split != nullptr && (ap.wt_split_kind == 3 || ap.wt_split_kind == 2) && ap.wt_split_bn == 256 && ap.Cout == 256 && ap.splitk <= 1 &&
                     ap.res_mode == 0 && ap.in2 == nullptr && ap.relu <= 1 && bp.in == ap.out && bp.kh == 1 && bp.kw == 1 &&
                     bp.Cin == 256 && bp.Cout == 15 && bp.out_ldc == 16 && bp.stride == 1 && bp.res_mode == 0 && bp.relu == 0 &&
                     bp.out_oy == 0 && bp.out_ox == 0 && bp.out_H == bp.Ho && bp.out_W == bp.Wo && bp.Ho == ap.Ho && bp.Wo == ap.Wo &&
@@ -280,6 +307,7 @@ int fuse_rpn_heads(odt_model* m) {
     }
     ap.head_wt = hw; ap.head_bias = hb; ap.head_out = bp.out; ap.head_ldc = bp.out_ldc;
     ap.out = nullptr;                      // nothing else reads the 256-channel tensor
+    ap.out_amax = nullptr;
     ob.skip = true;
     m->conv_fused[ob.conv] = 1;
   }

@@ -163,6 +163,13 @@ static int finish_profile(odt_model* m, hipStream_t st) {
   return 0;
 }
 
+// the |max| slots the split conv kernels of a group of ops fill (0: trunk, 1: tail) start a forward at zero
+static int clear_amax(odt_model* m, int group, hipStream_t st) {
+  if (m->amax_dev == nullptr || m->amax_used[group] == 0) return 0;
+  ODT_HIP(hipMemsetAsync(m->amax_dev + group * odt_model::kAmaxSlots, 0, (size_t)m->amax_used[group] * sizeof(unsigned), st));
+  return 0;
+}
+
 int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStream_t st) {
   const odt_config& cfg = m->cfg;
   ODT_CHECK(m->finalized, "odt_forward: call odt_finalize_weights first");
@@ -197,11 +204,13 @@ int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStre
       ODT_HIP(hipEventCreateWithFlags(&m->trunk_done, hipEventDisableTiming));
       ODT_HIP(hipEventCreateWithFlags(&m->tail_done, hipEventDisableTiming));
     }
+    if (clear_amax(m, 0, st)) return 1;
     if (run_ops(m, src, dtype, st, &ev_i, 0, m->op_first_fpn)) return 1;
     if (m->tail_pending) ODT_HIP(hipStreamWaitEvent(st, m->tail_done, 0));
     if (run_ops(m, src, dtype, st, &ev_i, m->op_first_fpn, m->op_tail)) return 1;
     ODT_HIP(hipEventRecord(m->trunk_done, st));
     ODT_HIP(hipStreamWaitEvent(m->tail_stream, m->trunk_done, 0));
+    if (clear_amax(m, 1, m->tail_stream)) return 1;
     if (run_ops(m, src, dtype, m->tail_stream, &ev_i, m->op_tail)) return 1;
     if (enqueue_small_d2h(m, m->tail_stream)) return 1;
     ODT_HIP(hipEventRecord(m->tail_done, m->tail_stream));
@@ -214,6 +223,7 @@ int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStre
     ODT_HIP(hipStreamWaitEvent(st, m->tail_done, 0));
     m->tail_pending = false;
   }
+  if (clear_amax(m, 0, st) || clear_amax(m, 1, st)) return 1;
   if (run_ops(m, src, dtype, st, &ev_i)) return 1;
   if (enqueue_small_d2h(m, st)) return 1;
   if (m->profile) return finish_profile(m, st);
@@ -573,7 +583,7 @@ int odt_profile_layer(odt_handle h, int index, char* name, int name_cap, double*
   if (name && name_cap > 0) {    // layers on the bf16x3 split kernel are tagged (bench.py / profile_layers.py group by it)
     const bool fused = index < (int)h->conv_fused.size() && h->conv_fused[index];
     const std::string nm = c.name + (fused ? "[fused into the producer's epilogue]" : (c.p.head_wt != nullptr ? "+head" : "")) +
-                           (!fused && c.p.wt_split != nullptr ? "[bf16x3]" : "");
+                           (!fused && c.p.wt_split != nullptr ? (c.p.wt_split_kind == 2 ? "[fp16x2]" : "[bf16x3]") : "");
     std::strncpy(name, nm.c_str(), name_cap - 1); name[name_cap - 1] = 0;
   }
   if (flops) *flops = (index < (int)h->conv_fused.size() && h->conv_fused[index]) ? 0.0 : conv_flops(c.p);
@@ -595,16 +605,17 @@ int odt_describe(odt_handle h, char* buf, int cap) {
   for (const auto& b : h->bufs) dev_bytes += b->bytes;
   dev_bytes += h->frames_src.bytes;
   for (const auto& sl : h->slot) dev_bytes += sl.dev_in_bytes;
-  char tmp[1024];
+  char tmp[2048];
   std::snprintf(tmp, sizeof(tmp),
                 "{\"conv_arith\": \"%s\", \"conv_launches\": %d, \"convs_fused_into_epilogues\": %d, \"exact_f32_mfma_launches\": %d, "
-                "\"bf16x3_split_launches\": %d, \"split_launches_by_family\": {\"split3_8wave_lds_dma\": %d, "
-                "\"one_stage_bk32\": %d, \"of_split3_with_split_k\": %d}, \"policy\": {\"family\": %d, \"min_tiles\": %ld, "
+                "\"bf16x3_split_launches\": %d, \"fp16x2_split_launches\": %d, \"split_launches_by_family\": {\"split3_8wave_lds_dma\": %d, "
+                "\"one_stage_bk32\": %d, \"h2_8wave_lds_dma\": %d, \"of_split3_with_split_k\": %d}, \"policy\": {\"family\": %d, \"min_tiles\": %ld, "
                 "\"min_tiles3\": %ld, \"min_k\": %d}, \"env_overrides_applied\": %d, "
                 "\"memory\": {\"device_bytes\": %zu, \"activation_arena_bytes\": [%zu, %zu], \"arena_tensors\": %zu, "
                 "\"arena_tensor_bytes_unshared\": %zu, \"dedicated_tensor_bytes\": %zu, \"keep_taps\": %d}, \"convs_cut_into_batch_ranges\": %d}",
-                h->policy.arith != 0 && fam[1] + fam[3] > 0 ? "f32 through bf16x3 split products" : "exact f32 MFMA",
-                (int)h->convs.size() - nfused, nfused, fam[0], fam[1] + fam[3], fam[3], fam[1], nsk, h->policy.family,
+                h->policy.arith != 0 && fam[2] > 0 ? "f32 through fp16x2 / bf16x3 split products"
+                    : (h->policy.arith != 0 && fam[1] + fam[3] > 0 ? "f32 through bf16x3 split products" : "exact f32 MFMA"),
+                (int)h->convs.size() - nfused, nfused, fam[0], fam[1] + fam[3], fam[2], fam[3], fam[1], fam[2], nsk, h->policy.family,
                 h->policy.min_tiles, h->policy.min_tiles3, h->policy.min_k, h->policy.env_overrides,
                 dev_bytes, h->arena_bytes[0], h->arena_bytes[1], h->vt.size(), h->virtual_tensor_bytes,
                 h->dedicated_tensor_bytes, h->cfg.keep_taps, h->chunked_convs);

@@ -270,6 +270,51 @@ inline unsigned hipemu_bf16_rne(float f) {
   return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 #define ODT_CVT_PK_BF16(a0, a1) (hipemu_bf16_rne(a0) | (hipemu_bf16_rne(a1) << 16))
+// v_mfma_f32_32x32x16_f16: the bf16 form's layout with IEEE half operands (subnormals at full precision, as gfx950
+// does: tools/experiments/mfma_f16_denorm_probe.hip); f16 x f16 products are exact in f32.
+typedef short hipemu_f16x8 __attribute__((vector_size(16)));
+inline float hipemu_f16_to_f32(unsigned short h) {
+  const unsigned s = (unsigned)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+  float f;
+  if (e == 0) { f = (float)m * 5.9604644775390625e-08f; return s ? -f : f; }      // m * 2^-24
+  const unsigned u = e == 31 ? (s | 0x7f800000u | (m << 13)) : (s | ((e + 112u) << 23) | (m << 13));
+  memcpy(&f, &u, 4);
+  return f;
+}
+inline unsigned hipemu_f16_rne(float f) {      // v_cvt_f16_f32: round to nearest even, subnormals kept, >= 65520 -> inf
+  unsigned u; memcpy(&u, &f, 4);
+  const unsigned sign = (u >> 16) & 0x8000u;
+  u &= 0x7fffffffu;
+  if (u > 0x7f800000u) return sign | 0x7e00u;
+  if (u >= 0x477ff000u) return sign | 0x7c00u;
+  if (u < 0x38800000u) {                         // below 2^-14: a multiple of 2^-24
+    float a; memcpy(&a, &u, 4);
+    return sign | (unsigned)nearbyint((double)a * 16777216.0);
+  }
+  const unsigned v = u + 0xfffu + ((u >> 13) & 1u);
+  return sign | ((v - 0x38000000u) >> 13);
+}
+inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16(hipemu_f16x8 a, hipemu_f16x8 b, hipemu_f32x16 c,
+                                                            int, int, int) {
+  int s = hipemu::wave_sync_begin();
+  hipemu::WaveX& x = hipemu::wavex();
+  int l = hipemu::lane_id();
+  for (int e = 0; e < 8; ++e) { x.wa[s][l][e] = (unsigned short)a[e]; x.wb[s][l][e] = (unsigned short)b[e]; }
+  hipemu::wave_sync_end();
+  int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    double acc = c[r];
+    for (int g = 0; g < 2; ++g)
+      for (int e = 0; e < 8; ++e)
+        acc += (double)hipemu_f16_to_f32(x.wa[s][row + 32 * g][e]) * (double)hipemu_f16_to_f32(x.wb[s][col + 32 * g][e]);
+    c[r] = (float)acc;
+  }
+  return c;
+}
+#define ODT_CVT_PK_F16(a0, a1) (hipemu_f16_rne(a0) | (hipemu_f16_rne(a1) << 16))
+#define ODT_F16_LO_F32(u) hipemu_f16_to_f32((unsigned short)((u) & 0xffffu))
+#define ODT_F16_HI_F32(u) hipemu_f16_to_f32((unsigned short)((u) >> 16))
 // v_perm_b32: byte select from {s0 (bytes 4..7), s1 (bytes 0..3)}; selectors 0..7 only
 inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned sel) {
   const unsigned long long v = ((unsigned long long)s0 << 32) | s1;

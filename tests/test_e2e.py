@@ -386,6 +386,42 @@ def test_rpn_head_fused_into_conv_epilogue(backend, monkeypatch):
 
 
 
+def test_fp16x2_family_agrees_with_bf16x3(backend, monkeypatch):
+  """conv_split_family = 2: the layers with 256-row tiles at least 128 columns wide and a recorded input range run on the
+  fp16x2 kernels (conv_h2.hip: three exact f16 products per MAC, operands scaled by the |max| the producing kernel recorded),
+  the rest stays on bf16x3.  Stage tensors agree with the bf16x3 handle at f32 rounding level, detections as matched sets;
+  the fp16x2 handle is also checked against the oracle."""
+  name, lib = backend
+  monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1"); monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "1")
+  monkeypatch.setenv("ODT_CONV_SPLIT3_BM", "256")
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1] if name == "emu" else [1, 1, 2, 3])
+  w = weights_for(cfg)
+  H, W = (64, 96) if name == "emu" else (160, 224)
+  fr = synthetic_frames(1, H, W, seed=5)
+  out = {}
+  for fam in (3, 2):
+    c = _with_taps(cfg); c.conv_split_family = fam
+    m = models.get_model(c, 0, weights=w, lib=lib)
+    try:
+      boxes, labels, probs, feats = m.predict(fr[0])
+      e = m.engine(1, H, W)
+      out[fam] = (boxes, labels, probs, {k: e.tap(k) for k in ("c2", "c3", "c4", "c5", "p2", "p5", "rpn2", "rpn4")}, e.describe())
+      if fam == 2:          # a second frame through the same handle: the range slots start every forward at zero
+        b2, l2, p2, _ = m.predict(fr[0])
+        assert np.array_equal(b2, boxes) and np.array_equal(p2, probs)
+    finally:
+      m.close()
+  assert out[3][4]["fp16x2_split_launches"] == 0 and out[2][4]["fp16x2_split_launches"] >= 10, out[2][4]
+  for k, t in out[3][3].items():
+    assert _rel(out[2][3][k], t) < 2e-5, k
+  miss, extra = match_detections(out[2][0], out[2][1], out[2][2], out[3][0], out[3][1], out[3][2], 1e-3, 1e-4)
+  assert miss + extra <= 2, (miss, extra)
+  if name == "hip":
+    c = small_config(resnet_num_block=[1, 1, 2, 3]); c.conv_split_family = 2
+    miss, extra = _run_single(lib, c, H, W)
+    assert miss == 0 and extra == 0
+
+
 def test_convs_cut_into_batch_ranges_are_bit_identical(backend, monkeypatch):
   """A conv whose tensors would reach 2 GiB (32-bit buffer offsets; b = 16 @1080p) runs as several launches over batch
   ranges.  With the limit lowered (test knob) a small batched plan takes that path for most layers: same bits out."""

@@ -511,7 +511,9 @@ SPLIT_CASES = [
 # stages, three-stage ring; the default) with 256- / 128-row tiles; "1": the one-stage BK = 32 loop (the 64-wide layers)
 # "3/128/k3": the same with the reduction cut into three split-K ranges + split_reduce_kernel
 # "3/256/nokwr": 256-row tiles with the kw-reuse kernel (conv_split3k_kernel, the default for stride-1 KH x 3 convs) off
-SPLIT_PIPES = ["3/256", "3/256/nokwr", "3/128", "3/128/k3", "1"]
+# "2/256...": the fp16x2 kernels (conv_h2.hip: conv_h2k_kernel for the stride-1 KH x 3 convs, conv_h2_kernel otherwise; the
+# stand-alone call records the input's |max| itself) where a case has an n-tile of 128 / 256 -- bf16x3 kernels elsewhere
+SPLIT_PIPES = ["3/256", "3/256/nokwr", "3/128", "3/128/k3", "1", "2/256", "2/256/nokwr", "2/256/k3"]
 
 
 def _split_env(monkeypatch, pipe="3/256"):
@@ -540,7 +542,7 @@ def test_conv2d_split(backend, case, pipe, monkeypatch):
   _run_conv(lib, case, np.random.default_rng(11))
 
 
-@pytest.mark.parametrize("pipe", ["3/256", "1"])
+@pytest.mark.parametrize("pipe", ["3/256", "1", "2/256"])
 def test_conv2d_split_matches_f32_kernel_at_f32_rounding(backend, pipe, monkeypatch):
   """The split result must sit as close to the f64 truth as the exact-f32 MFMA kernel does
   (error of an f32 dot product, not of a bf16 one), incl. operands spanning many binades."""
@@ -569,6 +571,30 @@ def test_conv2d_split_matches_f32_kernel_at_f32_rounding(backend, pipe, monkeypa
   # would be at ~4e-3.
   assert esp <= 1.5 * e32 + 1.2e-7, (esp, e32)
   assert esp < 4e-6, esp
+
+
+def test_conv2d_fp16x2_dynamic_range(backend, monkeypatch):
+  """fp16x2 pieces scale the A operand by ONE power of two per tensor (from its |max|): rows down to 2^-15 of the tensor
+  maximum keep the f32-rounding-level error of the other kernels; below that the lo piece runs into the f16 subnormal grid
+  and the error is bounded in ABSOLUTE terms by 2^-39 max|A| per unit weight -- the bound DESIGN.md states."""
+  name, lib = backend
+  _split_env(monkeypatch, "2/256")
+  rng = np.random.default_rng(21)
+  K, N, G = 256, 256, 8
+  x = np.maximum(rng.standard_normal((1, G, 40, K)), 0).astype(F) + F(0.01)
+  for g in range(G):
+    x[0, g] *= F(2.0 ** (-5 * g))
+  w = (rng.standard_normal((1, 1, K, N)) * np.sqrt(2.0 / K)).astype(F)
+  b = np.zeros(N, F)
+  y = ops.conv2d(x, w, b, 1, 1, 0, 0, (G, 40), lib=lib)
+  ref = x.astype(np.float64) @ w[0, 0].astype(np.float64)
+  mag = np.abs(x.astype(np.float64)) @ np.abs(w[0, 0].astype(np.float64))
+  wsum = np.abs(w[0, 0].astype(np.float64)).sum(axis=0)
+  amax = float(np.abs(x).max())
+  err = np.abs(y - ref)
+  assert np.all(err <= 4e-7 * mag + 2.0 ** -38 * amax * wsum)
+  for g in range(4):                    # rows within 2^-15 of the maximum: the f32-level bound alone
+    assert np.max(err[0, g] / mag[0, g]) < 4e-7, g
 
 
 @pytest.mark.parametrize("pipe", SPLIT_PIPES)
