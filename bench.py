@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+H2_PRODUCTS = 3                 # f16 MFMA products per f32 MAC in the fp16x2 kernels (csrc/conv_h2.hip)
 SPLIT_PRODUCTS = 6              # bf16 MFMA products per f32 MAC in the conv_split kernels (csrc/conv_split3.hip, conv_split1.hip)
 
 
@@ -172,13 +173,17 @@ def main():
   # the two kernel families of the conv launches: conv_split_kernel (bf16x3 split: six exact bf16
   # MFMA products per f32 MAC) and conv_igemm_kernel (exact-f32 MFMA)
   nprof = max(1, args.profile_steps)
-  fam = {"split": [0, 0.0, 0.0], "f32": [0, 0.0, 0.0]}           # launches, flops (per step), ms (sum)
+  fam = {"h2": [0, 0.0, 0.0], "b3": [0, 0.0, 0.0], "f32": [0, 0.0, 0.0]}           # launches, flops (per step), ms (sum)
   for name, fl, ms, _ in layers:
-    f = fam["split" if name.endswith("[bf16x3]") else "f32"]
+    f = fam["h2" if name.endswith("[fp16x2]") else ("b3" if name.endswith("[bf16x3]") else "f32")]
     f[0] += 1; f[1] += fl; f[2] += ms
+  # the split kernels as one family: fp16x2 (three f16 MFMA products per f32 MAC) + bf16x3 (six bf16 products)
+  fam["split"] = [fam["h2"][0] + fam["b3"][0], fam["h2"][1] + fam["b3"][1], fam["h2"][2] + fam["b3"][2]]
   def tf(f):
     return f[1] * nprof / (f[2] * 1e-3) / 1e12 if f[2] > 0 else 0.0
   split_tf, f32_tf = tf(fam["split"]), tf(fam["f32"])
+  # matrix-pipe products the split launches execute per algorithmic f32 MAC (FLOP-weighted over the two kinds)
+  split_products = ((H2_PRODUCTS * fam["h2"][1] + SPLIT_PRODUCTS * fam["b3"][1]) / fam["split"][1]) if fam["split"][1] > 0 else SPLIT_PRODUCTS
 
   sustained = None
   if rank == 0:
@@ -227,6 +232,23 @@ def main():
         eng.synchronize(); e2.synchronize()
         extra["two_streams_per_gpu_fps"] = 2 * 6 * B / (time.perf_counter() - t1)
         m2.close()
+        # (d0) the same step with conv_split_family = 3: every split layer on the bf16x3 kernels (six products per MAC),
+        # the round-2 arithmetic -- the fp16x2 kernels' gain, same process, same box
+        try:
+          cfg4 = make_config(rpn_test_post_nms_topk=args.topk, im_batch_size=B, max_size=max(H, W),
+                             short_edge_size=min(H, W), conv_split_family=3)
+          m4 = models.get_model(cfg4, local_rank, weights=weights, is_multi=multi)
+          e4 = m4.engine(B, H, W)
+          for k in range(2 + 8):
+            if k == 2:
+              e4.synchronize(); t1 = time.perf_counter()
+            e4.forward_device_async(dev_frames.data_ptr(), ODT_DTYPE_U8)
+          e4.synchronize()
+          extra["bf16x3_only_fps"] = 8 * B / (time.perf_counter() - t1)
+          extra["bf16x3_only_handle"] = {k: e4.describe()[k] for k in ("conv_arith", "bf16x3_split_launches", "fp16x2_split_launches")}
+          m4.close()
+        except Exception as ex:     # never fatal: `value` above is already measured
+          extra["bf16x3_only_fps"] = "failed: %r" % (ex,)
         # (d) the same step with every conv on the exact-f32 MFMA kernel (config conv_arith = "f32"): the
         # other arithmetic mode of the library, measured in the same process on the same box
         try:
@@ -305,17 +327,26 @@ def main():
       # dominant kernel (most of the FLOPs): the split kernel.  `achieved` is ALGORITHMIC f32
       # FLOP/s; every f32 MAC costs six bf16 MFMA MACs, so the matrix-pipe ceiling for it is the
       # dense bf16 peak / 6 (executed bf16 rate and its fraction of the bf16 peak given beside it).
-      peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
+      peak = BF16_MFMA_PEAK_TFLOPS / split_products
       roofline = {
           "bound": "mfma",
-          "kernel": "conv_split_kernel (f32 through 6 exact v_mfma_f32_32x32x16_bf16 products per MAC, "
-                    "%d launches/step, %.0f%% of the conv FLOPs)" %
-                    (fam["split"][0], 100.0 * fam["split"][1] / max(1.0, fam["split"][1] + fam["f32"][1])),
+          "kernel": "split conv kernels: f32 through exact 16-bit MFMA products -- conv_h2 kernels (3 x v_mfma_f32_32x32x16_f16 "
+                    "per MAC, %d launches/step, %.0f%% of the conv FLOPs) + conv_split kernels (6 x v_mfma_f32_32x32x16_bf16 "
+                    "per MAC, %d launches/step, %.0f%%)" %
+                    (fam["h2"][0], 100.0 * fam["h2"][1] / max(1.0, fam["split"][1] + fam["f32"][1]),
+                     fam["b3"][0], 100.0 * fam["b3"][1] / max(1.0, fam["split"][1] + fam["f32"][1])),
           "achieved": split_tf, "peak": peak, "unit": "TFLOP/s", "frac": split_tf / peak,
-          "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 6 products per f32 MAC",
-          "executed_bf16_tflops": split_tf * SPLIT_PRODUCTS,
+          "peak_note": "dense 16-bit MFMA peak 2500 TFLOP/s / %.3f products per f32 MAC (FLOP-weighted: 3 on the fp16x2 "
+                       "launches, 6 on the bf16x3 ones); frac = executed 16-bit MFMA rate / 2500" % split_products,
+          "products_per_mac": split_products,
+          "executed_bf16_tflops": split_tf * split_products,
           "vs_f32_mfma_peak": split_tf / F32_MFMA_PEAK_TFLOPS,
           "ms_per_step": fam["split"][2] / nprof,
+          "by_kind": {
+              "fp16x2": {"launches": fam["h2"][0], "achieved": tf(fam["h2"]), "ms_per_step": fam["h2"][2] / nprof,
+                         "frac": tf(fam["h2"]) * H2_PRODUCTS / BF16_MFMA_PEAK_TFLOPS},
+              "bf16x3": {"launches": fam["b3"][0], "achieved": tf(fam["b3"]), "ms_per_step": fam["b3"][2] / nprof,
+                         "frac": tf(fam["b3"]) * SPLIT_PRODUCTS / BF16_MFMA_PEAK_TFLOPS}},
           "traffic": pmc_traffic("split") if (B, H, W) == (8, 1080, 1920) else None,
           "f32_mfma_family": f32_family,
       }
@@ -327,7 +358,7 @@ def main():
       # what the bf16 matrix pipe of THIS box sustains on the split kernels' own MFMA mix (random operands, >= 300 ms
       # of back-to-back launches, measured a moment ago in this process): the ceiling under the box's power budget
       roofline["sustained_peak"] = sustained
-      roofline["frac_of_sustained"] = split_tf / (sustained["bf16_tflops"] / SPLIT_PRODUCTS)
+      roofline["frac_of_sustained"] = split_tf * split_products / sustained["bf16_tflops"]
     out = {
         "metric": "detector FPS @%dx%d b=%d per MI355X" % (W, H, B),
         "value": fps,

@@ -71,7 +71,9 @@ typedef struct odt_config {
   int32_t eff_topk;         /* efficientdet_max_detection_topk (5000)         */
   float eff_image_scale;    /* image_scale_to_original applied to the output boxes (wrapper :57) */
   int32_t conv_arith;       /* ODT_ARITH_*: how the conv / FC products are evaluated (fixed per handle, see odt_describe) */
-  int32_t conv_split_family;/* 0 library default (3); 1: one-stage bf16x3 kernel only; 3: conv_split3 kernels where they fit (A/B runs) */
+  int32_t conv_split_family;/* 0 library default (2); 1: one-stage bf16x3 kernel only; 3: + the 8-wave bf16x3 kernels where they fit;
+                               2: + the fp16x2 kernels (three f16 products per MAC) for layers with 256-row tiles whose input range
+                               the producing kernel recorded (A/B runs) */
   int32_t keep_taps;        /* 0 (production): activations live in a liveness-planned arena -- a stage tensor's memory is
                              * reused as soon as its last consumer has run, and odt_tap can only read the tensors that
                              * outlive the forward (outputs, proposals, zero-bordered buffers); 1 (debug / parity runs):
@@ -80,10 +82,12 @@ typedef struct odt_config {
 } odt_config;
 
 /* conv_arith: all modes keep f32 tensors and f32 accumulation.  ODT_ARITH_F32: every product on the exact-f32 MFMA
- * (v_mfma_f32_32x32x2_f32); ODT_ARITH_BF16X3: layers large enough to fill the chip evaluate each f32 product as six
- * exact bf16 x bf16 MFMA products of a 3-way bf16 split of both operands (error at the f32 kernel's level; csrc/
- * conv_split.hip); ODT_ARITH_DEFAULT = BF16X3.  The ODT_CONV_* environment variables are debug overrides, read once
- * when the handle is created and reported by odt_describe. */
+ * (v_mfma_f32_32x32x2_f32); ODT_ARITH_BF16X3 ("split"): layers large enough to fill the chip evaluate each f32 product
+ * through exact low-precision MFMA products of split operands -- six bf16 x bf16 products of a 3-way bf16 split (csrc/
+ * conv_split3.hip), or, conv_split_family = 2, three f16 x f16 products of a 2-way f16 split of operands scaled by the
+ * tensor's recorded maximum (csrc/conv_h2.hip) -- with the error of an f32 dot product either way (bounds in csrc/
+ * conv_split_common.hpp, asserted in tests/test_ops.py); ODT_ARITH_DEFAULT = the split mode.  The ODT_CONV_* environment
+ * variables are debug overrides, read once when the handle is created and reported by odt_describe. */
 #define ODT_ARITH_DEFAULT 0
 #define ODT_ARITH_F32 1
 #define ODT_ARITH_BF16X3 2

@@ -62,6 +62,8 @@ def make_config(**overrides):
   c.nn_budget = 5
   c.tracking_objs = "Person,Vehicle"
   c.frame_gap = 8
+  c.conv_arith = None             # None / "default": split arithmetic where it pays | "f32": exact-f32 MFMA everywhere | "bf16x3"
+  c.conv_split_family = 0         # 0 library default (2: fp16x2 kernels where eligible, bf16x3 elsewhere) | 3: bf16x3 only | 1
   c.keep_taps = False             # True: dedicated buffers for every stage tensor (engine.tap() of backbone stages; ~5x the activation memory)
   for k, v in overrides.items():
     setattr(c, k, v)

@@ -89,7 +89,8 @@ bool conv_split_supported(const ConvParams& p) {
 ConvPolicy conv_policy_default() {
   ConvPolicy q;
   q.arith = 1;            // bf16x3 split where it pays (same-box A/B at b=8 1080p: 116 -> 178 FPS, parity suite green)
-  q.family = 3;           // conv_split3_kernel where its tiles fill the chip
+  q.family = 2;           // fp16x2 kernels where a layer has 256-row tiles and a recorded input range (same-box A/B at b=8
+                          // 1080p: 188 -> 259 FPS, profiles/r03_fp16x2_vs_bf16x3_ab.txt), conv_split3_kernel where its tiles fill the chip
   q.min_tiles = 256;      // one- / two-stage kernels: A/B at b=8 and b=1: 256 > 384 > 128 >> 64
   q.min_tiles3 = 200;
   q.min_k = 64;           // A/B at b=8: K >= 256: 155.0, >= 128: 156.2, >= 64: 156.6 FPS

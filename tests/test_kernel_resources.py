@@ -35,8 +35,9 @@ def _resources(src):
 def test_hot_kernels_use_no_scratch_memory():
   res = dict(_resources("conv_split3.hip"))
   res.update(_resources("conv_split1.hip"))
-  hot = {k: v for k, v in res.items() if "conv_split3" in k or "conv_split_kernelILi4ELi1ELi2E" in k}      # (the 256 x 64 one-stage tile is the one the plans use)
-  assert len(hot) >= 12, sorted(res)
+  res.update(_resources("conv_h2.hip"))
+  hot = {k: v for k, v in res.items() if "conv_split3" in k or "conv_split_kernelILi4ELi1ELi2E" in k or "conv_h2" in k}      # (the 256 x 64 one-stage tile is the one the plans use)
+  assert len(hot) >= 18, sorted(res)
   for k, v in hot.items():
     assert v.get("scratch", 0) == 0, (k, v)
     assert v.get("occupancy", 0) >= 2, (k, v)          # two waves per SIMD: one 8-wave workgroup per CU (or two 4-wave ones)

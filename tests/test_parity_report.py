@@ -114,7 +114,7 @@ def _measure(lib, cfg, B, H, W, ref, multi):
     rec["detections"] = {"count": ndet, "unmatched_ours": miss, "unmatched_oracle": extra, "max_box_diff_px": dbox,
                          "max_box_diff_rel_to_side": dbox / side, "max_prob_diff": dprob, "labels_equal_in_order": lab_eq}
     rec["box_tolerance_px"] = tol_box
-    rec["split_conv_launches"] = sum(1 for nm, _, _, _ in e.profile_layers() if nm.endswith("[bf16x3]"))
+    rec["split_conv_launches"] = sum(1 for nm, _, _, _ in e.profile_layers() if nm.endswith("[bf16x3]") or nm.endswith("[fp16x2]"))
     if rec["detections"]["unmatched_ours"] + rec["detections"]["unmatched_oracle"] == 0 and lab_eq:
       rec["fpn_box_feat_max_rel_err"] = _rel(feats, ref["fpn_box_feat"])
     return rec

@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 3: fp16x2 kernels (conv_h2.hip) -- parity on the GPU, per-layer profile and same-box A/B against bf16x3
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_ops.py tests/test_e2e.py -q -m gpu -x -k "(split and 2/256) or fp16x2 or matches_f32_kernel" 2>&1 | tail -6 | tee gpurun_out/r3_h2_1_pytest.log
+for fam in 2 3; do
+  ODT_CONV_SPLIT_PIPE=$fam timeout 300 python tools/profile_layers.py --batch 8 --steps 3 2>&1 | tail -45 > gpurun_out/r3_h2_1_layers_fam$fam.txt
+  tail -1 gpurun_out/r3_h2_1_layers_fam$fam.txt
+done
+q() { timeout 300 python bench.py --steps 20 --warmup 3 --no-extras --no-cpu-baseline "$@" 2>>gpurun_out/r3_h2_1_err.log | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); r = d['roofline']
+print('%-10s fps %.2f  ms/step %.3f  conv_ms %.3f verified %s fp16x2 launches %s crc %s' % (sys.argv[1], d['value'], d['ms_per_step'], r['conv_ms_per_step'], d['verified'], d['handle'].get('fp16x2_split_launches'), d['verification']['streams'][0]['checksum_crc32']))" "$TAG"; }
+for rep in 1 2; do
+  TAG="family=2" ODT_CONV_SPLIT_PIPE=2 q | tee -a gpurun_out/r3_h2_1_ab.txt
+  TAG="family=3" ODT_CONV_SPLIT_PIPE=3 q | tee -a gpurun_out/r3_h2_1_ab.txt
+done

@@ -1,14 +1,14 @@
 #!/usr/bin/env python
 """Per-layer roofline table from a tools/profile_layers.py table (profiles/r01_conv_layers_*.txt).
 
-For every conv shape: the measured time next to the two ceilings -- matrix pipe (dense bf16 MFMA peak / 6
-products for the split kernel's layers, f32 MFMA peak for the exact-f32 kernel's) and HBM (algorithmic
+For every conv shape: the measured time next to the two ceilings -- matrix pipe (dense 16-bit MFMA peak / 6
+products for the bf16x3 kernels' layers, / 3 for the fp16x2 kernels', f32 MFMA peak for the exact-f32 kernel's) and HBM (algorithmic
 bytes: input + output activations once, weights once, residual once; 8 TB/s) -- and which one binds.
   python tools/roofline_table.py profiles/r01_conv_layers_b8_v11.txt
 """
 import sys
 
-F32_PEAK, SPLIT_PEAK, HBM = 157.3e12, 2500e12 / 6, 8.0e12
+F32_PEAK, SPLIT_PEAK, H2_PEAK, HBM = 157.3e12, 2500e12 / 6, 2500e12 / 3, 8.0e12
 
 
 def main(path):
@@ -22,8 +22,8 @@ def main(path):
         ("layer (first of its shape)", "n", "M", "N", "K", "ms", "TF", "mfma ms", "hbm ms", "bound", "frac"))
   tot = [0.0, 0.0]
   for name, n, M, N, K, ms, tf in sorted(rows, key=lambda r: -r[5]):
-    split = name.endswith("[bf16x3]")
-    base = name.replace("[bf16x3]", "")
+    split, h2 = name.endswith("[bf16x3]"), name.endswith("[fp16x2]")
+    base = name.replace("[bf16x3]", "").replace("[fp16x2]", "")
     k3 = base.endswith("conv2") or "posthoc_3x3" in base or base.startswith("rpn/conv0")
     cin_bytes = M * (K // 9 if k3 else K) * 4.0            # every input pixel once (stride-1 3x3: K/9 channels)
     if base == "conv0":
@@ -31,7 +31,7 @@ def main(path):
     byt = cin_bytes + M * N * 4.0 + N * K * 4.0
     if "conv3" in base or "lateral" in base:
       byt += M * N * 4.0 * (0.25 if "lateral" in base else 1.0)   # residual (2x-upsampled: a quarter)
-    t_m = n * 2.0 * M * N * K / (SPLIT_PEAK if split else F32_PEAK) * 1e3
+    t_m = n * 2.0 * M * N * K / (H2_PEAK if h2 else (SPLIT_PEAK if split else F32_PEAK)) * 1e3
     t_h = n * byt / HBM * 1e3
     bound = max(t_m, t_h)
     tot[0] += ms; tot[1] += bound
