@@ -27,24 +27,28 @@ namespace {
 #define ODT_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #endif
 
-template <int TN>
+template <int TN, int WM>
 struct H2Cfg {
-  static constexpr int BM = 256, BN = 64 * TN;
+  static constexpr int BM = 64 * WM, BN = 64 * TN;
+  static constexpr int NWV = 2 * WM, NTHR = 64 * NWV;                       // waves (WM x 2), threads
   static constexpr int AKG = BM * 16 + 64, APL = 4 * AKG, ASTG = 2 * APL;   // A stage: [piece 2][k-group 4][row][8 f16], 64-B pad per k-group
   static constexpr int BKG = BN * 16, BPL = 4 * BKG, STAGE_B = 2 * BPL;     // B stage: the linear image the DMA writes
   static constexpr int BOFF = 2 * ASTG;
   static constexpr int RING = BOFF + 2 * STAGE_B;
   static constexpr int CTILE = 128 * (BN + 4) * 4;                          // two 128-row epilogue passes
   static constexpr int LDS = RING > CTILE ? RING : CTILE;
-  static constexpr int NW = STAGE_B / 1024 / 8;                             // DMA instructions per wave and stage
-  static constexpr int RA = 4;                                              // A rows (16-byte loads) per thread and stage
-  static_assert(LDS <= 160 * 1024 && STAGE_B % 8192 == 0, "LDS ring");
+  static constexpr int NW = STAGE_B / 1024 / NWV;                           // DMA instructions per wave and stage
+  static constexpr int RA = 4;                                              // A rows (16-byte loads) per thread and stage: BM / (NTHR / 8)
+  static_assert(LDS <= 160 * 1024 && STAGE_B % (1024 * NWV) == 0, "LDS ring");
 };
 
-template <int TN, bool TRACE = false>
-__global__ void __launch_bounds__(512, 2) conv_h2_kernel(const ConvParams* __restrict__ pp) {
-  using G = H2Cfg<TN>;
-  constexpr int WM = 4, WN = 2;
+// <TN, WM>: <4, 4> 256 x 256, <2, 4> 256 x 128 (8 waves, one workgroup per CU); <2, 2> 128 x 128 with 4 waves and 66 KB of LDS --
+// TWO workgroups per CU, each in its own phase: for the layers whose tiles spend as long in the prologue and the epilogue
+// (HBM) as in the reduction (MFMA) -- the short 1x1 reductions -- and for the layers with too few 256-row tiles
+template <int TN, int WM, bool TRACE = false>
+__global__ void __launch_bounds__(128 * WM, 2) conv_h2_kernel(const ConvParams* __restrict__ pp) {
+  using G = H2Cfg<TN, WM>;
+  constexpr int WN = 2, NWV = G::NWV, AR = G::NTHR / 8;
   constexpr int BM = G::BM, BN = G::BN, AKG = G::AKG, APL = G::APL, ASTG = G::ASTG, BKG = G::BKG, BPL = G::BPL;
   constexpr int STAGE_B = G::STAGE_B, BOFF = G::BOFF, NW = G::NW, RA = G::RA;
   const ConvParams p = *pp;
@@ -98,16 +102,23 @@ __global__ void __launch_bounds__(512, 2) conv_h2_kernel(const ConvParams* __res
       (void*)p.wt_split, 0, (int)((unsigned)ntn * nsteps_all * (unsigned)STAGE_B), 0x00020000);
 
   // ---- weights: wave w, instruction i copies the 1-KB piece i * 8 + w of the stage image
-  unsigned l_b = ((unsigned)nt * (unsigned)nsteps_all + (unsigned)s_begin) * (unsigned)STAGE_B;
+  // K-slice rotation (single-source 1x1 convs without split-K): workgroup (mt, .) starts its reduction at slice mt mod
+  // nsteps and wraps.  All workgroups of such a launch start together and walk the channels at the same pace: without
+  // the rotation every request in flight addresses the SAME 128-byte column of the pixels' 4-KB (1-KB ...) rows -- the same
+  // few HBM channels (res4 conv1 streamed its input at 2 TB/s).  The summation order of a tile depends on mt.
+  const int rot = (ntaps == 1 && cpt2 == 0 && splitk == 1 && (p.debug & 0x100) == 0) ? mt % nsteps : 0;
+  unsigned l_b = ((unsigned)nt * (unsigned)nsteps_all + (unsigned)(s_begin + rot)) * (unsigned)STAGE_B;
+  int b_wrap = nsteps - rot;                 // stages until the weight stream wraps to the first slice
   auto dma_b = [&](int boff) {
 #pragma unroll
     for (int i = 0; i < NW; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, ODT_LDS_PTR(lds + boff + (i * 8 + wave) * 1024), 16,
-                                               lane * 16 + (i * 8 + wave) * 1024, (int)l_b, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, ODT_LDS_PTR(lds + boff + (i * NWV + wave) * 1024), 16,
+                                               lane * 16 + (i * NWV + wave) * 1024, (int)l_b, 0, 0);
     l_b += (unsigned)STAGE_B;
+    if (--b_wrap == 0) l_b -= (unsigned)nsteps * (unsigned)STAGE_B;
   };
 
-  // ---- activations: thread -> (row (t >> 3) + 64 j, 16-byte column t & 7): eight lanes cover the 128 contiguous
+  // ---- activations: thread -> (row (t >> 3) + (threads / 8) j, 16-byte column t & 7): eight lanes cover the 128 contiguous
   // bytes (32 channels) of a row's stage.  Per row: the byte offset of the tap-(0,0) input pixel and a bit per tap
   // (inside the image and m < M); a stage's offset is base + tap offset, or out of range (the load returns zeros).
   const int a_c = tid & 7, a_r = tid >> 3;
@@ -118,7 +129,7 @@ __global__ void __launch_bounds__(512, 2) conv_h2_kernel(const ConvParams* __res
                         p.H == p.in_Ha && p.W == p.in_Wa && p.Ho == p.H && p.Wo == p.W;
 #pragma unroll
   for (int j = 0; j < RA; ++j) {
-    const int m = m0 + a_r + 64 * j;
+    const int m = m0 + a_r + AR * j;
     const bool ok = m < M;
     if (dense_in) {
       a_base[j] = (int)((unsigned)m * pix_bytes + a_c * 16u);
@@ -140,7 +151,7 @@ __global__ void __launch_bounds__(512, 2) conv_h2_kernel(const ConvParams* __res
   }
   // load stream position: (32-channel slice, tap) with the tap innermost; then the second source's slices
   // (a split-K range starts inside the first source: the policy keeps split-K off for second-source convs)
-  int l_cs = s_begin / ntaps, l_tap = s_begin - l_cs * ntaps;
+  int l_cs = s_begin / ntaps + rot, l_tap = s_begin - (s_begin / ntaps) * ntaps;
   int l_kh = l_tap / p.kw, l_kw = l_tap - l_kh * p.kw;
   bool l_src2 = false;
   unsigned a_row[RA];
@@ -152,7 +163,7 @@ __global__ void __launch_bounds__(512, 2) conv_h2_kernel(const ConvParams* __res
   auto set_src2 = [&]() {
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
-      const int m = m0 + a_r + 64 * j;
+      const int m = m0 + a_r + AR * j;
       const bool ok = m < M;
       const int mm = ok ? m : 0;
       const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), r = mm - n * HoWo;
@@ -171,7 +182,10 @@ __global__ void __launch_bounds__(512, 2) conv_h2_kernel(const ConvParams* __res
     if (l_src2) {
       ++l_cs;
     } else if (ntaps == 1) {
-      if (++l_cs == cpt && cpt2 > 0) { l_cs = 0; l_src2 = true; set_src2(); }
+      if (++l_cs == cpt) {
+        l_cs = 0;                              // (second source: its first slice; rotation: wrap to the first slice)
+        if (cpt2 > 0) { l_src2 = true; set_src2(); }
+      }
     } else {
       ++l_tap;
       if (++l_kw == p.kw) { l_kw = 0; ++l_kh; }
@@ -183,7 +197,7 @@ __global__ void __launch_bounds__(512, 2) conv_h2_kernel(const ConvParams* __res
     unsigned h0, l0, h1, l1;
     split2h(ga[j][0], ga[j][1], a_scale, h0, l0);
     split2h(ga[j][2], ga[j][3], a_scale, h1, l1);
-    unsigned char* d = lds + abuf + (a_c >> 1) * AKG + (a_r + 64 * j) * 16 + (a_c & 1) * 8;
+    unsigned char* d = lds + abuf + (a_c >> 1) * AKG + (a_r + AR * j) * 16 + (a_c & 1) * 8;
     *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
     *reinterpret_cast<u32x2*>(d + APL) = u32x2{l0, l1};
   };
@@ -289,283 +303,7 @@ __global__ void __launch_bounds__(512, 2) conv_h2_kernel(const ConvParams* __res
     step(std::false_type{}, std::false_type{});
   }
   stamp(2);
-  split3_epilogue<WM, WN, TN, G::LDS, TRACE>(p, acc, lds, m0, n0, M, HoWo, ks, splitk, tid, wm, wn, fr, fg, h2_inv);
-  stamp(5);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// conv_h2d_kernel: conv_h2_kernel with the ACTIVATIONS on the LDS-DMA path too (the 1x1 layers: every stage's A tile is
-// fresh HBM data, and one stage of register prefetch -- 32 KB in flight per CU -- left the loop waiting for it:
-// profiles/r03_conv_layers_b8_fp16x2_first.txt, res4 conv1 at 248 TF against 415 on the 3x3 layers):
-//   * A: the raw f32 rows go global -> LDS by LDS-DMA into a ring of THREE stages, two stages ahead (64 KB in flight per
-//     CU, no prefetch registers, no ds_write); out-of-image taps / rows past M use an out-of-range offset (the DMA writes
-//     zeros).  LDS slot of (row, 16-byte chunk c): 8 row + (c ^ ((row >> 1) & 7)) -- a lane group of a ds_read_b128
-//     (16 consecutive rows, same chunk) touches every bank once;
-//   * fragments: a lane reads its row's 8 k-values of a k-step (2 x ds_read_b128 of f32), scales and splits them in
-//     registers (hi / lo f16x8) one k-step ahead of the MFMAs -- both wn-waves of a row block split it (twice the VALU work
-//     of the shared LDS planes, no LDS stores, no A-store -> barrier dependence);
-//   * B: as conv_h2_kernel (two-deep DMA ring).  LDS = 3 x 32 KB + 2 x 32 KB = 160 KB for the 256-wide tile.
-template <int TN>
-struct H2dCfg {
-  static constexpr int BM = 256, BN = 64 * TN;
-  static constexpr int ASTG = BM * 128;                                     // raw f32 A stage: [row][32 channels], chunks swizzled
-  static constexpr int NA = 3;                                              // A ring depth
-  static constexpr int BKG = BN * 16, BPL = 4 * BKG, STAGE_B = 2 * BPL;
-  static constexpr int BOFF = NA * ASTG;
-  static constexpr int RING = BOFF + 2 * STAGE_B;
-  static constexpr int CTILE = 128 * (BN + 4) * 4;
-  static constexpr int LDS = RING > CTILE ? RING : CTILE;
-  static constexpr int NW = STAGE_B / 1024 / 8;                             // B DMA instructions per wave and stage
-  static constexpr int NWA = ASTG / 1024 / 8;                               // A DMA instructions per wave and stage (4)
-  static_assert(LDS <= 160 * 1024 && STAGE_B % 8192 == 0, "LDS ring");
-};
-
-template <int TN, bool TRACE = false>
-__global__ void __launch_bounds__(512, 2) conv_h2d_kernel(const ConvParams* __restrict__ pp) {
-  using G = H2dCfg<TN>;
-  constexpr int WM = 4, WN = 2;
-  constexpr int BM = G::BM, BN = G::BN, ASTG = G::ASTG, BKG = G::BKG, BPL = G::BPL;
-  constexpr int STAGE_B = G::STAGE_B, BOFF = G::BOFF, NW = G::NW, NWA = G::NWA;
-  const ConvParams p = *pp;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  auto stamp = [&](int i) {
-    if constexpr (TRACE) {
-      if (tid == 0) p.trace[(size_t)blockIdx.x * 16 + i] = wall_clock64();
-    }
-  };
-  stamp(0);
-  if constexpr (TRACE) {
-    if (tid == 0) {
-      p.trace[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-      p.trace[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-    }
-  }
-  const int ntn = cout_padded(p.Cout) / BN;
-  int wg = (int)blockIdx.x;
-  {
-    const int nwg = (int)gridDim.x, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
-  }
-  const int splitk = p.splitk > 1 ? p.splitk : 1;
-  const int ks = wg % splitk;
-  wg /= splitk;
-  const int mt = wg / ntn, nt = wg - mt * ntn;
-  const int m0 = mt * BM, n0 = nt * BN;
-  const int HoWo = p.Ho * p.Wo;
-  const int M = p.B * HoWo;
-  const int ntaps = p.kh * p.kw;
-  const int cpt = p.Cin >> 5;
-  const int cpt2 = p.in2 != nullptr ? p.Cin2 >> 5 : 0;
-  const int nsteps1 = ntaps * cpt, nsteps_all = nsteps1 + cpt2;
-  const int s_begin = (int)(((long)nsteps_all * ks) / splitk);
-  const int nsteps = (int)(((long)nsteps_all * (ks + 1)) / splitk) - s_begin;
-  const int sexp = h2_in_scale_exp(p);
-  const float a_scale = pow2f(sexp), h2_inv = pow2f(-sexp);
-
-  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.in, 0, (int)((unsigned)p.B * p.in_Ha * p.in_Wa * p.in_ldc * 4u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.in2 != nullptr ? p.in2 : p.in), 0,
-      (int)(p.in2 != nullptr ? (unsigned)p.B * p.in2_Ha * p.in2_Wa * p.in2_ldc * 4u : 0u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.wt_split, 0, (int)((unsigned)ntn * nsteps_all * (unsigned)STAGE_B), 0x00020000);
-
-  unsigned l_b = ((unsigned)nt * (unsigned)nsteps_all + (unsigned)s_begin) * (unsigned)STAGE_B;
-  auto dma_b = [&](int boff) {
-#pragma unroll
-    for (int i = 0; i < NW; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, ODT_LDS_PTR(lds + boff + (i * 8 + wave) * 1024), 16,
-                                               lane * 16 + (i * 8 + wave) * 1024, (int)l_b, 0, 0);
-    l_b += (unsigned)STAGE_B;
-  };
-
-  // ---- activations: DMA piece (j, wave) = stage rows 64 j + 8 wave .. + 8, lane -> (row + (lane >> 3), slot position
-  // lane & 7) = chunk (lane & 7) ^ swizzle(row).  Per row: the byte offset of the tap-(0,0) input pixel and a bit per tap.
-  const int a_r = tid >> 3;
-  const int a_c = (tid & 7) ^ ((a_r >> 1) & 7);
-  const unsigned pix_bytes = (unsigned)p.in_ldc * 4u;
-  int a_base[NWA];
-  unsigned a_mask[NWA];
-  const bool dense_in = ntaps == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 &&
-                        p.H == p.in_Ha && p.W == p.in_Wa && p.Ho == p.H && p.Wo == p.W;
-#pragma unroll
-  for (int j = 0; j < NWA; ++j) {
-    const int m = m0 + a_r + 64 * j;
-    const bool ok = m < M;
-    if (dense_in) {
-      a_base[j] = (int)((unsigned)m * pix_bytes + a_c * 16u);
-      a_mask[j] = ok ? 1u : 0u;
-    } else {
-      const int mm = ok ? m : 0;
-      const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), r = mm - n * HoWo;
-      const int ho = sfast_div(r, p.div_wo_mul, p.div_wo_sh), wo = r - ho * p.Wo;
-      const int hi0 = ho * p.stride - p.pad_t, wi0 = wo * p.stride - p.pad_l;
-      a_base[j] = (int)(((unsigned)n * p.in_Ha * p.in_Wa + (unsigned)(hi0 * p.in_Wa + wi0)) * pix_bytes + a_c * 16u);
-      unsigned mk = 0;
-      for (int t = 0, khh = 0, kww = 0; t < ntaps; ++t) {
-        const int hi = hi0 + khh * p.dil, wi = wi0 + kww * p.dil;
-        if (ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) mk |= 1u << t;
-        if (++kww == p.kw) { kww = 0; ++khh; }
-      }
-      a_mask[j] = mk;
-    }
-  }
-  int l_cs = s_begin / ntaps, l_tap = s_begin - l_cs * ntaps;
-  int l_kh = l_tap / p.kw, l_kw = l_tap - l_kh * p.kw;
-  bool l_src2 = false;
-  unsigned a_row[NWA];
-  auto set_rows = [&]() {
-    const unsigned tapoff = (unsigned)(l_kh * p.dil * p.in_Wa + l_kw * p.dil) * pix_bytes;
-#pragma unroll
-    for (int j = 0; j < NWA; ++j) a_row[j] = ((a_mask[j] >> l_tap) & 1u) ? (unsigned)a_base[j] + tapoff : kOOB;
-  };
-  auto set_src2 = [&]() {
-#pragma unroll
-    for (int j = 0; j < NWA; ++j) {
-      const int m = m0 + a_r + 64 * j;
-      const bool ok = m < M;
-      const int mm = ok ? m : 0;
-      const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), r = mm - n * HoWo;
-      const int ho = sfast_div(r, p.div_wo_mul, p.div_wo_sh), wo = r - ho * p.Wo;
-      const unsigned pix = ((unsigned)n * p.in2_Ha + (unsigned)(ho * p.in2_stride)) * p.in2_Wa + (unsigned)(wo * p.in2_stride);
-      a_row[j] = ok ? pix * (unsigned)p.in2_ldc * 4u + a_c * 16u : kOOB;
-    }
-  };
-  set_rows();
-  auto dma_a = [&](int abuf) {
-#pragma unroll
-    for (int j = 0; j < NWA; ++j) {
-      if (l_src2)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in2, ODT_LDS_PTR(lds + abuf + (j * 8 + wave) * 1024), 16, (int)a_row[j], l_cs * 128, 0, 0);
-      else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, ODT_LDS_PTR(lds + abuf + (j * 8 + wave) * 1024), 16, (int)a_row[j], l_cs * 128, 0, 0);
-    }
-    // advance the stream position
-    if (l_src2) {
-      ++l_cs;
-    } else if (ntaps == 1) {
-      if (++l_cs == cpt && cpt2 > 0) { l_cs = 0; l_src2 = true; set_src2(); }
-    } else {
-      ++l_tap;
-      if (++l_kw == p.kw) { l_kw = 0; ++l_kh; }
-      if (l_tap == ntaps) { l_tap = 0; l_kh = 0; l_kw = 0; ++l_cs; }
-      set_rows();
-    }
-  };
-
-  f32x16 acc[2][TN];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int fr = lane & 31, fg = lane >> 5;
-  // fragment source of this lane: row (wm, t, fr); k-step kst, half fg -> chunks c0 = 4 kst + 2 fg and c0 + 1
-  int fa_off[2][2];                         // [t][kst]: byte offset of chunk c0's slot inside a stage; chunk c0 + 1 sits at ^ 16
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int row = wm * 64 + t * 32 + fr, sw = (row >> 1) & 7;
-#pragma unroll
-    for (int kst = 0; kst < 2; ++kst) fa_off[t][kst] = row * 128 + (((4 * kst + 2 * fg) ^ sw) << 4);
-  }
-  const int b_rd = fg * BKG + (wn * TN * 32 + fr) * 16;
-  f16x8 fa[2][2][2], fb[2][2];              // fa[k-step][piece][t], fb[buffer][piece]
-  f32x4 raw[2][2];                          // [t][half]: the 8 f32 of a row's k-step
-  auto rd_raw = [&](int abuf, int kst) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      raw[t][0] = *reinterpret_cast<const f32x4*>(lds + abuf + fa_off[t][kst]);
-      raw[t][1] = *reinterpret_cast<const f32x4*>(lds + abuf + (fa_off[t][kst] ^ 16));
-    }
-  };
-  auto split_raw = [&](int kst, int t) {
-    unsigned h[4], l[4];
-    split2h(raw[t][0][0], raw[t][0][1], a_scale, h[0], l[0]);
-    split2h(raw[t][0][2], raw[t][0][3], a_scale, h[1], l[1]);
-    split2h(raw[t][1][0], raw[t][1][1], a_scale, h[2], l[2]);
-    split2h(raw[t][1][2], raw[t][1][3], a_scale, h[3], l[3]);
-    const u32x4 hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
-    fa[kst][0][t] = (f16x8)hv;
-    fa[kst][1][t] = (f16x8)lv;
-  };
-  auto rdB = [&](int bbuf, int kst, int j, int dst) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) fb[dst][q] = *reinterpret_cast<const f16x8*>(lds + bbuf + q * BPL + kst * 2 * BKG + b_rd + j * 512);
-  };
-
-  // ---- prologue: stage 0 landed (B(0), A(0)); A(1) in flight; behind the barrier B(1) and A(2) start
-  dma_b(BOFF);
-  dma_a(0);
-  if (nsteps > 1) dma_a(ASTG);
-  stamp(6);
-  if (nsteps > 1) ODT_WAIT_VM_LGKM0(NWA); else ODT_WAIT_VM_LGKM0(0);
-  __builtin_amdgcn_s_barrier();
-  if (nsteps > 1) dma_b(BOFF + STAGE_B);
-  if (nsteps > 2) dma_a(2 * ASTG);
-  stamp(7); stamp(1);
-  rd_raw(0, 0);
-  rdB(BOFF, 0, 0, 0);
-  split_raw(0, 0); split_raw(0, 1);
-
-#define ODT_MF(kst, qa, qb, j, bsel) { acc[0][j] = ODT_MFMA_F16(fa[kst][qa][0], fb[bsel][qb], acc[0][j]); \
-                                        acc[1][j] = ODT_MFMA_F16(fa[kst][qa][1], fb[bsel][qb], acc[1][j]); }
-#define ODT_FENCE() __builtin_amdgcn_sched_barrier(0)
-  int a_cur = 0, a_nxt = ASTG, a_nn = 2 * ASTG, b_cur = BOFF, b_nxt = BOFF + STAGE_B;
-  // One stage = 2 TN column groups.  NEXT: stage c+1 exists; PRE2 / PRE3: stages c+2 / c+3 exist (their weight / activation
-  // DMA starts behind this stage's barrier, into the buffers stage c is leaving).  The barrier sits in front of the stage's
-  // last two groups: their MFMAs cover the first raw reads and the split of stage c+1.
-  auto step = [&](auto NEXT, auto PRE2, auto PRE3) {
-    constexpr bool next = decltype(NEXT)::value, pre2 = decltype(PRE2)::value, pre3 = decltype(PRE3)::value;
-    constexpr int NG = 2 * TN;
-    ODT_FENCE();
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const int kst = g / TN, j = g % TN, bsel = g & 1;
-      if (g < NG - 1) rdB(b_cur, (g + 1) / TN, (g + 1) % TN, bsel ^ 1);
-      if (g == NG - 2) {
-        // stage c+1 must be complete before its first reads below: own DMA of B(c+1) and A(c+1) (A(c+2), issued behind
-        // them, may stay in flight), all own LDS reads of stage c done (the last group's operands are in registers)
-        if constexpr (pre2) ODT_WAIT_VM_LGKM0(NWA); else ODT_WAIT_VM_LGKM0(0);
-        __builtin_amdgcn_s_barrier();
-        ODT_FENCE();
-        if constexpr (pre2) dma_b(b_cur);
-        if constexpr (pre3) dma_a(a_cur);
-        if constexpr (next) rd_raw(a_nxt, 0);
-      }
-      if (g == NG - 1) { if constexpr (next) rdB(b_nxt, 0, 0, bsel ^ 1); }
-      if (g == 0) rd_raw(a_cur, 1);
-      ODT_FENCE();
-      ODT_MF(kst, 1, 0, j, bsel); ODT_FENCE();             // lo * hi
-      if (g == NG - 1) { if constexpr (next) split_raw(0, 1); }
-      if (TN == 4) { if (g == 1) split_raw(1, 0); }
-      else if (g == 0) split_raw(1, 0);
-      ODT_FENCE();
-      ODT_MF(kst, 0, 1, j, bsel); ODT_FENCE();             // hi * lo
-      if (g == NG - 2) { if constexpr (next) split_raw(0, 0); }
-      if (TN == 4) { if (g == 2) split_raw(1, 1); }
-      else if (g == 0) split_raw(1, 1);
-      ODT_FENCE();
-      ODT_MF(kst, 0, 0, j, bsel); ODT_FENCE();             // hi * hi
-    }
-    { const int t = a_cur; a_cur = a_nxt; a_nxt = a_nn; a_nn = t; }
-    { const int t = b_cur; b_cur = b_nxt; b_nxt = t; }
-  };
-  {
-    using T = std::true_type; using F = std::false_type;
-    int c = 0;
-    for (; c + 3 < nsteps; ++c) step(T{}, T{}, T{});
-    if (c + 2 < nsteps) { step(T{}, T{}, F{}); ++c; }
-    if (c + 1 < nsteps) { step(T{}, F{}, F{}); ++c; }
-    step(F{}, F{}, F{});
-  }
-  stamp(2);
-  split3_epilogue<WM, WN, TN, G::LDS, TRACE>(p, acc, lds, m0, n0, M, HoWo, ks, splitk, tid, wm, wn, fr, fg, h2_inv);
+  split3_epilogue<WM, WN, TN, G::LDS, TRACE, G::NTHR>(p, acc, lds, m0, n0, M, HoWo, ks, splitk, tid, wm, wn, fr, fg, h2_inv);
   stamp(5);
 }
 
@@ -924,13 +662,14 @@ int launch_tensor_amax(const float* x, size_t n, unsigned* slot, hipStream_t str
 int launch_conv_h2(const ConvParams& p, const ConvParams* dev, hipStream_t stream) {
   const long M = (long)p.B * p.Ho * p.Wo;
   const int bn = p.wt_split_bn;
-  ODT_CHECK(p.wt_split_bm == 256 && (bn == 256 || bn == 128) && p.Cin % 32 == 0 && p.kh * p.kw <= 32 && p.in_amax != nullptr &&
+  const int bm = p.wt_split_bm;
+  ODT_CHECK((bm == 256 || (bm == 128 && bn == 128 && !p.wt_split_kwr)) && (bn == 256 || bn == 128) && p.Cin % 32 == 0 && p.kh * p.kw <= 32 && p.in_amax != nullptr &&
             p.h2_chinv != nullptr && (p.in2 == nullptr || (p.in2_amax != nullptr && p.Cin2 % 32 == 0)) && p.nlvl <= 1,
             "conv h2: unsupported tile / shape, or no recorded input range");
   const int sk = p.splitk > 1 ? p.splitk : 1;
   ODT_CHECK(sk == 1 || (p.partial != nullptr && p.in2 == nullptr && p.head_wt == nullptr && (p.kh * p.kw * p.Cin >> 5) >= sk),
             "conv h2: split-K needs a partial buffer, a single source and at least one stage per range");
-  const unsigned grid = (unsigned)(((M + 255) / 256) * (cout_padded(p.Cout) / bn) * sk);
+  const unsigned grid = (unsigned)(((M + bm - 1) / bm) * (cout_padded(p.Cout) / bn) * sk);
   if (p.wt_split_kwr) {
     ODT_CHECK(sk == 1 && p.kw == 3 && p.stride == 1 && p.in_Wa == p.Wo && p.in2 == nullptr && 2 * p.dil <= 4, "conv h2k: unsupported shape");
     if (bn == 256) {
@@ -939,22 +678,14 @@ int launch_conv_h2(const ConvParams& p, const ConvParams* dev, hipStream_t strea
     } else {
       hipLaunchKernelGGL((conv_h2k_kernel<2, false>), dim3(grid), dim3(512), 0, stream, dev);
     }
+  } else if (bn == 256) {
+    if (p.trace != nullptr) hipLaunchKernelGGL((conv_h2_kernel<4, 4, true>), dim3(grid), dim3(512), 0, stream, dev);
+    else hipLaunchKernelGGL((conv_h2_kernel<4, 4, false>), dim3(grid), dim3(512), 0, stream, dev);
+  } else if (bm == 256) {
+    hipLaunchKernelGGL((conv_h2_kernel<2, 4, false>), dim3(grid), dim3(512), 0, stream, dev);
   } else {
-    // activations by LDS-DMA (conv_h2d_kernel) unless ODT_CONV_H2_ADMA=0 (A/B: the register-prefetch loop)
-    static const bool adma = !(getenv("ODT_CONV_H2_ADMA") != nullptr && getenv("ODT_CONV_H2_ADMA")[0] == '0');
-    if (adma) {
-      if (bn == 256) {
-        if (p.trace != nullptr) hipLaunchKernelGGL((conv_h2d_kernel<4, true>), dim3(grid), dim3(512), 0, stream, dev);
-        else hipLaunchKernelGGL((conv_h2d_kernel<4, false>), dim3(grid), dim3(512), 0, stream, dev);
-      } else {
-        hipLaunchKernelGGL((conv_h2d_kernel<2, false>), dim3(grid), dim3(512), 0, stream, dev);
-      }
-    } else if (bn == 256) {
-      if (p.trace != nullptr) hipLaunchKernelGGL((conv_h2_kernel<4, true>), dim3(grid), dim3(512), 0, stream, dev);
-      else hipLaunchKernelGGL((conv_h2_kernel<4, false>), dim3(grid), dim3(512), 0, stream, dev);
-    } else {
-      hipLaunchKernelGGL((conv_h2_kernel<2, false>), dim3(grid), dim3(512), 0, stream, dev);
-    }
+    if (p.trace != nullptr) hipLaunchKernelGGL((conv_h2_kernel<2, 2, true>), dim3(grid), dim3(256), 0, stream, dev);
+    else hipLaunchKernelGGL((conv_h2_kernel<2, 2, false>), dim3(grid), dim3(256), 0, stream, dev);
   }
   if (sk > 1) launch_split_reduce(p, dev, stream);
   ODT_HIP(hipGetLastError());

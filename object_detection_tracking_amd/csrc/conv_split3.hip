@@ -586,41 +586,54 @@ __global__ void __launch_bounds__(512, 2) conv_split3k_kernel(const ConvParams* 
   stamp(5);
 }
 
-// split-K combine: out = act(sum over ranges (in range order: deterministic) + bias (+ residual)); one thread per
-// 16-byte chunk of an output row
+// split-K combine: out = act(sum over ranges (in range order: deterministic) + bias (+ residual)); a thread per 16-byte
+// chunk of an output row, grid-stride; the block's |max| goes to the output's range slot by (at most) one atomic
 __global__ void __launch_bounds__(256) split_reduce_kernel(const ConvParams* __restrict__ pp) {
   const ConvParams p = *pp;
+  __shared__ float red[4];
   const int Np = cout_padded(p.Cout), C4 = Np >> 2;
   const long M = (long)p.B * p.Ho * p.Wo;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= M * C4) { publish_amax(p.out_amax, 0.f, (int)threadIdx.x); return; }
-  const int m = (int)(idx / C4), col = (int)(idx - (long)m * C4) * 4;
   const size_t slab = (size_t)M * Np;
-  f32x4 v = *reinterpret_cast<const f32x4*>(p.partial + (size_t)m * Np + col);
-  for (int k = 1; k < p.splitk; ++k) v += *reinterpret_cast<const f32x4*>(p.partial + (size_t)k * slab + (size_t)m * Np + col);
-  if (p.h2_chinv != nullptr) {          // fp16x2 pieces: undo the powers of two of the weight columns and of the A operand
-    const float inv = pow2f(-h2_in_scale_exp(p));
-    for (int e = 0; e < 4; ++e) v[e] *= p.h2_chinv[col + e] * inv;
-  }
-  for (int e = 0; e < 4; ++e) v[e] += col + e < p.Cout ? p.bias[col + e] : 0.f;
   const int HoWo = p.Ho * p.Wo;
-  const int n = sfast_div(m, p.div_howo_mul, p.div_howo_sh), rr = m - n * HoWo;
-  const int ho = sfast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
-  if (p.res_mode != 0) {
-    const size_t rpix = p.res_mode == 2 ? ((size_t)n * p.res_H + (size_t)(ho >> 1)) * p.res_W + (size_t)(wo >> 1)
-                                        : ((size_t)n * p.res_H + (size_t)ho) * p.res_W + (size_t)wo;
-    v += *reinterpret_cast<const f32x4*>(p.res + rpix * p.res_ldc + col);
+  // fp16x2 pieces: undo the powers of two of the weight columns and of the A operand
+  const float inv = p.h2_chinv != nullptr ? pow2f(-h2_in_scale_exp(p)) : 1.0f;
+  float vmax = 0.f;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < M * C4; idx += (long)gridDim.x * 256) {
+    const int m = (int)(idx / C4), col = (int)(idx - (long)m * C4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.partial + (size_t)m * Np + col);
+    for (int k = 1; k < p.splitk; ++k) v += *reinterpret_cast<const f32x4*>(p.partial + (size_t)k * slab + (size_t)m * Np + col);
+    if (p.h2_chinv != nullptr) {
+      for (int e = 0; e < 4; ++e) v[e] *= p.h2_chinv[col + e] * inv;
+    }
+    for (int e = 0; e < 4; ++e) v[e] += col + e < p.Cout ? p.bias[col + e] : 0.f;
+    const int n = sfast_div(m, p.div_howo_mul, p.div_howo_sh), rr = m - n * HoWo;
+    const int ho = sfast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
+    if (p.res_mode != 0) {
+      const size_t rpix = p.res_mode == 2 ? ((size_t)n * p.res_H + (size_t)(ho >> 1)) * p.res_W + (size_t)(wo >> 1)
+                                          : ((size_t)n * p.res_H + (size_t)ho) * p.res_W + (size_t)wo;
+      v += *reinterpret_cast<const f32x4*>(p.res + rpix * p.res_ldc + col);
+    }
+    if (p.relu == 1) {
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    } else if (p.relu == 2) {
+      for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f / (1.0f + expf(-v[e])));
+    } else if (p.relu == 3) {
+      for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
+    }
+    const size_t opix = ((size_t)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
+    *reinterpret_cast<f32x4*>(p.out + opix * p.out_ldc + col) = v;
+    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
   }
-  if (p.relu == 1) {
-    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-  } else if (p.relu == 2) {
-    for (int e = 0; e < 4; ++e) v[e] = v[e] * (1.0f / (1.0f + expf(-v[e])));
-  } else if (p.relu == 3) {
-    for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
+  if (p.out_amax != nullptr) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned b = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+      if (b > __atomic_load_n(p.out_amax, __ATOMIC_RELAXED)) atomicMax(p.out_amax, b);
+    }
   }
-  const size_t opix = ((size_t)n * p.out_H + ho + p.out_oy) * p.out_W + wo + p.out_ox;
-  *reinterpret_cast<f32x4*>(p.out + opix * p.out_ldc + col) = v;
-  publish_amax(p.out_amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), (int)threadIdx.x);
 }
 
 }  // namespace
@@ -634,7 +647,8 @@ static void launch_split3(const ConvParams& p, const ConvParams* dev, unsigned g
 
 void launch_split_reduce(const ConvParams& p, const ConvParams* dev, hipStream_t stream) {
   const long chunks = (long)p.B * p.Ho * p.Wo * (cout_padded(p.Cout) / 4);
-  hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, dev);
+  const long blocks = (chunks + 255) / 256;
+  hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream, dev);
 }
 
 int launch_conv_split3(const ConvParams& p, const ConvParams* dev, hipStream_t stream) {

@@ -1,7 +1,7 @@
-// Shared pieces of the bf16x3 split convolution kernels (conv_split1.hip: one-stage 4-wave loop; conv_split3.hip: 8-wave
-// LDS-DMA kernels; conv_split.hip: weight images, policy, dispatch).
+// Shared pieces of the split convolution kernels (conv_split1.hip: one-stage 4-wave bf16x3 loop; conv_split3.hip: 8-wave
+// LDS-DMA bf16x3 kernels; conv_h2.hip: the fp16x2 kernels; conv_split.hip: weight images, policy, dispatch).
 //
-// Arithmetic.  Every f32 operand is cut into three bf16 pieces by round-to-nearest,
+// bf16x3 arithmetic.  Every f32 operand is cut into three bf16 pieces by round-to-nearest,
 //     x = hi + mid + lo   exactly   (3 x 8 significand bits = the 24 bits of an f32),
 // |mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|, so a*b is the sum of nine piece products.  The six largest
 // are evaluated on v_mfma_f32_32x32x16_bf16 (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid); the

@@ -21,7 +21,7 @@ __device__ __forceinline__ void publish_amax(unsigned* slot, float vmax, int tid
 
 // Epilogue shared by the conv_split3 kernels: accumulators of the 8 waves (wave tile 64 x 32 TN at (wm, wn)) -> LDS ->
 // rows of 16-byte chunks -> bias (+ residual) + activation -> global, or the raw partial tile of a split-K range.
-template <int WM, int WN, int TN, int LDSB, bool TRACE>
+template <int WM, int WN, int TN, int LDSB, bool TRACE, int NTHR = 512>
 __device__ __forceinline__ void split3_epilogue(const ConvParams& p, f32x16 (&acc)[2][TN], unsigned char* lds, int m0, int n0,
                                                 int M, int HoWo, int ks, int splitk, int tid, int wm, int wn, int fr, int fg,
                                                 float h2_inv = 1.0f) {
@@ -33,7 +33,7 @@ __device__ __forceinline__ void split3_epilogue(const ConvParams& p, f32x16 (&ac
   constexpr int FIT = LDSB / (CS * 4);                    // rows of the C tile the ring's LDS holds
   constexpr int RP = FIT >= BM ? BM : (FIT >= BM / 2 ? BM / 2 : (FIT >= BM / 4 ? BM / 4 : 64));   // rows per pass
   constexpr int NPASS = BM / RP, WPP = RP / 64;
-  constexpr int C4 = BN / 4, RSTEP = 512 / C4, NCH = RP / RSTEP;
+  constexpr int C4 = BN / 4, RSTEP = NTHR / C4, NCH = RP / RSTEP;
   static_assert(RP >= 64 && BM % RP == 0 && RP % RSTEP == 0, "epilogue passes");
   float* Ct = reinterpret_cast<float*>(lds);
   const bool dense_io = p.out_oy == 0 && p.out_ox == 0 && p.out_H == p.Ho && p.out_W == p.Wo &&
@@ -140,7 +140,7 @@ __device__ __forceinline__ void split3_epilogue(const ConvParams& p, f32x16 (&ac
           *q = v;
         }
         ODT_BARRIER_LDS();
-        for (int rt = wave; rt < RT; rt += 8) {
+        for (int rt = wave; rt < RT; rt += NTHR / 64) {
           f32x4 c = {0.f, 0.f, 0.f, 0.f};
           const float* arow = &Ct[(rt * 16 + hn) * CS + 4 * hj];
 #pragma unroll

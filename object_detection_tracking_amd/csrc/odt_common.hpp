@@ -118,6 +118,8 @@ struct ConvPolicy {
   long min_tiles;       // tiles a layer must offer the one- / two-stage kernels (256)
   long min_tiles3;      // ... conv_split3_kernel's 256- / 128-row tiles (200)
   int min_k, min_bn;    // shortest reduction / narrowest n-tile taken
+  int h2s_maxk;         // fp16x2: longest reduction that takes the 128 x 128 4-wave tile (two workgroups per CU); 0: none
+  bool h2_few_tiles;    // fp16x2: 128 x 128 tiles for the layers without enough 256-row tiles
   int force_bm3;        // 0 auto | 128 | 256: force conv_split3_kernel with that tile height (tests)
   int splitk_max;       // conv_split3_kernel: largest split-K factor the policy may choose (1 = off)
   bool kw_reuse;        // conv_split3k_kernel for the stride-1 KH x 3 layers it fits (ODT_CONV_SPLIT3_KWR=0: off)

@@ -229,12 +229,15 @@ int attach_split_weights(odt_model* m) {
       it = made.emplace(key, img).first;
     }
     c.p.wt_split = it->second;
-    if (c.p.wt_split_kind == 2) { c.p.h2_chinv = conv_h2_chinv(c.p.wt_split, c.p.Cout, K); ++m->convs_h2; }
+    if (c.p.wt_split_kind == 2) {
+      c.p.h2_chinv = conv_h2_chinv(c.p.wt_split, c.p.Cout, K); ++m->convs_h2;
+      static const bool norot = getenv("ODT_CONV_H2_ROT") != nullptr && getenv("ODT_CONV_H2_ROT")[0] == '0';
+      if (norot) c.p.debug |= 0x100;          // A/B: every workgroup walks the K slices in the same order
+    }
     need_partial = std::max(need_partial, conv_split_partial_bytes(c.p));
-    // the output's slot (split-K layers -- the small ones -- record none: their combine pass is a short memory-bound
-    // kernel of thousands of waves, and one hot atomic per wave cost it 2x; their consumers stay on bf16x3)
-    if (c.p.splitk > 1) slot_of.erase(c.p.out);
-    else if (c.p.out != nullptr) {
+    // the output's slot (split-K layers: the combine pass records it, one atomic per block -- one per WAVE cost that short
+    // memory-bound kernel 2x)
+    if (c.p.out != nullptr) {
       auto so = slot_of.find(c.p.out);
       int slot;
       if (so != slot_of.end() && (so->second >= odt_model::kAmaxSlots) == tail) slot = so->second;

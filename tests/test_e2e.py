@@ -386,14 +386,19 @@ def test_rpn_head_fused_into_conv_epilogue(backend, monkeypatch):
 
 
 
-def test_fp16x2_family_agrees_with_bf16x3(backend, monkeypatch):
+@pytest.mark.parametrize("tiles", ["256", "128/k2"])
+def test_fp16x2_family_agrees_with_bf16x3(backend, tiles, monkeypatch):
   """conv_split_family = 2: the layers with 256-row tiles at least 128 columns wide and a recorded input range run on the
   fp16x2 kernels (conv_h2.hip: three exact f16 products per MAC, operands scaled by the |max| the producing kernel recorded),
   the rest stays on bf16x3.  Stage tensors agree with the bf16x3 handle at f32 rounding level, detections as matched sets;
   the fp16x2 handle is also checked against the oracle."""
   name, lib = backend
   monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1"); monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "1")
-  monkeypatch.setenv("ODT_CONV_SPLIT3_BM", "256")
+  # "256": 256-row tiles (conv_h2k_kernel / conv_h2_kernel<., 4>); "128/k2": the 128 x 128 4-wave tile with the reduction cut
+  # in two (what b = 1 runs below res3): the ranges' combine pass applies the scales and records the output's range
+  monkeypatch.setenv("ODT_CONV_SPLIT3_BM", tiles.split("/")[0])
+  if "/" in tiles:
+    monkeypatch.setenv("ODT_CONV_SPLIT3_FORCE_SPLITK", tiles.split("/")[1][1:])
   cfg = small_config(resnet_num_block=[1, 1, 1, 1] if name == "emu" else [1, 1, 2, 3])
   w = weights_for(cfg)
   H, W = (64, 96) if name == "emu" else (160, 224)

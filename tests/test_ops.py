@@ -504,6 +504,7 @@ SPLIT_CASES = [
     (3, 17, 19, 32, 256, 3, 1, 1, 1, 1, 17, 19, True),       # M = 969: 4 tiles, boundaries inside tiles 1, 2 and 3
     (2, 20, 21, 96, 128, 3, 1, 2, 2, 2, 20, 21, False),      # dilation 2 (res5 conv2 class), N = 128, six 16-channel slices
     (2, 19, 17, 32, 256, 3, 1, 1, 0, 1, 17, 17, True),       # VALID rows (no top / bottom pad), SAME columns
+    (2, 20, 21, 128, 256, 1, 1, 1, 0, 0, 20, 21, True),      # dense 1x1 over four 256-row tiles, four 32-channel slices (fp16x2: each tile starts at its own slice)
 ]
 
 
@@ -513,7 +514,8 @@ SPLIT_CASES = [
 # "3/256/nokwr": 256-row tiles with the kw-reuse kernel (conv_split3k_kernel, the default for stride-1 KH x 3 convs) off
 # "2/256...": the fp16x2 kernels (conv_h2.hip: conv_h2k_kernel for the stride-1 KH x 3 convs, conv_h2_kernel otherwise; the
 # stand-alone call records the input's |max| itself) where a case has an n-tile of 128 / 256 -- bf16x3 kernels elsewhere
-SPLIT_PIPES = ["3/256", "3/256/nokwr", "3/128", "3/128/k3", "1", "2/256", "2/256/nokwr", "2/256/k3"]
+# "2/128": the 128 x 128 4-wave tile of conv_h2_kernel (the library's choice for short reductions and few-tile layers)
+SPLIT_PIPES = ["3/256", "3/256/nokwr", "3/128", "3/128/k3", "1", "2/256", "2/256/nokwr", "2/256/k3", "2/128", "2/128/k3"]
 
 
 def _split_env(monkeypatch, pipe="3/256"):
