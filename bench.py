@@ -10,8 +10,9 @@ batch of 8 synthetic 1920x1080 frames that are already resident in HBM (uint8). 
 per GPU, one video stream per GPU, weights replicated, no data-path collective (streams are
 independent: "weak" scaling; RCCL only carries the barrier and the max-over-ranks timing).
 Rank 0 prints ONE JSON line with the contract fields plus `roofline` (the conv implicit-GEMM
-launches, HIP-event timed on their launch stream, split by kernel family: `conv_split_kernel` --
-f32 convolution through six exact bf16 MFMA products per MAC -- and the exact-f32 `conv_igemm_kernel`) and, at N=1, `cpu_baseline` (the oracle -- a CPU
+launches, HIP-event timed on their launch stream, split by kernel family: the split kernels -- f32 convolution
+through exact 16-bit MFMA products, three f16 products per MAC on the `conv_h2` kernels, six bf16 ones on the
+`conv_split` kernels -- and the exact-f32 `conv_igemm_kernel`) and, at N=1, `cpu_baseline` (the oracle -- a CPU
 restatement of the reference's TF graph, kind "port" -- timed on the host cores over a bounded
 sample of the same workload).
 """
@@ -465,16 +466,19 @@ def sustained_peak(lib, device):
   import ctypes as C
   out = {}
   try:
-    for key, lds in (("", 0), ("with_lds_fragment_reads_", 1)):
+    for key, lds in (("", 0), ("with_lds_fragment_reads_", 1), ("fp16x2_mix_", 2)):
       tf = C.c_double(); ghz = C.c_double(); ms = C.c_double(); n = C.c_int()
       lib.check(lib.dll.odt_probe_mfma_bf16(device, 100.0, 300.0, lds, C.byref(tf), C.byref(ghz), C.byref(ms), C.byref(n)))
       out[key + "bf16_tflops"] = tf.value
       out[key + "clock_ghz"] = ghz.value
       out[key + "measured_ms"] = ms.value
+    # (the third loop is the fp16x2 kernels' own mix: v_mfma_f32_32x32x16_f16, three products per tile and k16 step, 24 LDS
+    # fragment reads per two k-steps; "bf16_tflops" in its keys means 16-bit MFMA TFLOP/s)
+    out["fp16x2_mix_f16_tflops"] = out.pop("fp16x2_mix_bf16_tflops")
     # the ceiling is the better of the two loops: on some boxes the bare register-operand stream is throttled harder
     # (lower matrix-pipe duty at the same clock) than the one that pauses for its LDS fragment reads
     out["registers_only_bf16_tflops"] = out["bf16_tflops"]
-    out["bf16_tflops"] = max(out["bf16_tflops"], out["with_lds_fragment_reads_bf16_tflops"])
+    out["bf16_tflops"] = max(out["bf16_tflops"], out["with_lds_fragment_reads_bf16_tflops"], out["fp16x2_mix_f16_tflops"])
     out["f32_work_tflops"] = out["bf16_tflops"] / SPLIT_PRODUCTS
     out["frac_of_datasheet_bf16_peak"] = out["bf16_tflops"] / BF16_MFMA_PEAK_TFLOPS
     out["what"] = ("v_mfma_f32_32x32x16_bf16 in the split kernels' mix (2 x 4 accumulator tiles per wave, 6 products per k16 "

@@ -211,10 +211,11 @@ int odt_profile_layer(odt_handle h, int index, char* name, int name_cap,
  * device sustains on the instruction mix of the bf16x3 split conv kernels (csrc/conv_split.hip: six
  * v_mfma_f32_32x32x16_bf16 products per f32 MAC, a 2 x 4 accumulator-tile wave, one 8-wave workgroup per CU) with
  * random bf16 operands held in registers -- the upper bound of that kernel family under this box's power budget.
- * Runs back-to-back launches: `warm_ms` uncounted, then at least `min_ms` timed as one region.  lds_reads != 0: the
- * 18 operand fragments of every k16 step are re-read from LDS as the conv kernels do.  tflops_bf16 = executed bf16
- * TFLOP/s (divide by 6 for the f32-work ceiling); clock_ghz = shader clock read in the kernel (s_memtime per
- * s_memrealtime). */
+ * Runs back-to-back launches: `warm_ms` uncounted, then at least `min_ms` timed as one region.  lds_reads = 1: the
+ * 18 operand fragments of every k16 step are re-read from LDS as the conv kernels do; lds_reads = 2: the fp16x2 kernels'
+ * mix instead (csrc/conv_h2.hip: three v_mfma_f32_32x32x16_f16 products per tile and k16 step, 24 fragment reads per
+ * BK = 32 stage).  tflops_bf16 = executed 16-bit MFMA TFLOP/s (divide by the products per f32 MAC -- 6 or 3 -- for the
+ * f32-work ceiling); clock_ghz = shader clock read in the kernel (s_memtime per s_memrealtime). */
 int odt_probe_mfma_bf16(int device, double warm_ms, double min_ms, int lds_reads, double* tflops_bf16,
                         double* clock_ghz, double* measured_ms, int* launches);
 

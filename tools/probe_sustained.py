@@ -10,13 +10,14 @@ def main():
   dev = int(sys.argv[1]) if len(sys.argv) > 1 else 0
   lib = _lib.get_lib()
   print("# odt_probe_mfma_bf16(device %d, warm 100 ms, timed >= 300 ms): v_mfma_f32_32x32x16_bf16, 2 x 4 tiles per wave, six piece products per k16 step" % dev)
-  print("%-28s %12s %12s %10s %9s %9s" % ("variant", "bf16 TF", "f32-work TF", "clock GHz", "ms", "launches"))
+  print("%-28s %12s %12s %10s %9s %9s" % ("variant", "16-bit TF", "f32-work TF", "clock GHz", "ms", "launches"))
   for rnd in range(3):
-    for name, lds in (("operands in registers", 0), ("LDS fragment reads per step", 1)):
+    for name, lds, prod in (("operands in registers", 0, 6), ("LDS fragment reads per step", 1, 6),
+                            ("fp16x2 mix (f16, 3 products)", 2, 3)):
       tf = C.c_double(); ghz = C.c_double(); ms = C.c_double(); n = C.c_int()
       lib.check(lib.dll.odt_probe_mfma_bf16(dev, 100.0, 300.0, lds, C.byref(tf), C.byref(ghz), C.byref(ms), C.byref(n)))
-      print("%-28s %12.1f %12.1f %10.3f %9.1f %9d" % (name, tf.value, tf.value / 6, ghz.value, ms.value, n.value))
-  print("# datasheet: 2500 TF dense bf16 at 2.4 GHz (MI355X_MICROARCH.md); f32 work = bf16 / 6 products per MAC")
+      print("%-28s %12.1f %12.1f %10.3f %9.1f %9d" % (name, tf.value, tf.value / prod, ghz.value, ms.value, n.value))
+  print("# datasheet: 2500 TF dense 16-bit MFMA at 2.4 GHz (MI355X_MICROARCH.md); f32 work = 16-bit rate / products per MAC (6 bf16x3, 3 fp16x2)")
 
 if __name__ == "__main__":
   main()
