@@ -359,7 +359,12 @@ def main():
       # what the bf16 matrix pipe of THIS box sustains on the split kernels' own MFMA mix (random operands, >= 300 ms
       # of back-to-back launches, measured a moment ago in this process): the ceiling under the box's power budget
       roofline["sustained_peak"] = sustained
-      roofline["frac_of_sustained"] = split_tf * split_products / sustained["bf16_tflops"]
+      # ceiling of the step's split launches at the sustained rates of their own mixes (fp16x2 launches: the f16 three-product
+      # mix; bf16x3 launches: the bf16 six-product mix) over their measured time
+      sus_h2 = sustained.get("fp16x2_mix_f16_tflops") or sustained["bf16_tflops"]
+      ceil_ms = (H2_PRODUCTS * fam["h2"][1] / sus_h2 + SPLIT_PRODUCTS * fam["b3"][1] / sustained["bf16_tflops"]) * nprof / 1e9
+      roofline["frac_of_sustained"] = ceil_ms / fam["split"][2] if fam["split"][2] > 0 else 0.0
+      roofline["sustained_f32_work_tflops"] = {"fp16x2": sus_h2 / H2_PRODUCTS, "bf16x3": sustained["bf16_tflops"] / SPLIT_PRODUCTS}
     out = {
         "metric": "detector FPS @%dx%d b=%d per MI355X" % (W, H, B),
         "value": fps,
@@ -478,13 +483,14 @@ def sustained_peak(lib, device):
     # the ceiling is the better of the two loops: on some boxes the bare register-operand stream is throttled harder
     # (lower matrix-pipe duty at the same clock) than the one that pauses for its LDS fragment reads
     out["registers_only_bf16_tflops"] = out["bf16_tflops"]
-    out["bf16_tflops"] = max(out["bf16_tflops"], out["with_lds_fragment_reads_bf16_tflops"], out["fp16x2_mix_f16_tflops"])
+    out["bf16_tflops"] = max(out["bf16_tflops"], out["with_lds_fragment_reads_bf16_tflops"])
     out["f32_work_tflops"] = out["bf16_tflops"] / SPLIT_PRODUCTS
     out["frac_of_datasheet_bf16_peak"] = out["bf16_tflops"] / BF16_MFMA_PEAK_TFLOPS
-    out["what"] = ("v_mfma_f32_32x32x16_bf16 in the split kernels' mix (2 x 4 accumulator tiles per wave, 6 products per k16 "
+    out["what"] = ("v_mfma_f32_32x32x16_bf16 in the bf16x3 kernels' mix (2 x 4 accumulator tiles per wave, 6 products per k16 "
                    "step, one 8-wave workgroup per CU), random bf16 operands, no global-memory traffic; operands held in "
                    "registers / re-read from LDS per k16 step as the conv kernels do -- bf16_tflops is the better of the two; "
-                   "back-to-back launches, 100 ms warm-up, >= 300 ms timed each")
+                   "fp16x2_mix_*: v_mfma_f32_32x32x16_f16 in the fp16x2 kernels' mix (3 products per k16 step, 24 LDS fragment "
+                   "reads per two k-steps), random f16 operands; back-to-back launches, 100 ms warm-up, >= 300 ms timed each")
   except Exception as ex:
     out["failed"] = repr(ex)
   return out

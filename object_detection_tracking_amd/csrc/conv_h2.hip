@@ -31,7 +31,10 @@ template <int TN, int WM>
 struct H2Cfg {
   static constexpr int BM = 64 * WM, BN = 64 * TN;
   static constexpr int NWV = 2 * WM, NTHR = 64 * NWV;                       // waves (WM x 2), threads
-  static constexpr int AKG = BM * 16 + 64, APL = 4 * AKG, ASTG = 2 * APL;   // A stage: [piece 2][k-group 4][row][8 f16], 64-B pad per k-group
+  // A stage: [piece 2][k-group 4][row][8 f16]; 32-B pad per k-group: the four k-groups a store instruction touches (8 lanes
+  // per row, two rows per 16-lane group) start 8 banks apart (ds_write_b64 banks are mod 32; a 64-B pad put k-groups 0 / 2 and
+  // 1 / 3 on the same banks: 18 % of the LDS cycles were conflict cycles, profiles/r03_pmc_lds_wait_by_kernel.txt)
+  static constexpr int AKG = BM * 16 + 32, APL = 4 * AKG, ASTG = 2 * APL;
   static constexpr int BKG = BN * 16, BPL = 4 * BKG, STAGE_B = 2 * BPL;     // B stage: the linear image the DMA writes
   static constexpr int BOFF = 2 * ASTG;
   static constexpr int RING = BOFF + 2 * STAGE_B;
@@ -322,7 +325,7 @@ struct H2kCfg {
   static constexpr int BM = 256, BN = 64 * TN;
   static constexpr int PR = 272;                             // stage rows: 256 + 2 runs x 2 dil (dil <= 2) + the zero row, padded
   static constexpr int ZR = PR - 1;                          // the zero row
-  static constexpr int AKG = PR * 16 + 64, APL = 4 * AKG, ABUF = 2 * APL;
+  static constexpr int AKG = PR * 16 + 32, APL = 4 * AKG, ABUF = 2 * APL;   // (32-B pad: see H2Cfg)
   static constexpr int BKG = BN * 16, BPL = 4 * BKG, STAGE_B = 2 * BPL;
   static constexpr int BOFF = 2 * ABUF;
   static constexpr int RING = BOFF + 2 * STAGE_B;

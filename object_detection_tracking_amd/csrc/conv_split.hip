@@ -202,7 +202,7 @@ void conv_split_choose(ConvParams& p, const ConvPolicy& q) {
         // (two of these workgroups share a CU: the chip has twice min_tiles3 slots for them -- res4 at b=1 ran its 128 tiles
         // x 2 ranges one 4-wave workgroup per CU, a single wave per SIMD)
         int k = 1;
-        if (t128 < 2 * q.min_tiles3 && q.splitk_max > 1 && p.in2 == nullptr) {
+        if (t128 < q.min_tiles3 && q.splitk_max > 1 && p.in2 == nullptr) {
           k = (int)((2 * q.min_tiles3 + t128 - 1) / t128);
           if (k > q.splitk_max) k = q.splitk_max;
           while (k > 1 && (K >> 5) / k < 4) --k;

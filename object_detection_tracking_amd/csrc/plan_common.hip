@@ -236,8 +236,8 @@ int attach_split_weights(odt_model* m) {
     }
     need_partial = std::max(need_partial, conv_split_partial_bytes(c.p));
     // the output's slot (split-K layers: the combine pass records it, one atomic per block -- one per WAVE cost that short
-    // memory-bound kernel 2x)
-    if (c.p.out != nullptr) {
+    // memory-bound kernel 2x); only where the fp16x2 kernels may read it
+    if (c.p.out != nullptr && pol.family == 2) {
       auto so = slot_of.find(c.p.out);
       int slot;
       if (so != slot_of.end() && (so->second >= odt_model::kAmaxSlots) == tail) slot = so->second;
