@@ -21,11 +21,7 @@ namespace odt {
 
 namespace {
 
-#ifdef ODT_HIP_EMULATOR
 #define ODT_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
-#else
-#define ODT_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
-#endif
 
 template <int TN, int WM>
 struct H2Cfg {
