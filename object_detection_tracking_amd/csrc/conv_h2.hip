@@ -41,6 +41,8 @@ struct H2Cfg {
   static_assert(LDS <= 160 * 1024 && STAGE_B % (1024 * NWV) == 0, "LDS ring");
 };
 
+// (<1, 2>: 128 x 64 on 4 waves for the 64-wide layers -- one column group per k-step, 12 MFMAs per wave and stage, 50 KB of
+// LDS: three workgroups per CU)
 // <TN, WM>: <4, 4> 256 x 256, <2, 4> 256 x 128 (8 waves, one workgroup per CU); <2, 2> 128 x 128 with 4 waves and 66 KB of LDS --
 // TWO workgroups per CU, each in its own phase: for the layers whose tiles spend as long in the prologue and the epilogue
 // (HBM) as in the reduction (MFMA) -- the short 1x1 reductions -- and for the layers with too few 256-row tiles
@@ -153,12 +155,8 @@ __global__ void __launch_bounds__(128 * WM, 2) conv_h2_kernel(const ConvParams* 
   int l_cs = s_begin / ntaps + rot, l_tap = s_begin - (s_begin / ntaps) * ntaps;
   int l_kh = l_tap / p.kw, l_kw = l_tap - l_kh * p.kw;
   bool l_src2 = false;
-  unsigned a_row[RA];
-  auto set_rows = [&]() {
-    const unsigned tapoff = (unsigned)(l_kh * p.dil * p.in_Wa + l_kw * p.dil) * pix_bytes;
-#pragma unroll
-    for (int j = 0; j < RA; ++j) a_row[j] = ((a_mask[j] >> l_tap) & 1u) ? (unsigned)a_base[j] + tapoff : kOOB;
-  };
+  unsigned tapoff = (unsigned)(l_kh * p.dil * p.in_Wa + l_kw * p.dil) * pix_bytes;     // byte offset of the stream's tap (wave-uniform)
+  // second source: its pixel offsets replace the first source's (one "tap", valid wherever the row is)
   auto set_src2 = [&]() {
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
@@ -168,15 +166,18 @@ __global__ void __launch_bounds__(128 * WM, 2) conv_h2_kernel(const ConvParams* 
       const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), r = mm - n * HoWo;
       const int ho = sfast_div(r, p.div_wo_mul, p.div_wo_sh), wo = r - ho * p.Wo;
       const unsigned pix = ((unsigned)n * p.in2_Ha + (unsigned)(ho * p.in2_stride)) * p.in2_Wa + (unsigned)(wo * p.in2_stride);
-      a_row[j] = ok ? pix * (unsigned)p.in2_ldc * 4u + a_c * 16u : kOOB;
+      a_base[j] = (int)(pix * (unsigned)p.in2_ldc * 4u + a_c * 16u);
+      a_mask[j] = ok ? 1u : 0u;
     }
+    tapoff = 0; l_tap = 0;
   };
-  set_rows();
   f32x4 ga[RA];
   auto load_a = [&]() {
 #pragma unroll
-    for (int j = 0; j < RA; ++j)
-      ga[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(l_src2 ? rs_in2 : rs_in, (int)a_row[j], l_cs * 128, 0);
+    for (int j = 0; j < RA; ++j) {
+      const unsigned off = ((a_mask[j] >> l_tap) & 1u) ? (unsigned)a_base[j] + tapoff : kOOB;
+      ga[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(l_src2 ? rs_in2 : rs_in, (int)off, l_cs * 128, 0);
+    }
     // advance
     if (l_src2) {
       ++l_cs;
@@ -189,7 +190,7 @@ __global__ void __launch_bounds__(128 * WM, 2) conv_h2_kernel(const ConvParams* 
       ++l_tap;
       if (++l_kw == p.kw) { l_kw = 0; ++l_kh; }
       if (l_tap == ntaps) { l_tap = 0; l_kh = 0; l_kw = 0; ++l_cs; }
-      set_rows();            // (harmless past the last stage: never loaded)
+      tapoff = (unsigned)(l_kh * p.dil * p.in_Wa + l_kw * p.dil) * pix_bytes;
     }
   };
   auto store_slot = [&](int abuf, int j) {
@@ -263,6 +264,8 @@ __global__ void __launch_bounds__(128 * WM, 2) conv_h2_kernel(const ConvParams* 
         if constexpr (next) rdB(b_nxt, 0, 0, bsel ^ 1);
       } else {
         rdB(b_cur, (g + 1) / TN, (g + 1) % TN, bsel ^ 1);
+        // (a single column group per k-step: the second k-step's A fragments go out with the first group's operands)
+        if (TN == 1) { rdA(a_cur, 1, 1); rdA(a_cur, 1, 0); }
       }
       ODT_FENCE();
       ODT_MF(kst, 1, 0, j, bsel); ODT_FENCE();             // lo * hi
@@ -273,9 +276,11 @@ __global__ void __launch_bounds__(128 * WM, 2) conv_h2_kernel(const ConvParams* 
         if (g == 1) { if constexpr (next) store_slot(a_nxt, 2); }
         if (g == 2) { if constexpr (pre) load_a(); }
         if (g == 3) rdA(a_cur, 1, 0);
-      } else {
+      } else if (TN == 2) {
         if (g == 0) { if constexpr (next) { store_slot(a_nxt, 0); store_slot(a_nxt, 1); } }
         if (g == 1) { if constexpr (next) { store_slot(a_nxt, 2); store_slot(a_nxt, 3); } }
+      } else {
+        if constexpr (next) { store_slot(a_nxt, 0); store_slot(a_nxt, 1); }
       }
       ODT_FENCE();
       ODT_MF(kst, 0, 1, j, bsel); ODT_FENCE();             // hi * lo
@@ -285,9 +290,12 @@ __global__ void __launch_bounds__(128 * WM, 2) conv_h2_kernel(const ConvParams* 
         if (g == 0) { if constexpr (next) store_slot(a_nxt, 1); }
         if (g == 1) { if constexpr (next) store_slot(a_nxt, 3); }
         if (g == 2) rdA(a_cur, 1, 1);
-      } else {
+      } else if (TN == 2) {
         if (g == 0) { rdA(a_cur, 1, 1); rdA(a_cur, 1, 0); }
         if (g == 1) { if constexpr (pre) load_a(); }
+      } else {
+        if constexpr (next) { store_slot(a_nxt, 2); store_slot(a_nxt, 3); }
+        if constexpr (pre) load_a();
       }
       ODT_FENCE();
       ODT_MF(kst, 0, 0, j, bsel); ODT_FENCE();             // hi * hi
@@ -529,6 +537,7 @@ __global__ void __launch_bounds__(512, 2) conv_h2k_kernel(const ConvParams* __re
         }
       } else {
         rdB(b_cur, (g + 1) / TN, (g + 1) % TN, bsel ^ 1);
+        if (TN == 1) { rdA(1, 1); rdA(1, 0); }
       }
       ODT_FENCE();
       ODT_MF(kst, 1, 0, j, bsel); ODT_FENCE();             // lo * hi
@@ -538,17 +547,19 @@ __global__ void __launch_bounds__(512, 2) conv_h2k_kernel(const ConvParams* __re
         if constexpr (gn && KWI == 2) {
           // the next group's run: registers -> LDS, in the group's third stage, two stages behind the fetch
           if (TN == 4) { if (g < 5) store_slot(a_nxt, g); }
-          else if (g < 3) { store_slot(a_nxt, 2 * g); if (2 * g + 1 < RA) store_slot(a_nxt, 2 * g + 1); }
+          else if (TN == 2) { if (g < 3) { store_slot(a_nxt, 2 * g); if (2 * g + 1 < RA) store_slot(a_nxt, 2 * g + 1); } }
+          else { store_slot(a_nxt, 0); store_slot(a_nxt, 1); store_slot(a_nxt, 2); }
         }
-        if constexpr (gn && KWI == 0) { if (g == 1) load_group(); }
+        if constexpr (gn && KWI == 0) { if (g == (TN == 1 ? 0 : 1)) load_group(); }
       }
       ODT_FENCE();
       ODT_MF(kst, 0, 1, j, bsel); ODT_FENCE();             // hi * lo
       if (last) {
         if constexpr (next) rdA_n(0);
       } else {
-        if (g == TN - 2) rdA(1, 1);
-        if (g == TN - 1) rdA(1, 0);
+        if (TN > 1 && g == TN - 2) rdA(1, 1);
+        if (TN > 1 && g == TN - 1) rdA(1, 0);
+        if constexpr (gn && KWI == 2) { if (TN == 1) { store_slot(a_nxt, 3); store_slot(a_nxt, 4); } }
       }
       ODT_FENCE();
       ODT_MF(kst, 0, 0, j, bsel); ODT_FENCE();             // hi * hi
@@ -640,8 +651,8 @@ const float* conv_h2_chinv(const void* img, int Cout, int K) {
 int conv_make_h2_weights(const ConvParams& p, void* img_dev, hipStream_t stream) {
   const int K = p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0);
   const int bn = p.wt_split_bn;
-  ODT_CHECK((bn == 256 || bn == 128) && p.Cin % 32 == 0 && (p.in2 == nullptr || p.Cin2 % 32 == 0) && cout_padded(p.Cout) % bn == 0,
-            "conv_make_h2_weights: 256- / 128-wide n-tiles and 32-channel slices required");
+  ODT_CHECK((bn == 256 || bn == 128 || bn == 64) && p.Cin % 32 == 0 && (p.in2 == nullptr || p.Cin2 % 32 == 0) && cout_padded(p.Cout) % bn == 0,
+            "conv_make_h2_weights: 256- / 128- / 64-wide n-tiles and 32-channel slices required");
   float* chinv = const_cast<float*>(conv_h2_chinv(img_dev, p.Cout, K));
   hipLaunchKernelGGL(h2_rowscale_kernel, dim3((unsigned)cout_padded(p.Cout)), dim3(256), 0, stream, p.wt, p.Cout, K, chinv);
   const long total = (long)cout_padded(p.Cout) * (K >> 5) * 4;
@@ -662,7 +673,7 @@ int launch_conv_h2(const ConvParams& p, const ConvParams* dev, hipStream_t strea
   const long M = (long)p.B * p.Ho * p.Wo;
   const int bn = p.wt_split_bn;
   const int bm = p.wt_split_bm;
-  ODT_CHECK((bm == 256 || (bm == 128 && bn == 128 && !p.wt_split_kwr)) && (bn == 256 || bn == 128) && p.Cin % 32 == 0 && p.kh * p.kw <= 32 && p.in_amax != nullptr &&
+  ODT_CHECK(((bm == 256 && (bn >= 128 || p.wt_split_kwr)) || (bm == 128 && bn <= 128 && !p.wt_split_kwr)) && (bn == 256 || bn == 128 || bn == 64) && p.Cin % 32 == 0 && p.kh * p.kw <= 32 && p.in_amax != nullptr &&
             p.h2_chinv != nullptr && (p.in2 == nullptr || (p.in2_amax != nullptr && p.Cin2 % 32 == 0)) && p.nlvl <= 1,
             "conv h2: unsupported tile / shape, or no recorded input range");
   const int sk = p.splitk > 1 ? p.splitk : 1;
@@ -674,9 +685,13 @@ int launch_conv_h2(const ConvParams& p, const ConvParams* dev, hipStream_t strea
     if (bn == 256) {
       if (p.trace != nullptr) hipLaunchKernelGGL((conv_h2k_kernel<4, true>), dim3(grid), dim3(512), 0, stream, dev);
       else hipLaunchKernelGGL((conv_h2k_kernel<4, false>), dim3(grid), dim3(512), 0, stream, dev);
-    } else {
+    } else if (bn == 128) {
       hipLaunchKernelGGL((conv_h2k_kernel<2, false>), dim3(grid), dim3(512), 0, stream, dev);
+    } else {
+      hipLaunchKernelGGL((conv_h2k_kernel<1, false>), dim3(grid), dim3(512), 0, stream, dev);
     }
+  } else if (bn == 64) {
+    hipLaunchKernelGGL((conv_h2_kernel<1, 2, false>), dim3(grid), dim3(256), 0, stream, dev);
   } else if (bn == 256) {
     if (p.trace != nullptr) hipLaunchKernelGGL((conv_h2_kernel<4, 4, true>), dim3(grid), dim3(512), 0, stream, dev);
     else hipLaunchKernelGGL((conv_h2_kernel<4, 4, false>), dim3(grid), dim3(512), 0, stream, dev);

@@ -96,6 +96,7 @@ ConvPolicy conv_policy_default() {
   q.min_k = 64;           // A/B at b=8: K >= 256: 155.0, >= 128: 156.2, >= 64: 156.6 FPS
   q.h2s_maxk = 0;         // fp16x2: reductions up to this K take the 128 x 128 two-per-CU tile (A/B knob; measured: no gain)
   q.h2_few_tiles = true;  // fp16x2: layers without enough 256-row tiles take 128 x 128 tiles instead of bf16x3 + split-K
+  q.h2_n64 = true;        // fp16x2: the 64-wide layers too
   q.min_bn = 0; q.force_bm3 = 0; q.splitk_max = 8; q.force_splitk = 0; q.kw_reuse = true; q.kwr_n64 = true; q.src2 = true; q.res2 = true; q.env_overrides = 0;
   return q;
 }
@@ -114,6 +115,7 @@ ConvPolicy conv_policy_from_env(ConvPolicy q) {
   v = q.min_bn; geti("ODT_CONV_SPLIT_MINBN", &v); q.min_bn = (int)v;
   v = q.h2s_maxk; geti("ODT_CONV_H2S_MAXK", &v); q.h2s_maxk = (int)v;
   v = q.h2_few_tiles; geti("ODT_CONV_H2_FEW_TILES", &v); q.h2_few_tiles = v != 0;
+  v = q.h2_n64; geti("ODT_CONV_H2_N64", &v); q.h2_n64 = v != 0;
   v = q.force_bm3; geti("ODT_CONV_SPLIT3_BM", &v); q.force_bm3 = (int)v;
   v = q.splitk_max; geti("ODT_CONV_SPLIT3_SPLITK", &v); q.splitk_max = v < 1 ? 1 : (v > 16 ? 16 : (int)v);
   v = 1; geti("ODT_CONV_SPLIT3_KWR", &v); q.kw_reuse = v != 0;
@@ -187,15 +189,18 @@ void conv_split_choose(ConvParams& p, const ConvPolicy& q) {
     p.wt_split_kwr = (q.kw_reuse && b3 == 256 && k3 == 1 && (n3 >= 128 || q.kwr_n64) && p.kw == 3 && p.stride == 1 && p.in_Wa == p.Wo &&
                       p.in2 == nullptr && 2 * p.dil <= 4 && p.Ho * p.Wo >= 256 && p.kh * 3 <= 30) ? 1 : 0;
     // fp16x2 pieces: tiles at least 128 wide whose source tensor(s) come with a recorded |max|
-    if (q.family == 2 && n3 >= 128 && p.in_amax != nullptr && (p.in2 == nullptr || (p.in2_amax != nullptr && p.Cin2 % 32 == 0)) &&
+    if (q.family == 2 && (n3 >= 128 || q.h2_n64) && p.in_amax != nullptr && (p.in2 == nullptr || (p.in2_amax != nullptr && p.Cin2 % 32 == 0)) &&
         p.Cin % 32 == 0 && p.nlvl <= 1 && p.lvl_scale == nullptr && p.head_wt == nullptr) {
       const long t128 = ((M + 127) / 128) * (cout_padded(p.Cout) / 128);
-      if (b3 == 256 && (K >> 5) >= k3) {
+      if (n3 == 64 && !p.wt_split_kwr) {
+        // (a forced tile height took a 64-wide layer past the size rule below: same choice as there)
+        if (q.h2_n64 && p.in2 == nullptr) { p.wt_split_kind = 2; p.wt_split_bm = 128; p.wt_split_bn = 64; p.splitk = 1; }
+      } else if (b3 == 256 && (K >> 5) >= k3) {
         p.wt_split_kind = 2;
         // (A/B knob, off: short reductions on 128 x 128 tiles, two workgroups per CU in different phases -- measured no gain:
         // res4 conv3 4.28 -> 4.38 ms, res2 / res3 conv3 and the laterals 3-12 % slower, profiles/r03_h2_small_tile_ab.txt)
         if (!p.wt_split_kwr && k3 == 1 && K <= q.h2s_maxk && t128 >= q.min_tiles3) { p.wt_split_bm = 128; p.wt_split_bn = 128; }
-      } else if (b3 == 128 && q.h2_few_tiles) {
+      } else if (b3 == 128 && n3 >= 128 && q.h2_few_tiles) {
         // too few 256-row tiles (res5, P5 at b=8; everything below res3 at b=1): 128 x 128 tiles on 4 waves -- without split-K
         // where they fill the chip (res5 conv2 0.690 -> 0.465 ms, conv1 0.338 -> 0.219, same file), else with the reduction
         // cut into ranges (at least four 32-channel stages each)
@@ -212,6 +217,12 @@ void conv_split_choose(ConvParams& p, const ConvPolicy& q) {
       }
     }
     return;
+  }
+  // the 64-wide layers outside the kw-reuse kernel (conv0, res2 conv1): fp16x2 pieces on 128 x 64 tiles of 4 waves (three
+  // workgroups per CU) instead of the one-stage bf16x3 loop
+  if (q.family == 2 && q.h2_n64 && bn == 64 && p.in_amax != nullptr && p.in2 == nullptr && p.Cin % 32 == 0 && p.nlvl <= 1 &&
+      p.lvl_scale == nullptr && p.head_wt == nullptr && p.kh * p.kw <= 32 && ((M + 127) / 128) * (cout_padded(p.Cout) / 64) >= q.min_tiles) {
+    p.wt_split_kind = 2; p.wt_split_bm = 128; p.wt_split_bn = 64;
   }
 }
 

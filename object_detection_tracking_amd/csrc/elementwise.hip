@@ -8,11 +8,23 @@
 namespace odt {
 namespace {
 
+// a wave's maximum into the tensor's range slot (f32 bit pattern of a non-negative value; see ConvParams::out_amax)
+__device__ __forceinline__ void record_amax(unsigned* slot, float vmax) {
+  if (slot == nullptr) return;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned b = __float_as_uint(vmax);
+    if (b > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, b);
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) preprocess_kernel(const T* __restrict__ frames, int B, int H,
                                                          int W, int pad_t, int pad_l, int Hp, int Wp,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, unsigned* __restrict__ amax) {
   const long total = (long)B * Hp * Wp;
+  float vmax = 0.f;                      // |max| of what this thread writes (the fp16x2 conv kernels' range record)
   // BGR mean / std (models.py:343-351: RGB constants reversed)
   const float mean0 = 0.406f, mean1 = 0.456f, mean2 = 0.485f;
   const float std0 = 0.225f, std1 = 0.224f, std2 = 0.229f;
@@ -32,7 +44,9 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const T* __restrict__ f
       v[2] = ((float)src[2] * inv255 - mean2) / std2;
     }
     *reinterpret_cast<f32x4*>(out + i * 4) = v;
+    vmax = fmaxf(vmax, fmaxf(fabsf(v[0]), fmaxf(fabsf(v[1]), fabsf(v[2]))));
   }
+  record_amax(amax, vmax);
 }
 
 // Same, with the reference's host-side frame resize (nn.py:1540-1546: cv2.resize(frame.astype
@@ -44,8 +58,10 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const T* __restrict__ f
 template <typename T>
 __global__ void __launch_bounds__(256) preprocess_resize_kernel(const T* __restrict__ frames, int B, int Hs,
                                                                 int Ws, int H, int W, int pad_t, int pad_l,
-                                                                int Hp, int Wp, float* __restrict__ out) {
+                                                                int Hp, int Wp, float* __restrict__ out,
+                                                                unsigned* __restrict__ amax) {
   const long total = (long)B * Hp * Wp;
+  float vmax = 0.f;
   const float mean0 = 0.406f, mean1 = 0.456f, mean2 = 0.485f;
   const float std0 = 0.225f, std1 = 0.224f, std2 = 0.229f;
   const float inv255 = (float)(1.0 / 255);
@@ -84,7 +100,9 @@ __global__ void __launch_bounds__(256) preprocess_resize_kernel(const T* __restr
       v[2] = (px[2] * inv255 - mean2) / std2;
     }
     *reinterpret_cast<f32x4*>(out + i * 4) = v;
+    vmax = fmaxf(vmax, fmaxf(fabsf(v[0]), fmaxf(fabsf(v[1]), fabsf(v[2]))));
   }
+  record_amax(amax, vmax);
 }
 
 // one thread per (pixel, 4-channel group); channels contiguous -> 16-byte accesses
@@ -156,15 +174,15 @@ inline unsigned grid_for(long total) {
 }  // namespace
 
 int launch_preprocess_resize(const void* frames, int dtype, int B, int Hs, int Ws, int H, int W, int pad_t,
-                             int pad_l, int Hp, int Wp, float* out, hipStream_t stream) {
+                             int pad_l, int Hp, int Wp, float* out, hipStream_t stream, unsigned* amax) {
   const long total = (long)B * Hp * Wp;
   ODT_CHECK(Hs > 0 && Ws > 0, "preprocess: empty source frame");
   if (dtype == 0) {
     hipLaunchKernelGGL(preprocess_resize_kernel<unsigned char>, dim3(grid_for(total)), dim3(256), 0, stream,
-                       (const unsigned char*)frames, B, Hs, Ws, H, W, pad_t, pad_l, Hp, Wp, out);
+                       (const unsigned char*)frames, B, Hs, Ws, H, W, pad_t, pad_l, Hp, Wp, out, amax);
   } else if (dtype == 1) {
     hipLaunchKernelGGL(preprocess_resize_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream,
-                       (const float*)frames, B, Hs, Ws, H, W, pad_t, pad_l, Hp, Wp, out);
+                       (const float*)frames, B, Hs, Ws, H, W, pad_t, pad_l, Hp, Wp, out, amax);
   } else {
     set_error("preprocess: dtype must be ODT_DTYPE_U8 or ODT_DTYPE_F32");
     return 1;
@@ -174,14 +192,14 @@ int launch_preprocess_resize(const void* frames, int dtype, int B, int Hs, int W
 }
 
 int launch_preprocess(const void* frames, int dtype, int B, int H, int W, int pad_t, int pad_l,
-                      int Hp, int Wp, float* out, hipStream_t stream) {
+                      int Hp, int Wp, float* out, hipStream_t stream, unsigned* amax) {
   const long total = (long)B * Hp * Wp;
   if (dtype == 0) {
     hipLaunchKernelGGL(preprocess_kernel<unsigned char>, dim3(grid_for(total)), dim3(256), 0, stream,
-                       (const unsigned char*)frames, B, H, W, pad_t, pad_l, Hp, Wp, out);
+                       (const unsigned char*)frames, B, H, W, pad_t, pad_l, Hp, Wp, out, amax);
   } else if (dtype == 1) {
     hipLaunchKernelGGL(preprocess_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream,
-                       (const float*)frames, B, H, W, pad_t, pad_l, Hp, Wp, out);
+                       (const float*)frames, B, H, W, pad_t, pad_l, Hp, Wp, out, amax);
   } else {
     set_error("preprocess: dtype must be ODT_DTYPE_U8 or ODT_DTYPE_F32");
     return 1;

@@ -120,6 +120,7 @@ struct ConvPolicy {
   int min_k, min_bn;    // shortest reduction / narrowest n-tile taken
   int h2s_maxk;         // fp16x2: longest reduction that takes the 128 x 128 4-wave tile (two workgroups per CU); 0: none
   bool h2_few_tiles;    // fp16x2: 128 x 128 tiles for the layers without enough 256-row tiles
+  bool h2_n64;          // fp16x2: also the 64-wide layers (128 x 64 tiles on 4 waves; the kw-reuse kernel's 256 x 64 tile)
   int force_bm3;        // 0 auto | 128 | 256: force conv_split3_kernel with that tile height (tests)
   int splitk_max;       // conv_split3_kernel: largest split-K factor the policy may choose (1 = off)
   bool kw_reuse;        // conv_split3k_kernel for the stride-1 KH x 3 layers it fits (ODT_CONV_SPLIT3_KWR=0: off)
@@ -154,10 +155,11 @@ int launch_tensor_amax(const float* x, size_t n, unsigned* slot, hipStream_t str
 size_t conv_split_partial_bytes(const ConvParams& p);   // scratch a split-K conv needs (0: none)
 
 // ------------------------------------------------------------ elementwise (K1,K4)
+// (amax: optional range slot of the output tensor -- the |max| of what is written goes there, see ConvParams::in_amax)
 int launch_preprocess(const void* frames, int dtype, int B, int H, int W, int pad_t, int pad_l,
-                      int Hp, int Wp, float* out, hipStream_t stream);
+                      int Hp, int Wp, float* out, hipStream_t stream, unsigned* amax = nullptr);
 int launch_preprocess_resize(const void* frames, int dtype, int B, int Hs, int Ws, int H, int W, int pad_t,
-                             int pad_l, int Hp, int Wp, float* out, hipStream_t stream);
+                             int pad_l, int Hp, int Wp, float* out, hipStream_t stream, unsigned* amax = nullptr);
 int launch_maxpool3x3s2(const float* in, int B, int H, int W, int C, float* out, int Ho, int Wo,
                         hipStream_t stream);
 

@@ -100,6 +100,7 @@ struct odt_model {
   unsigned* amax_dev = nullptr;
   int amax_used[2] = {0, 0};
   int convs_h2 = 0;                  // convs on the fp16x2 kernels
+  unsigned* pre_amax = nullptr;      // range slot of the preprocessed frames (OP_PRE records it; conv0 reads it)
   std::vector<Op> ops;
   // geometry
   int Hp = 0, Wp = 0;

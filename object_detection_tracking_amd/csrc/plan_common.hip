@@ -208,6 +208,12 @@ int attach_split_weights(odt_model* m) {
   for (size_t oi = 0; oi < m->ops.size(); ++oi) {
     const Op& op = m->ops[oi];
     const bool tail = m->op_tail > 0 && oi >= m->op_tail;
+    if (op.kind == OP_PRE && pol.family == 2) {        // the preprocess kernel records the range of the padded frames
+      ODT_CHECK(m->amax_used[0] < odt_model::kAmaxSlots, "too many conv outputs for the range slots");
+      slot_of[m->image_pad.d] = m->amax_used[0];
+      m->pre_amax = m->amax_dev + m->amax_used[0]++;
+      continue;
+    }
     if (op.kind == OP_POOL || op.kind == OP_SUB2) {
       auto it = slot_of.find(op.in.d);
       if (it != slot_of.end()) slot_of[op.out.d] = it->second; else slot_of.erase(op.out.d);

@@ -27,9 +27,9 @@ static int run_ops(odt_model* m, const void* src, int dtype, hipStream_t st, siz
     switch (op.kind) {
       case OP_PRE:
         if (m->src_h == cfg.height && m->src_w == cfg.width) {
-          if (launch_preprocess(src, dtype, cfg.batch, cfg.height, cfg.width, 3, 3, m->Hp, m->Wp, m->image_pad.d, st)) return 1;
+          if (launch_preprocess(src, dtype, cfg.batch, cfg.height, cfg.width, 3, 3, m->Hp, m->Wp, m->image_pad.d, st, m->pre_amax)) return 1;
         } else if (launch_preprocess_resize(src, dtype, cfg.batch, m->src_h, m->src_w, cfg.height, cfg.width, 3, 3,
-                                            m->Hp, m->Wp, m->image_pad.d, st)) {
+                                            m->Hp, m->Wp, m->image_pad.d, st, m->pre_amax)) {
           return 1;
         }
         break;
