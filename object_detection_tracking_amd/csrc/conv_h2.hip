@@ -118,6 +118,7 @@ __global__ void __launch_bounds__(128 * WM, 2) conv_h2_kernel(const ConvParams* 
     l_b += (unsigned)STAGE_B;
     if (--b_wrap == 0) l_b -= (unsigned)nsteps * (unsigned)STAGE_B;
   };
+  dma_b(BOFF);                               // stage 0's weights: requested before the per-row address set-up below
 
   // ---- activations: thread -> (row (t >> 3) + (threads / 8) j, 16-byte column t & 7): eight lanes cover the 128 contiguous
   // bytes (32 channels) of a row's stage.  Per row: the byte offset of the tap-(0,0) input pixel and a bit per tap
@@ -172,11 +173,14 @@ __global__ void __launch_bounds__(128 * WM, 2) conv_h2_kernel(const ConvParams* 
     tapoff = 0; l_tap = 0;
   };
   f32x4 ga[RA];
+  // A/B: a 1x1 layer with one n-tile reads every activation byte once, by one workgroup: non-temporal hint on those loads
+  const bool a_nt = (p.debug & 0x800) != 0 && ntn == 1 && ntaps == 1;
   auto load_a = [&]() {
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
       const unsigned off = ((a_mask[j] >> l_tap) & 1u) ? (unsigned)a_base[j] + tapoff : kOOB;
-      ga[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(l_src2 ? rs_in2 : rs_in, (int)off, l_cs * 128, 0);
+      ga[j] = a_nt ? (f32x4)__builtin_amdgcn_raw_buffer_load_b128(l_src2 ? rs_in2 : rs_in, (int)off, l_cs * 128, 2)
+                   : (f32x4)__builtin_amdgcn_raw_buffer_load_b128(l_src2 ? rs_in2 : rs_in, (int)off, l_cs * 128, 0);
     }
     // advance
     if (l_src2) {
@@ -213,7 +217,6 @@ __global__ void __launch_bounds__(128 * WM, 2) conv_h2_kernel(const ConvParams* 
   const int fr = lane & 31, fg = lane >> 5;
   // ---- prologue: stage 0 complete, stage 1's A in registers, its weights in flight behind the barrier
   load_a();
-  dma_b(BOFF);
   stamp(6);
 #pragma unroll
   for (int j = 0; j < RA; ++j) store_slot(0, j);
@@ -393,6 +396,7 @@ __global__ void __launch_bounds__(512, 2) conv_h2k_kernel(const ConvParams* __re
                                                lane * 16 + (i * 8 + wave) * 1024, (int)l_b, 0, 0);
     l_b += (unsigned)STAGE_B;
   };
+  dma_b(BOFF);                               // stage 0's weights: requested before the address set-up below
 
   // ---- the tile's two runs of input pixels (tap (kh, 0) of row r: run0 for r < len0, run1 behind it)
   const int pix_bytes = p.in_ldc * 4;
@@ -470,7 +474,6 @@ __global__ void __launch_bounds__(512, 2) conv_h2k_kernel(const ConvParams* __re
 
   // ---- prologue: group 0 staged, B stage 0 landed, stage 1's DMA in flight behind the barrier
   load_group();
-  dma_b(BOFF);
   stamp(6);
 #pragma unroll
   for (int j = 0; j < RA; ++j) store_slot(0, j);

@@ -129,11 +129,15 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams* __
 
   f32x4 ga[RA];
   u32x4 gb[NB];
+  // a 1x1 layer with one n-tile reads every activation byte once, by one workgroup: non-temporal hint (ConvParams::debug 0x800,
+  // set by the plan; see conv_h2.hip)
+  const bool a_nt = (p.debug & 0x800) != 0 && ntn == 1 && p.kh * p.kw == 1;
   const int b_st = (tid / SBN) * BKG + (tid % SBN) * 16;   // this thread's place inside a 256-chunk run
   auto load_slice = [&]() {
 #pragma unroll
     for (int j = 0; j < RA; ++j)
-      ga[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(l_src2 ? rs_in2 : rs_in, (int)a_row[j], l_cc * 128, 0);
+      ga[j] = a_nt ? (f32x4)__builtin_amdgcn_raw_buffer_load_b128(l_src2 ? rs_in2 : rs_in, (int)a_row[j], l_cc * 128, 2)
+                   : (f32x4)__builtin_amdgcn_raw_buffer_load_b128(l_src2 ? rs_in2 : rs_in, (int)a_row[j], l_cc * 128, 0);
 #pragma unroll
     for (int i = 0; i < NB; ++i)
       gb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, tid * 16 + i * 4096, (int)l_b, 0);

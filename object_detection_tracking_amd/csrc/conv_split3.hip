@@ -172,10 +172,12 @@ __global__ void __launch_bounds__(512, 2) conv_split3_kernel(const ConvParams* _
   };
   set_rows();
   f32x4 ga[RA];
+  const bool a_nt = (p.debug & 0x800) != 0 && ntn == 1 && ntaps == 1;     // single-use activations: non-temporal hint (see conv_h2.hip)
   auto load_a = [&]() {
 #pragma unroll
     for (int j = 0; j < RA; ++j)
-      ga[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(l_src2 ? rs_in2 : rs_in, (int)a_row[j], l_cs * 64, 0);
+      ga[j] = a_nt ? (f32x4)__builtin_amdgcn_raw_buffer_load_b128(l_src2 ? rs_in2 : rs_in, (int)a_row[j], l_cs * 64, 2)
+                   : (f32x4)__builtin_amdgcn_raw_buffer_load_b128(l_src2 ? rs_in2 : rs_in, (int)a_row[j], l_cs * 64, 0);
     // advance
     if (l_src2) {
       ++l_cs;

@@ -162,6 +162,9 @@ __device__ __forceinline__ void split3_epilogue(const ConvParams& p, f32x16 (&ac
   }
   // (no barrier needed here: the last stage's barrier sits behind every fragment read of the ring)
   float vmax = 0.f;                          // |max| of what this thread stores (out_amax)
+  const bool res_nt = (p.debug & 0x400) != 0;      // A/B: residual chunks (read once, by this workgroup only) with the non-temporal hint
+  // A/B: outputs larger than the last-level cache (>= 128 MB: the 1024-channel res4 tensors, the res2 / P2 ones) stored non-temporally
+  const bool out_nt = (p.debug & 0x1000) != 0 && (double)p.B * p.out_H * p.out_W * p.out_ldc * 4.0 >= 134217728.0;
   auto run = [&](auto act_c, auto res_c) {
     constexpr int ACT = decltype(act_c)::value;
     constexpr bool RES = decltype(res_c)::value;
@@ -184,7 +187,8 @@ __device__ __forceinline__ void split3_epilogue(const ConvParams& p, f32x16 (&ac
         }
         ooff[s2] = ok ? (opix * p.out_ldc + col) * 4u : kOOB;
         if constexpr (RES)
-          rres[s2] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_res, ok ? (int)((rpix * p.res_ldc + col) * 4u) : (int)kOOB, 0, 0);
+          rres[s2] = res_nt ? (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_res, ok ? (int)((rpix * p.res_ldc + col) * 4u) : (int)kOOB, 0, 2)
+                            : (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_res, ok ? (int)((rpix * p.res_ldc + col) * 4u) : (int)kOOB, 0, 0);
       }
       if (pass > 0) ODT_BARRIER_LDS();        // the previous pass has been read
       if (wm / WPP == pass) {
@@ -214,7 +218,8 @@ __device__ __forceinline__ void split3_epilogue(const ConvParams& p, f32x16 (&ac
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
         }
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)ooff[s2], 0, 0);
+        if (out_nt) __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)ooff[s2], 0, 2);
+        else __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)ooff[s2], 0, 0);
         if (ooff[s2] != kOOB) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
       }
       if (pass == 0) ODT_STAMP(4);

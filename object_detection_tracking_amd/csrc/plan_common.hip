@@ -235,6 +235,15 @@ int attach_split_weights(odt_model* m) {
       it = made.emplace(key, img).first;
     }
     c.p.wt_split = it->second;
+    {
+      // non-temporal hints on the loads of data that one workgroup reads once -- residual chunks (1), the activations of a 1x1
+      // layer with a single n-tile (2) -- keep them from pushing the weights and the re-read tensors out of L2 / MALL: same-box
+      // A/B at b=8 1080p 30.8 -> 29.8 ms of conv time, res4 conv1 275 -> 317 TF (profiles/r03_h2_nt_ab.txt; 4: large-output
+      // stores, measured no gain).  ODT_CONV_NT overrides the mask (A/B).
+      int nt = 3;
+      if (const char* e = getenv("ODT_CONV_NT")) nt = atoi(e);
+      c.p.debug |= (nt & 7) << 10;
+    }
     if (c.p.wt_split_kind == 2) {
       c.p.h2_chinv = conv_h2_chinv(c.p.wt_split, c.p.Cout, K); ++m->convs_h2;
       static const bool norot = getenv("ODT_CONV_H2_ROT") != nullptr && getenv("ODT_CONV_H2_ROT")[0] == '0';
