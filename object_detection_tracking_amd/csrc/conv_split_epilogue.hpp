@@ -19,6 +19,26 @@ __device__ __forceinline__ void publish_amax(unsigned* slot, float vmax, int tid
   }
 }
 
+// ... once per workgroup: the waves' maxima meet in LDS (two barriers), thread 0 folds them into the slot -- an eighth of the
+// slot reads, and of the same-address atomics of a layer's first round of tiles (every wave of it finds the slot empty)
+template <int NTHR>
+__device__ __forceinline__ void publish_amax_wg(unsigned* slot, float vmax, int tid, unsigned char* lds) {
+  if (slot == nullptr) return;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
+  float* red = reinterpret_cast<float*>(lds);
+  ODT_BARRIER_LDS();                                   // the last pass of the C tile has been read
+  if ((tid & 63) == 0) red[tid >> 6] = vmax;
+  ODT_BARRIER_LDS();
+  if (tid == 0) {
+    float m = red[0];
+#pragma unroll
+    for (int w = 1; w < NTHR / 64; ++w) m = fmaxf(m, red[w]);
+    const unsigned b = __float_as_uint(m);
+    if (b > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, b);
+  }
+}
+
 // Epilogue shared by the conv_split3 kernels: accumulators of the 8 waves (wave tile 64 x 32 TN at (wm, wn)) -> LDS ->
 // rows of 16-byte chunks -> bias (+ residual) + activation -> global, or the raw partial tile of a split-K range.
 template <int WM, int WN, int TN, int LDSB, bool TRACE, int NTHR = 512>
@@ -236,7 +256,8 @@ __device__ __forceinline__ void split3_epilogue(const ConvParams& p, f32x16 (&ac
     else if (p.relu == 2) run(std::integral_constant<int, 2>{}, std::false_type{});
     else run(std::integral_constant<int, 3>{}, std::false_type{});
   }
-  publish_amax(p.out_amax, vmax, tid);
+  if ((p.debug & 0x4000) != 0) publish_amax(p.out_amax, vmax, tid);       // A/B: one record per wave
+  else publish_amax_wg<NTHR>(p.out_amax, vmax, tid, lds);
 }
 
 }  // namespace

@@ -244,6 +244,10 @@ int attach_split_weights(odt_model* m) {
       if (const char* e = getenv("ODT_CONV_NT")) nt = atoi(e);
       c.p.debug |= (nt & 7) << 10;
     }
+    {
+      static const bool per_wave = getenv("ODT_AMAX_PER_WAVE") != nullptr && getenv("ODT_AMAX_PER_WAVE")[0] == '1';
+      if (per_wave) c.p.debug |= 0x4000;      // A/B: range record per wave instead of per workgroup
+    }
     if (c.p.wt_split_kind == 2) {
       c.p.h2_chinv = conv_h2_chinv(c.p.wt_split, c.p.Cout, K); ++m->convs_h2;
       static const bool norot = getenv("ODT_CONV_H2_ROT") != nullptr && getenv("ODT_CONV_H2_ROT")[0] == '0';
