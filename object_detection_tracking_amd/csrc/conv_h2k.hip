@@ -1,0 +1,300 @@
+// conv_h2k_kernel: the kw-reuse kernel of the fp16x2 family (see conv_h2.hip for the family's arithmetic and loop structure; a
+// translation unit of its own: the two kernels' instantiations compile in parallel).
+#include "conv_split_epilogue.hpp"
+
+namespace odt {
+
+namespace {
+
+#define ODT_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define ODT_MF(kst, qa, qb, j, bsel) { acc[0][j] = ODT_MFMA_F16(fa[kst][qa][0], fb[bsel][qb], acc[0][j]); \
+                                        acc[1][j] = ODT_MFMA_F16(fa[kst][qa][1], fb[bsel][qb], acc[1][j]); }
+#define ODT_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// ---------------------------------------------------------------------------------------------------------
+// conv_h2k_kernel: conv_h2_kernel for stride-1 KH x 3 convs whose input rows have the output's pitch (in_Wa == Wo: the 3x3
+// layers of res3 / res4 / res5, the FPN post-hoc and RPN convs).  A group = (32-channel slice, kh): its three stages (kw =
+// 0, 1, 2) read ONE staged run of input pixels at row offsets 0, dil, 2 dil (conv_split3k_kernel's scheme):
+//   * the 256 output pixels of a tile are consecutive in (n, ho, wo); within an image their tap-(kh, 0) input pixels are
+//     consecutive too, so a group's stage is the run [first - pad_l, last - pad_l + 2 dil]; a tile that crosses an image
+//     boundary stages two runs back to back (capacity 256 + 2 x 2 dil rows);
+//   * taps outside the image read a zero row of the stage: a per-lane 9-bit validity mask picks the fragment address;
+//   * A: two buffers (this group / next group); the next group's fetch (5 x 16 B per thread) is issued in the group's first
+//     stage and split + stored in its third; B: the two-deep DMA ring of conv_h2_kernel.
+template <int TN>
+struct H2kCfg {
+  static constexpr int BM = 256, BN = 64 * TN;
+  static constexpr int PR = 272;                             // stage rows: 256 + 2 runs x 2 dil (dil <= 2) + the zero row, padded
+  static constexpr int ZR = PR - 1;                          // the zero row
+  static constexpr int AKG = PR * 16 + 32, APL = 4 * AKG, ABUF = 2 * APL;   // (32-B pad: see H2Cfg)
+  static constexpr int BKG = BN * 16, BPL = 4 * BKG, STAGE_B = 2 * BPL;
+  static constexpr int BOFF = 2 * ABUF;
+  static constexpr int RING = BOFF + 2 * STAGE_B;
+  static constexpr int CTILE = 128 * (BN + 4) * 4;
+  static constexpr int LDS = RING > CTILE ? RING : CTILE;
+  static constexpr int NW = STAGE_B / 1024 / 8;
+  static constexpr int RA = 5;                               // A fetch instructions per thread and group (rows t >> 3 + 64 j)
+  static_assert(LDS <= 160 * 1024 && STAGE_B % 8192 == 0, "LDS");
+};
+
+template <int TN, bool TRACE = false>
+__global__ void __launch_bounds__(512, 2) conv_h2k_kernel(const ConvParams* __restrict__ pp) {
+  using G = H2kCfg<TN>;
+  constexpr int WM = 4, WN = 2, KW = 3;
+  constexpr int BM = G::BM, BN = G::BN, AKG = G::AKG, APL = G::APL, ABUF = G::ABUF, BKG = G::BKG, BPL = G::BPL;
+  constexpr int STAGE_B = G::STAGE_B, BOFF = G::BOFF, NW = G::NW, ZR = G::ZR, RA = G::RA;
+  const ConvParams p = *pp;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  auto stamp = [&](int i) {
+    if constexpr (TRACE) {
+      if (tid == 0) p.trace[(size_t)blockIdx.x * 16 + i] = wall_clock64();
+    }
+  };
+  stamp(0);
+  if constexpr (TRACE) {
+    if (tid == 0) {
+      p.trace[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+      p.trace[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+  }
+  const int ntn = cout_padded(p.Cout) / BN;
+  int wg = (int)blockIdx.x;
+  {
+    const int nwg = (int)gridDim.x, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  const int mt = wg / ntn, nt = wg - mt * ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int HoWo = p.Ho * p.Wo;
+  const int M = p.B * HoWo;
+  const int cpt = p.Cin >> 5;
+  const int nsteps = p.kh * KW * cpt, ngroups = p.kh * cpt;
+  const int halo = (KW - 1) * p.dil;
+  const int sexp = h2_in_scale_exp(p);
+  const float a_scale = pow2f(sexp), h2_inv = pow2f(-sexp);
+
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.in, 0, (int)((unsigned)p.B * p.in_Ha * p.in_Wa * p.in_ldc * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.wt_split, 0, (int)((unsigned)ntn * nsteps * (unsigned)STAGE_B), 0x00020000);
+
+  unsigned l_b = (unsigned)nt * (unsigned)nsteps * (unsigned)STAGE_B;
+  auto dma_b = [&](int boff) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, ODT_LDS_PTR(lds + boff + (i * 8 + wave) * 1024), 16,
+                                               lane * 16 + (i * 8 + wave) * 1024, (int)l_b, 0, 0);
+    l_b += (unsigned)STAGE_B;
+  };
+  dma_b(BOFF);                               // stage 0's weights: requested before the address set-up below
+
+  // ---- the tile's two runs of input pixels (tap (kh, 0) of row r: run0 for r < len0, run1 behind it)
+  const int pix_bytes = p.in_ldc * 4;
+  const int n_first = sfast_div(m0, p.div_howo_mul, p.div_howo_sh), r_img = m0 - n_first * HoWo;
+  const int len0 = HoWo - r_img < BM ? HoWo - r_img : BM;
+  const int pix0 = (n_first * p.in_Ha - p.pad_t) * p.in_Wa + r_img - p.pad_l;          // (pitch == Wo: r_img = ho * Wo + wo)
+  const int pix1 = ((n_first + 1) * p.in_Ha - p.pad_t) * p.in_Wa - p.pad_l;
+  // loader: thread -> stage row (t >> 3) + 64 j, 16-byte column t & 7 (eight lanes: the 128 bytes of a row's 32 channels)
+  const int a_c = tid & 7, a_r = tid >> 3;
+  int a_base[RA];
+#pragma unroll
+  for (int j = 0; j < RA; ++j) {
+    const int pr = a_r + 64 * j;
+    const int pix = pr < len0 + halo ? pix0 + pr : pix1 + (pr - len0 - halo);
+    a_base[j] = pr < BM + 2 * halo ? pix * pix_bytes + a_c * 16 : (int)kOOB;
+  }
+  int l_cs = 0, l_kh = 0;                    // next group to fetch
+  f32x4 ga[RA];
+  auto load_group = [&]() {
+    const int khoff = l_kh * p.dil * p.in_Wa * pix_bytes;
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+      const unsigned v = (unsigned)a_base[j] == kOOB ? kOOB : (unsigned)(a_base[j] + khoff);
+      ga[j] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)v, l_cs * 128, 0);
+    }
+    if (++l_kh == p.kh) { l_kh = 0; ++l_cs; }
+  };
+  auto store_slot = [&](int abuf, int j) {
+    const int pr = a_r + 64 * j;
+    if (pr < BM + 2 * halo) {
+      unsigned h0, l0, h1, l1;
+      split2h(ga[j][0], ga[j][1], a_scale, h0, l0);
+      split2h(ga[j][2], ga[j][3], a_scale, h1, l1);
+      unsigned char* d = lds + abuf + (a_c >> 1) * AKG + pr * 16 + (a_c & 1) * 8;
+      *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(d + APL) = u32x2{l0, l1};
+    }
+  };
+  // the zero rows of both A buffers (never overwritten: stage rows stop at 256 + 2 halo <= ZR)
+  if (tid < 16) {
+    const int b = tid >> 3, q = (tid >> 2) & 1, kg = tid & 3;
+    *reinterpret_cast<u32x4*>(lds + b * ABUF + q * APL + kg * AKG + ZR * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+
+  // ---- fragment rows of this lane: stage row of (row, tap kw = 0) and the 9-bit tap validity
+  const int fr = lane & 31, fg = lane >> 5;
+  int fa_base[2];
+  unsigned fa_mask[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int row = wm * 64 + t * 32 + fr, m = m0 + row;
+    const bool ok = m < M;
+    const int mm = ok ? m : 0;
+    const int n = sfast_div(mm, p.div_howo_mul, p.div_howo_sh), r = mm - n * HoWo;
+    const int ho = sfast_div(r, p.div_wo_mul, p.div_wo_sh), wo = r - ho * p.Wo;
+    unsigned mk = 0;
+    for (int khh = 0; khh < p.kh; ++khh)
+      for (int kww = 0; kww < KW; ++kww) {
+        const int hi = ho - p.pad_t + khh * p.dil, wi = wo - p.pad_l + kww * p.dil;
+        if (ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) mk |= 1u << (khh * KW + kww);
+      }
+    fa_mask[t] = mk;
+    fa_base[t] = fg * AKG + (row < len0 ? row : row + halo) * 16;
+  }
+  const int fa_zero = fg * AKG + ZR * 16;
+  const int b_rd = fg * BKG + (wn * TN * 32 + fr) * 16;
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- prologue: group 0 staged, B stage 0 landed, stage 1's DMA in flight behind the barrier
+  load_group();
+  stamp(6);
+#pragma unroll
+  for (int j = 0; j < RA; ++j) store_slot(0, j);
+  ODT_WAIT_VM_LGKM0(0);
+  __builtin_amdgcn_s_barrier();
+  if (nsteps > 1) dma_b(BOFF + STAGE_B);
+  stamp(7); stamp(1);
+
+  f16x8 fa[2][2][2], fb[2][2];
+  int fa_addr[2];                            // this stage's fragment addresses (A buffer + row + tap, or the zero row)
+  int c_kh = 0;                              // kh of the group being computed
+  auto tap_addr = [&](int abuf, int khh, int kww) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      fa_addr[t] = abuf + (((fa_mask[t] >> (khh * KW + kww)) & 1u) ? fa_base[t] + kww * p.dil * 16 : fa_zero);
+  };
+  int fa_addr_n[2];                          // ... of the stage behind the barrier
+  auto tap_addr_n = [&](int abuf, int khh, int kww) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      fa_addr_n[t] = abuf + (((fa_mask[t] >> (khh * KW + kww)) & 1u) ? fa_base[t] + kww * p.dil * 16 : fa_zero);
+  };
+  auto rdA = [&](int kst, int q) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) fa[kst][q][t] = *reinterpret_cast<const f16x8*>(lds + q * APL + kst * 2 * AKG + fa_addr[t]);
+  };
+  auto rdA_n = [&](int q) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) fa[0][q][t] = *reinterpret_cast<const f16x8*>(lds + q * APL + fa_addr_n[t]);
+  };
+  auto rdB = [&](int bbuf, int kst, int j, int dst) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) fb[dst][q] = *reinterpret_cast<const f16x8*>(lds + bbuf + q * BPL + kst * 2 * BKG + b_rd + j * 512);
+  };
+  int a_cur = 0, a_nxt = ABUF;
+  int b_cur = BOFF, b_nxt = BOFF + STAGE_B;
+  tap_addr(a_cur, 0, 0);
+  rdA(0, 1); rdA(0, 0);
+  rdB(b_cur, 0, 0, 0);
+
+  // One stage = tap kw = KWI of the current group.  NEXT / PRE as in conv_h2_kernel (stage c+1 / c+2 exist); GN: a next
+  // group exists (fetch it in the first stage, split + store it in the third)
+  auto step = [&](auto KWIC, auto NEXT, auto PRE, auto GNC) {
+    constexpr int KWI = decltype(KWIC)::value;
+    constexpr bool next = decltype(NEXT)::value, pre = decltype(PRE)::value, gn = decltype(GNC)::value;
+    constexpr int NG = 2 * TN;
+    ODT_FENCE();
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int kst = g / TN, j = g % TN, bsel = g & 1;
+      const bool last = g == NG - 1;
+      if (last) {
+        // (first stage of a group: the group fetch issued in it may stay in flight; later stages: the fetch is older than
+        // the DMA this wait is about, so everything has landed)
+        if constexpr (KWI == 0 && gn) ODT_WAIT_VM_LGKM0(RA); else ODT_WAIT_VM_LGKM0(0);
+        __builtin_amdgcn_s_barrier();
+        ODT_FENCE();
+        if constexpr (pre) dma_b(b_cur);
+        // fragment addresses of the next stage: next tap of this group, or tap 0 of the next group's buffer
+        if constexpr (next) {
+          if constexpr (KWI + 1 < KW) tap_addr_n(a_cur, c_kh, KWI + 1);
+          else tap_addr_n(a_nxt, c_kh + 1 == p.kh ? 0 : c_kh + 1, 0);
+          rdB(b_nxt, 0, 0, bsel ^ 1);
+        }
+      } else {
+        rdB(b_cur, (g + 1) / TN, (g + 1) % TN, bsel ^ 1);
+        if (TN == 1) { rdA(1, 1); rdA(1, 0); }
+      }
+      ODT_FENCE();
+      ODT_MF(kst, 1, 0, j, bsel); ODT_FENCE();             // lo * hi
+      if (last) {
+        if constexpr (next) rdA_n(1);
+      } else {
+        if constexpr (gn && KWI == 2) {
+          // the next group's run: registers -> LDS, in the group's third stage, two stages behind the fetch
+          if (TN == 4) { if (g < 5) store_slot(a_nxt, g); }
+          else if (TN == 2) { if (g < 3) { store_slot(a_nxt, 2 * g); if (2 * g + 1 < RA) store_slot(a_nxt, 2 * g + 1); } }
+          else { store_slot(a_nxt, 0); store_slot(a_nxt, 1); store_slot(a_nxt, 2); }
+        }
+        if constexpr (gn && KWI == 0) { if (g == (TN == 1 ? 0 : 1)) load_group(); }
+      }
+      ODT_FENCE();
+      ODT_MF(kst, 0, 1, j, bsel); ODT_FENCE();             // hi * lo
+      if (last) {
+        if constexpr (next) rdA_n(0);
+      } else {
+        if (TN > 1 && g == TN - 2) rdA(1, 1);
+        if (TN > 1 && g == TN - 1) rdA(1, 0);
+        if constexpr (gn && KWI == 2) { if (TN == 1) { store_slot(a_nxt, 3); store_slot(a_nxt, 4); } }
+      }
+      ODT_FENCE();
+      ODT_MF(kst, 0, 0, j, bsel); ODT_FENCE();             // hi * hi
+    }
+    fa_addr[0] = fa_addr_n[0]; fa_addr[1] = fa_addr_n[1];
+    { const int t = b_cur; b_cur = b_nxt; b_nxt = t; }
+    if constexpr (KWI == KW - 1) {
+      const int u = a_cur; a_cur = a_nxt; a_nxt = u;
+      if (++c_kh == p.kh) c_kh = 0;
+    }
+  };
+  {
+    using T = std::true_type; using F = std::false_type;
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+    for (int g = 0; g + 1 < ngroups; ++g) { step(K0{}, T{}, T{}, T{}); step(K1{}, T{}, T{}, T{}); step(K2{}, T{}, T{}, T{}); }
+    step(K0{}, T{}, T{}, F{});
+    step(K1{}, T{}, F{}, F{});
+    step(K2{}, F{}, F{}, F{});
+  }
+#undef ODT_MF
+#undef ODT_FENCE
+  stamp(2);
+  split3_epilogue<WM, WN, TN, G::LDS, TRACE>(p, acc, lds, m0, n0, M, HoWo, 0, 1, tid, wm, wn, fr, fg, h2_inv);
+  stamp(5);
+}
+
+}  // namespace
+
+void launch_conv_h2k(const ConvParams& p, const ConvParams* dev, unsigned grid, hipStream_t stream) {
+  const int bn = p.wt_split_bn;
+  if (bn == 256) {
+    if (p.trace != nullptr) hipLaunchKernelGGL((conv_h2k_kernel<4, true>), dim3(grid), dim3(512), 0, stream, dev);
+    else hipLaunchKernelGGL((conv_h2k_kernel<4, false>), dim3(grid), dim3(512), 0, stream, dev);
+  } else if (bn == 128) {
+    hipLaunchKernelGGL((conv_h2k_kernel<2, false>), dim3(grid), dim3(512), 0, stream, dev);
+  } else {
+    hipLaunchKernelGGL((conv_h2k_kernel<1, false>), dim3(grid), dim3(512), 0, stream, dev);
+  }
+}
+
+}  // namespace odt

@@ -1,5 +1,5 @@
 // Shared pieces of the split convolution kernels (conv_split1.hip: one-stage 4-wave bf16x3 loop; conv_split3.hip: 8-wave
-// LDS-DMA bf16x3 kernels; conv_h2.hip: the fp16x2 kernels; conv_split.hip: weight images, policy, dispatch).
+// LDS-DMA bf16x3 kernels; conv_h2.hip / conv_h2k.hip: the fp16x2 kernels; conv_split.hip: weight images, policy, dispatch).
 //
 // bf16x3 arithmetic.  Every f32 operand is cut into three bf16 pieces by round-to-nearest,
 //     x = hi + mid + lo   exactly   (3 x 8 significand bits = the 24 bits of an f32),
@@ -135,6 +135,7 @@ __device__ __forceinline__ int h2_in_scale_exp(const ConvParams& p) {
 int launch_conv_split1(const ConvParams& p, const ConvParams* dev, hipStream_t stream);
 int launch_conv_split3(const ConvParams& p, const ConvParams* dev, hipStream_t stream);
 int launch_conv_h2(const ConvParams& p, const ConvParams* dev, hipStream_t stream);
+void launch_conv_h2k(const ConvParams& p, const ConvParams* dev, unsigned grid, hipStream_t stream);   // conv_h2k.hip
 void launch_split_reduce(const ConvParams& p, const ConvParams* dev, hipStream_t stream);   // split-K combine (conv_split3.hip)
 
 }  // namespace odt

@@ -34,10 +34,10 @@ def _resources(src):
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") and "HIPCC" not in os.environ, reason="hipcc not installed")
 def test_hot_kernels_use_no_scratch_memory():
   from concurrent.futures import ThreadPoolExecutor
-  with ThreadPoolExecutor(max_workers=4) as ex:          # (four independent hipcc runs)
-    parts = list(ex.map(_resources, ["conv_split3.hip", "conv_split1.hip", "conv_h2.hip", "effnet.hip"]))
+  with ThreadPoolExecutor(max_workers=5) as ex:          # (five independent hipcc runs)
+    parts = list(ex.map(_resources, ["conv_split3.hip", "conv_split1.hip", "conv_h2.hip", "effnet.hip", "conv_h2k.hip"]))
   res = {}
-  for part in parts[:3]:
+  for part in parts[:3] + parts[4:]:
     res.update(part)
   hot = {k: v for k, v in res.items() if "conv_split3" in k or "conv_split_kernelILi4ELi1ELi2E" in k or "conv_h2" in k}      # (the 256 x 64 one-stage tile is the one the plans use)
   assert len(hot) >= 18, sorted(res)
