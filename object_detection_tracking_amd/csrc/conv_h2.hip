@@ -2,7 +2,8 @@
 // fp16x2 split convolution: f32 implicit GEMM through THREE exact f16 MFMA products per MAC (conv_split_common.hpp has the
 // arithmetic: x 2^s = hi + lo to 2^-22, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, f32 accumulation) -- half the
 // matrix-pipe work of the bf16x3 kernels of conv_split3.hip, whose loop structure these kernels keep:
-//   * 8 waves / 512 threads, ONE workgroup per CU, 256-row tiles, wave tile 64 x 32 TN, <TN = 4> 256 x 256, <TN = 2> 256 x 128;
+//   * 8 waves / 512 threads, ONE workgroup per CU, 256-row tiles, wave tile 64 x 32 TN, <TN = 4> 256 x 256, <TN = 2> 256 x 128
+//     (and 4-wave 128 x 128 / 128 x 64 tiles for the layers with few tiles / 64 output channels: several workgroups per CU);
 //   * BK = 32 per LDS stage (two MFMA k-steps: the stage carries the MFMA time of a bf16x3 BK = 16 stage), TWO stages
 //     of A and of B, ONE barrier per stage in front of the stage's last column group;
 //   * weights: the pre-split, pre-scaled image goes global -> LDS by LDS-DMA (buffer_load ... lds) into the buffer the
@@ -41,11 +42,10 @@ struct H2Cfg {
   static_assert(LDS <= 160 * 1024 && STAGE_B % (1024 * NWV) == 0, "LDS ring");
 };
 
-// (<1, 2>: 128 x 64 on 4 waves for the 64-wide layers -- one column group per k-step, 12 MFMAs per wave and stage, 50 KB of
-// LDS: three workgroups per CU)
 // <TN, WM>: <4, 4> 256 x 256, <2, 4> 256 x 128 (8 waves, one workgroup per CU); <2, 2> 128 x 128 with 4 waves and 66 KB of LDS --
-// TWO workgroups per CU, each in its own phase: for the layers whose tiles spend as long in the prologue and the epilogue
-// (HBM) as in the reduction (MFMA) -- the short 1x1 reductions -- and for the layers with too few 256-row tiles
+// two workgroups per CU -- for the layers with too few 256-row tiles (res5, P5; with split-K below res3 at b=1; as an A/B knob
+// also for short 1x1 reductions: measured no gain); <1, 2> 128 x 64 on 4 waves for the 64-wide layers -- one column group per
+// k-step, 12 MFMAs per wave and stage, 50 KB of LDS: three workgroups per CU
 template <int TN, int WM, bool TRACE = false>
 __global__ void __launch_bounds__(128 * WM, 2) conv_h2_kernel(const ConvParams* __restrict__ pp) {
   using G = H2Cfg<TN, WM>;
