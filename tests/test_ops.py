@@ -599,6 +599,25 @@ def test_conv2d_fp16x2_dynamic_range(backend, monkeypatch):
     assert np.max(err[0, g] / mag[0, g]) < 4e-7, g
 
 
+@pytest.mark.parametrize("pipe", ["2/256", "2/256/nokwr", "2/128"])
+def test_conv2d_fp16x2_power_of_two_equivariance(backend, pipe, monkeypatch):
+  """The fp16x2 kernels scale their A operand by a power of two taken from the tensor's recorded |max|: multiplying the
+  whole input by 2^k moves that power by -k and leaves every f16 piece unchanged, so the (bias-free, linear) result is the
+  old one times 2^k EXACTLY -- for inputs from 2^-40 to 2^+40 of the reference scale.  (A size-independent property of the
+  range plumbing: a stale or missing range record breaks it at once.)"""
+  name, lib = backend
+  _split_env(monkeypatch, pipe)
+  rng = np.random.default_rng(31)
+  x = rng.standard_normal((2, 13, 15, 64)).astype(F)
+  w = (rng.standard_normal((3, 3, 64, 256)) * 0.05).astype(F)
+  b = np.zeros(256, F)
+  y0 = ops.conv2d(x, w, b, 1, 1, 1, 1, (13, 15), lib=lib)
+  assert np.isfinite(y0).all() and np.abs(y0).max() > 0
+  for k in (-40, -7, 5, 40):
+    yk = ops.conv2d(x * F(2.0 ** k), w, b, 1, 1, 1, 1, (13, 15), lib=lib)
+    assert np.array_equal(yk, y0 * F(2.0 ** k)), k
+
+
 @pytest.mark.parametrize("pipe", SPLIT_PIPES)
 def test_conv2d_split_output_offset_and_residual(backend, pipe, monkeypatch):
   name, lib = backend
