@@ -245,12 +245,12 @@ int attach_split_weights(odt_model* m) {
       c.p.debug |= (nt & 7) << 10;
     }
     {
-      static const bool per_wave = getenv("ODT_AMAX_PER_WAVE") != nullptr && getenv("ODT_AMAX_PER_WAVE")[0] == '1';
+      const bool per_wave = getenv("ODT_AMAX_PER_WAVE") != nullptr && getenv("ODT_AMAX_PER_WAVE")[0] == '1';
       if (per_wave) c.p.debug |= 0x4000;      // A/B: range record per wave instead of per workgroup
     }
     if (c.p.wt_split_kind == 2) {
       c.p.h2_chinv = conv_h2_chinv(c.p.wt_split, c.p.Cout, K); ++m->convs_h2;
-      static const bool norot = getenv("ODT_CONV_H2_ROT") != nullptr && getenv("ODT_CONV_H2_ROT")[0] == '0';
+      const bool norot = getenv("ODT_CONV_H2_ROT") != nullptr && getenv("ODT_CONV_H2_ROT")[0] == '0';
       if (norot) c.p.debug |= 0x100;          // A/B: every workgroup walks the K slices in the same order
     }
     need_partial = std::max(need_partial, conv_split_partial_bytes(c.p));

@@ -435,6 +435,31 @@ def test_fp16x2_family_agrees_with_bf16x3(backend, tiles, monkeypatch):
     assert miss == 0 and extra == 0
 
 
+def test_cache_hints_and_record_granularity_do_not_change_results(backend, monkeypatch):
+  """The non-temporal load hints (ODT_CONV_NT), the K-slice rotation being on, and the range record per workgroup / per wave
+  are performance knobs: the forward's outputs are bit-identical with them off (the rotation changes the summation order of
+  the 1x1 tiles and is therefore NOT part of this list)."""
+  name, lib = backend
+  monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1"); monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "1")
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1])
+  w = weights_for(cfg)
+  H, W = (64, 96) if name == "emu" else (160, 224)
+  fr = synthetic_frames(1, H, W, seed=7)
+  out = []
+  for env in ({}, {"ODT_CONV_NT": "0", "ODT_AMAX_PER_WAVE": "1"}):
+    for k in ("ODT_CONV_NT", "ODT_AMAX_PER_WAVE"):
+      monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+      monkeypatch.setenv(k, v)
+    m = models.get_model(cfg, 0, weights=w, lib=lib)
+    try:
+      out.append(m.predict(fr[0]))
+    finally:
+      m.close()
+  for a, b in zip(out[0], out[1]):
+    assert np.array_equal(a, b)
+
+
 def test_convs_cut_into_batch_ranges_are_bit_identical(backend, monkeypatch):
   """A conv whose tensors would reach 2 GiB (32-bit buffer offsets; b = 16 @1080p) runs as several launches over batch
   ranges.  With the limit lowered (test knob) a small batched plan takes that path for most layers: same bits out."""
