@@ -366,6 +366,32 @@ __global__ void split_weights_h2_kernel(const float* __restrict__ wt, int Cout, 
   }
 }
 
+// image of a fused 1x1 conv (ConvParams::f_wt; conv_h2k_kernel<.., FUSE>): [chunk of 32 columns][piece 2][K half 2][k16 step
+// NS][lane half fg 2][column 32][8 f16].  The producer's wave (wm, wn) holds, for each of its pixels, the channels
+// wn * KH + [0, KH) (KH = K / 2) in accumulator registers; step s = (32-channel block j = s / 2, register half h = s % 2) takes,
+// from lane half fg, element e the channel j * 32 + 16 h + (e % 4) + 8 (e / 4) + 4 fg -- the MFMA C layout read as an operand
+// fragment -- so the weights' k runs in that order too.  wt is [Cout][K]; row n is multiplied by 2^t_n = 1 / chinv[n].
+__global__ void split_weights_h2f_kernel(const float* __restrict__ wt, int Cout, int K, unsigned short* __restrict__ img,
+                                         const float* __restrict__ chinv) {
+  const int KH = K >> 1, NS = KH >> 4;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;       // (n, K half, step, lane half)
+  const long total = (long)Cout * 2 * NS * 2;
+  if (idx >= total) return;
+  const int fg = (int)(idx & 1), s = (int)((idx >> 1) % NS), wn = (int)((idx / (2 * NS)) & 1), n = (int)(idx / (4 * NS));
+  const int c = n >> 5, fr = n & 31;
+  const float sc = 1.0f / chinv[n];
+  for (int e = 0; e < 8; e += 2) {
+    const int k0 = wn * KH + (s >> 1) * 32 + (s & 1) * 16 + (e & 3) + 8 * (e >> 2) + 4 * fg;     // (e even: k0 + 1 is element e + 1)
+    unsigned piece[2];
+    split2h(wt[(size_t)n * K + k0], wt[(size_t)n * K + k0 + 1], sc, piece[0], piece[1]);
+    for (int q = 0; q < 2; ++q) {
+      const size_t at = ((((((size_t)c * 2 + q) * 2 + wn) * NS + s) * 2 + fg) * 32 + fr) * 8 + e;
+      img[at] = (unsigned short)(piece[q] & 0xffffu);
+      img[at + 1] = (unsigned short)(piece[q] >> 16);
+    }
+  }
+}
+
 // |max| of a dense f32 array into *slot (stand-alone calls: a tensor nobody recorded a range for)
 __global__ void __launch_bounds__(256) tensor_amax_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ slot) {
   float m = 0.f;
@@ -396,6 +422,39 @@ int conv_make_h2_weights(const ConvParams& p, void* img_dev, hipStream_t stream)
   return 0;
 }
 
+size_t conv_h2f_weight_bytes(int Cout, int K) { return (size_t)Cout * K * 4 + (size_t)Cout * 4; }
+const float* conv_h2f_chinv(const void* img, int Cout, int K) {
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(img) + (size_t)Cout * K * 4);
+}
+int conv_make_h2f_weights(const float* wt, int Cout, int K, void* img_dev, hipStream_t stream) {
+  ODT_CHECK((K == 256 || K == 128) && Cout % 32 == 0 && Cout > 0, "conv_make_h2f_weights: K = 128 / 256 and Cout % 32 == 0 required");
+  float* chinv = const_cast<float*>(conv_h2f_chinv(img_dev, Cout, K));
+  hipLaunchKernelGGL(h2_rowscale_kernel, dim3((unsigned)Cout), dim3(256), 0, stream, wt, Cout, K, chinv);
+  const long total = (long)Cout * (K >> 3);
+  hipLaunchKernelGGL(split_weights_h2f_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, wt, Cout, K,
+                     (unsigned short*)img_dev, chinv);
+  ODT_HIP(hipGetLastError());
+  return 0;
+}
+
+// may the 1x1 conv b (reading a.out and nothing else of a) run in the epilogue of the KH x 3 conv a?  a: conv_h2k_kernel on
+// 256-wide (or 128-wide) n-tiles = its whole Cout, plain dense output, ReLU or none; b: dense same-size 1x1, single source,
+// no residual or a same-shape one, on the fp16x2 family as well (so its consumers find a recorded range)
+bool conv_h2f_fusable(const ConvParams& a, const ConvParams& b) {
+  const bool a_ok = a.wt_split != nullptr && a.wt_split_kind == 2 && a.wt_split_kwr == 1 && a.wt_split_bm == 256 &&
+                    a.wt_split_bn == a.Cout && a.Cout == 256 && a.splitk <= 1 && a.head_wt == nullptr &&
+                    a.res_mode == 0 && a.in2 == nullptr && a.relu <= 1 && a.nlvl <= 1 && a.out_oy == 0 && a.out_ox == 0 &&
+                    a.out_H == a.Ho && a.out_W == a.Wo && a.f_wt == nullptr;
+  const bool b_ok = b.in == a.out && b.kh == 1 && b.kw == 1 && b.stride == 1 && b.pad_t == 0 && b.pad_l == 0 && b.Cin == a.Cout &&
+                    b.in_ldc == a.out_ldc && b.in2 == nullptr && b.B == a.B && b.H == a.Ho && b.W == a.Wo && b.Ho == a.Ho &&
+                    b.Wo == a.Wo && b.in_Ha == a.out_H && b.in_Wa == a.out_W && b.Cout % 32 == 0 && b.out_oy == 0 && b.out_ox == 0 &&
+                    b.out_H == b.Ho && b.out_W == b.Wo && b.out_ldc % 4 == 0 && b.out_ldc >= b.Cout &&
+                    (b.res_mode == 0 || (b.res_mode == 1 && b.res_H == b.Ho && b.res_W == b.Wo && b.res_ldc % 4 == 0)) &&
+                    b.relu <= 1 && b.nlvl <= 1 && b.head_wt == nullptr && b.splitk <= 1 && b.wt_split != nullptr && b.wt_split_kind == 2 &&
+                    b.f_wt == nullptr && (double)b.B * b.Ho * b.Wo * b.out_ldc * 4.0 < 2147483648.0;
+  return a_ok && b_ok;
+}
+
 int launch_tensor_amax(const float* x, size_t n, unsigned* slot, hipStream_t stream) {
   const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
   hipLaunchKernelGGL(tensor_amax_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, x, n, slot);
@@ -416,7 +475,14 @@ int launch_conv_h2(const ConvParams& p, const ConvParams* dev, hipStream_t strea
   const unsigned grid = (unsigned)(((M + bm - 1) / bm) * (cout_padded(p.Cout) / bn) * sk);
   if (p.wt_split_kwr) {
     ODT_CHECK(sk == 1 && p.kw == 3 && p.stride == 1 && p.in_Wa == p.Wo && p.in2 == nullptr && 2 * p.dil <= 4, "conv h2k: unsupported shape");
+    ODT_CHECK(p.f_wt == nullptr || (bn == 256 && p.Cout == 256 && p.head_wt == nullptr && p.res_mode == 0 && p.relu <= 1 && p.f_cout % 32 == 0 &&
+                                    p.f_cout > 0 && p.f_out != nullptr && p.f_chinv != nullptr && p.f_bias != nullptr && p.f_out_ldc % 4 == 0 &&
+                                    (p.f_res == nullptr || p.f_res_ldc % 4 == 0) && (double)M * p.f_out_ldc * 4.0 < 2147483648.0 &&
+                                    (p.f_res == nullptr || (double)M * p.f_res_ldc * 4.0 < 2147483648.0)),
+              "conv h2k: unsupported fused 1x1 tail");
     launch_conv_h2k(p, dev, grid, stream);
+  } else if (p.f_wt != nullptr) {
+    ODT_CHECK(false, "conv h2: a fused 1x1 tail needs the kw-reuse kernel");
   } else if (bn == 64) {
     hipLaunchKernelGGL((conv_h2_kernel<1, 2, false>), dim3(grid), dim3(256), 0, stream, dev);
   } else if (bn == 256) {

@@ -7,8 +7,14 @@ namespace odt {
 namespace {
 
 #define ODT_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
-#define ODT_MF(kst, qa, qb, j, bsel) { acc[0][j] = ODT_MFMA_F16(fa[kst][qa][0], fb[bsel][qb], acc[0][j]); \
-                                        acc[1][j] = ODT_MFMA_F16(fa[kst][qa][1], fb[bsel][qb], acc[1][j]); }
+// (FUSE: operands swapped -- the tile comes out transposed, lanes along the pixels and registers along the channels, which
+// is the layout the fused 1x1 conv consumes as its operand fragment)
+#define ODT_MF(kst, qa, qb, j, bsel) { if constexpr (FUSE) {                                                   \
+                                          acc[0][j] = ODT_MFMA_F16(fb[bsel][qb], fa[kst][qa][0], acc[0][j]);   \
+                                          acc[1][j] = ODT_MFMA_F16(fb[bsel][qb], fa[kst][qa][1], acc[1][j]);   \
+                                        } else {                                                                \
+                                          acc[0][j] = ODT_MFMA_F16(fa[kst][qa][0], fb[bsel][qb], acc[0][j]);   \
+                                          acc[1][j] = ODT_MFMA_F16(fa[kst][qa][1], fb[bsel][qb], acc[1][j]); } }
 #define ODT_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // ---------------------------------------------------------------------------------------------------------
@@ -21,7 +27,7 @@ namespace {
 //   * taps outside the image read a zero row of the stage: a per-lane 9-bit validity mask picks the fragment address;
 //   * A: two buffers (this group / next group); the next group's fetch (5 x 16 B per thread) is issued in the group's first
 //     stage and split + stored in its third; B: the two-deep DMA ring of conv_h2_kernel.
-template <int TN>
+template <int TN, bool FUSE = false>
 struct H2kCfg {
   static constexpr int BM = 256, BN = 64 * TN;
   static constexpr int PR = 272;                             // stage rows: 256 + 2 runs x 2 dil (dil <= 2) + the zero row, padded
@@ -31,15 +37,222 @@ struct H2kCfg {
   static constexpr int BOFF = 2 * ABUF;
   static constexpr int RING = BOFF + 2 * STAGE_B;
   static constexpr int CTILE = 128 * (BN + 4) * 4;
-  static constexpr int LDS = RING > CTILE ? RING : CTILE;
+  // fused 1x1 tail: two 32-column chunks of its weight image + the two K halves' partial tiles [256][32 + 4] f32
+  // (+ the producer's own column constants, [2][256] f32 behind everything the main loop and the tail use)
+  static constexpr int F_WCH = 2 * 2 * (2 * TN) * 1024, F_CS = 36, F_COFF = 2 * F_WCH, F_CEND = F_COFF + 2 * 256 * F_CS * 4;
+  static constexpr int LDS0 = RING > CTILE ? RING : CTILE;
+  static constexpr int F_KOFF = F_CEND > LDS0 ? F_CEND : LDS0;
+  static constexpr int LDS = FUSE ? F_KOFF + 2048 : LDS0;
   static constexpr int NW = STAGE_B / 1024 / 8;
   static constexpr int RA = 5;                               // A fetch instructions per thread and group (rows t >> 3 + 64 j)
   static_assert(LDS <= 160 * 1024 && STAGE_B % 8192 == 0, "LDS");
 };
 
-template <int TN, bool TRACE = false>
+// ---------------------------------------------------------------------------------------------------------
+// Fused 1x1 conv behind the KH x 3 conv (ConvParams::f_wt; the bottleneck's conv2 -> conv3 (+ shortcut) + ReLU,
+// nn.py:503-521).  On entry acc[i][j] holds the TRANSPOSED tile of the wave (operands swapped in the main loop): lane
+// (fr, fg), register r = pixel row wm 64 + i 32 + fr, channel wn 32 TN + j 32 + (r % 4) + 8 (r / 4) + 4 fg, in scaled units.
+//   1. y = act(acc * 2^-s 2^-t_c + bias_c) in registers (the values the unfused conv would have stored, bit for bit);
+//   2. per pixel row and K half (= per lane pair fr / fr + 32 of a wave) the power of two that takes the row's |max| into
+//      [2^14, 2^15); y 2^sy = hi + lo (f16 pairs): registers 8 h .. 8 h + 7 of acc[i][j] ARE the operand fragment of k16 step
+//      (j, h) -- nothing moves (the weight image carries k in this order: split_weights_h2f_kernel);
+//   3. per 32-column chunk of the 1x1 conv: the chunk's weight pieces (LDS-DMA, two chunks ahead) x the wave's K half:
+//      2 TN steps x 2 pixel blocks x 3 products; the two K halves' partial tiles (each scaled back by its rows' 2^-sy) meet in
+//      LDS, then rows of 16-byte chunks: (p0 + p1) 2^-t_n + bias (+ residual), activation, store, |max|.
+// Two barriers per chunk; the residual chunks and the column constants of chunk c + 1 are fetched under chunk c's stores.
+template <int TN, bool TRACE>
+__device__ __forceinline__ void h2f_tail(const ConvParams& p, f32x16 (&acc)[2][TN], unsigned char* lds, int m0, int M,
+                                         int wave, int wm, int wn, float h2_inv) {
+  using G = H2kCfg<TN, true>;
+  constexpr int NS = 2 * TN, WCH = G::F_WCH, CS = G::F_CS, COFF = G::F_COFF;
+  // (the lane id is recomputed here: nothing per-lane stays live across the main loop, whose registers are all taken)
+  ODT_FENCE();
+  const int lane = ODT_LANE_ID();
+  const int tid = wave * 64 + lane, fr = lane & 31, fg = lane >> 5;
+  const int nch = p.f_cout >> 5;
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.f_wt, 0, (int)((unsigned)nch * (unsigned)WCH), 0x00020000);
+  auto dma_w = [&](int c, int buf) {
+#pragma unroll
+    for (int i = 0; i < WCH / 8192; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, ODT_LDS_PTR(lds + buf * WCH + (i * 8 + wave) * 1024), 16,
+                                               lane * 16 + (i * 8 + wave) * 1024, c * WCH, 0, 0);
+  };
+  // (the ring is free: the main loop's last barrier sits behind every fragment read)
+  dma_w(0, 0);
+  if (nch > 1) dma_w(1, 1);
+
+  // ---- 1. + 2. the producer's epilogue arithmetic in registers, the per-row power of two, the pieces.  Two passes over the
+  // accumulators (row |max| first, then value -> pieces), the column constants (2^-s 2^-t_c, bias_c: staged in LDS by the
+  // prologue) read twice: the values are never written back, so the pieces take the registers the accumulators leave
+  const float* kc = reinterpret_cast<const float*>(lds + G::F_KOFF);
+  const float act2_lo = p.relu == 1 ? 0.f : -__builtin_huge_valf();
+  float mx[2] = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = wn * 32 * TN + j * 32 + 8 * g + 4 * fg;
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(kc + col), bs = *reinterpret_cast<const f32x4*>(kc + 256 + col);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[i][j][4 * g + e] * sc[e];
+          v += bs[e];
+          mx[i] = fmaxf(mx[i], fabsf(fmaxf(v, act2_lo)));
+        }
+      if (g & 1) ODT_FENCE();               // (bounds the constants in flight: the accumulators hold half the registers)
+    }
+  // (both maxima are complete HERE and the second pass re-reads the constants: without the pins the compiler sinks one
+  // row block's pass behind the other's exponent arithmetic and keeps all 128 constants in registers across -- spills)
+  ODT_PIN2(mx[0], mx[1]);
+  asm volatile("" ::: "memory");
+  float ys[2], yinv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float m = fmaxf(mx[i], __shfl_xor(mx[i], 32));
+    // h2_scale_exp without control flow
+    const int be = (int)((__float_as_uint(m) >> 23) & 0xffu);
+    int e = 14 - (be - 127);
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    e = (be == 0) | (be == 255) ? 0 : e;
+    ys[i] = pow2f(e); yinv[i] = pow2f(-e);
+  }
+  ODT_PIN2(ys[0], ys[1]);
+  f16x8 yh[2][TN][2], yl[2][TN][2];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int col = wn * 32 * TN + j * 32 + 16 * h + 4 * fg;
+      const f32x4 sc0 = *reinterpret_cast<const f32x4*>(kc + col), bs0 = *reinterpret_cast<const f32x4*>(kc + 256 + col);
+      const f32x4 sc1 = *reinterpret_cast<const f32x4*>(kc + col + 8), bs1 = *reinterpret_cast<const f32x4*>(kc + 256 + col + 8);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t0 = acc[i][j][8 * h + e] * sc0[e], t1 = acc[i][j][8 * h + 4 + e] * sc1[e];
+          t0 += bs0[e]; t1 += bs1[e];
+          v[e] = fmaxf(t0, act2_lo); v[4 + e] = fmaxf(t1, act2_lo);
+        }
+        u32x4 hq, lq;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          unsigned a, b;
+          split2h(v[2 * t], v[2 * t + 1], ys[i], a, b);
+          hq[t] = a; lq[t] = b;
+        }
+        ODT_PIN2(hq, lq);                   // (computed HERE, from constants that die here: see the pins above)
+        __builtin_memcpy(&yh[i][j][h], &hq, 16);
+        __builtin_memcpy(&yl[i][j][h], &lq, 16);
+      }
+      ODT_FENCE();
+    }
+  ODT_STAMP(3);
+
+  // ---- 3. the 1x1 conv, 32 output columns at a time
+  const unsigned mrows = (unsigned)M;
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.f_res != nullptr ? p.f_res : p.f_bias), 0, (int)(p.f_res != nullptr ? mrows * (unsigned)p.f_res_ldc * 4u : 0u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.f_out, 0, (int)(mrows * (unsigned)p.f_out_ldc * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ch3 = __builtin_amdgcn_make_buffer_rsrc((void*)p.f_chinv, 0, (int)((unsigned)p.f_cout * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b3 = __builtin_amdgcn_make_buffer_rsrc((void*)p.f_bias, 0, (int)((unsigned)p.f_cout * 4u), 0x00020000);
+  const int c4 = tid & 7, row0 = tid >> 3;
+  // rows row0 + 64 s2 of the tile: byte offsets of the thread's 16-byte chunk in the residual / output rows
+  const unsigned m_first = (unsigned)(m0 + row0);
+  const unsigned roff0 = (m_first * (unsigned)p.f_res_ldc + c4 * 4u) * 4u, rstep = 64u * (unsigned)p.f_res_ldc * 4u;
+  const unsigned ooff0 = (m_first * (unsigned)p.f_out_ldc + c4 * 4u) * 4u, ostep = 64u * (unsigned)p.f_out_ldc * 4u;
+  const bool has_res = p.f_res != nullptr;
+  const bool res_nt = (p.debug & 0x400) != 0;
+  const float act_lo = p.f_relu == 1 ? 0.f : -__builtin_huge_valf();
+  f32x4 rres[4], sc3, b3;
+  auto fetch_cols = [&](int c) {            // residual chunks + column constants of chunk c
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const unsigned off = has_res && m_first + 64u * s2 < mrows ? roff0 + s2 * rstep : kOOB;
+      rres[s2] = res_nt ? (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)off, c * 128, 2)
+                        : (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)off, c * 128, 0);
+    }
+    sc3 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_ch3, c4 * 16, c * 128, 0);
+    b3 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_b3, c4 * 16, c * 128, 0);
+  };
+  fetch_cols(0);
+  float* C0 = reinterpret_cast<float*>(lds + COFF);
+  float* C1 = C0 + 256 * CS;
+  float* Cw = wn != 0 ? C1 : C0;
+  const unsigned char* wrd = lds + wn * NS * 1024 + lane * 16;
+  float vmax = 0.f;
+  ODT_WAIT_VM_LGKM0(0);
+  __builtin_amdgcn_s_barrier();             // chunks 0 / 1 of the weight image have landed
+#pragma unroll 1
+  for (int c = 0; c < nch; ++c) {
+    const int buf = c & 1;
+    f32x16 cacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cacc[i][r] = 0.f;
+    f16x8 wf[2][2];                         // [buffer][piece]: the next step's fragments are read under this step's MFMAs
+    wf[0][0] = *reinterpret_cast<const f16x8*>(wrd + buf * WCH);
+    wf[0][1] = *reinterpret_cast<const f16x8*>(wrd + buf * WCH + 2 * NS * 1024);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if (s + 1 < NS) {
+        wf[(s + 1) & 1][0] = *reinterpret_cast<const f16x8*>(wrd + buf * WCH + (s + 1) * 1024);
+        wf[(s + 1) & 1][1] = *reinterpret_cast<const f16x8*>(wrd + buf * WCH + 2 * NS * 1024 + (s + 1) * 1024);
+      }
+      ODT_FENCE();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        cacc[i] = ODT_MFMA_F16(wf[s & 1][1], yh[i][s >> 1][s & 1], cacc[i]);
+        cacc[i] = ODT_MFMA_F16(wf[s & 1][0], yl[i][s >> 1][s & 1], cacc[i]);
+        cacc[i] = ODT_MFMA_F16(wf[s & 1][0], yh[i][s >> 1][s & 1], cacc[i]);
+      }
+      ODT_FENCE();
+    }
+    ODT_BARRIER_LDS();                      // the previous chunk's partial tiles have been read; this chunk's weights too
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v = {cacc[i][4 * g], cacc[i][4 * g + 1], cacc[i][4 * g + 2], cacc[i][4 * g + 3]};
+        v = v * yinv[i];
+        *reinterpret_cast<f32x4*>(&Cw[(wm * 64 + i * 32 + fr) * CS + 8 * g + 4 * fg]) = v;
+      }
+    // own DMA of chunk c + 1 and this chunk's residual / constants have landed (the 4 stores of the previous chunk may fly)
+    if (c > 0) ODT_WAIT_VM_LGKM0(4); else ODT_WAIT_VM_LGKM0(0);
+    __builtin_amdgcn_s_barrier();
+    ODT_FENCE();
+    if (c + 2 < nch) dma_w(c + 2, buf);
+    f32x4 v4[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const int at = (row0 + 64 * s2) * CS + c4 * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&C0[at]) + *reinterpret_cast<const f32x4*>(&C1[at]);
+      v = v * sc3;
+      v += b3;
+      v += rres[s2];                        // (no residual: the descriptor is empty, the chunks read as zeros)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], act_lo);
+      v4[s2] = v;
+      const float vm = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      vmax = fmaxf(vmax, m_first + 64u * s2 < mrows ? vm : 0.f);
+    }
+    ODT_FENCE();
+    if (c + 1 < nch) fetch_cols(c + 1);     // (issued before the stores: a load behind a store waits for its acknowledgement)
+    ODT_FENCE();
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2)
+      __builtin_amdgcn_raw_buffer_store_b128((u32x4)v4[s2], rs_out, (int)(m_first + 64u * s2 < mrows ? ooff0 + s2 * ostep : kOOB), c * 128, 0);
+    ODT_FENCE();
+  }
+  publish_amax_wg<512>(p.f_out_amax, vmax, tid, lds);
+}
+
+template <int TN, bool TRACE = false, bool FUSE = false>
 __global__ void __launch_bounds__(512, 2) conv_h2k_kernel(const ConvParams* __restrict__ pp) {
-  using G = H2kCfg<TN>;
+  using G = H2kCfg<TN, FUSE>;
   constexpr int WM = 4, WN = 2, KW = 3;
   constexpr int BM = G::BM, BN = G::BN, AKG = G::AKG, APL = G::APL, ABUF = G::ABUF, BKG = G::BKG, BPL = G::BPL;
   constexpr int STAGE_B = G::STAGE_B, BOFF = G::BOFF, NW = G::NW, ZR = G::ZR, RA = G::RA;
@@ -166,6 +379,17 @@ __global__ void __launch_bounds__(512, 2) conv_h2k_kernel(const ConvParams* __re
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  if constexpr (FUSE) {
+    // the fused tail's view of this conv's epilogue constants: [0] 2^-s 2^-t_c, [1] bias_c (visible behind the prologue's barrier)
+    if (tid < 128) {
+      const int q = tid & 63;
+      const __amdgpu_buffer_rsrc_t rs_ch = __builtin_amdgcn_make_buffer_rsrc((void*)p.h2_chinv, 0, (int)((unsigned)cout_padded(p.Cout) * 4u), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (int)((unsigned)p.Cout * 4u), 0x00020000);
+      f32x4 v = tid < 64 ? (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_ch, q * 16, 0, 0) * h2_inv
+                         : (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, q * 16, 0, 0);
+      *reinterpret_cast<f32x4*>(lds + G::F_KOFF + (tid >> 6) * 1024 + q * 16) = v;
+    }
+  }
   // ---- prologue: group 0 staged, B stage 0 landed, stage 1's DMA in flight behind the barrier
   load_group();
   stamp(6);
@@ -277,17 +501,21 @@ __global__ void __launch_bounds__(512, 2) conv_h2k_kernel(const ConvParams* __re
     step(K2{}, F{}, F{}, F{});
   }
 #undef ODT_MF
-#undef ODT_FENCE
   stamp(2);
-  split3_epilogue<WM, WN, TN, G::LDS, TRACE>(p, acc, lds, m0, n0, M, HoWo, 0, 1, tid, wm, wn, fr, fg, h2_inv);
+  if constexpr (FUSE) h2f_tail<TN, TRACE>(p, acc, lds, m0, M, wave, wm, wn, h2_inv);
+  else split3_epilogue<WM, WN, TN, G::LDS, TRACE>(p, acc, lds, m0, n0, M, HoWo, 0, 1, tid, wm, wn, fr, fg, h2_inv);
   stamp(5);
 }
+#undef ODT_FENCE
 
 }  // namespace
 
 void launch_conv_h2k(const ConvParams& p, const ConvParams* dev, unsigned grid, hipStream_t stream) {
   const int bn = p.wt_split_bn;
-  if (bn == 256) {
+  if (p.f_wt != nullptr) {                   // fused 1x1 tail (launch_conv_h2 checked the shape)
+    if (p.trace != nullptr) hipLaunchKernelGGL((conv_h2k_kernel<4, true, true>), dim3(grid), dim3(512), 0, stream, dev);
+    else hipLaunchKernelGGL((conv_h2k_kernel<4, false, true>), dim3(grid), dim3(512), 0, stream, dev);
+  } else if (bn == 256) {
     if (p.trace != nullptr) hipLaunchKernelGGL((conv_h2k_kernel<4, true>), dim3(grid), dim3(512), 0, stream, dev);
     else hipLaunchKernelGGL((conv_h2k_kernel<4, false>), dim3(grid), dim3(512), 0, stream, dev);
   } else if (bn == 128) {

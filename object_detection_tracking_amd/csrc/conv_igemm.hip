@@ -614,7 +614,8 @@ void conv_prepare(ConvParams& p) {
 double conv_flops(const ConvParams& p) {
   return 2.0 * (double)p.B * p.Ho * p.Wo * (double)p.Cout *
              (double)(p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0)) +
-         (p.head_wt != nullptr ? 2.0 * (double)p.B * p.Ho * p.Wo * (double)p.Cout * 15.0 : 0.0);   // fused 1x1 head (15 real columns)
+         (p.head_wt != nullptr ? 2.0 * (double)p.B * p.Ho * p.Wo * (double)p.Cout * 15.0 : 0.0) +   // fused 1x1 head (15 real columns)
+         (p.f_wt != nullptr ? 2.0 * (double)p.B * p.Ho * p.Wo * (double)p.Cout * (double)p.f_cout : 0.0);   // fused 1x1 conv
 }
 
 int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_params) {

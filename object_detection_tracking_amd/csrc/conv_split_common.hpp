@@ -116,10 +116,17 @@ __device__ __forceinline__ int h2_in_scale_exp(const ConvParams& p) {
 
 // counted waits / LDS-only barrier / LDS pointer type of the LDS-DMA kernels (the simulator runs the DMA synchronously)
 #ifdef ODT_HIP_EMULATOR
+#define ODT_LANE_ID() (hipemu::lane_id())
+#define ODT_PIN2(a, b) do { } while (0)
 #define ODT_WAIT_VM_LGKM0(n) do { } while (0)
 #define ODT_BARRIER_LDS() __syncthreads()
 #define ODT_LDS_PTR(p) ((void*)(p))
 #else
+// the lane id from the execution mask (v_mbcnt): recomputed where needed instead of held in a register
+#define ODT_LANE_ID() ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
+// an opaque use + redefinition of two values: everything they depend on is computed before this point, nothing that uses
+// them moves above it (keeps IR-level code sinking from stretching live ranges across a register-tight region)
+#define ODT_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
 // counted wait: at most n vector-memory operations (A fetches / DMA of younger stages) stay in flight; all LDS done
 #define ODT_WAIT_VM_LGKM0(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(n) : "memory")
 // workgroup barrier that orders LDS traffic only (__syncthreads() would also drain the global stores in flight)

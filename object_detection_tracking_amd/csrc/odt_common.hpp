@@ -102,6 +102,19 @@ struct ConvParams {
   const float* head_bias;  // [16]
   float* head_out;         // [M][head_ldc] dense rows (m = (n, ho, wo))
   int head_ldc;
+  // optional fused 1x1 conv behind this conv (conv_h2k_kernel<.., FUSE>: the bottleneck's conv2 3x3 + BN + ReLU followed by
+  // conv3 1x1 + BN (+ shortcut) + ReLU, nn.py:503-521): the tile's accumulators never leave the CU -- scaled, biased and
+  // activated in registers, split into fp16x2 pieces with a power of two PER PIXEL ROW (not per tensor), they are the
+  // second GEMM's operand as they sit (MFMA C layout == operand layout under a k permutation that the weight image
+  // f_wt carries); f_out[m][n] = act(sum_k y[m][k] w[n][k] + f_bias[n] (+ f_res[m][n])), rows m dense over (n, ho, wo).
+  // `out` is not written (nullptr) and the 1x1 conv's own launch disappears.
+  const void* f_wt;        // conv_make_h2f_weights image of the 1x1 conv (K = this conv's Cout), or nullptr
+  const float* f_chinv;    // [f_cout] inverse powers of two of the image's rows
+  const float* f_bias;     // [f_cout]
+  const float* f_res;      // [M][f_res_ldc] same-shape residual or nullptr
+  float* f_out;            // [M][f_out_ldc]
+  unsigned* f_out_amax;    // range slot of f_out or nullptr
+  int f_cout, f_out_ldc, f_res_ldc, f_relu;
 };
 // fills the derived fields (multiply-shift divisors); call before copying a record to the device
 void conv_prepare(ConvParams& p);
@@ -152,6 +165,13 @@ int launch_conv_split(const ConvParams& p, const ConvParams* dev, hipStream_t st
 const float* conv_h2_chinv(const void* img, int Cout, int K);
 int conv_make_h2_weights(const ConvParams& p, void* img_dev, hipStream_t stream);
 int launch_tensor_amax(const float* x, size_t n, unsigned* slot, hipStream_t stream);
+// fused 1x1 conv behind a conv_h2k launch (ConvParams::f_wt): image of wt [Cout][K] (K = 128 or 256: the producer's
+// Cout), chunks of 32 output columns, k in the order the producer's accumulator registers hold it; the rows' inverse
+// powers of two sit behind the pieces (conv_h2f_chinv)
+size_t conv_h2f_weight_bytes(int Cout, int K);
+const float* conv_h2f_chinv(const void* img, int Cout, int K);
+int conv_make_h2f_weights(const float* wt, int Cout, int K, void* img_dev, hipStream_t stream);
+bool conv_h2f_fusable(const ConvParams& a, const ConvParams& b);   // a: the KH x 3 producer, b: the 1x1 conv reading a.out
 size_t conv_split_partial_bytes(const ConvParams& p);   // scratch a split-K conv needs (0: none)
 
 // ------------------------------------------------------------ elementwise (K1,K4)

@@ -88,7 +88,7 @@ struct odt_model {
   std::vector<std::unique_ptr<DevBuf>> bufs;
   std::map<std::string, Tensor> taps;
   std::vector<ConvOp> convs;
-  std::vector<char> conv_fused;      // convs[i] is evaluated inside another conv's epilogue (no launch of its own)
+  std::vector<char> conv_fused;      // convs[i] is evaluated inside another conv's kernel (no launch of its own): 1 RPN head, 2 bottleneck conv3
   ConvParams* convs_dev = nullptr;   // device copies of conv_recs
   std::vector<ConvParams> conv_recs; // launch records: convs[i] runs as records [conv_rec0[i], + conv_nrec[i]) (batch ranges,
   std::vector<int> conv_rec0, conv_nrec;   // more than one only where a tensor would reach 2 GiB: upload_conv_records)
@@ -100,6 +100,7 @@ struct odt_model {
   unsigned* amax_dev = nullptr;
   int amax_used[2] = {0, 0};
   int convs_h2 = 0;                  // convs on the fp16x2 kernels
+  int convs_h2f = 0;                 // ... of them with the following 1x1 conv folded into the kernel (fuse_bottleneck_tails)
   unsigned* pre_amax = nullptr;      // range slot of the preprocessed frames (OP_PRE records it; conv0 reads it)
   std::vector<Op> ops;
   // geometry
@@ -207,6 +208,7 @@ int create_side_stream(hipStream_t* s);
 ConvPolicy resolve_conv_policy(const odt_model* m);
 int attach_split_weights(odt_model* m);
 int fuse_rpn_heads(odt_model* m);
+int fuse_bottleneck_tails(odt_model* m);
 void find_overlap_points(odt_model* m);
 int plan_arena(odt_model* m);
 int upload_conv_records(odt_model* m);
@@ -228,7 +230,7 @@ void visit_op_ptrs(odt_model* m, size_t oi, F&& f) {
   f(op.in.d); f(op.out.d);
   switch (op.kind) {
     case OP_PRE: case OP_PRE_RGB: f(m->image_pad.d); break;
-    case OP_CONV: { ConvParams& c = m->convs[op.conv].p; f(c.in); f(c.res); f(c.out); f(c.in2); break; }
+    case OP_CONV: { ConvParams& c = m->convs[op.conv].p; f(c.in); f(c.res); f(c.out); f(c.in2); f(c.head_out); f(c.f_res); f(c.f_out); break; }
     case OP_PROPOSALS: for (auto& l : m->prop.lvl) f(l.rpn); f(m->prop.props); break;
     case OP_ROI_HEAD: roi(m->roi_head); break;
     case OP_ROI_FINAL: roi(m->roi_final); break;

@@ -189,6 +189,69 @@ int odt_op_conv2d_cat(int device, const float* a, int B, int Ho, int Wo, int Ca,
   return dout.get(out, nout);
 }
 
+// conv2 (3x3, stride 1, 'SAME' for dilation dil, C -> C, bias, ReLU) -> conv3 (1x1, C -> C3, bias (+ residual), ReLU?) on the
+// fp16x2 kernels, C = 256: fuse = 1 as ONE conv_h2k_kernel launch with the fused tail (the plan's fuse_bottleneck_tails),
+// fuse = 0 as the two launches the fused form replaces (conv_h2k_kernel -> [M,C] tensor + recorded range -> conv_h2_kernel).
+int odt_op_bottleneck_tail(int device, const float* in, int B, int H, int W, int C, const float* w2_hwio, const float* b2,
+                           int dil, const float* w3_io, const float* b3, int C3, const float* res, int relu3, int fuse,
+                           float* out) {
+  ODT_CHECK(in && w2_hwio && b2 && w3_io && b3 && out, "odt_op_bottleneck_tail: null argument");
+  ODT_CHECK(C == 256 && C3 % 64 == 0 && C3 > 0 && (dil == 1 || dil == 2), "odt_op_bottleneck_tail: C = 256, C3 % 64 == 0, dil 1 or 2");
+  if (set_dev(device)) return 1;
+  const size_t M = (size_t)B * H * W;
+  std::vector<float> w2((size_t)C * 9 * C), w3((size_t)C3 * C);
+  for (int y = 0; y < 3; ++y) for (int x = 0; x < 3; ++x) for (int i = 0; i < C; ++i) for (int o = 0; o < C; ++o)
+    w2[(((size_t)o * 3 + y) * 3 + x) * C + i] = w2_hwio[(((size_t)y * 3 + x) * C + i) * C + o];
+  for (int i = 0; i < C; ++i) for (int o = 0; o < C3; ++o) w3[(size_t)o * C + i] = w3_io[(size_t)i * C3 + o];
+  Tmp<float> di, dw2, db2, dw3, db3, dres, dmid, dout, img2, img3, imgf;
+  Tmp<unsigned> amax;
+  if (di.alloc(M * C) || dw2.alloc(w2.size()) || db2.alloc(C) || dw3.alloc(w3.size()) || db3.alloc(C3) || dmid.alloc(M * C) ||
+      dout.alloc(M * C3) || dout.zero() || amax.alloc(4) || amax.zero()) return 1;
+  if (di.put(in) || dw2.put(w2.data()) || db2.put(b2) || dw3.put(w3.data()) || db3.put(b3)) return 1;
+  if (res) { if (dres.alloc(M * C3) || dres.put(res)) return 1; }
+  if (launch_tensor_amax(di.d, M * C, amax.d, nullptr)) return 1;
+  ConvParams a; std::memset(&a, 0, sizeof(a));
+  a.in = di.d; a.wt = dw2.d; a.bias = db2.d; a.out = dmid.d;
+  a.B = B; a.H = H; a.W = W; a.Cin = C; a.in_ldc = C; a.in_Ha = H; a.in_Wa = W; a.Ho = H; a.Wo = W; a.Cout = C;
+  a.kh = 3; a.kw = 3; a.stride = 1; a.dil = dil; a.pad_t = dil; a.pad_l = dil;
+  a.out_H = H; a.out_W = W; a.out_ldc = C; a.relu = 1;
+  a.wt_split_kind = 2; a.wt_split_bm = 256; a.wt_split_bn = 256; a.wt_split_kwr = 1; a.splitk = 1;
+  a.in_amax = amax.d; a.out_amax = amax.d + 1; a.debug = 0x400;
+  conv_prepare(a);
+  if (img2.alloc((conv_split_weight_bytes(C, 9 * C) + 3) / 4) || conv_make_split_weights(a, img2.d, nullptr)) return 1;
+  a.wt_split = img2.d; a.h2_chinv = conv_h2_chinv(img2.d, C, 9 * C);
+  ConvParams b; std::memset(&b, 0, sizeof(b));
+  b.in = dmid.d; b.wt = dw3.d; b.bias = db3.d; b.out = dout.d; b.res = res ? dres.d : nullptr;
+  b.B = B; b.H = H; b.W = W; b.Cin = C; b.in_ldc = C; b.in_Ha = H; b.in_Wa = W; b.Ho = H; b.Wo = W; b.Cout = C3;
+  b.kh = 1; b.kw = 1; b.stride = 1; b.dil = 1;
+  b.out_H = H; b.out_W = W; b.out_ldc = C3; b.relu = relu3 ? 1 : 0;
+  b.res_mode = res ? 1 : 0; b.res_H = H; b.res_W = W; b.res_ldc = C3;
+  b.wt_split_kind = 2; b.wt_split_bm = 256; b.wt_split_bn = C3 % 256 == 0 ? 256 : (C3 % 128 == 0 ? 128 : 64); b.splitk = 1;
+  if (b.wt_split_bn == 64) b.wt_split_bm = 128;
+  b.in_amax = amax.d + 1; b.out_amax = amax.d + 2; b.debug = 0x400;
+  conv_prepare(b);
+  if (img3.alloc((conv_split_weight_bytes(C3, C) + 3) / 4) || conv_make_split_weights(b, img3.d, nullptr)) return 1;
+  b.wt_split = img3.d; b.h2_chinv = conv_h2_chinv(img3.d, C3, C);
+  Tmp<ConvParams> rec;
+  if (rec.alloc(2)) return 1;
+  if (fuse) {
+    ODT_CHECK(conv_h2f_fusable(a, b), "odt_op_bottleneck_tail: this pair is not fusable");
+    if (imgf.alloc((conv_h2f_weight_bytes(C3, C) + 3) / 4) || conv_make_h2f_weights(dw3.d, C3, C, imgf.d, nullptr)) return 1;
+    a.f_wt = imgf.d; a.f_chinv = conv_h2f_chinv(imgf.d, C3, C); a.f_bias = db3.d; a.f_res = b.res; a.f_res_ldc = C3;
+    a.f_out = dout.d; a.f_out_ldc = C3; a.f_cout = C3; a.f_relu = b.relu; a.f_out_amax = amax.d + 2;
+    a.out = nullptr; a.out_amax = nullptr;
+    ConvParams recs[2] = {a, b};
+    if (rec.put(recs)) return 1;
+    if (launch_conv_split(a, rec.d, nullptr)) return 1;
+  } else {
+    ConvParams recs[2] = {a, b};
+    if (rec.put(recs)) return 1;
+    if (launch_conv_split(a, rec.d, nullptr) || launch_conv_split(b, rec.d + 1, nullptr)) return 1;
+  }
+  ODT_HIP(hipDeviceSynchronize());
+  return dout.get(out, M * C3);
+}
+
 int odt_op_preprocess(int device, const void* frames, int dtype, int B, int H, int W, int pad_t, int pad_l,
                       int Hp, int Wp, float* out) {
   ODT_CHECK(frames && out, "odt_op_preprocess: null argument");

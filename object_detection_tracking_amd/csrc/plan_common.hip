@@ -338,6 +338,55 @@ int fuse_rpn_heads(odt_model* m) {
   return 0;
 }
 
+// ---- bottleneck tail folded into the 3x3 conv's kernel ----------------------------------------------------------------
+// block/conv2 (3x3, ch -> ch, BN, ReLU) is read by block/conv3 (1x1, ch -> 4 ch, BN, + shortcut, ReLU) and by nothing else
+// (nn.py:503-521).  Where conv2 runs on conv_h2k_kernel with its whole Cout in one 256-wide n-tile (res4 at b >= 4 @1080p)
+// and conv3 is a plain dense 1x1 (conv_h2f_fusable), conv3 is evaluated from conv2's accumulators inside that kernel
+// (conv_h2k.hip: h2f_tail): conv2's [M,256] tensor is neither written nor read back, conv3's launch -- prologue, A stream,
+// its own lock-step store phase behind an idle matrix pipe -- disappears, and conv3's operand gets its power of two per
+// pixel row instead of per tensor.  ODT_FUSE_BOTTLENECK=0 keeps the two launches (A/B).  Called after
+// attach_split_weights, before plan_arena.
+int fuse_bottleneck_tails(odt_model* m) {
+  if (m->conv_fused.size() < m->convs.size()) m->conv_fused.resize(m->convs.size(), 0);
+  const char* e = getenv("ODT_FUSE_BOTTLENECK");
+  if (e != nullptr && e[0] == '0') return 0;
+  if (m->policy.arith == 0 || m->policy.family != 2) return 0;
+  std::map<const float*, const void*> made;
+  for (size_t oi = 0; oi + 1 < m->ops.size(); ++oi) {
+    Op& oa = m->ops[oi]; Op& ob = m->ops[oi + 1];
+    if (oa.kind != OP_CONV || ob.kind != OP_CONV || oa.skip || ob.skip) continue;
+    ConvOp& a = m->convs[oa.conv]; ConvOp& b = m->convs[ob.conv];
+    if (!conv_h2f_fusable(a.p, b.p)) continue;
+    // nothing else may read conv2's output (taps: a keep_taps handle exposes no stage tensor under this name, see add_conv)
+    bool other = false;
+    for (size_t k = 0; k < m->ops.size() && !other; ++k) {
+      if (k == oi || k == oi + 1) continue;
+      visit_op_ptrs(m, k, [&](auto& ptr) { if ((const void*)ptr == (const void*)a.p.out) other = true; });
+    }
+    for (const auto& kv : m->taps) if (kv.second.d == a.p.out) other = true;
+    if (other) continue;
+    const int K = b.p.Cin;
+    auto it = made.find(b.p.wt);
+    if (it == made.end()) {
+      float* img = m->alloc_f((conv_h2f_weight_bytes(b.p.Cout, K) + 3) / 4, false);
+      ODT_CHECK(img != nullptr, "device allocation failed (fused 1x1 weights of " + b.name + ")");
+      if (conv_make_h2f_weights(b.p.wt, b.p.Cout, K, img, 0)) return 1;
+      it = made.emplace(b.p.wt, img).first;
+    }
+    ConvParams& ap = a.p;
+    ap.f_wt = it->second; ap.f_chinv = conv_h2f_chinv(it->second, b.p.Cout, K); ap.f_bias = b.p.bias;
+    ap.f_res = b.p.res_mode != 0 ? b.p.res : nullptr; ap.f_res_ldc = b.p.res_ldc;
+    ap.f_out = b.p.out; ap.f_out_ldc = b.p.out_ldc; ap.f_cout = b.p.Cout; ap.f_relu = b.p.relu; ap.f_out_amax = b.p.out_amax;
+    ap.debug |= b.p.debug & 0x400;           // the residual's non-temporal hint travels with it
+    ap.out = nullptr; ap.out_amax = nullptr;
+    ob.skip = true;
+    m->conv_fused[ob.conv] = 2;
+    ++m->convs_h2f;
+  }
+  ODT_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
 // ---- activation arena -----------------------------------------------------------------------------------------------
 // ops [op_tail, end) of forward i (selection / ROIAlign / box head / NMS / features) may run on the side stream under ops
 // [0, op_first_fpn) of forward i+1 (run_plan: tail overlap); 0 / 0 when the graph has no such split
@@ -375,6 +424,9 @@ int plan_arena(odt_model* m) {
     if (v.last < 0 && !tapped[i]) { v.bytes = 0; v.first = v.last = 0; }     // no op touches it (its producer was fused away)
     if (v.last < 0) { v.first = 0; v.last = nops - 1; }          // never referenced by an op (tap only): keep it apart
     v.region = split && v.last >= (int)m->op_tail ? 1 : 0;
+    // forward i + 1 waits for forward i's tail only in front of op_first_fpn: what the tail reads must not be (re)written earlier
+    ODT_CHECK(v.region == 0 || v.bytes == 0 || v.first >= (int)m->op_first_fpn || tapped[i],
+              "activation arena: a tensor the tail ops read is produced before the FPN stage (tail overlap would race)");
     if (v.region == 1) v.last = nops - 1;                        // readable after the forward (appearance features / taps of the pyramid)
   }
   std::vector<int> order(m->vt.size());
@@ -422,6 +474,16 @@ int plan_arena(odt_model* m) {
   }
   for (size_t oi = 0; oi < m->ops.size(); ++oi) visit_op_ptrs(m, oi, fix);
   fix(m->image_pad.d);
+  // every pointer a launched conv dereferences must be real memory by now (a field visit_op_ptrs does not enumerate would
+  // still hold its virtual address)
+  for (size_t oi = 0; oi < m->ops.size(); ++oi) {
+    const Op& op = m->ops[oi];
+    if (op.kind != OP_CONV || op.skip) continue;
+    const ConvParams& c = m->convs[op.conv].p;
+    for (const void* q : {(const void*)c.in, (const void*)c.res, (const void*)c.out, (const void*)c.in2, (const void*)c.head_out,
+                          (const void*)c.f_res, (const void*)c.f_out})
+      ODT_CHECK(q == nullptr || !m->is_virtual(q), "activation arena: unmapped pointer left in " + m->convs[op.conv].name);
+  }
   return 0;
 }
 
@@ -435,7 +497,8 @@ static int conv_batch_chunks(const ConvParams& p, double limit) {
     const double b = (double)(p.B / n);
     return b * p.in_Ha * p.in_Wa * p.in_ldc * 4.0 < limit && b * p.out_H * p.out_W * p.out_ldc * 4.0 < limit &&
            (p.res_mode == 0 || b * p.res_H * p.res_W * p.res_ldc * 4.0 < limit) &&
-           (p.in2 == nullptr || b * p.in2_Ha * p.in2_Wa * p.in2_ldc * 4.0 < limit);
+           (p.in2 == nullptr || b * p.in2_Ha * p.in2_Wa * p.in2_ldc * 4.0 < limit) &&
+           (p.f_wt == nullptr || (b * p.Ho * p.Wo * p.f_out_ldc * 4.0 < limit && (p.f_res == nullptr || b * p.Ho * p.Wo * p.f_res_ldc * 4.0 < limit)));
   };
   for (int n = 1; n <= p.B; ++n)
     if (p.B % n == 0 && fits(n)) return n;
@@ -460,6 +523,8 @@ int upload_conv_records(odt_model* m) {
       if (p.res != nullptr) q.res = p.res + b0 * p.res_H * p.res_W * p.res_ldc;
       if (p.in2 != nullptr) q.in2 = p.in2 + b0 * p.in2_Ha * p.in2_Wa * p.in2_ldc;
       if (p.head_out != nullptr) q.head_out = p.head_out + b0 * p.Ho * p.Wo * p.head_ldc;
+      if (p.f_out != nullptr) q.f_out = p.f_out + b0 * p.Ho * p.Wo * p.f_out_ldc;
+      if (p.f_res != nullptr) q.f_res = p.f_res + b0 * p.Ho * p.Wo * p.f_res_ldc;
       m->conv_recs.push_back(q);
     }
     if (n > 1) ++m->chunked_convs;

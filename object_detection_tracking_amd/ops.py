@@ -56,6 +56,20 @@ def conv2d_cat(a, b2, wa, wb, bias=None, stride_b=1, relu=False, lib=None, devic
   return out
 
 
+def bottleneck_tail(x, w2, b2, w3, b3, res=None, dil=1, relu3=True, fuse=True, lib=None, device=0):
+  """conv2 (3x3, 'SAME', ReLU) -> conv3 (1x1 (+ res), ReLU) of a bottleneck block (reference nn.py:503-521) on the fp16x2
+  kernels; fuse=True: conv3 inside the 3x3 kernel (one launch), False: the two launches it replaces."""
+  lib = _L(lib)
+  x = f32(x); w2 = f32(w2); b2 = f32(b2); w3 = f32(w3); b3 = f32(b3)
+  B, H, W, Cc = x.shape
+  C3 = w3.shape[1]
+  r = f32(res) if res is not None else None
+  out = np.zeros((B, H, W, C3), np.float32)
+  lib.check(lib.dll.odt_op_bottleneck_tail(device, fptr(x), B, H, W, Cc, fptr(w2), fptr(b2), dil, fptr(w3), fptr(b3), C3,
+                                           fptr(r) if r is not None else None, int(relu3), int(fuse), fptr(out)))
+  return out
+
+
 def preprocess(frames, pad_t, pad_l, Hp, Wp, lib=None, device=0):
   """reference models.py:340-355 + zero pad; returns [B,Hp,Wp,4]."""
   lib = _L(lib)

@@ -386,6 +386,44 @@ def test_rpn_head_fused_into_conv_epilogue(backend, monkeypatch):
 
 
 
+def test_bottleneck_conv3_fused_into_conv2_kernel(backend, monkeypatch):
+  """block/conv3 (1x1 + BN + shortcut + ReLU) evaluated from block/conv2's accumulators inside conv_h2k_kernel where conv2
+  runs there with its whole Cout in one 256-wide n-tile (at 1080p, b = 8: the 22 identity blocks of res4; here forced by
+  the tile thresholds on a 256 x 256 frame: res4 has 16 x 16 pixels): stage tensors agree with the two-launch form at f32
+  rounding level, detections as sets, the handle reports the folded launches, and (GPU) the fused form agrees with the
+  oracle through both the arena and the keep_taps handle."""
+  name, lib = backend
+  monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1"); monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "1")
+  monkeypatch.setenv("ODT_CONV_SPLIT3_BM", "256")
+  cfg = small_config(resnet_num_block=[1, 1, 2, 1] if name == "emu" else [1, 1, 4, 3], max_size=256, short_edge_size=256)
+  w = weights_for(cfg)
+  H, W = 256, 256
+  fr = synthetic_frames(1, H, W, seed=5)
+  out = {}
+  for mode in ("0", "1"):
+    monkeypatch.setenv("ODT_FUSE_BOTTLENECK", mode)
+    m = models.get_model(_with_taps(cfg), 0, weights=w, lib=lib)
+    try:
+      det = m.predict(fr[0])
+      e = m.engine(1, H, W)
+      out[mode] = (det, {k: e.tap(k) for k in ("c3", "c4", "c5", "p4", "rpn4")}, e.describe(), [nm for nm, _, _, _ in e.profile_layers()])
+    finally:
+      m.close()
+  nf = out["1"][2]["bottleneck_tails_fused"]
+  assert out["0"][2]["bottleneck_tails_fused"] == 0 and nf == (1 if name == "emu" else 3), out["1"][2]
+  assert out["1"][2]["conv_launches"] + nf == out["0"][2]["conv_launches"]
+  assert sum(1 for nm in out["1"][3] if "conv2+conv3[fp16x2]" in nm) == nf, out["1"][3]
+  assert np.array_equal(out["1"][1]["c3"], out["0"][1]["c3"])             # (nothing in front of res4 changes)
+  for k in ("c4", "c5", "p4", "rpn4"):
+    assert _rel(out["1"][1][k], out["0"][1][k]) < 1e-5, k
+  miss, extra = match_detections(out["1"][0][0], out["1"][0][1], out["1"][0][2], out["0"][0][0], out["0"][0][1], out["0"][0][2], 1e-3, 1e-4)
+  assert miss + extra == 0
+  if name == "hip":
+    monkeypatch.setenv("ODT_FUSE_BOTTLENECK", "1")
+    miss, extra = _run_single(lib, cfg, H, W)
+    assert miss == 0 and extra == 0
+
+
 @pytest.mark.parametrize("tiles", ["256", "128/k2"])
 def test_fp16x2_family_agrees_with_bf16x3(backend, tiles, monkeypatch):
   """conv_split_family = 2: the layers with 256-row tiles at least 128 columns wide and a recorded input range run on the
