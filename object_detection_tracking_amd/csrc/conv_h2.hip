@@ -476,7 +476,7 @@ int launch_conv_h2(const ConvParams& p, const ConvParams* dev, hipStream_t strea
   if (p.wt_split_kwr) {
     ODT_CHECK(sk == 1 && p.kw == 3 && p.stride == 1 && p.in_Wa == p.Wo && p.in2 == nullptr && 2 * p.dil <= 4, "conv h2k: unsupported shape");
     ODT_CHECK(p.f_wt == nullptr || (bn == 256 && p.Cout == 256 && p.head_wt == nullptr && p.res_mode == 0 && p.relu <= 1 && p.f_cout % 32 == 0 &&
-                                    p.f_cout > 0 && p.f_out != nullptr && p.f_chinv != nullptr && p.f_bias != nullptr && p.f_out_ldc % 4 == 0 &&
+                                    p.f_cout > 0 && p.f_cout <= 1024 && p.f_out != nullptr && p.f_chinv != nullptr && p.f_bias != nullptr && p.f_out_ldc % 4 == 0 &&
                                     (p.f_res == nullptr || p.f_res_ldc % 4 == 0) && (double)M * p.f_out_ldc * 4.0 < 2147483648.0 &&
                                     (p.f_res == nullptr || (double)M * p.f_res_ldc * 4.0 < 2147483648.0)),
               "conv h2k: unsupported fused 1x1 tail");

@@ -37,12 +37,13 @@ struct H2kCfg {
   static constexpr int BOFF = 2 * ABUF;
   static constexpr int RING = BOFF + 2 * STAGE_B;
   static constexpr int CTILE = 128 * (BN + 4) * 4;
-  // fused 1x1 tail: two 32-column chunks of its weight image + the two K halves' partial tiles [256][32 + 4] f32
+  // fused 1x1 tail: two 32-column chunks of its weight image + two result tiles [256][32 + 4] f32 (this chunk / the previous one)
   // (+ the producer's own column constants, [2][256] f32 behind everything the main loop and the tail use)
   static constexpr int F_WCH = 2 * 2 * (2 * TN) * 1024, F_CS = 36, F_COFF = 2 * F_WCH, F_CEND = F_COFF + 2 * 256 * F_CS * 4;
   static constexpr int LDS0 = RING > CTILE ? RING : CTILE;
   static constexpr int F_KOFF = F_CEND > LDS0 ? F_CEND : LDS0;
-  static constexpr int LDS = FUSE ? F_KOFF + 2048 : LDS0;
+  static constexpr int F_K3OFF = F_KOFF + 2048;              // the fused conv's column constants, [2][1024] f32
+  static constexpr int LDS = FUSE ? F_K3OFF + 8192 : LDS0;
   static constexpr int NW = STAGE_B / 1024 / 8;
   static constexpr int RA = 5;                               // A fetch instructions per thread and group (rows t >> 3 + 64 j)
   static_assert(LDS <= 160 * 1024 && STAGE_B % 8192 == 0, "LDS");
@@ -56,30 +57,24 @@ struct H2kCfg {
 //   2. per pixel row and K half (= per lane pair fr / fr + 32 of a wave) the power of two that takes the row's |max| into
 //      [2^14, 2^15); y 2^sy = hi + lo (f16 pairs): registers 8 h .. 8 h + 7 of acc[i][j] ARE the operand fragment of k16 step
 //      (j, h) -- nothing moves (the weight image carries k in this order: split_weights_h2f_kernel);
-//   3. per 32-column chunk of the 1x1 conv: the chunk's weight pieces (LDS-DMA, two chunks ahead) x the wave's K half:
-//      2 TN steps x 2 pixel blocks x 3 products; the two K halves' partial tiles (each scaled back by its rows' 2^-sy) meet in
-//      LDS, then rows of 16-byte chunks: (p0 + p1) 2^-t_n + bias (+ residual), activation, store, |max|.
-// Two barriers per chunk; the residual chunks and the column constants of chunk c + 1 are fetched under chunk c's stores.
+//   3. the two waves of a row block (wm, 0) / (wm, 1) swap halves through LDS, once per tile: wave (wm, wn) keeps pixel
+//      block i = wn and receives that block's other K half (pieces + the rows' powers of two), lane for lane -- afterwards
+//      every wave owns 32 pixels x the whole K, and no partial sums ever have to meet;
+//   4. per 32-column chunk of the 1x1 conv: weight pieces by LDS-DMA two chunks ahead, 4 TN k16 steps x 3 products into two
+//      accumulators (own half / received half: each scaled back by its rows' 2^-sy), the [256][32] result to one of two LDS
+//      tiles, ONE barrier, and the rows of 16-byte chunks (x 2^-t_n + bias (+ residual), activation, store, |max|) go out
+//      UNDER the next chunk's MFMAs; the residual chunks are fetched two chunks ahead into the registers the previous
+//      chunk's have just left.
 template <int TN, bool TRACE>
 __device__ __forceinline__ void h2f_tail(const ConvParams& p, f32x16 (&acc)[2][TN], unsigned char* lds, int m0, int M,
                                          int wave, int wm, int wn, float h2_inv) {
   using G = H2kCfg<TN, true>;
-  constexpr int NS = 2 * TN, WCH = G::F_WCH, CS = G::F_CS, COFF = G::F_COFF;
+  constexpr int NS = 2 * TN, WCH = G::F_WCH, CS = G::F_CS, COFF = G::F_COFF, CBUF = 256 * CS * 4;
   // (the lane id is recomputed here: nothing per-lane stays live across the main loop, whose registers are all taken)
   ODT_FENCE();
   const int lane = ODT_LANE_ID();
   const int tid = wave * 64 + lane, fr = lane & 31, fg = lane >> 5;
   const int nch = p.f_cout >> 5;
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.f_wt, 0, (int)((unsigned)nch * (unsigned)WCH), 0x00020000);
-  auto dma_w = [&](int c, int buf) {
-#pragma unroll
-    for (int i = 0; i < WCH / 8192; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, ODT_LDS_PTR(lds + buf * WCH + (i * 8 + wave) * 1024), 16,
-                                               lane * 16 + (i * 8 + wave) * 1024, c * WCH, 0, 0);
-  };
-  // (the ring is free: the main loop's last barrier sits behind every fragment read)
-  dma_w(0, 0);
-  if (nch > 1) dma_w(1, 1);
 
   // ---- 1. + 2. the producer's epilogue arithmetic in registers, the per-row power of two, the pieces.  Two passes over the
   // accumulators (row |max| first, then value -> pieces), the column constants (2^-s 2^-t_c, bias_c: staged in LDS by the
@@ -107,10 +102,19 @@ __device__ __forceinline__ void h2f_tail(const ConvParams& p, f32x16 (&acc)[2][T
   // row block's pass behind the other's exponent arithmetic and keeps all 128 constants in registers across -- spills)
   ODT_PIN2(mx[0], mx[1]);
   asm volatile("" ::: "memory");
+  // the row's |max| over BOTH K halves: the partner wave (wm, 1 - wn) covers the other 32 TN channels of the same 64 rows
+  constexpr int XS = 8 * 2 * NS * 1024;     // (behind the piece exchange area of step 3)
+  float* xs = reinterpret_cast<float*>(lds + XS);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], 32));
+    xs[wave * 128 + i * 64 + lane] = mx[i];
+  }
+  ODT_BARRIER_LDS();
   float ys[2], yinv[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const float m = fmaxf(mx[i], __shfl_xor(mx[i], 32));
+    const float m = fmaxf(mx[i], xs[(wave ^ 1) * 128 + i * 64 + lane]);
     // h2_scale_exp without control flow
     const int be = (int)((__float_as_uint(m) >> 23) & 0xffu);
     int e = 14 - (be - 127);
@@ -119,7 +123,8 @@ __device__ __forceinline__ void h2f_tail(const ConvParams& p, f32x16 (&acc)[2][T
     ys[i] = pow2f(e); yinv[i] = pow2f(-e);
   }
   ODT_PIN2(ys[0], ys[1]);
-  f16x8 yh[2][TN][2], yl[2][TN][2];
+  // pieces: [pixel block][hi / lo][k16 step t = 2 j + h of this wave's K half]
+  u32x4 yq[2][2][NS];
 #pragma unroll
   for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -144,108 +149,159 @@ __device__ __forceinline__ void h2f_tail(const ConvParams& p, f32x16 (&acc)[2][T
           hq[t] = a; lq[t] = b;
         }
         ODT_PIN2(hq, lq);                   // (computed HERE, from constants that die here: see the pins above)
-        __builtin_memcpy(&yh[i][j][h], &hq, 16);
-        __builtin_memcpy(&yl[i][j][h], &lq, 16);
+        yq[i][0][2 * j + h] = hq; yq[i][1][2 * j + h] = lq;
       }
       ODT_FENCE();
     }
   ODT_STAMP(3);
 
-  // ---- 3. the 1x1 conv, 32 output columns at a time
+  // ---- 3. swap halves with the partner wave (wm, 1 - wn): give pixel block 1 - wn, keep block wn.  Exchange area: wave w's
+  // 2 * NS fragments at w * XW (lane-linear kilobytes), its rows' inverse powers of two behind all of them.  The main loop's
+  // ring is free (its last barrier sits behind every fragment read) and the weight DMA starts after the swap.
+  constexpr int XW = 2 * NS * 1024;
+  static_assert(XS == 8 * XW && XS + 8 * 512 <= G::F_KOFF, "exchange area");
+  u32x4 yo[2][NS], yr[2][NS];               // own / received K half of the kept block: [hi / lo][step]
+  const float yinv_k = wn == 0 ? yinv[0] : yinv[1];
+  {
+    unsigned char* xw = lds + wave * XW + lane * 16;
+    const unsigned char* xr = lds + (wave ^ 1) * XW + lane * 16;
+    auto give = [&](auto IC) {
+      constexpr int ig = decltype(IC)::value;       // the block given away
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+          *reinterpret_cast<u32x4*>(xw + (q * NS + t) * 1024) = yq[ig][q][t];
+          yo[q][t] = yq[1 - ig][q][t];
+        }
+    };
+    if (wn == 0) give(std::integral_constant<int, 1>{}); else give(std::integral_constant<int, 0>{});
+    ODT_BARRIER_LDS();
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int t = 0; t < NS; ++t) yr[q][t] = *reinterpret_cast<const u32x4*>(xr + (q * NS + t) * 1024);
+    ODT_BARRIER_LDS();
+  }
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.f_wt, 0, (int)((unsigned)nch * (unsigned)WCH), 0x00020000);
+  auto dma_w = [&](int c, int buf) {          // (a chunk past the image: out-of-range offsets, zeros -- every issue count below is static)
+#pragma unroll
+    for (int i = 0; i < WCH / 8192; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, ODT_LDS_PTR(lds + buf * WCH + (i * 8 + wave) * 1024), 16,
+                                               c < nch ? lane * 16 + (i * 8 + wave) * 1024 : (int)kOOB, c < nch ? c * WCH : 0, 0, 0);
+  };
+  dma_w(0, 0);
+  dma_w(1, 1);
+
+  // ---- 4. the 1x1 conv, 32 output columns at a time
   const unsigned mrows = (unsigned)M;
   const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.f_res != nullptr ? p.f_res : p.f_bias), 0, (int)(p.f_res != nullptr ? mrows * (unsigned)p.f_res_ldc * 4u : 0u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.f_out, 0, (int)(mrows * (unsigned)p.f_out_ldc * 4u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_ch3 = __builtin_amdgcn_make_buffer_rsrc((void*)p.f_chinv, 0, (int)((unsigned)p.f_cout * 4u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_b3 = __builtin_amdgcn_make_buffer_rsrc((void*)p.f_bias, 0, (int)((unsigned)p.f_cout * 4u), 0x00020000);
   const int c4 = tid & 7, row0 = tid >> 3;
   // rows row0 + 64 s2 of the tile: byte offsets of the thread's 16-byte chunk in the residual / output rows
   const unsigned m_first = (unsigned)(m0 + row0);
   const unsigned roff0 = (m_first * (unsigned)p.f_res_ldc + c4 * 4u) * 4u, rstep = 64u * (unsigned)p.f_res_ldc * 4u;
   const unsigned ooff0 = (m_first * (unsigned)p.f_out_ldc + c4 * 4u) * 4u, ostep = 64u * (unsigned)p.f_out_ldc * 4u;
   const bool has_res = p.f_res != nullptr;
-  const bool res_nt = (p.debug & 0x400) != 0;
   const float act_lo = p.f_relu == 1 ? 0.f : -__builtin_huge_valf();
-  f32x4 rres[4], sc3, b3;
-  auto fetch_cols = [&](int c) {            // residual chunks + column constants of chunk c
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) {
-      const unsigned off = has_res && m_first + 64u * s2 < mrows ? roff0 + s2 * rstep : kOOB;
-      rres[s2] = res_nt ? (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)off, c * 128, 2)
-                        : (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)off, c * 128, 0);
-    }
-    sc3 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_ch3, c4 * 16, c * 128, 0);
-    b3 = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_b3, c4 * 16, c * 128, 0);
+  const float* k3 = reinterpret_cast<const float*>(lds + G::F_K3OFF);      // [0] 2^-t_n, [1] bias_n of the 1x1 conv (prologue)
+  auto fetch_res = [&](int c, int s2) -> f32x4 {
+    // (read once, by this workgroup only: non-temporal, like the unfused epilogue's residual chunks; past the last chunk or
+    // without a residual: out of range, zeros)
+    const unsigned off = has_res && c < nch && m_first + 64u * s2 < mrows ? roff0 + s2 * rstep : kOOB;
+    return (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)off, c * 128, 2);
   };
-  fetch_cols(0);
-  float* C0 = reinterpret_cast<float*>(lds + COFF);
-  float* C1 = C0 + 256 * CS;
-  float* Cw = wn != 0 ? C1 : C0;
-  const unsigned char* wrd = lds + wn * NS * 1024 + lane * 16;
+  // residual chunks in flight: ra = chunk c - 1 (consumed under chunk c's MFMAs, each register refilled with chunk c + 1's
+  // right behind its use), rb = chunk c
+  f32x4 ra[4], rb[4];
+#pragma unroll
+  for (int s2 = 0; s2 < 4; ++s2) ra[s2] = fetch_res(0, s2);
+#pragma unroll
+  for (int s2 = 0; s2 < 4; ++s2) rb[s2] = fetch_res(1, s2);
+  const unsigned char* wrd = lds + lane * 16;
+  float* Cst = reinterpret_cast<float*>(lds + COFF);
+  const int cw_at = (wm * 64 + wn * 32 + fr) * CS + 4 * fg;     // this lane's pixel row in the result tile
+  const int cr_at = row0 * CS + c4 * 4;
   float vmax = 0.f;
-  ODT_WAIT_VM_LGKM0(0);
-  __builtin_amdgcn_s_barrier();             // chunks 0 / 1 of the weight image have landed
-#pragma unroll 1
-  for (int c = 0; c < nch; ++c) {
+  // one row-phase item: rows row0 + 64 s2 of chunk c's result tile -> global; the residual register is refilled for chunk c + 2
+  auto row_item = [&](int c, int s2, f32x4& rr) {
+    const float* Cb = Cst + (c & 1) * (CBUF / 4);
+    f32x4 v = *reinterpret_cast<const f32x4*>(Cb + cr_at + 64 * s2 * CS);
+    const f32x4 sc3 = *reinterpret_cast<const f32x4*>(k3 + c * 32 + c4 * 4), b3 = *reinterpret_cast<const f32x4*>(k3 + 1024 + c * 32 + c4 * 4);
+    v = v * sc3;
+    v += b3;
+    v += rr;                                // (no residual: the descriptor is empty, the chunks read as zeros)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], act_lo);
+    const float vm = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    const bool ok = m_first + 64u * s2 < mrows;
+    vmax = fmaxf(vmax, ok ? vm : 0.f);
+    __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)(ok ? ooff0 + s2 * ostep : kOOB), c * 128, 0);
+    rr = fetch_res(c + 2, s2);
+  };
+  ODT_WAIT_VM_LGKM0(8);                     // (own pieces of chunks 0 / 1 have landed; the residual fetches may fly)
+  __builtin_amdgcn_s_barrier();
+  // chunk c: MFMAs (own half: steps wn NS + t, received half: (1 - wn) NS + t of the image) with the row phase of chunk
+  // c - 1 under the first steps; result -> LDS tile c & 1; barrier; weight DMA of chunk c + 2 into the buffer just left
+  auto chunk = [&](int c, f32x4 (&rprev)[4], auto HP) {
+    constexpr bool has_prev = decltype(HP)::value;
     const int buf = c & 1;
-    f32x16 cacc[2];
+    const unsigned char* wo = wrd + buf * WCH + wn * NS * 1024;
+    const unsigned char* wr = wrd + buf * WCH + (1 - wn) * NS * 1024;
+    f32x16 co;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int r = 0; r < 16; ++r) co[r] = 0.f;
+    // half-steps u = 2 t + (0: own K half, 1: received half): the next half-step's weight fragments (hi, lo) are read under
+    // this one's three MFMAs; the previous chunk's row items go behind half-steps 1, 3, 5, 7
+    f16x8 wf[2][2];
+    wf[0][0] = *reinterpret_cast<const f16x8*>(wo);
+    wf[0][1] = *reinterpret_cast<const f16x8*>(wo + 2 * NS * 1024);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) cacc[i][r] = 0.f;
-    f16x8 wf[2][2];                         // [buffer][piece]: the next step's fragments are read under this step's MFMAs
-    wf[0][0] = *reinterpret_cast<const f16x8*>(wrd + buf * WCH);
-    wf[0][1] = *reinterpret_cast<const f16x8*>(wrd + buf * WCH + 2 * NS * 1024);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      if (s + 1 < NS) {
-        wf[(s + 1) & 1][0] = *reinterpret_cast<const f16x8*>(wrd + buf * WCH + (s + 1) * 1024);
-        wf[(s + 1) & 1][1] = *reinterpret_cast<const f16x8*>(wrd + buf * WCH + 2 * NS * 1024 + (s + 1) * 1024);
+    for (int u = 0; u < 2 * NS; ++u) {
+      if (u + 1 < 2 * NS) {
+        const unsigned char* w = ((u + 1) & 1 ? wr : wo) + ((u + 1) >> 1) * 1024;
+        wf[(u + 1) & 1][0] = *reinterpret_cast<const f16x8*>(w);
+        wf[(u + 1) & 1][1] = *reinterpret_cast<const f16x8*>(w + 2 * NS * 1024);
       }
+      f16x8 yhh, yll;
+      if (u & 1) { __builtin_memcpy(&yhh, &yr[0][u >> 1], 16); __builtin_memcpy(&yll, &yr[1][u >> 1], 16); }
+      else { __builtin_memcpy(&yhh, &yo[0][u >> 1], 16); __builtin_memcpy(&yll, &yo[1][u >> 1], 16); }
       ODT_FENCE();
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        cacc[i] = ODT_MFMA_F16(wf[s & 1][1], yh[i][s >> 1][s & 1], cacc[i]);
-        cacc[i] = ODT_MFMA_F16(wf[s & 1][0], yl[i][s >> 1][s & 1], cacc[i]);
-        cacc[i] = ODT_MFMA_F16(wf[s & 1][0], yh[i][s >> 1][s & 1], cacc[i]);
-      }
+      co = ODT_MFMA_F16(wf[u & 1][1], yhh, co);
+      co = ODT_MFMA_F16(wf[u & 1][0], yll, co);
+      co = ODT_MFMA_F16(wf[u & 1][0], yhh, co);
       ODT_FENCE();
+      if constexpr (has_prev) { if ((u & 1) && u < 8) row_item(c - 1, u >> 1, rprev[u >> 1]); }
     }
-    ODT_BARRIER_LDS();                      // the previous chunk's partial tiles have been read; this chunk's weights too
+    float* Cb = Cst + buf * (CBUF / 4) + cw_at;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 v = {cacc[i][4 * g], cacc[i][4 * g + 1], cacc[i][4 * g + 2], cacc[i][4 * g + 3]};
-        v = v * yinv[i];
-        *reinterpret_cast<f32x4*>(&Cw[(wm * 64 + i * 32 + fr) * CS + 8 * g + 4 * fg]) = v;
-      }
-    // own DMA of chunk c + 1 and this chunk's residual / constants have landed (the 4 stores of the previous chunk may fly)
-    if (c > 0) ODT_WAIT_VM_LGKM0(4); else ODT_WAIT_VM_LGKM0(0);
+    for (int g = 0; g < 4; ++g) {
+      f32x4 a = {co[4 * g], co[4 * g + 1], co[4 * g + 2], co[4 * g + 3]};
+      a = a * yinv_k;
+      *reinterpret_cast<f32x4*>(Cb + 8 * g) = a;
+    }
+    // own pieces of chunk c + 1's weights have landed (issued a chunk ago; the row phase's 4 stores + 4 fetches may fly)
+    if constexpr (has_prev) ODT_WAIT_VM_LGKM0(8); else ODT_WAIT_VM_LGKM0(0);
     __builtin_amdgcn_s_barrier();
     ODT_FENCE();
-    if (c + 2 < nch) dma_w(c + 2, buf);
-    f32x4 v4[4];
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) {
-      const int at = (row0 + 64 * s2) * CS + c4 * 4;
-      f32x4 v = *reinterpret_cast<const f32x4*>(&C0[at]) + *reinterpret_cast<const f32x4*>(&C1[at]);
-      v = v * sc3;
-      v += b3;
-      v += rres[s2];                        // (no residual: the descriptor is empty, the chunks read as zeros)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], act_lo);
-      v4[s2] = v;
-      const float vm = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-      vmax = fmaxf(vmax, m_first + 64u * s2 < mrows ? vm : 0.f);
-    }
+    dma_w(c + 2, buf);
     ODT_FENCE();
-    if (c + 1 < nch) fetch_cols(c + 1);     // (issued before the stores: a load behind a store waits for its acknowledgement)
-    ODT_FENCE();
+  };
+  chunk(0, ra, std::false_type{});
+  int c = 1;
+#pragma unroll 1
+  for (; c + 1 < nch; c += 2) {
+    chunk(c, ra, std::true_type{});         // consumes chunk c - 1's residual (ra), refills ra with chunk c + 1's
+    chunk(c + 1, rb, std::true_type{});
+  }
+  if (c < nch) {
+    chunk(c, ra, std::true_type{});
 #pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2)
-      __builtin_amdgcn_raw_buffer_store_b128((u32x4)v4[s2], rs_out, (int)(m_first + 64u * s2 < mrows ? ooff0 + s2 * ostep : kOOB), c * 128, 0);
-    ODT_FENCE();
+    for (int s2 = 0; s2 < 4; ++s2) row_item(c, s2, rb[s2]);
+  } else {
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) row_item(c - 1, s2, ra[s2]);
   }
   publish_amax_wg<512>(p.f_out_amax, vmax, tid, lds);
 }
@@ -388,6 +444,12 @@ __global__ void __launch_bounds__(512, 2) conv_h2k_kernel(const ConvParams* __re
       f32x4 v = tid < 64 ? (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_ch, q * 16, 0, 0) * h2_inv
                          : (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_bias, q * 16, 0, 0);
       *reinterpret_cast<f32x4*>(lds + G::F_KOFF + (tid >> 6) * 1024 + q * 16) = v;
+    }
+    {   // ... and the fused conv's: [0] 2^-t_n, [1] bias_n (f_cout <= 1024: launch_conv_h2)
+      const int q = tid & 255;
+      const __amdgpu_buffer_rsrc_t rs_k3 = __builtin_amdgcn_make_buffer_rsrc((void*)(tid < 256 ? p.f_chinv : p.f_bias), 0, (int)((unsigned)p.f_cout * 4u), 0x00020000);
+      const f32x4 v = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_k3, q * 16, 0, 0);
+      *reinterpret_cast<f32x4*>(lds + G::F_K3OFF + (tid >> 8) * 4096 + q * 16) = v;
     }
   }
   // ---- prologue: group 0 staged, B stage 0 landed, stage 1's DMA in flight behind the barrier
