@@ -52,6 +52,9 @@ def main():
   ap.add_argument("--no-extras", action="store_true", help="skip the `extra` measurements (A/B runs)")
   ap.add_argument("--cpu-frames", type=int, default=1, help="frames in the bounded CPU sample (7 passes: 2 warm-up + 5 timed)")
   ap.add_argument("--profile-steps", type=int, default=2)
+  ap.add_argument("--rotate", type=int, default=4,
+                  help="resident batches (different seeds) rotated through the timed region, so that range slots, proposal "
+                       "counts and cache contents change from step to step (1: replay one batch)")
   ap.add_argument("--dist-backend", default="nccl",
                   help="nccl (= RCCL, the default) | gloo (debug: lets N ranks share one GPU)")
   ap.add_argument("--streams", type=int, default=1,
@@ -122,16 +125,22 @@ def main():
   all_models = [models.get_model(cfg, local_rank, weights=weights, is_multi=multi) for _ in range(S)]
   engs = [m.engine(B, H, W) for m in all_models]
   model, eng = all_models[0], engs[0]
-  # one video stream per handle: each gets its own seeded frames
-  frames = synthetic_frames(B, H, W, seed=1234 + rank)
-  all_frames = [frames] + [synthetic_frames(B, H, W, seed=1234 + rank + 1000 * i) for i in range(1, S)]
-  dev_all = [torch.from_numpy(f).cuda(local_rank) for f in all_frames]      # HBM-resident uint8 input
-  dev_frames = dev_all[0]
+  # one video stream per handle: each gets its own seeded frames -- NROT different batches per stream, all resident in
+  # HBM, taken in turn by the steps of the timed region (frame content, recorded tensor ranges, proposal / detection
+  # counts and what the caches hold differ from one step to the next, as they do on a video)
+  NROT = max(1, args.rotate)
+  rot_frames = [[synthetic_frames(B, H, W, seed=1234 + rank + 1000 * i + 77 * r) for r in range(NROT)] for i in range(S)]
+  frames = rot_frames[0][0]
+  dev_rot = [[torch.from_numpy(f).cuda(local_rank) for f in fs] for fs in rot_frames]      # HBM-resident uint8 input
+  dev_frames = dev_rot[0][0]
   torch.cuda.synchronize()
+  step_no = [0]
 
   def step():
-    for e, d in zip(engs, dev_all):
-      e.forward_device_async(d.data_ptr(), ODT_DTYPE_U8)
+    r = step_no[0] % NROT
+    step_no[0] += 1
+    for e, ds in zip(engs, dev_rot):
+      e.forward_device_async(ds[r].data_ptr(), ODT_DTYPE_U8)
 
   def sync_all():
     for e in engs:
@@ -159,32 +168,15 @@ def main():
 
   # the timed region, checked: the outputs the LAST replayed forward of every stream left in HBM must equal, bit for
   # bit, a blocking odt_forward of the same frames through the host boundary -- and must be a non-trivial detection set
-  verified = verify_timed_region(engs, all_frames)
+  last = (step_no[0] - 1) % NROT
+  verified = verify_timed_region(engs, [fs[last] for fs in rot_frames])
+  verified["resident_batches_rotated"] = NROT
+  verified["batch_verified"] = last
 
   # roofline of the dominant kernel family (implicit-GEMM conv, ~99% of the FLOPs): HIP events
   # around every launch on the launch stream, outside the timed region.
-  eng.profile(True)
-  for _ in range(max(1, args.profile_steps)):
-    eng.forward_device_async(dev_frames.data_ptr(), ODT_DTYPE_U8)
-  eng.synchronize()
-  prof = eng.profile_read()
-  layers = eng.profile_layers()
-  eng.profile(False)
-  achieved = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12 if prof["conv_ms"] > 0 else 0.0
-  # the two kernel families of the conv launches: conv_split_kernel (bf16x3 split: six exact bf16
-  # MFMA products per f32 MAC) and conv_igemm_kernel (exact-f32 MFMA)
   nprof = max(1, args.profile_steps)
-  fam = {"h2": [0, 0.0, 0.0], "b3": [0, 0.0, 0.0], "f32": [0, 0.0, 0.0]}           # launches, flops (per step), ms (sum)
-  for name, fl, ms, _ in layers:
-    f = fam["h2" if name.endswith("[fp16x2]") else ("b3" if name.endswith("[bf16x3]") else "f32")]
-    f[0] += 1; f[1] += fl; f[2] += ms
-  # the split kernels as one family: fp16x2 (three f16 MFMA products per f32 MAC) + bf16x3 (six bf16 products)
-  fam["split"] = [fam["h2"][0] + fam["b3"][0], fam["h2"][1] + fam["b3"][1], fam["h2"][2] + fam["b3"][2]]
-  def tf(f):
-    return f[1] * nprof / (f[2] * 1e-3) / 1e12 if f[2] > 0 else 0.0
-  split_tf, f32_tf = tf(fam["split"]), tf(fam["f32"])
-  # matrix-pipe products the split launches execute per algorithmic f32 MAC (FLOP-weighted over the two kinds)
-  split_products = ((H2_PRODUCTS * fam["h2"][1] + SPLIT_PRODUCTS * fam["b3"][1]) / fam["split"][1]) if fam["split"][1] > 0 else SPLIT_PRODUCTS
+  prof = profile_convs(eng, dev_frames.data_ptr(), nprof)
 
   sustained = None
   if rank == 0:
@@ -219,6 +211,14 @@ def main():
       # same, through the pipelined ingest (pinned double-buffered staging, H2D / D2H on copy
       # streams overlapping the forward; odt_submit / odt_collect)
       extra.update(pipelined_leg(eng, frames, B, nbatches=10))
+      if NROT > 1:
+        # the timed region's step with ONE resident batch replayed (rounds 1-3 timed this): what the rotation changes
+        for k in range(2 + 10):
+          if k == 2:
+            eng.synchronize(); t1 = time.perf_counter()
+          eng.forward_device_async(dev_frames.data_ptr(), ODT_DTYPE_U8)
+        eng.synchronize()
+        extra["single_resident_batch_replayed_fps"] = 10 * B / (time.perf_counter() - t1)
       if world == 1 and S == 1:
         # (c) two independent video streams (two handles, one HIP stream each) sharing the GPU: the
         # tails / low-occupancy layers of one forward overlap with the other stream's kernels
@@ -296,7 +296,7 @@ def main():
       if world == 1 and S == 1 and multi and (B, H, W) == (8, 1080, 1920):
         # (f) BASELINE config #2 on the graph the config names: Mask_RCNN_FPN (models.py:488-973), batch 1
         try:
-          extra.update(single_graph_leg(models, make_config, weights, args.topk, H, W, local_rank))
+          extra.update(single_graph_leg(models, make_config, weights, args.topk, H, W, local_rank, sustained=sustained, rotate=NROT))
         except Exception as ex:
           extra["b1_single_graph_fps"] = "failed: %r" % (ex,)
       rng = np.random.default_rng(0)
@@ -313,58 +313,8 @@ def main():
       extra["extras_failed"] = repr(ex)
   if rank == 0:
     fps = world * S * B * args.steps / dt
-    common = {
-        "all_conv_launches": {"achieved": achieved, "unit": "TFLOP/s (algorithmic f32)",
-                              "launches_per_step": prof["conv_launches"] // nprof,
-                              "vs_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS},
-        "conv_ms_per_step": prof["conv_ms"] / nprof,
-        "step_ms_profiled": prof["total_ms"] / nprof,
-        "algorithmic_gflop_per_step": prof["conv_flops"] / nprof / 1e9,
-    }
-    f32_family = {"kernel": "conv_igemm_kernel (v_mfma_f32_32x32x2_f32 implicit GEMM, %d launches/step)" % fam["f32"][0],
-                  "achieved": f32_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                  "frac": f32_tf / F32_MFMA_PEAK_TFLOPS, "ms_per_step": fam["f32"][2] / nprof}
-    if fam["split"][2] > fam["f32"][2] * 0.5:
-      # dominant kernel (most of the FLOPs): the split kernel.  `achieved` is ALGORITHMIC f32
-      # FLOP/s; every f32 MAC costs six bf16 MFMA MACs, so the matrix-pipe ceiling for it is the
-      # dense bf16 peak / 6 (executed bf16 rate and its fraction of the bf16 peak given beside it).
-      peak = BF16_MFMA_PEAK_TFLOPS / split_products
-      roofline = {
-          "bound": "mfma",
-          "kernel": "split conv kernels: f32 through exact 16-bit MFMA products -- conv_h2 kernels (3 x v_mfma_f32_32x32x16_f16 "
-                    "per MAC, %d launches/step, %.0f%% of the conv FLOPs) + conv_split kernels (6 x v_mfma_f32_32x32x16_bf16 "
-                    "per MAC, %d launches/step, %.0f%%)" %
-                    (fam["h2"][0], 100.0 * fam["h2"][1] / max(1.0, fam["split"][1] + fam["f32"][1]),
-                     fam["b3"][0], 100.0 * fam["b3"][1] / max(1.0, fam["split"][1] + fam["f32"][1])),
-          "achieved": split_tf, "peak": peak, "unit": "TFLOP/s", "frac": split_tf / peak,
-          "peak_note": "dense 16-bit MFMA peak 2500 TFLOP/s / %.3f products per f32 MAC (FLOP-weighted: 3 on the fp16x2 "
-                       "launches, 6 on the bf16x3 ones); frac = executed 16-bit MFMA rate / 2500" % split_products,
-          "products_per_mac": split_products,
-          "executed_bf16_tflops": split_tf * split_products,
-          "vs_f32_mfma_peak": split_tf / F32_MFMA_PEAK_TFLOPS,
-          "ms_per_step": fam["split"][2] / nprof,
-          "by_kind": {
-              "fp16x2": {"launches": fam["h2"][0], "achieved": tf(fam["h2"]), "ms_per_step": fam["h2"][2] / nprof,
-                         "frac": tf(fam["h2"]) * H2_PRODUCTS / BF16_MFMA_PEAK_TFLOPS},
-              "bf16x3": {"launches": fam["b3"][0], "achieved": tf(fam["b3"]), "ms_per_step": fam["b3"][2] / nprof,
-                         "frac": tf(fam["b3"]) * SPLIT_PRODUCTS / BF16_MFMA_PEAK_TFLOPS}},
-          "traffic": pmc_traffic("split") if (B, H, W) == (8, 1080, 1920) else None,
-          "f32_mfma_family": f32_family,
-      }
-    else:
-      roofline = dict(f32_family)
-      roofline.update({"bound": "mfma", "traffic": pmc_traffic("f32") if (B, H, W) == (8, 1080, 1920) else None})
-    roofline.update(common)
-    if sustained is not None and "bf16_tflops" in sustained and fam["split"][0] > 0:
-      # what the bf16 matrix pipe of THIS box sustains on the split kernels' own MFMA mix (random operands, >= 300 ms
-      # of back-to-back launches, measured a moment ago in this process): the ceiling under the box's power budget
-      roofline["sustained_peak"] = sustained
-      # ceiling of the step's split launches at the sustained rates of their own mixes (fp16x2 launches: the f16 three-product
-      # mix; bf16x3 launches: the bf16 six-product mix) over their measured time
-      sus_h2 = sustained.get("fp16x2_mix_f16_tflops") or sustained["bf16_tflops"]
-      ceil_ms = (H2_PRODUCTS * fam["h2"][1] / sus_h2 + SPLIT_PRODUCTS * fam["b3"][1] / sustained["bf16_tflops"]) * nprof / 1e9
-      roofline["frac_of_sustained"] = ceil_ms / fam["split"][2] if fam["split"][2] > 0 else 0.0
-      roofline["sustained_f32_work_tflops"] = {"fp16x2": sus_h2 / H2_PRODUCTS, "bf16x3": sustained["bf16_tflops"] / SPLIT_PRODUCTS}
+    roofline = conv_roofline(prof, sustained, (B, H, W) == (8, 1080, 1920))
+    fam = prof["fam"]
     out = {
         "metric": "detector FPS @%dx%d b=%d per MI355X" % (W, H, B),
         "value": fps,
@@ -381,14 +331,11 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "value_scope": "device-resident: uint8 frames already in HBM when the timed region starts, outputs left in HBM "
-                       "(the PCIe-inclusive pipelined rate and the detect+track rate are under `extra`)",
+        "value_scope": "device-resident: uint8 frames already in HBM when the timed region starts (%d different batches per "
+                       "stream, taken in turn), outputs left in HBM (the PCIe-inclusive pipelined rate and the detect+track "
+                       "rate are under `extra`)" % NROT,
         "dtype": "f32",
-        "arithmetic": ("f32 tensors, f32 accumulation; exact-f32 MFMA products" if fam["split"][0] == 0 else
-                       "f32 tensors, f32 accumulation; the products of %d of the %d conv launches are evaluated as six "
-                       "exact bf16 x bf16 MFMA products of a 3-way bf16 split of both f32 operands (error at the "
-                       "exact-f32 kernel's level, DESIGN.md section 3; ODT_CONV_SPLIT=0: exact-f32 MFMA everywhere)"
-                       % (fam["split"][0], fam["split"][0] + fam["f32"][0])),
+        "arithmetic": arithmetic_of(eng.describe()),
         "handle": eng.describe(),      # the arithmetic mode / kernel families as the handle itself reports them
         "data": "synthetic",
         "config": {"workload": "ResNet-101-dilated+FPN detector + RoI appearance features, "
@@ -416,10 +363,115 @@ def main():
     dist.destroy_process_group()
 
 
+
+def profile_convs(eng, dev_ptr, nprof):
+  """HIP-event times of every conv launch over `nprof` profiled forwards of the device-resident batch at dev_ptr, grouped
+  by kernel family (odt_profile_layer tags the layers [fp16x2] / [bf16x3])."""
+  from object_detection_tracking_amd._lib import ODT_DTYPE_U8
+  eng.profile(True)
+  for _ in range(nprof):
+    eng.forward_device_async(dev_ptr, ODT_DTYPE_U8)
+  eng.synchronize()
+  prof = eng.profile_read()
+  layers = eng.profile_layers()
+  eng.profile(False)
+  fam = {"h2": [0, 0.0, 0.0], "b3": [0, 0.0, 0.0], "f32": [0, 0.0, 0.0]}           # launches, flops (per step), ms (sum)
+  for name, fl, ms, _ in layers:
+    if "[fused into" in name:
+      continue                                   # no launch of its own: its FLOPs are counted with the kernel that evaluates it
+    f = fam["h2" if name.endswith("[fp16x2]") else ("b3" if name.endswith("[bf16x3]") else "f32")]
+    f[0] += 1; f[1] += fl; f[2] += ms
+  # the split kernels as one family: fp16x2 (three f16 MFMA products per f32 MAC) + bf16x3 (six bf16 products)
+  fam["split"] = [fam["h2"][0] + fam["b3"][0], fam["h2"][1] + fam["b3"][1], fam["h2"][2] + fam["b3"][2]]
+  prof["fam"] = fam
+  prof["nprof"] = nprof
+  return prof
+
+
+def conv_roofline(prof, sustained, with_pmc_traffic):
+  """The `roofline` object of a bench leg from profile_convs()'s event times (see the module docstring / DESIGN.md section 5)."""
+  fam, nprof = prof["fam"], prof["nprof"]
+  def tf(f):
+    return f[1] * nprof / (f[2] * 1e-3) / 1e12 if f[2] > 0 else 0.0
+  achieved = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12 if prof["conv_ms"] > 0 else 0.0
+  split_tf, f32_tf = tf(fam["split"]), tf(fam["f32"])
+  # matrix-pipe products the split launches execute per algorithmic f32 MAC (FLOP-weighted over the two kinds)
+  split_products = ((H2_PRODUCTS * fam["h2"][1] + SPLIT_PRODUCTS * fam["b3"][1]) / fam["split"][1]) if fam["split"][1] > 0 else SPLIT_PRODUCTS
+  common = {
+      "all_conv_launches": {"achieved": achieved, "unit": "TFLOP/s (algorithmic f32)",
+                            "launches_per_step": prof["conv_launches"] // nprof,
+                            "vs_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS},
+      "conv_ms_per_step": prof["conv_ms"] / nprof,
+      "step_ms_profiled": prof["total_ms"] / nprof,
+      "algorithmic_gflop_per_step": prof["conv_flops"] / nprof / 1e9,
+  }
+  f32_family = {"kernel": "conv_igemm_kernel (v_mfma_f32_32x32x2_f32 implicit GEMM, %d launches/step)" % fam["f32"][0],
+                "achieved": f32_tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": f32_tf / F32_MFMA_PEAK_TFLOPS, "ms_per_step": fam["f32"][2] / nprof}
+  if fam["split"][2] > fam["f32"][2] * 0.5:
+    # dominant kernel (most of the FLOPs): the split kernels.  `achieved` is ALGORITHMIC f32 FLOP/s; every f32 MAC costs
+    # three f16 (fp16x2 launches) or six bf16 (bf16x3 launches) MFMA MACs, so the matrix-pipe ceiling for it is the dense
+    # 16-bit peak / products per MAC (executed rate and its fraction of the 16-bit peak given beside it).
+    peak = BF16_MFMA_PEAK_TFLOPS / split_products
+    roofline = {
+        "bound": "mfma",
+        "kernel": "split conv kernels: f32 through exact 16-bit MFMA products -- conv_h2 kernels (3 x v_mfma_f32_32x32x16_f16 "
+                  "per MAC, %d launches/step, %.0f%% of the conv FLOPs) + conv_split kernels (6 x v_mfma_f32_32x32x16_bf16 "
+                  "per MAC, %d launches/step, %.0f%%)" %
+                  (fam["h2"][0], 100.0 * fam["h2"][1] / max(1.0, fam["split"][1] + fam["f32"][1]),
+                   fam["b3"][0], 100.0 * fam["b3"][1] / max(1.0, fam["split"][1] + fam["f32"][1])),
+        "achieved": split_tf, "peak": peak, "unit": "TFLOP/s", "frac": split_tf / peak,
+        "peak_note": "dense 16-bit MFMA peak 2500 TFLOP/s / %.3f products per f32 MAC (FLOP-weighted: 3 on the fp16x2 "
+                     "launches, 6 on the bf16x3 ones); frac = executed 16-bit MFMA rate / 2500" % split_products,
+        "products_per_mac": split_products,
+        "executed_bf16_tflops": split_tf * split_products,
+        "vs_f32_mfma_peak": split_tf / F32_MFMA_PEAK_TFLOPS,
+        "ms_per_step": fam["split"][2] / nprof,
+        "by_kind": {
+            "fp16x2": {"launches": fam["h2"][0], "achieved": tf(fam["h2"]), "ms_per_step": fam["h2"][2] / nprof,
+                       "frac": tf(fam["h2"]) * H2_PRODUCTS / BF16_MFMA_PEAK_TFLOPS},
+            "bf16x3": {"launches": fam["b3"][0], "achieved": tf(fam["b3"]), "ms_per_step": fam["b3"][2] / nprof,
+                       "frac": tf(fam["b3"]) * SPLIT_PRODUCTS / BF16_MFMA_PEAK_TFLOPS}},
+        "traffic": pmc_traffic("split") if with_pmc_traffic else None,
+        "f32_mfma_family": f32_family,
+    }
+  else:
+    roofline = dict(f32_family)
+    roofline.update({"bound": "mfma", "traffic": pmc_traffic("f32") if with_pmc_traffic else None})
+  roofline.update(common)
+  if sustained is not None and "bf16_tflops" in sustained and fam["split"][0] > 0:
+    # what the bf16 matrix pipe of THIS box sustains on the split kernels' own MFMA mix (random operands, >= 300 ms
+    # of back-to-back launches, measured a moment ago in this process): the ceiling under the box's power budget
+    roofline["sustained_peak"] = sustained
+    # ceiling of the step's split launches at the sustained rates of their own mixes (fp16x2 launches: the f16 three-product
+    # mix; bf16x3 launches: the bf16 six-product mix) over their measured time
+    sus_h2 = sustained.get("fp16x2_mix_f16_tflops") or sustained["bf16_tflops"]
+    ceil_ms = (H2_PRODUCTS * fam["h2"][1] / sus_h2 + SPLIT_PRODUCTS * fam["b3"][1] / sustained["bf16_tflops"]) * nprof / 1e9
+    roofline["frac_of_sustained"] = ceil_ms / fam["split"][2] if fam["split"][2] > 0 else 0.0
+    roofline["sustained_f32_work_tflops"] = {"fp16x2": sus_h2 / H2_PRODUCTS, "bf16x3": sustained["bf16_tflops"] / SPLIT_PRODUCTS}
+  return roofline
+
+
+def arithmetic_of(desc):
+  """The line's `arithmetic` field, written from what the timed handle reports about itself (odt_describe)."""
+  nh2, nb3, nf32 = desc.get("fp16x2_split_launches", 0), desc.get("bf16x3_split_launches", 0), desc.get("exact_f32_mfma_launches", 0)
+  nfold, ntail = desc.get("convs_fused_into_epilogues", 0), desc.get("bottleneck_tails_fused", 0)
+  if nh2 + nb3 == 0:
+    return "f32 tensors, f32 accumulation; exact-f32 MFMA products (v_mfma_f32_32x32x2_f32) in all %d conv launches" % nf32
+  return ("f32 tensors, f32 accumulation; of the %d conv launches %d evaluate every f32 product as THREE exact f16 x f16 MFMA "
+          "products of a 2-way f16 split of both operands (fp16x2: 22 significand bits per operand, one power of two per weight "
+          "row and per activation tensor from its recorded |max| -- per pixel row inside the %d fused bottleneck tails; lo x lo "
+          "dropped), %d as SIX exact bf16 x bf16 products of a 3-way bf16 split (bf16x3: all 24 bits), %d on the exact-f32 MFMA "
+          "(v_mfma_f32_32x32x2_f32); %d further convs run inside another launch's epilogue.  Error at the exact-f32 kernel's "
+          "level on this workload (DESIGN.md section 3 and 4; conv_split_family = 3 / conv_arith = \"f32\" select the stricter modes)"
+          % (nh2 + nb3 + nf32, nh2, ntail, nb3, nf32, nfold))
+
+
 def pmc_traffic(mode):
   """HBM bytes per conv launch from the separate rocprofv3 --pmc passes of this same command
   (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; tools/pmc_summary.py), or None."""
-  names = ["r03_pmc_summary.json", "r02_pmc_summary.json"] if mode == "f32" else ["r03_pmc_summary_split.json", "r02_pmc_summary_split.json"]
+  names = ["r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"] if mode == "f32" else \
+          ["r04_pmc_summary_split.json", "r03_pmc_summary_split.json", "r02_pmc_summary_split.json"]
   for name in names:         # the newest committed summary
     try:
       with open(os.path.join(ROOT, "profiles", name)) as fh:
@@ -528,7 +580,7 @@ def pipelined_leg(eng, frames, B, nbatches=10):
   return out
 
 
-def single_graph_leg(models, make_config, weights, topk, H, W, device, steps=20, warmup=3):
+def single_graph_leg(models, make_config, weights, topk, H, W, device, steps=20, warmup=3, sustained=None, rotate=4):
   """BASELINE config #2: ResNet-101-dilated+FPN, 1920x1080, batch 1, on `Mask_RCNN_FPN` (reference models.py:488-973:
   min-size filter, prob > 1e-4, per-class tf.image.non_max_suppression) -- device-resident like the headline."""
   import torch
@@ -538,19 +590,28 @@ def single_graph_leg(models, make_config, weights, topk, H, W, device, steps=20,
   m = models.get_model(cfg1, device, weights=weights, is_multi=False)
   try:
     e = m.engine(1, H, W)
-    fr = synthetic_frames(1, H, W, seed=1234)
-    d = torch.from_numpy(fr).cuda(device)
+    frs = [synthetic_frames(1, H, W, seed=1234 + 77 * r) for r in range(max(1, rotate))]      # resident frames, taken in turn
+    ds = [torch.from_numpy(fr).cuda(device) for fr in frs]
     for k in range(warmup + steps):
       if k == warmup:
         e.synchronize(); t1 = time.perf_counter()
-      e.forward_device_async(d.data_ptr(), ODT_DTYPE_U8)
+      e.forward_device_async(ds[k % len(ds)].data_ptr(), ODT_DTYPE_U8)
     e.synchronize()
     dt = (time.perf_counter() - t1) / steps
-    got = e.read_outputs(want_feats=False, want_pooled=True)
-    ref = e.forward(fr, want_feats=False, want_pooled=True)
-    ok = all(np.array_equal(a, b) for a, b in zip(got[:4], ref[:4])) and int(got[3].sum()) > 0
+    # the timed region checks itself like the headline's: what the last forward left in HBM == a blocking forward of that frame
+    last = (warmup + steps - 1) % len(ds)
+    got = e.read_outputs(want_feats=True, want_pooled=True)
+    ref = e.forward(frs[last], want_feats=True, want_pooled=True)
+    names = ("final_boxes", "final_labels", "final_probs", "final_valid_indices", "fpn_box_feat", "pooled")
+    equal = {n: bool(np.array_equal(a, b)) for n, a, b in zip(names, got, ref)}
+    ok = all(equal.values()) and int(got[3].sum()) > 0 and bool(np.isfinite(got[0]).all())
+    prof = profile_convs(e, ds[0].data_ptr(), 3)
     return {"b1_single_graph_fps": 1.0 / dt, "b1_single_graph": {"graph": "Mask_RCNN_FPN", "ms_per_frame": 1e3 * dt, "steps": steps,
                                                                "detections": int(got[3].sum()), "verified": bool(ok),
+                                                               "verification": {"bit_equal_to_blocking_forward": equal,
+                                                                                "resident_frames_rotated": len(ds)},
+                                                               "roofline": conv_roofline(prof, sustained, False),
+                                                               "arithmetic": arithmetic_of(e.describe()),
                                                                "handle": e.describe()}}
   finally:
     m.close()

@@ -24,10 +24,10 @@ namespace {
 
 #define ODT_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 
-template <int TN, int WM>
+template <int TN, int WM, int WN = 2>
 struct H2Cfg {
-  static constexpr int BM = 64 * WM, BN = 64 * TN;
-  static constexpr int NWV = 2 * WM, NTHR = 64 * NWV;                       // waves (WM x 2), threads
+  static constexpr int BM = 64 * WM, BN = 32 * TN * WN;
+  static constexpr int NWV = WN * WM, NTHR = 64 * NWV;                      // waves (WM x WN), threads
   // A stage: [piece 2][k-group 4][row][8 f16]; 32-B pad per k-group: the four k-groups a store instruction touches (8 lanes
   // per row, two rows per 16-lane group) start 8 banks apart (ds_write_b64 banks are mod 32; a 64-B pad put k-groups 0 / 2 and
   // 1 / 3 on the same banks: 18 % of the LDS cycles were conflict cycles, profiles/r03_pmc_lds_wait_by_kernel.txt)
@@ -38,7 +38,7 @@ struct H2Cfg {
   static constexpr int CTILE = 128 * (BN + 4) * 4;                          // two 128-row epilogue passes
   static constexpr int LDS = RING > CTILE ? RING : CTILE;
   static constexpr int NW = STAGE_B / 1024 / NWV;                           // DMA instructions per wave and stage
-  static constexpr int RA = 4;                                              // A rows (16-byte loads) per thread and stage: BM / (NTHR / 8)
+  static constexpr int RA = BM * 8 / NTHR;                                  // A rows (16-byte loads) per thread and stage: BM / (NTHR / 8)
   static_assert(LDS <= 160 * 1024 && STAGE_B % (1024 * NWV) == 0, "LDS ring");
 };
 
@@ -46,10 +46,11 @@ struct H2Cfg {
 // two workgroups per CU -- for the layers with too few 256-row tiles (res5, P5; with split-K below res3 at b=1; as an A/B knob
 // also for short 1x1 reductions: measured no gain); <1, 2> 128 x 64 on 4 waves for the 64-wide layers -- one column group per
 // k-step, 12 MFMAs per wave and stage, 50 KB of LDS: three workgroups per CU
-template <int TN, int WM, bool TRACE = false>
-__global__ void __launch_bounds__(128 * WM, 2) conv_h2_kernel(const ConvParams* __restrict__ pp) {
-  using G = H2Cfg<TN, WM>;
-  constexpr int WN = 2, NWV = G::NWV, AR = G::NTHR / 8;
+// <2, 8, ., 1>: 512 x 64 on 8 waves stacked along M (a 64 x 64 wave tile: 24 MFMAs per stage) for the 64-wide layers with many rows
+template <int TN, int WM, bool TRACE = false, int WN = 2>
+__global__ void __launch_bounds__(64 * WN * WM, 2) conv_h2_kernel(const ConvParams* __restrict__ pp) {
+  using G = H2Cfg<TN, WM, WN>;
+  constexpr int NWV = G::NWV, AR = G::NTHR / 8;
   constexpr int BM = G::BM, BN = G::BN, AKG = G::AKG, APL = G::APL, ASTG = G::ASTG, BKG = G::BKG, BPL = G::BPL;
   constexpr int STAGE_B = G::STAGE_B, BOFF = G::BOFF, NW = G::NW, RA = G::RA;
   const ConvParams p = *pp;
@@ -280,8 +281,12 @@ __global__ void __launch_bounds__(128 * WM, 2) conv_h2_kernel(const ConvParams* 
         if (g == 2) { if constexpr (pre) load_a(); }
         if (g == 3) rdA(a_cur, 1, 0);
       } else if (TN == 2) {
-        if (g == 0) { if constexpr (next) { store_slot(a_nxt, 0); store_slot(a_nxt, 1); } }
-        if (g == 1) { if constexpr (next) { store_slot(a_nxt, 2); store_slot(a_nxt, 3); } }
+        if constexpr (next) {                  // RA slots over the three column groups in front of the barrier
+          constexpr int SPG = (RA + 2) / 3;
+#pragma unroll
+          for (int q = 0; q < SPG; ++q)
+            if (g * SPG + q < RA) store_slot(a_nxt, g * SPG + q);
+        }
       } else {
         if constexpr (next) { store_slot(a_nxt, 0); store_slot(a_nxt, 1); }
       }
@@ -295,7 +300,8 @@ __global__ void __launch_bounds__(128 * WM, 2) conv_h2_kernel(const ConvParams* 
         if (g == 2) rdA(a_cur, 1, 1);
       } else if (TN == 2) {
         if (g == 0) { rdA(a_cur, 1, 1); rdA(a_cur, 1, 0); }
-        if (g == 1) { if constexpr (pre) load_a(); }
+        // (the next fetch reuses the registers: behind the last slot's store)
+        if (g == (RA > 2 * ((RA + 2) / 3) ? 2 : 1)) { if constexpr (pre) load_a(); }
       } else {
         if constexpr (next) { store_slot(a_nxt, 2); store_slot(a_nxt, 3); }
         if constexpr (pre) load_a();
@@ -466,7 +472,8 @@ int launch_conv_h2(const ConvParams& p, const ConvParams* dev, hipStream_t strea
   const long M = (long)p.B * p.Ho * p.Wo;
   const int bn = p.wt_split_bn;
   const int bm = p.wt_split_bm;
-  ODT_CHECK(((bm == 256 && (bn >= 128 || p.wt_split_kwr)) || (bm == 128 && bn <= 128 && !p.wt_split_kwr)) && (bn == 256 || bn == 128 || bn == 64) && p.Cin % 32 == 0 && p.kh * p.kw <= 32 && p.in_amax != nullptr &&
+  ODT_CHECK(((bm == 256 && (bn >= 128 || p.wt_split_kwr)) || (bm == 128 && bn <= 128 && !p.wt_split_kwr) ||
+             (bm == 512 && bn == 64 && (!p.wt_split_kwr || p.Ho * p.Wo >= 512))) && (bn == 256 || bn == 128 || bn == 64) && p.Cin % 32 == 0 && p.kh * p.kw <= 32 && p.in_amax != nullptr &&
             p.h2_chinv != nullptr && (p.in2 == nullptr || (p.in2_amax != nullptr && p.Cin2 % 32 == 0)) && p.nlvl <= 1,
             "conv h2: unsupported tile / shape, or no recorded input range");
   const int sk = p.splitk > 1 ? p.splitk : 1;
@@ -483,6 +490,8 @@ int launch_conv_h2(const ConvParams& p, const ConvParams* dev, hipStream_t strea
     launch_conv_h2k(p, dev, grid, stream);
   } else if (p.f_wt != nullptr) {
     ODT_CHECK(false, "conv h2: a fused 1x1 tail needs the kw-reuse kernel");
+  } else if (bn == 64 && bm == 512) {
+    hipLaunchKernelGGL((conv_h2_kernel<2, 8, false, 1>), dim3(grid), dim3(512), 0, stream, dev);
   } else if (bn == 64) {
     hipLaunchKernelGGL((conv_h2_kernel<1, 2, false>), dim3(grid), dim3(256), 0, stream, dev);
   } else if (bn == 256) {

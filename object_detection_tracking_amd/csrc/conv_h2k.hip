@@ -27,10 +27,13 @@ namespace {
 //   * taps outside the image read a zero row of the stage: a per-lane 9-bit validity mask picks the fragment address;
 //   * A: two buffers (this group / next group); the next group's fetch (5 x 16 B per thread) is issued in the group's first
 //     stage and split + stored in its third; B: the two-deep DMA ring of conv_h2_kernel.
-template <int TN, bool FUSE = false>
+// WN = 2 (default): waves 4 x 2, tile 256 x 64 TN; WN = 1: the eight waves stacked along M, tile 512 x 32 TN -- for the 64-wide
+// layers (TN = 2): a wave tile of 64 x 64 carries 24 MFMAs per stage instead of the 12 of a 64 x 32 one (res2 conv2)
+template <int TN, bool FUSE = false, int WN = 2>
 struct H2kCfg {
-  static constexpr int BM = 256, BN = 64 * TN;
-  static constexpr int PR = 272;                             // stage rows: 256 + 2 runs x 2 dil (dil <= 2) + the zero row, padded
+  static constexpr int WM = 8 / WN;
+  static constexpr int BM = 64 * WM, BN = 32 * TN * WN;
+  static constexpr int PR = BM + 16;                         // stage rows: BM + 2 runs x 2 dil (dil <= 2) + the zero row, padded
   static constexpr int ZR = PR - 1;                          // the zero row
   static constexpr int AKG = PR * 16 + 32, APL = 4 * AKG, ABUF = 2 * APL;   // (32-B pad: see H2Cfg)
   static constexpr int BKG = BN * 16, BPL = 4 * BKG, STAGE_B = 2 * BPL;
@@ -45,8 +48,8 @@ struct H2kCfg {
   static constexpr int F_K3OFF = F_KOFF + 2048;              // the fused conv's column constants, [2][1024] f32
   static constexpr int LDS = FUSE ? F_K3OFF + 8192 : LDS0;
   static constexpr int NW = STAGE_B / 1024 / 8;
-  static constexpr int RA = 5;                               // A fetch instructions per thread and group (rows t >> 3 + 64 j)
-  static_assert(LDS <= 160 * 1024 && STAGE_B % 8192 == 0, "LDS");
+  static constexpr int RA = (PR + 63) / 64;                  // A fetch instructions per thread and group (rows t >> 3 + 64 j)
+  static_assert(LDS <= 160 * 1024 && STAGE_B % 8192 == 0 && (!FUSE || WN == 2), "LDS");
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -306,10 +309,10 @@ __device__ __forceinline__ void h2f_tail(const ConvParams& p, f32x16 (&acc)[2][T
   publish_amax_wg<512>(p.f_out_amax, vmax, tid, lds);
 }
 
-template <int TN, bool TRACE = false, bool FUSE = false>
+template <int TN, bool TRACE = false, bool FUSE = false, int WN = 2>
 __global__ void __launch_bounds__(512, 2) conv_h2k_kernel(const ConvParams* __restrict__ pp) {
-  using G = H2kCfg<TN, FUSE>;
-  constexpr int WM = 4, WN = 2, KW = 3;
+  using G = H2kCfg<TN, FUSE, WN>;
+  constexpr int WM = G::WM, KW = 3;
   constexpr int BM = G::BM, BN = G::BN, AKG = G::AKG, APL = G::APL, ABUF = G::ABUF, BKG = G::BKG, BPL = G::BPL;
   constexpr int STAGE_B = G::STAGE_B, BOFF = G::BOFF, NW = G::NW, ZR = G::ZR, RA = G::RA;
   const ConvParams p = *pp;
@@ -398,7 +401,7 @@ __global__ void __launch_bounds__(512, 2) conv_h2k_kernel(const ConvParams* __re
       *reinterpret_cast<u32x2*>(d + APL) = u32x2{l0, l1};
     }
   };
-  // the zero rows of both A buffers (never overwritten: stage rows stop at 256 + 2 halo <= ZR)
+  // the zero rows of both A buffers (never overwritten: stage rows stop at BM + 2 halo <= ZR)
   if (tid < 16) {
     const int b = tid >> 3, q = (tid >> 2) & 1, kg = tid & 3;
     *reinterpret_cast<u32x4*>(lds + b * ABUF + q * APL + kg * AKG + ZR * 16) = u32x4{0u, 0u, 0u, 0u};
@@ -529,9 +532,12 @@ __global__ void __launch_bounds__(512, 2) conv_h2k_kernel(const ConvParams* __re
       } else {
         if constexpr (gn && KWI == 2) {
           // the next group's run: registers -> LDS, in the group's third stage, two stages behind the fetch
-          if (TN == 4) { if (g < 5) store_slot(a_nxt, g); }
-          else if (TN == 2) { if (g < 3) { store_slot(a_nxt, 2 * g); if (2 * g + 1 < RA) store_slot(a_nxt, 2 * g + 1); } }
-          else { store_slot(a_nxt, 0); store_slot(a_nxt, 1); store_slot(a_nxt, 2); }
+          if (TN > 1) {
+            constexpr int SPG = (RA + NG - 2) / (NG - 1);       // slots per column group (the last group sits behind the barrier)
+#pragma unroll
+            for (int q = 0; q < SPG; ++q)
+              if (g * SPG + q < RA) store_slot(a_nxt, g * SPG + q);
+          } else { store_slot(a_nxt, 0); store_slot(a_nxt, 1); store_slot(a_nxt, 2); }
         }
         if constexpr (gn && KWI == 0) { if (g == (TN == 1 ? 0 : 1)) load_group(); }
       }
@@ -582,6 +588,8 @@ void launch_conv_h2k(const ConvParams& p, const ConvParams* dev, unsigned grid, 
     else hipLaunchKernelGGL((conv_h2k_kernel<4, false>), dim3(grid), dim3(512), 0, stream, dev);
   } else if (bn == 128) {
     hipLaunchKernelGGL((conv_h2k_kernel<2, false>), dim3(grid), dim3(512), 0, stream, dev);
+  } else if (p.wt_split_bm == 512) {          // 64-wide layer, eight waves stacked along M: 512 x 64 tiles
+    hipLaunchKernelGGL((conv_h2k_kernel<2, false, false, 1>), dim3(grid), dim3(512), 0, stream, dev);
   } else {
     hipLaunchKernelGGL((conv_h2k_kernel<1, false>), dim3(grid), dim3(512), 0, stream, dev);
   }

@@ -647,53 +647,56 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
   }
   // bf16x3 split path: plan convs carry their weight image; stand-alone calls (tests, tuning)
   // build a temporary one
-  void* tmp_img = nullptr;
-  float* tmp_partial = nullptr;
   // (a plan conv without an image stays on the exact-f32 kernel: no allocation on the hot path)
   // (plan convs: the handle's policy decided at plan build -- an attached image means "split"; stand-alone calls:
   // library defaults + ODT_CONV_* overrides, resolved per call)
+  struct Temps {                      // temporaries of a stand-alone call: released on every path out of this function
+    void* img = nullptr; float* partial = nullptr; unsigned* amax = nullptr; ConvParams* rec = nullptr;
+    hipStream_t stream = nullptr; bool used = false;
+    ~Temps() {
+      if (!used) return;
+      (void)hipStreamSynchronize(stream);
+      if (rec) (void)hipFree(rec);
+      if (img) (void)hipFree(img);
+      if (partial) (void)hipFree(partial);
+      if (amax) (void)hipFree(amax);
+    }
+  } tmp;
+  tmp.stream = stream;
   ConvPolicy pol{};
   if (q.wt_split == nullptr && dev_params == nullptr) pol = conv_policy_from_env(conv_policy_default());
   const bool split = q.wt_split != nullptr ? true : (dev_params == nullptr && conv_split_wanted(q, pol));
-  unsigned* tmp_amax = nullptr;
   if (split && q.wt_split == nullptr) {
     const int Ksp = q.kh * q.kw * q.Cin + (q.in2 != nullptr ? q.Cin2 : 0);
-    ODT_HIP(hipMalloc(&tmp_img, conv_split_weight_bytes(q.Cout, Ksp)));
+    tmp.used = true;
+    ODT_HIP(hipMalloc(&tmp.img, conv_split_weight_bytes(q.Cout, Ksp)));
     if (pol.family == 2 && q.in_amax == nullptr) {      // fp16x2 pieces need the sources' |max|: nobody recorded it for a stand-alone call
-      ODT_HIP(hipMalloc((void**)&tmp_amax, 2 * sizeof(unsigned)));
-      ODT_HIP(hipMemsetAsync(tmp_amax, 0, 2 * sizeof(unsigned), stream));
-      if (launch_tensor_amax(q.in, (size_t)q.B * q.in_Ha * q.in_Wa * q.in_ldc, tmp_amax, stream)) return 1;
-      q.in_amax = tmp_amax;
+      // (the scan covers the whole allocation B x in_Ha x in_Wa x in_ldc of a source: a stand-alone caller hands over
+      // dense tensors -- odt_op_conv2d* -- so this is the logical view; a sliced view would have to bring its own range)
+      ODT_HIP(hipMalloc((void**)&tmp.amax, 2 * sizeof(unsigned)));
+      ODT_HIP(hipMemsetAsync(tmp.amax, 0, 2 * sizeof(unsigned), stream));
+      if (launch_tensor_amax(q.in, (size_t)q.B * q.in_Ha * q.in_Wa * q.in_ldc, tmp.amax, stream)) return 1;
+      q.in_amax = tmp.amax;
       if (q.in2 != nullptr) {
-        if (launch_tensor_amax(q.in2, (size_t)q.B * q.in2_Ha * q.in2_Wa * q.in2_ldc, tmp_amax + 1, stream)) return 1;
-        q.in2_amax = tmp_amax + 1;
+        if (launch_tensor_amax(q.in2, (size_t)q.B * q.in2_Ha * q.in2_Wa * q.in2_ldc, tmp.amax + 1, stream)) return 1;
+        q.in2_amax = tmp.amax + 1;
       }
     }
     conv_split_choose(q, pol);
-    if (conv_make_split_weights(q, tmp_img, stream)) { (void)hipFree(tmp_img); return 1; }
-    if (q.wt_split_kind == 2) q.h2_chinv = conv_h2_chinv(tmp_img, q.Cout, Ksp);
-    q.wt_split = tmp_img; modified = true;
-    if (conv_split_partial_bytes(q) > 0) ODT_HIP(hipMalloc((void**)&tmp_partial, conv_split_partial_bytes(q)));
-    q.partial = tmp_partial;
+    if (conv_make_split_weights(q, tmp.img, stream)) return 1;
+    if (q.wt_split_kind == 2) q.h2_chinv = conv_h2_chinv(tmp.img, q.Cout, Ksp);
+    q.wt_split = tmp.img; modified = true;
+    if (conv_split_partial_bytes(q) > 0) ODT_HIP(hipMalloc((void**)&tmp.partial, conv_split_partial_bytes(q)));
+    q.partial = tmp.partial;
   }
   // stand-alone calls (tests, tuning) and debug overrides: stage the record in a temporary
-  ConvParams* tmp = nullptr;
   if (dev_params == nullptr || modified) {
-    ODT_HIP(hipMalloc((void**)&tmp, sizeof(ConvParams)));
-    ODT_HIP(hipMemcpy(tmp, &q, sizeof(ConvParams), hipMemcpyHostToDevice));
-    dev_params = tmp;
+    tmp.used = true;
+    ODT_HIP(hipMalloc((void**)&tmp.rec, sizeof(ConvParams)));
+    ODT_HIP(hipMemcpy(tmp.rec, &q, sizeof(ConvParams), hipMemcpyHostToDevice));
+    dev_params = tmp.rec;
   }
-  if (split) {
-    if (launch_conv_split(q, dev_params, stream)) return 1;
-    if (tmp != nullptr || tmp_img != nullptr) {
-      ODT_HIP(hipStreamSynchronize(stream));
-      if (tmp != nullptr) ODT_HIP(hipFree(tmp));
-      if (tmp_img != nullptr) ODT_HIP(hipFree(tmp_img));
-      if (tmp_partial != nullptr) ODT_HIP(hipFree(tmp_partial));
-      if (tmp_amax != nullptr) ODT_HIP(hipFree(tmp_amax));
-    }
-    return 0;
-  }
+  if (split) return launch_conv_split(q, dev_params, stream);
   // short reductions (K <= 384: EfficientNet / BiFPN 1x1 convs, the res2 / res3 1x1 layers): the
   // 64x64 tile wins -- more workgroups per CU hide the per-tile prologue / epilogue that a two-to-
   // twelve-slice main loop cannot amortise (measured per layer; ODT_CONV_SMALLK=0 for the A/B)
@@ -733,10 +736,6 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
     if (fine) launch_variant<2, 2, 2, 2, 2, true>(q, dev_params, stream); else launch_variant<2, 2, 2, 2, 2, false>(q, dev_params, stream);
   }
   ODT_HIP(hipGetLastError());
-  if (tmp != nullptr) {
-    ODT_HIP(hipStreamSynchronize(stream));
-    ODT_HIP(hipFree(tmp));
-  }
   return 0;
 }
 

@@ -97,6 +97,8 @@ ConvPolicy conv_policy_default() {
   q.h2s_maxk = 0;         // fp16x2: reductions up to this K take the 128 x 128 two-per-CU tile (A/B knob; measured: no gain)
   q.h2_few_tiles = true;  // fp16x2: layers without enough 256-row tiles take 128 x 128 tiles instead of bf16x3 + split-K
   q.h2_n64 = true;        // fp16x2: the 64-wide layers too
+  q.h2_n64_bm512 = 1;     // fp16x2 kw-reuse kernel on 64-wide layers: 512 x 64 tiles (eight waves stacked along M: 24 MFMAs per wave and
+                          // stage instead of 12) where they fill the chip; 0 off, 2 wherever the shape allows (tests)
   q.min_bn = 0; q.force_bm3 = 0; q.splitk_max = 8; q.force_splitk = 0; q.kw_reuse = true; q.kwr_n64 = true; q.src2 = true; q.res2 = true; q.env_overrides = 0;
   return q;
 }
@@ -116,6 +118,7 @@ ConvPolicy conv_policy_from_env(ConvPolicy q) {
   v = q.h2s_maxk; geti("ODT_CONV_H2S_MAXK", &v); q.h2s_maxk = (int)v;
   v = q.h2_few_tiles; geti("ODT_CONV_H2_FEW_TILES", &v); q.h2_few_tiles = v != 0;
   v = q.h2_n64; geti("ODT_CONV_H2_N64", &v); q.h2_n64 = v != 0;
+  v = q.h2_n64_bm512; geti("ODT_CONV_H2_N64_BM512", &v); q.h2_n64_bm512 = (int)v;
   v = q.force_bm3; geti("ODT_CONV_SPLIT3_BM", &v); q.force_bm3 = (int)v;
   v = q.splitk_max; geti("ODT_CONV_SPLIT3_SPLITK", &v); q.splitk_max = v < 1 ? 1 : (v > 16 ? 16 : (int)v);
   v = 1; geti("ODT_CONV_SPLIT3_KWR", &v); q.kw_reuse = v != 0;
@@ -194,9 +197,16 @@ void conv_split_choose(ConvParams& p, const ConvPolicy& q) {
       const long t128 = ((M + 127) / 128) * (cout_padded(p.Cout) / 128);
       if (n3 == 64 && !p.wt_split_kwr) {
         // (a forced tile height took a 64-wide layer past the size rule below: same choice as there)
-        if (q.h2_n64 && p.in2 == nullptr) { p.wt_split_kind = 2; p.wt_split_bm = 128; p.wt_split_bn = 64; p.splitk = 1; }
+        if (q.h2_n64 && p.in2 == nullptr) {
+          p.wt_split_kind = 2; p.wt_split_bm = 128; p.wt_split_bn = 64; p.splitk = 1;
+          if (cout_padded(p.Cout) == 64 && (q.h2_n64_bm512 == 2 || (q.h2_n64_bm512 == 1 && (M + 511) / 512 >= q.min_tiles3))) p.wt_split_bm = 512;
+        }
       } else if (b3 == 256 && (K >> 5) >= k3) {
         p.wt_split_kind = 2;
+        // 64-wide kw-reuse layers (res2 conv2): 512 x 64 tiles, a 64 x 64 wave tile (a tile may cross ONE image boundary)
+        if (n3 == 64 && p.wt_split_kwr && k3 == 1 && p.Ho * p.Wo >= 512 && cout_padded(p.Cout) == 64 &&
+            (q.h2_n64_bm512 == 2 || (q.h2_n64_bm512 == 1 && (M + 511) / 512 >= q.min_tiles3)))
+          p.wt_split_bm = 512;
         // (A/B knob, off: short reductions on 128 x 128 tiles, two workgroups per CU in different phases -- measured no gain:
         // res4 conv3 4.28 -> 4.38 ms, res2 / res3 conv3 and the laterals 3-12 % slower, profiles/r03_h2_small_tile_ab.txt)
         if (!p.wt_split_kwr && k3 == 1 && K <= q.h2s_maxk && t128 >= q.min_tiles3) { p.wt_split_bm = 128; p.wt_split_bn = 128; }
@@ -223,6 +233,8 @@ void conv_split_choose(ConvParams& p, const ConvPolicy& q) {
   if (q.family == 2 && q.h2_n64 && bn == 64 && p.in_amax != nullptr && p.in2 == nullptr && p.Cin % 32 == 0 && p.nlvl <= 1 &&
       p.lvl_scale == nullptr && p.head_wt == nullptr && p.kh * p.kw <= 32 && ((M + 127) / 128) * (cout_padded(p.Cout) / 64) >= q.min_tiles) {
     p.wt_split_kind = 2; p.wt_split_bm = 128; p.wt_split_bn = 64;
+    // many rows: 512 x 64 tiles on 8 waves stacked along M (conv0, res2 conv1)
+    if (cout_padded(p.Cout) == 64 && (q.h2_n64_bm512 == 2 || (q.h2_n64_bm512 == 1 && (M + 511) / 512 >= q.min_tiles3))) p.wt_split_bm = 512;
   }
 }
 

@@ -134,6 +134,7 @@ struct ConvPolicy {
   int h2s_maxk;         // fp16x2: longest reduction that takes the 128 x 128 4-wave tile (two workgroups per CU); 0: none
   bool h2_few_tiles;    // fp16x2: 128 x 128 tiles for the layers without enough 256-row tiles
   bool h2_n64;          // fp16x2: also the 64-wide layers (128 x 64 tiles on 4 waves; the kw-reuse kernel's 256 x 64 tile)
+  int h2_n64_bm512;     // fp16x2 kw-reuse kernel on 64-wide layers: 512 x 64 tiles -- 0 off | 1 where they fill the chip | 2 wherever valid
   int force_bm3;        // 0 auto | 128 | 256: force conv_split3_kernel with that tile height (tests)
   int splitk_max;       // conv_split3_kernel: largest split-K factor the policy may choose (1 = off)
   bool kw_reuse;        // conv_split3k_kernel for the stride-1 KH x 3 layers it fits (ODT_CONV_SPLIT3_KWR=0: off)

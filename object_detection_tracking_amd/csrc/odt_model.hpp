@@ -145,6 +145,8 @@ struct odt_model {
     int *pin_labels = nullptr, *pin_valid = nullptr;
     hipEvent_t h2d_done = nullptr, fwd_done = nullptr, d2h_done = nullptr;
     int ticket = -1;            // outstanding ticket or -1
+    int ingest_armed = -1;      // ticket number odt_ingest_buffer() handed pin_in out for (-1: none), and its dtype
+    int ingest_dtype = 0;
     int want = 0;               // ODT_WANT_* bits of the outstanding ticket
   } slot[2];
   hipStream_t copy_in = nullptr, copy_out = nullptr;

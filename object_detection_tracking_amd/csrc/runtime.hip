@@ -17,7 +17,7 @@ using namespace odt;
 
 namespace odt {
 
-// the op list of the static plan, launched on `st` (directly, or while the stream is being captured)
+// the op list of the static plan (ops [begin, end)), launched on `st`
 static int run_ops(odt_model* m, const void* src, int dtype, hipStream_t st, size_t* ev_io, size_t begin = 0,
                    size_t end = (size_t)-1) {
   const odt_config& cfg = m->cfg;
@@ -444,6 +444,7 @@ int odt_ingest_buffer(odt_handle h, int dtype, void** buffer, size_t* bytes) {
   ODT_CHECK(sl.ticket < 0, "odt_ingest_buffer: slot still in flight (collect its ticket first)");
   if (slot_prepare(h, sl, n)) return 1;
   *buffer = sl.pin_in; *bytes = n;
+  sl.ingest_armed = h->next_ticket; sl.ingest_dtype = dtype;     // odt_submit_ex(frames = NULL) takes exactly this buffer
   return 0;
 }
 
@@ -465,6 +466,11 @@ int odt_submit_ex(odt_handle h, const void* frames, int dtype, int want, int* ti
   odt_model::Slot& sl = h->slot[t & 1];
   odt_model::Slot& prev = h->slot[(t & 1) ^ 1];
   ODT_CHECK(sl.ticket < 0, "odt_submit: two tickets already outstanding (collect one first)");
+  // frames == NULL: the caller filled odt_ingest_buffer()'s memory -- which must have been handed out for THIS ticket and
+  // dtype (otherwise the slot's pinned buffer holds stale or no frames, or slot_prepare below would even reallocate it)
+  ODT_CHECK(frames != nullptr || (sl.ingest_armed == t && sl.ingest_dtype == dtype && sl.pin_in != nullptr && sl.pin_in_bytes >= n),
+            "odt_submit: frames == NULL needs odt_ingest_buffer() for this ticket and dtype first");
+  sl.ingest_armed = -1;
   if (slot_prepare(h, sl, n)) return 1;
   if (frames != nullptr) std::memcpy(sl.pin_in, frames, n);
   ODT_HIP(hipMemcpyAsync(sl.dev_in, sl.pin_in, n, hipMemcpyHostToDevice, h->copy_in));
@@ -474,9 +480,8 @@ int odt_submit_ex(odt_handle h, const void* frames, int dtype, int want, int* ti
   sl.want = want;
   if (!(want & ODT_WANT_FEATS)) {
     // nothing large goes back: the outputs are copied right behind the forward on the compute stream (stream order
-    // keeps the next forward's tail off the single device output buffers), no event wait inside the plan, so the
-    // forward + copies replay as one cached hipGraph per slot.  A previous ticket that used the copy stream for
-    // its [M,C,7,7] features still has to be waited for.
+    // keeps the next forward's tail off the single device output buffers), no event wait inside the plan.  A previous
+    // ticket that used the copy stream for its [M,C,7,7] features still has to be waited for.
     if (prev.ticket >= 0 && (prev.want & ODT_WANT_FEATS)) ODT_HIP(hipStreamWaitEvent(st, prev.d2h_done, 0));
     h->wait_before_detect = nullptr;
     h->d2h_slot = &sl; h->d2h_want = want;

@@ -108,7 +108,18 @@ class _Engine(object):
     # arithmetic of the conv / FC products (include/odt.h ODT_ARITH_*): None / "default" | "f32" | "bf16x3"
     arith = getattr(config, "conv_arith", None)
     c.conv_arith = {None: 0, "default": 0, "f32": _lib.ODT_ARITH_F32, "bf16x3": _lib.ODT_ARITH_BF16X3}[arith]
-    c.conv_split_family = int(getattr(config, "conv_split_family", 0) or 0)
+    # conv_split_family: 0 library default (fp16x2 kernels where eligible) | 3 bf16x3 only | 1 | "auto": start on the fp16x2
+    # kernels, run the first forward(s) on a bf16x3-only twin as well and stay on bf16x3 when the pyramid / RPN tensors of
+    # the two differ by more than f32 rounding level (_auto_calibrate) -- the guard for models whose activations do not fit
+    # the fp16x2 kernels' per-tensor range (useful content more than 2^17 below a tensor's maximum)
+    fam = getattr(config, "conv_split_family", 0) or 0
+    self._auto = None
+    if fam == "auto":
+      self._auto = {"pending": int(getattr(config, "conv_split_auto_frames", 1) or 1), "chosen": 2, "checks": [],
+                    "tolerance": float(getattr(config, "conv_split_auto_tol", 2e-5)),
+                    "args": (lib, config, graph, batch, height, width, weights, device, num_class)}
+      fam = 2
+    c.conv_split_family = int(fam)
     # debug / parity runs: every stage tensor keeps its own buffer and tap() can read it after a forward; the production
     # default plans the activations into an arena (a stage's memory is reused once its consumers have run)
     c.keep_taps = int(bool(getattr(config, "keep_taps", False)))
@@ -149,6 +160,9 @@ class _Engine(object):
                                                 C.cast(shape, c_i64_p), a.ndim))
 
   def close(self):
+    a = object.__getattribute__(self, "__dict__").get("_auto")
+    if a is not None and "twin" in a:
+      a.pop("twin").close()
     if self.h is not None:
       self.lib.dll.odt_destroy(self.h)
       self.h = None
@@ -191,9 +205,54 @@ class _Engine(object):
     assert fr.shape == (self.batch, self.src_height, self.src_width, 3), fr.shape
     return fr, dt
 
+  # ---- conv_split_family = "auto" --------------------------------------------------------------------------------------
+  AUTO_TAPS = ("p2", "p3", "p4", "p5", "p6", "rpn2", "rpn3", "rpn4", "rpn5", "rpn6")      # (readable after a forward in arena mode too)
+
+  def _auto_calibrate(self, run):
+    """One calibration forward: `run(engine)` puts the caller's input through an engine (blocking).  The fp16x2 handle
+    and a bf16x3-only twin (no range assumption at all) see the same input; if any pyramid / RPN tensor differs by more
+    than the tolerance (relative to the tensor's |max|), this engine continues as the twin."""
+    a = self._auto
+    if a is None or a["pending"] <= 0 or a["chosen"] != 2:
+      return
+    import copy
+    lib, config, graph, batch, height, width, weights, device, num_class = a["args"]
+    if "twin" not in a:
+      cfg3 = copy.copy(config)
+      cfg3.conv_split_family = 3
+      a["twin"] = _Engine(lib, cfg3, graph, batch, height, width, weights, device, num_class)
+      if (self.src_height, self.src_width) != (height, width):
+        a["twin"].set_source_size(self.src_height, self.src_width)
+    twin = a["twin"]
+    run(self); run(twin)
+    worst, where = 0.0, None
+    for name in self.AUTO_TAPS:
+      try:
+        x, y = self.tap(name), twin.tap(name)
+      except _lib.OdtError:
+        continue
+      d = float(np.abs(x - y).max() / max(1e-30, float(np.abs(y).max())))
+      if not np.isfinite(d):
+        d = float("inf")
+      if d > worst:
+        worst, where = d, name
+    a["checks"].append({"max_rel_diff": worst, "tensor": where})
+    a["pending"] -= 1
+    if worst > a["tolerance"]:
+      # stay on bf16x3: this engine takes over the twin's handle
+      self.h, twin.h = twin.h, self.h
+      a["chosen"] = 3
+    if a["chosen"] == 3 or a["pending"] <= 0:
+      twin.close()
+      a.pop("twin", None)
+      a.pop("args", None)
+
   def forward(self, frames, want_feats=True, want_pooled=False):
     """frames: [B,H,W,3] uint8/float32 BGR host array.  Returns fresh arrays."""
     fr, dt = self._frames(frames)
+    if self._auto is not None and self._auto["pending"] > 0 and self._auto["chosen"] == 2:
+      self._auto_calibrate(lambda e: e.lib.check(e.lib.dll.odt_forward(e.h, fr.ctypes.data_as(C.c_void_p), dt, 0, None,
+                                                                       C.byref(e._outputs(False, False)))))
     out = self._outputs(want_feats, want_pooled)
     self.lib.check(self.lib.dll.odt_forward(self.h, fr.ctypes.data_as(C.c_void_p), dt, 0, None,
                                             C.byref(out)))
@@ -215,6 +274,9 @@ class _Engine(object):
       fr, dt = None, self._ingest_dtype
     else:
       fr, dt = self._frames(frames)
+      if self._auto is not None and self._auto["pending"] > 0 and self._auto["chosen"] == 2:
+        self._auto_calibrate(lambda e: e.lib.check(e.lib.dll.odt_forward(e.h, fr.ctypes.data_as(C.c_void_p), dt, 0, None,
+                                                                         C.byref(e._outputs(False, False)))))
     t = C.c_int()
     want = (1 if want_feats else 0) | (2 if want_pooled else 0) | (4 if self.add_mask else 0)
     self.lib.check(self.lib.dll.odt_submit_ex(self.h, fr.ctypes.data_as(C.c_void_p) if fr is not None else None, dt, want,
@@ -261,6 +323,11 @@ class _Engine(object):
 
   def forward_device_async(self, dev_ptr, dtype, stream=None):
     """Enqueue one forward on frames already resident in HBM (bench path)."""
+    if self._auto is not None and self._auto["pending"] > 0 and self._auto["chosen"] == 2:
+      def run(e):
+        e.lib.check(e.lib.dll.odt_forward_async(e.h, C.c_void_p(dev_ptr), dtype, 1, None))
+        e.lib.check(e.lib.dll.odt_synchronize(e.h))
+      self._auto_calibrate(run)
     self.lib.check(self.lib.dll.odt_forward_async(self.h, C.c_void_p(dev_ptr), dtype, 1,
                                                   C.c_void_p(stream) if stream else None))
 
@@ -270,9 +337,28 @@ class _Engine(object):
   def describe(self):
     """What the handle runs (odt_describe): conv arithmetic mode, launches per kernel family, policy thresholds."""
     import json
-    buf = C.create_string_buffer(2048)
-    self.lib.check(self.lib.dll.odt_describe(self.h, buf, 2048))
-    return json.loads(buf.value.decode())
+    buf = C.create_string_buffer(4096)
+    self.lib.check(self.lib.dll.odt_describe(self.h, buf, 4096))
+    d = json.loads(buf.value.decode())
+    auto = getattr(self, "_auto", None)      # (EfficientNetBackbone borrows this method: no auto state there)
+    if auto is not None:
+      d["conv_split_family_auto"] = {"chosen": "bf16x3 (family 3)" if auto["chosen"] == 3 else "fp16x2 (family 2)",
+                                     "calibration_forwards_left": max(0, auto["pending"]) if auto["chosen"] == 2 else 0,
+                                     "tolerance": auto["tolerance"], "checks": list(auto["checks"])}
+    return d
+
+  def range_report(self, names=None):
+    """Debug handles (keep_taps): per stage tensor the |max| of the last forward and the share of its non-zero elements
+    more than 2^17 below it -- what the fp16x2 kernels' per-tensor power of two leaves in the f16 subnormal grid (absolute
+    instead of relative precision there).  {name: {"amax", "frac_nonzero_below_2^-17_amax", "elements"}}."""
+    out = {}
+    for name in (names or ("conv0", "pool0", "c2", "c3", "c4", "c5", "p2", "p3", "p4", "p5", "p6")):
+      t = np.abs(self.tap(name))
+      amax = float(t.max())
+      nz = t > 0
+      out[name] = {"amax": amax, "elements": int(t.size),
+                   "frac_nonzero_below_2^-17_amax": float(((t < amax * 2.0 ** -17) & nz).sum() / max(1, int(nz.sum())))}
+    return out
 
   def profile(self, enable):
     self.lib.check(self.lib.dll.odt_profile_enable(self.h, int(enable)))

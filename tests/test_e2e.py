@@ -3,8 +3,8 @@ the oracle, stage by stage through the debug taps, for both reference graphs.
 
 Tolerances: the network is ~105 sequential fp32 conv/FC layers accumulated in a different order
 than torch/TF, so stage tensors are compared with a relative tolerance on their own scale and
-boxes with 1e-3 * (image side / 128) px (the north_star's 1e-3 is quoted at O(100) px
-coordinates).  Selection stages (top-k / NMS / level assignment) are discontinuous, so final
+boxes with an ABSOLUTE 1e-3 px at every size up to 1920 x 1080 (the north_star's bound; measured worst case
+4.9e-4 px at 8 x 1080p, profiles/r03_parity.json).  Selection stages (top-k / NMS / level assignment) are discontinuous, so final
 detections are compared as matched sets with a reported mismatch count; the bit-exact index
 tests on identical inputs live in test_ops.py.
 """
@@ -62,7 +62,7 @@ def _run_single(lib, cfg, H, W, tol=2e-5, box_tol=None, budget=0):
       assert np.array_equal(a, b), "arena and keep_taps handles disagree"
     e = m.engine(1, H, W)
     _check_trunk(e, ref, tol)
-    box_tol = box_tol or 1e-3 * max(H, W) / 128
+    box_tol = box_tol or 1e-3
     assert boxes.dtype == np.float32 and labels.dtype == np.int64 and probs.dtype == np.float32
     assert feats.shape == (boxes.shape[0], 256, 7, 7)
     n = int(e.tap("nproposals")[0])
@@ -112,7 +112,7 @@ def _run_multi(lib, cfg, B, H, W, tol=2e-5, w=None, info=None, budget=0):
     assert feats.shape[0] == valid.sum()
     if info is not None:
       info["nproposals"] = e.tap("nproposals").reshape(-1).copy()
-    box_tol = 1e-3 * max(H, W) / 128
+    box_tol = 1e-3
     tot = 0
     for b in range(B):
       v = valid[b]
@@ -552,3 +552,160 @@ def test_forward_multi_b24_1080p(hip_lib):
       assert miss + extra == 0, (b, miss, extra)
   finally:
     m.close()
+
+
+# ---- the fp16x2 default's range assumption: guard (conv_split_family = "auto") and out-of-domain behaviour -----------------
+def _split_multi_ref(ref, B):
+  """Per image (boxes, labels, probs) of the oracle's batched outputs."""
+  out = []
+  for b in range(B):
+    v = int(ref["final_valid_indices"][b])
+    out.append((ref["final_boxes"][b, :v], ref["final_labels"][b, :v], ref["final_probs"][b, :v]))
+  return out
+
+
+def _outlier_weights(cfg, exp=30):
+  """Synthetic weights whose conv0 output carries ONE channel 2^exp above the rest -- and nothing downstream reads it
+  (zero rows in the convs that consume pool0): every useful value of that tensor sits 2^exp below the tensor's |max|,
+  outside what one power of two per tensor leaves an f16 pair."""
+  w = {k: np.array(v, copy=True) for k, v in weights_for(cfg).items()}
+  c = 5
+  w["conv0/bn/gamma"][c] *= np.float32(2.0 ** exp)
+  w["conv0/bn/beta"][c] = 0
+  w["group0/block0/conv1/W"][:, :, c, :] = 0
+  w["group0/block0/convshortcut/W"][:, :, c, :] = 0
+  return w
+
+
+def test_auto_family_guards_the_fp16x2_range_assumption(backend, monkeypatch):
+  """conv_split_family = "auto": the first forward also runs on a bf16x3-only twin handle; ordinary weights stay on the
+  fp16x2 kernels (pyramid / RPN tensors agree at f32 rounding level), weights with an outlier channel 2^30 above the useful
+  content of its tensor make the fp16x2 handle deviate by orders of magnitude more -- the engine continues on bf16x3 and
+  agrees with the oracle, which a forced fp16x2 handle does not."""
+  name, lib = backend
+  monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1"); monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "1")
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1])
+  H, W = (64, 96) if name == "emu" else (160, 224)
+  fr = synthetic_frames(1, H, W, seed=5)
+  import copy
+  # (simulator: the outlier case only -- ordinary weights on both families there: test_fp16x2_family_agrees_with_bf16x3)
+  for kind in (("outlier",) if name == "emu" else ("ordinary", "outlier")):
+    w = weights_for(cfg) if kind == "ordinary" else _outlier_weights(cfg)
+    ref = OracleModel(cfg, w).forward(fr[0])
+    ca = copy.copy(cfg); ca.conv_split_family = "auto"
+    m = models.get_model(ca, 0, weights=w, lib=lib)
+    try:
+      boxes, labels, probs, feats = m.predict(fr[0])
+      e = m.engine(1, H, W)
+      d = e.describe()
+      auto = d["conv_split_family_auto"]
+      assert len(auto["checks"]) == 1 and auto["calibration_forwards_left"] == 0, auto
+      p2 = e.tap("p2").transpose(0, 3, 1, 2)[:, :, :ref["p2"].shape[2], :ref["p2"].shape[3]]
+      if kind == "ordinary":
+        assert auto["chosen"].startswith("fp16x2") and auto["checks"][0]["max_rel_diff"] < 2e-5, auto
+        assert d["fp16x2_split_launches"] >= 10, d
+      else:
+        assert auto["chosen"].startswith("bf16x3") and auto["checks"][0]["max_rel_diff"] > 1e-4, auto
+        assert d["fp16x2_split_launches"] == 0, d
+      assert _rel(p2, ref["p2"]) < 2e-5, kind
+      miss, extra = match_detections(boxes, labels, probs, ref["final_boxes"], ref["final_labels"], ref["final_probs"], 1e-3, 1e-4)
+      assert miss + extra == 0, (kind, miss, extra)
+      if name == "hip":
+        b2, l2, p2b, _ = m.predict(fr[0])                # (the second forward runs on the chosen handle alone)
+        assert np.array_equal(b2, boxes) and np.array_equal(p2b, probs)
+    finally:
+      m.close()
+    if kind == "outlier" and name == "hip":
+      # what the guard is for: the same weights on a handle FORCED to the fp16x2 family leave f32 level
+      cf = _with_taps(cfg); cf.conv_split_family = 2
+      m = models.get_model(cf, 0, weights=w, lib=lib)
+      try:
+        m.predict(fr[0])
+        e = m.engine(1, H, W)
+        p2f = e.tap("p2").transpose(0, 3, 1, 2)[:, :, :ref["p2"].shape[2], :ref["p2"].shape[3]]
+        assert _rel(p2f, ref["p2"]) > 1e-4
+        rep = e.range_report(("conv0", "pool0", "c2"))
+        assert rep["pool0"]["frac_nonzero_below_2^-17_amax"] > 0.9 and rep["c2"]["frac_nonzero_below_2^-17_amax"] < 0.05, rep
+      finally:
+        m.close()
+
+
+@pytest.mark.gpu
+def test_mixed_exposure_batch_b8_1080p_and_batch_independence(hip_lib):
+  """Config #3's batch with frames 0-1 black, 2-3 saturated, 4-7 ordinary: the fp16x2 kernels take ONE power of two per
+  activation tensor ACROSS the batch, so a frame's arithmetic depends on its batch mates' range.  (i) the batch agrees with
+  the oracle at the usual budgets (0 unmatched, boxes within 1e-3 px); (ii) every frame's pyramid features and detections
+  from the b = 8 forward agree with the same frame alone (b = 1, same graph) at f32 rounding level."""
+  cfg = make_config(rpn_test_post_nms_topk=300, im_batch_size=8)
+  w = weights_for(cfg)
+  H, W = 1080, 1920
+  fr = synthetic_frames(8, H, W, seed=11)
+  fr[0:2] = 0
+  fr[2:4] = 255
+  ref = OracleModel(cfg, w).forward_multi(fr)
+  m = models.get_model(cfg, 0, weights=w, is_multi=True, lib=hip_lib)
+  try:
+    e = m.engine(8, H, W)
+    boxes, labels, probs, valid, feats, _ = e.forward(fr)
+    assert e.describe()["fp16x2_split_launches"] > 80
+    p3 = e.tap("p3")
+    got = (boxes, labels, probs, valid)
+  finally:
+    m.close()
+  # (i) against the oracle, image by image
+  per_ref = _split_multi_ref(ref, 8)
+  for b in range(8):
+    n = int(got[3][b])
+    rb, rl, rp = per_ref[b]
+    assert n == len(rb), (b, n, len(rb))
+    miss, extra = match_detections(got[0][b, :n], got[1][b, :n], got[2][b, :n], rb, rl, rp, 1e-3, 1e-4)
+    assert miss + extra == 0, (b, miss, extra)
+  # (ii) every frame alone
+  cfg1 = make_config(rpn_test_post_nms_topk=300, im_batch_size=1)
+  m1 = models.get_model(cfg1, 0, weights=w, is_multi=True, lib=hip_lib)
+  try:
+    e1 = m1.engine(1, H, W)
+    for b in range(8):
+      b1, l1, p1, v1, _, _ = e1.forward(fr[b:b + 1])
+      assert _rel(e1.tap("p3")[0], p3[b]) < 1e-5, b
+      n = int(got[3][b])
+      assert int(v1[0]) == n, (b, int(v1[0]), n)
+      miss, extra = match_detections(got[0][b, :n], got[1][b, :n], got[2][b, :n], b1[0, :n], l1[0, :n], p1[0, :n], 1e-3, 1e-4)
+      assert miss + extra == 0, (b, miss, extra)
+  finally:
+    m1.close()
+
+
+@pytest.mark.gpu
+def test_heavy_tailed_bn_gamma_1080p_auto_family(hip_lib):
+  """A 'trained-looking' pathology at full size (b = 2 @1080p): a few BN channels of conv0 and of the res2 / res3 stage
+  outputs scaled by 100 (activations with outlier channels two orders of magnitude above the rest, the regime of real
+  checkpoints) -- within the fp16x2 kernels' domain: the default handle agrees with the oracle at the usual budgets and
+  conv_split_family = "auto" keeps it; with ONE channel 2^30 up the auto engine leaves fp16x2 and still agrees."""
+  import copy
+  cfg = make_config(rpn_test_post_nms_topk=300, im_batch_size=2)
+  H, W = 1080, 1920
+  fr = synthetic_frames(2, H, W, seed=3)
+  base = weights_for(cfg)
+  heavy = {k: np.array(v, copy=True) for k, v in base.items()}
+  rng = np.random.default_rng(4)
+  for key in ("conv0/bn/gamma", "group0/block2/conv3/bn/gamma", "group1/block3/conv3/bn/gamma", "group2/block5/conv1/bn/gamma"):
+    idx = rng.choice(heavy[key].shape[0], 3, replace=False)
+    heavy[key][idx] *= np.float32(100.0)
+  for tag, w, want in (("gamma x 100", heavy, "fp16x2"), ("outlier 2^30", _outlier_weights(cfg), "bf16x3")):
+    ref = OracleModel(cfg, w).forward_multi(fr)
+    per_ref = _split_multi_ref(ref, 2)
+    ca = copy.copy(cfg); ca.conv_split_family = "auto"
+    m = models.get_model(ca, 0, weights=w, is_multi=True, lib=hip_lib)
+    try:
+      e = m.engine(2, H, W)
+      boxes, labels, probs, valid, _, _ = e.forward(fr)
+      auto = e.describe()["conv_split_family_auto"]
+      assert auto["chosen"].startswith(want), (tag, auto)
+      for b in range(2):
+        n = int(valid[b]); rb, rl, rp = per_ref[b]
+        assert n == len(rb), (tag, b, n, len(rb))
+        miss, extra = match_detections(boxes[b, :n], labels[b, :n], probs[b, :n], rb, rl, rp, 1e-3, 1e-4)
+        assert miss + extra == 0, (tag, b, miss, extra)
+    finally:
+      m.close()

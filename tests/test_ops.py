@@ -789,3 +789,60 @@ def test_bottleneck_tail_fused_row_scale(backend):
   err = np.abs(y - ref) / mag
   for r in range(15):
     assert err[0, r].max() < 4e-7, (r, err[0, r].max())
+
+
+def test_conv2d_fp16x2_512x64_tile(backend, monkeypatch):
+  """conv_h2k_kernel<2, ., ., WN = 1>: the 64-wide stride-1 3x3 layers (res2 conv2) on 512 x 64 tiles, eight waves stacked
+  along M (a 64 x 64 wave tile: 24 MFMAs per stage instead of 12).  Same K order and products as the 256 x 64 tile: the
+  results are bit-identical to it; tiles cross image boundaries (two staged runs), the last one is partial."""
+  name, lib = backend
+  _split_env(monkeypatch, "2/256")
+  rng = np.random.default_rng(64)
+  B, H, W, C = 3, 23, 24, 64                 # Ho Wo = 552 >= 512, M = 1656: four tiles, boundaries inside tiles 1 and 2
+  x = rng.standard_normal((B, H, W, C)).astype(F)
+  w = (rng.standard_normal((3, 3, C, 64)) * 0.06).astype(F)
+  b = rng.standard_normal(64).astype(F)
+  ref = np.maximum(torch_conv_nhwc(x, w, b, 1, 1, 1, 1, H, W), 0)
+  out = {}
+  for mode in ("0", "2"):
+    monkeypatch.setenv("ODT_CONV_H2_N64_BM512", mode)
+    out[mode] = ops.conv2d(x, w, b, 1, 1, 1, 1, (H, W), relu=True, lib=lib)
+    np.testing.assert_allclose(out[mode], ref, rtol=1e-4, atol=1e-4)
+  if k > 1:
+    assert np.array_equal(out["0"], out["2"])
+  else:
+    np.testing.assert_allclose(out["0"], out["2"], rtol=0, atol=2e-6 * float(np.abs(ref).max()))
+  # dilation 2 (the other halo width)
+  monkeypatch.setenv("ODT_CONV_H2_N64_BM512", "2")
+  y = ops.conv2d(x, w, b, 1, 2, 2, 2, (H, W), relu=False, lib=lib)
+  np.testing.assert_allclose(y, torch_conv_nhwc(x, w, b, 1, 2, 2, 2, H, W), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("case", [
+    (2, 20, 30, 256, 64, 1, 1, 1, 0, 0, 20, 30, True),       # dense 1x1 (res2 conv1), M = 1200: three tiles, the last partial
+    (1, 43, 47, 32, 64, 3, 2, 1, 1, 1, 22, 24, True),        # strided taps (conv0's class), M = 528
+    (1, 9, 11, 64, 64, 1, 1, 1, 0, 0, 9, 11, False),         # a single partial tile, K = 64 (two stages)
+])
+def test_conv2d_fp16x2_512x64_tile_generic_kernel(backend, case, monkeypatch):
+  """conv_h2_kernel<2, 8, ., WN = 1>: the 64-wide layers outside the kw-reuse kernel (conv0, res2 conv1) on 512 x 64 tiles of
+  eight waves stacked along M; same products as the 128 x 64 tile -- bit-identical to it where the K order is the same
+  (the single-source 1x1 layers start their reduction at slice `tile index mod slices`: summation order differs)."""
+  name, lib = backend
+  _split_env(monkeypatch, "2")
+  B, H, W, Cin, Cout, k, stride, dil, pt, pl, Ho, Wo, relu = case
+  rng = np.random.default_rng(65)
+  x = rng.standard_normal((B, H, W, Cin)).astype(F)
+  w = (rng.standard_normal((k, k, Cin, Cout)) * 0.08).astype(F)
+  b = rng.standard_normal(Cout).astype(F)
+  ref = torch_conv_nhwc(x, w, b, stride, dil, pt, pl, Ho, Wo)
+  if relu:
+    ref = np.maximum(ref, 0)
+  out = {}
+  for mode in ("0", "2"):
+    monkeypatch.setenv("ODT_CONV_H2_N64_BM512", mode)
+    out[mode] = ops.conv2d(x, w, b, stride, dil, pt, pl, (Ho, Wo), relu=relu, lib=lib)
+    np.testing.assert_allclose(out[mode], ref, rtol=1e-4, atol=1e-4)
+  if k > 1:
+    assert np.array_equal(out["0"], out["2"])
+  else:
+    np.testing.assert_allclose(out["0"], out["2"], rtol=0, atol=2e-6 * float(np.abs(ref).max()))

@@ -35,6 +35,17 @@ def measure(model="efficientdet-d7", size=0, frame="", steps=20, warmup=3, cpu_b
     step()
   e.synchronize(); torch.cuda.synchronize()
   dt = (time.perf_counter() - t0) / steps
+  # the timed region checks itself (as bench.py's headline does): what its last device-resident forward left in HBM must
+  # equal, bit for bit, a blocking host-to-host forward of the same frame -- and be a non-trivial detection set
+  m._inflight = (e, None)
+  got = m.predict_collect()
+  ref = m.predict(fr)
+  names = ("final_boxes", "final_labels", "final_probs", "fpn_box_feat")
+  equal = {n: bool(np.array_equal(a, b)) for n, a, b in zip(names, got, ref)}
+  verification = {"bit_equal_to_blocking_forward": equal, "detections": int(len(got[0])),
+                  "what": "outputs left in HBM by the last forward of the timed loop (odt_read_outputs) == blocking odt_forward of "
+                          "the same frame from host memory, all four output arrays bit for bit; detections > 0"}
+  verified = all(equal.values()) and len(got[0]) > 0 and bool(np.isfinite(got[0]).all())
   t1 = time.perf_counter()
   for _ in range(5):
     out = m.predict(fr)
@@ -111,7 +122,7 @@ def measure(model="efficientdet-d7", size=0, frame="", steps=20, warmup=3, cpu_b
            "sample": "one frame through oracle.effnet (torch-CPU fp32 + numpy tail), one pass, %.1f s" % cdt}
   traffic = None
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  for name in ([pmc_profile] if pmc_profile else ["r03_pmc_summary_effdet_d7.json", "r02_pmc_summary_effdet_d7.json"]):
+  for name in ([pmc_profile] if pmc_profile else ["r04_pmc_summary_effdet_d7.json", "r03_pmc_summary_effdet_d7.json", "r02_pmc_summary_effdet_d7.json"]):
     pmc = os.path.join(root, "profiles", name)
     if model == "efficientdet-d7" and S == 1536 and os.path.exists(pmc):
       # HBM bytes per forward from the committed rocprofv3 --pmc passes (tools/gpurun/r2_effdet_pmc.sh), FETCH_SIZE doubled
@@ -129,6 +140,7 @@ def measure(model="efficientdet-d7", size=0, frame="", steps=20, warmup=3, cpu_b
                               "the kernels' own PMC-counted HBM bytes per second"},
          "cpu_baseline": cpu, "metric": "%s FPS @%dx%d input per MI355X" % (model, S, S), "value": 1.0 / dt, "unit": "frames/s",
          "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": dt * 1e3, "dtype": "f32",
+         "verified": bool(verified), "verification": verification,
          "data": "synthetic", "config": {"workload": "%s (EfficientNet backbone + BiFPN + class/box nets + top-5000 / NMS / "
          "per-level ROI features), frame %dx%d scaled on the device, batch 1, 90 classes, random-init weights, frame "
          "resident in HBM (uint8)" % (model, fw, fh)},
