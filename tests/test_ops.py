@@ -808,10 +808,7 @@ def test_conv2d_fp16x2_512x64_tile(backend, monkeypatch):
     monkeypatch.setenv("ODT_CONV_H2_N64_BM512", mode)
     out[mode] = ops.conv2d(x, w, b, 1, 1, 1, 1, (H, W), relu=True, lib=lib)
     np.testing.assert_allclose(out[mode], ref, rtol=1e-4, atol=1e-4)
-  if k > 1:
-    assert np.array_equal(out["0"], out["2"])
-  else:
-    np.testing.assert_allclose(out["0"], out["2"], rtol=0, atol=2e-6 * float(np.abs(ref).max()))
+  assert np.array_equal(out["0"], out["2"])
   # dilation 2 (the other halo width)
   monkeypatch.setenv("ODT_CONV_H2_N64_BM512", "2")
   y = ops.conv2d(x, w, b, 1, 2, 2, 2, (H, W), relu=False, lib=lib)
