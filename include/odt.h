@@ -293,7 +293,7 @@ int odt_op_conv2d_cat(int device, const float* a, int B, int Ho, int Wo, int Ca,
                       int Wb, int Cb, int stride_b, const float* wa, const float* wb, const float* bias,
                       int Cout, int relu, float* out);
 /* The tail of a bottleneck block (nn.py:503-521) on the fp16x2 kernels: conv2 (3x3 stride 1, 'SAME' for dilation dil,
- * C -> C = 256, + bias, ReLU; w2 [3,3,C,C] HWIO) -> conv3 (1x1, C -> C3, + bias (+ res [B,H,W,C3]), ReLU if relu3;
+ * C -> C = 128 or 256, + bias, ReLU; w2 [3,3,C,C] HWIO) -> conv3 (1x1, C -> C3, + bias (+ res [B,H,W,C3]), ReLU if relu3;
  * w3 [C,C3]).  fuse = 1: one launch, conv3 evaluated from conv2's accumulators inside the 3x3 kernel (what the plan runs
  * for res4 at b = 8 @1080p); fuse = 0: the two launches it replaces.  in [B,H,W,C], out [B,H,W,C3]. */
 int odt_op_bottleneck_tail(int device, const float* in, int B, int H, int W, int C, const float* w2,

@@ -581,7 +581,8 @@ __global__ void __launch_bounds__(512, 2) conv_h2k_kernel(const ConvParams* __re
 void launch_conv_h2k(const ConvParams& p, const ConvParams* dev, unsigned grid, hipStream_t stream) {
   const int bn = p.wt_split_bn;
   if (p.f_wt != nullptr) {                   // fused 1x1 tail (launch_conv_h2 checked the shape)
-    if (p.trace != nullptr) hipLaunchKernelGGL((conv_h2k_kernel<4, true, true>), dim3(grid), dim3(512), 0, stream, dev);
+    if (bn == 128) hipLaunchKernelGGL((conv_h2k_kernel<2, false, true>), dim3(grid), dim3(512), 0, stream, dev);
+    else if (p.trace != nullptr) hipLaunchKernelGGL((conv_h2k_kernel<4, true, true>), dim3(grid), dim3(512), 0, stream, dev);
     else hipLaunchKernelGGL((conv_h2k_kernel<4, false, true>), dim3(grid), dim3(512), 0, stream, dev);
   } else if (bn == 256) {
     if (p.trace != nullptr) hipLaunchKernelGGL((conv_h2k_kernel<4, true>), dim3(grid), dim3(512), 0, stream, dev);

@@ -98,7 +98,8 @@ ConvPolicy conv_policy_default() {
   q.h2_few_tiles = true;  // fp16x2: layers without enough 256-row tiles take 128 x 128 tiles instead of bf16x3 + split-K
   q.h2_n64 = true;        // fp16x2: the 64-wide layers too
   q.h2_n64_bm512 = 1;     // fp16x2 kw-reuse kernel on 64-wide layers: 512 x 64 tiles (eight waves stacked along M: 24 MFMAs per wave and
-                          // stage instead of 12) where they fill the chip; 0 off, 2 wherever the shape allows (tests)
+                          // stage instead of 12) where they fill the chip (res2 conv2 1.035 -> 0.897 ms, same box); 0 off, 2 wherever
+                          // the shape allows, the generic kernel included (tests)
   q.min_bn = 0; q.force_bm3 = 0; q.splitk_max = 8; q.force_splitk = 0; q.kw_reuse = true; q.kwr_n64 = true; q.src2 = true; q.res2 = true; q.env_overrides = 0;
   return q;
 }
@@ -199,7 +200,7 @@ void conv_split_choose(ConvParams& p, const ConvPolicy& q) {
         // (a forced tile height took a 64-wide layer past the size rule below: same choice as there)
         if (q.h2_n64 && p.in2 == nullptr) {
           p.wt_split_kind = 2; p.wt_split_bm = 128; p.wt_split_bn = 64; p.splitk = 1;
-          if (cout_padded(p.Cout) == 64 && (q.h2_n64_bm512 == 2 || (q.h2_n64_bm512 == 1 && (M + 511) / 512 >= q.min_tiles3))) p.wt_split_bm = 512;
+          if (cout_padded(p.Cout) == 64 && q.h2_n64_bm512 == 2) p.wt_split_bm = 512;      // (tests only: see below)
         }
       } else if (b3 == 256 && (K >> 5) >= k3) {
         p.wt_split_kind = 2;
@@ -233,8 +234,10 @@ void conv_split_choose(ConvParams& p, const ConvPolicy& q) {
   if (q.family == 2 && q.h2_n64 && bn == 64 && p.in_amax != nullptr && p.in2 == nullptr && p.Cin % 32 == 0 && p.nlvl <= 1 &&
       p.lvl_scale == nullptr && p.head_wt == nullptr && p.kh * p.kw <= 32 && ((M + 127) / 128) * (cout_padded(p.Cout) / 64) >= q.min_tiles) {
     p.wt_split_kind = 2; p.wt_split_bm = 128; p.wt_split_bn = 64;
-    // many rows: 512 x 64 tiles on 8 waves stacked along M (conv0, res2 conv1)
-    if (cout_padded(p.Cout) == 64 && (q.h2_n64_bm512 == 2 || (q.h2_n64_bm512 == 1 && (M + 511) / 512 >= q.min_tiles3))) p.wt_split_bm = 512;
+    // 512 x 64 tiles on 8 waves stacked along M for these layers (conv0, res2 conv1): built, tested, and NOT the default --
+    // same-box A/B at b=8 1080p: conv0 0.767 -> 0.888 ms, res2 conv1 0.555 -> 0.587 (three 4-wave workgroups per CU in different
+    // phases hide these HBM-bound layers' loads and stores better than one 8-wave workgroup; profiles/r04_n64_bm512_ab.txt)
+    if (cout_padded(p.Cout) == 64 && q.h2_n64_bm512 == 2) p.wt_split_bm = 512;
   }
 }
 

@@ -196,7 +196,7 @@ int odt_op_bottleneck_tail(int device, const float* in, int B, int H, int W, int
                            int dil, const float* w3_io, const float* b3, int C3, const float* res, int relu3, int fuse,
                            float* out) {
   ODT_CHECK(in && w2_hwio && b2 && w3_io && b3 && out, "odt_op_bottleneck_tail: null argument");
-  ODT_CHECK(C == 256 && C3 % 64 == 0 && C3 > 0 && (dil == 1 || dil == 2), "odt_op_bottleneck_tail: C = 256, C3 % 64 == 0, dil 1 or 2");
+  ODT_CHECK((C == 256 || C == 128) && C3 % 64 == 0 && C3 > 0 && (dil == 1 || dil == 2), "odt_op_bottleneck_tail: C = 128 / 256, C3 % 64 == 0, dil 1 or 2");
   if (set_dev(device)) return 1;
   const size_t M = (size_t)B * H * W;
   std::vector<float> w2((size_t)C * 9 * C), w3((size_t)C3 * C);
@@ -215,7 +215,7 @@ int odt_op_bottleneck_tail(int device, const float* in, int B, int H, int W, int
   a.B = B; a.H = H; a.W = W; a.Cin = C; a.in_ldc = C; a.in_Ha = H; a.in_Wa = W; a.Ho = H; a.Wo = W; a.Cout = C;
   a.kh = 3; a.kw = 3; a.stride = 1; a.dil = dil; a.pad_t = dil; a.pad_l = dil;
   a.out_H = H; a.out_W = W; a.out_ldc = C; a.relu = 1;
-  a.wt_split_kind = 2; a.wt_split_bm = 256; a.wt_split_bn = 256; a.wt_split_kwr = 1; a.splitk = 1;
+  a.wt_split_kind = 2; a.wt_split_bm = 256; a.wt_split_bn = C; a.wt_split_kwr = 1; a.splitk = 1;
   a.in_amax = amax.d; a.out_amax = amax.d + 1; a.debug = 0x400;
   conv_prepare(a);
   if (img2.alloc((conv_split_weight_bytes(C, 9 * C) + 3) / 4) || conv_make_split_weights(a, img2.d, nullptr)) return 1;

@@ -348,15 +348,16 @@ int fuse_rpn_heads(odt_model* m) {
 // attach_split_weights, before plan_arena.
 int fuse_bottleneck_tails(odt_model* m) {
   if (m->conv_fused.size() < m->convs.size()) m->conv_fused.resize(m->convs.size(), 0);
-  const char* e = getenv("ODT_FUSE_BOTTLENECK");
+  const char* e = getenv("ODT_FUSE_BOTTLENECK");       // A/B: 0 off | 1 only the 256-wide blocks (res4) | otherwise every fusable block
   if (e != nullptr && e[0] == '0') return 0;
+  const bool only256 = e != nullptr && e[0] == '1';
   if (m->policy.arith == 0 || m->policy.family != 2) return 0;
   std::map<const float*, const void*> made;
   for (size_t oi = 0; oi + 1 < m->ops.size(); ++oi) {
     Op& oa = m->ops[oi]; Op& ob = m->ops[oi + 1];
     if (oa.kind != OP_CONV || ob.kind != OP_CONV || oa.skip || ob.skip) continue;
     ConvOp& a = m->convs[oa.conv]; ConvOp& b = m->convs[ob.conv];
-    if (!conv_h2f_fusable(a.p, b.p)) continue;
+    if (!conv_h2f_fusable(a.p, b.p) || (only256 && a.p.Cout != 256)) continue;
     // nothing else may read conv2's output (taps: a keep_taps handle exposes no stage tensor under this name, see add_conv)
     bool other = false;
     for (size_t k = 0; k < m->ops.size() && !other; ++k) {

@@ -736,7 +736,8 @@ def _bottleneck_ref(x, w2, b2, w3, b3, res, dil, relu3):
 
 
 BOTTLENECK_CASES = [
-    # B, H, W, C3, dil, residual, relu3
+    # B, H, W, C3, dil, residual, relu3 (, C)
+    (2, 11, 13, 128, 1, True, True, 128), # res3's shape class: 256 x 128 tile, the K halves are 64 wide
     (1, 12, 24, 64, 1, True, True),       # two tiles, the second partial
     (2, 9, 17, 128, 1, True, True),       # a tile that crosses the image boundary (two runs), odd sizes
     (1, 16, 16, 192, 2, False, False),    # dilation 2, six 32-column chunks, no residual, no activation
@@ -749,8 +750,8 @@ def test_bottleneck_tail_fused_vs_f64(backend, case):
   launches it replaces (both held to 4e-7: three exact f16 products per MAC + f32 accumulation), and the two forms agree
   to the f32 rounding of one more summation order."""
   name, lib = backend
-  B, H, W, C3, dil, with_res, relu3 = case
-  C = 256
+  B, H, W, C3, dil, with_res, relu3 = case[:7]
+  C = case[7] if len(case) > 7 else 256
   rng = np.random.default_rng(B * 1000 + H * 10 + C3)
   # post-ReLU input with a log-normal spread over pixels (what conv1 hands to conv2)
   x = (np.maximum(rng.standard_normal((B, H, W, C)), 0) * np.exp(rng.standard_normal((B, H, W, 1)))).astype(F)
