@@ -187,7 +187,14 @@ __device__ __forceinline__ void h2f_tail(const ConvParams& p, f32x16 (&acc)[2][T
     ODT_BARRIER_LDS();
   }
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.f_wt, 0, (int)((unsigned)nch * (unsigned)WCH), 0x00020000);
-  auto dma_w = [&](int c, int buf) {          // (a chunk past the image: out-of-range offsets, zeros -- every issue count below is static)
+  // chunk rotation: the workgroups of a launch reach this phase together and walk the output columns at the same pace --
+  // without it every residual fetch and store in flight on the chip addresses the SAME 128-byte column of the pixels' rows,
+  // i.e. the same few HBM channels (the 1x1 kernels' K-slice rotation, conv_h2.hip, for the same reason).  Workgroup mt
+  // starts at column chunk mt mod nch and wraps; `c` below counts the steps, ce(c) is the chunk they work on.
+  const int rot = (p.debug & 0x100) == 0 ? (m0 / G::BM) % nch : 0;
+  auto ce = [&](int c) { return c < nch ? (c + rot >= nch ? c + rot - nch : c + rot) : c; };
+  auto dma_w = [&](int cs, int buf) {
+    const int c = ce(cs);          // (a chunk past the image: out-of-range offsets, zeros -- every issue count below is static)
 #pragma unroll
     for (int i = 0; i < WCH / 8192; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, ODT_LDS_PTR(lds + buf * WCH + (i * 8 + wave) * 1024), 16,
@@ -209,7 +216,8 @@ __device__ __forceinline__ void h2f_tail(const ConvParams& p, f32x16 (&acc)[2][T
   const bool has_res = p.f_res != nullptr;
   const float act_lo = p.f_relu == 1 ? 0.f : -__builtin_huge_valf();
   const float* k3 = reinterpret_cast<const float*>(lds + G::F_K3OFF);      // [0] 2^-t_n, [1] bias_n of the 1x1 conv (prologue)
-  auto fetch_res = [&](int c, int s2) -> f32x4 {
+  auto fetch_res = [&](int cs, int s2) -> f32x4 {
+    const int c = ce(cs);
     // (read once, by this workgroup only: non-temporal, like the unfused epilogue's residual chunks; past the last chunk or
     // without a residual: out of range, zeros)
     const unsigned off = has_res && c < nch && m_first + 64u * s2 < mrows ? roff0 + s2 * rstep : kOOB;
@@ -228,8 +236,9 @@ __device__ __forceinline__ void h2f_tail(const ConvParams& p, f32x16 (&acc)[2][T
   const int cr_at = row0 * CS + c4 * 4;
   float vmax = 0.f;
   // one row-phase item: rows row0 + 64 s2 of chunk c's result tile -> global; the residual register is refilled for chunk c + 2
-  auto row_item = [&](int c, int s2, f32x4& rr) {
-    const float* Cb = Cst + (c & 1) * (CBUF / 4);
+  auto row_item = [&](int cs, int s2, f32x4& rr) {
+    const int c = ce(cs);
+    const float* Cb = Cst + (cs & 1) * (CBUF / 4);
     f32x4 v = *reinterpret_cast<const f32x4*>(Cb + cr_at + 64 * s2 * CS);
     const f32x4 sc3 = *reinterpret_cast<const f32x4*>(k3 + c * 32 + c4 * 4), b3 = *reinterpret_cast<const f32x4*>(k3 + 1024 + c * 32 + c4 * 4);
     v = v * sc3;
@@ -241,7 +250,7 @@ __device__ __forceinline__ void h2f_tail(const ConvParams& p, f32x16 (&acc)[2][T
     const bool ok = m_first + 64u * s2 < mrows;
     vmax = fmaxf(vmax, ok ? vm : 0.f);
     __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)(ok ? ooff0 + s2 * ostep : kOOB), c * 128, 0);
-    rr = fetch_res(c + 2, s2);
+    rr = fetch_res(cs + 2, s2);
   };
   ODT_WAIT_VM_LGKM0(8);                     // (own pieces of chunks 0 / 1 have landed; the residual fetches may fly)
   __builtin_amdgcn_s_barrier();

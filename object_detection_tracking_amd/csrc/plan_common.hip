@@ -379,6 +379,10 @@ int fuse_bottleneck_tails(odt_model* m) {
     ap.f_res = b.p.res_mode != 0 ? b.p.res : nullptr; ap.f_res_ldc = b.p.res_ldc;
     ap.f_out = b.p.out; ap.f_out_ldc = b.p.out_ldc; ap.f_cout = b.p.Cout; ap.f_relu = b.p.relu; ap.f_out_amax = b.p.out_amax;
     ap.debug |= b.p.debug & 0x400;           // the residual's non-temporal hint travels with it
+    {
+      const char* r = getenv("ODT_FUSE_ROT");           // A/B: 0 = every workgroup walks the output column chunks in the same order
+      if (r != nullptr && r[0] == '0') ap.debug |= 0x100;
+    }
     ap.out = nullptr; ap.out_amax = nullptr;
     ob.skip = true;
     m->conv_fused[ob.conv] = 2;
