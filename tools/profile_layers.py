@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Per-layer HIP-event timing of the conv launches of one forward (GPU only).
   python tools/profile_layers.py [--batch 8] [--steps 3] [--tile N]
-Groups identical GEMM shapes and prints TFLOP/s vs the 157.3 TF f32-MFMA peak."""
+Groups identical GEMM shapes and prints TFLOP/s and its fraction of the running kernel's own matrix-pipe ceiling
+(2500 / 3 TF of f32 work on the fp16x2 kernels, 2500 / 6 on the bf16x3 ones, 157.3 on the exact-f32 kernel)."""
 import argparse, os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -34,12 +35,17 @@ def main():
   for name, fl, ms, mnk in rows:
     kind = name.split("/")[-1].split("@")[0] if not name.startswith("fpn") and not name.startswith("rpn") and not name.startswith("fastrcnn") else name
     key = (mnk, kind if mnk[2] in (147, 224) else "")
-    g = groups.setdefault(mnk, [0, 0.0, 0.0, name])
+    if "[fused into" in name:
+      continue                       # no launch of its own: counted with the kernel that evaluates it
+    g = groups.setdefault((mnk, "+conv3" in name, "+head" in name), [0, 0.0, 0.0, name])
     g[0] += 1; g[1] += fl; g[2] += ms / a.steps
   print("%-44s %5s %9s %7s %7s %9s %8s %7s" % ("first layer of shape", "n", "M", "N", "K", "ms/step", "TFLOP/s", "frac"))
-  for mnk, (n, fl, ms, name) in sorted(groups.items(), key=lambda kv: -kv[1][2]):
+  for (mnk, _, _), (n, fl, ms, name) in sorted(groups.items(), key=lambda kv: -kv[1][2]):
     tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0
-    print("%-44s %5d %9d %7d %7d %9.3f %8.1f %7.3f" % (name[:44], n, mnk[0], mnk[1], mnk[2], ms, tf, tf / 157.3))
+    # frac: against the ceiling of the kernel that runs the layer -- dense 16-bit MFMA peak / 3 products (fp16x2), / 6 (bf16x3),
+    # the f32 MFMA peak (exact-f32 kernel)
+    ceil = 2500.0 / 3 if name.endswith("[fp16x2]") else (2500.0 / 6 if name.endswith("[bf16x3]") else 157.3)
+    print("%-44s %5d %9d %7d %7d %9.3f %8.1f %7.3f" % (name[:44], n, mnk[0], mnk[1], mnk[2], ms, tf, tf / ceil))
   cms = tot["conv_ms"] / a.steps
   print("conv total %.2f ms/step, %.1f TFLOP/s (%.3f of peak); step %.2f ms" %
         (cms, tot["conv_flops"] / a.steps / (cms * 1e-3) / 1e12, tot["conv_flops"] / a.steps / (cms * 1e-3) / 1e12 / 157.3, tot["total_ms"] / a.steps))
@@ -65,7 +71,9 @@ def effdet(a):
   tot = E.profile_read(e)
   groups = collections.OrderedDict()
   for name, fl, ms, mnk in rows:
-    g = groups.setdefault(mnk, [0, 0.0, 0.0, name])
+    if "[fused into" in name:
+      continue                       # no launch of its own: counted with the kernel that evaluates it
+    g = groups.setdefault((mnk, "+conv3" in name, "+head" in name), [0, 0.0, 0.0, name])
     g[0] += 1; g[1] += fl; g[2] += ms / a.steps
   print("%-60s %5s %9s %7s %7s %9s %8s %9s" % ("first layer of shape", "n", "M", "N", "K", "ms/step", "TFLOP/s", "us/launch"))
   srt = sorted(groups.items(), key=lambda kv: -kv[1][2])

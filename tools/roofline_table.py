@@ -24,6 +24,8 @@ def main(path):
   for name, n, M, N, K, ms, tf in sorted(rows, key=lambda r: -r[5]):
     split, h2 = name.endswith("[bf16x3]"), name.endswith("[fp16x2]")
     base = name.replace("[bf16x3]", "").replace("[fp16x2]", "")
+    fused3 = base.endswith("+conv3")            # conv2 with the block's conv3 (1x1 to 4 N channels + shortcut) evaluated in its kernel
+    base = base.replace("+conv3", "").replace("+head", "")
     k3 = base.endswith("conv2") or "posthoc_3x3" in base or base.startswith("rpn/conv0")
     cin_bytes = M * (K // 9 if k3 else K) * 4.0            # every input pixel once (stride-1 3x3: K/9 channels)
     if base == "conv0":
@@ -31,7 +33,12 @@ def main(path):
     byt = cin_bytes + M * N * 4.0 + N * K * 4.0
     if "conv3" in base or "lateral" in base:
       byt += M * N * 4.0 * (0.25 if "lateral" in base else 1.0)   # residual (2x-upsampled: a quarter)
-    t_m = n * 2.0 * M * N * K / (H2_PEAK if h2 else (SPLIT_PEAK if split else F32_PEAK)) * 1e3
+    flops = 2.0 * M * N * K
+    if fused3:
+      # the [M, N] tensor between the two convs is neither written nor read; the 1x1 conv's output and residual (4 N wide) are
+      byt = cin_bytes + N * K * 4.0 + 4 * N * N * 4.0 + 2 * M * 4 * N * 4.0
+      flops += 2.0 * M * N * 4 * N
+    t_m = n * flops / (H2_PEAK if h2 else (SPLIT_PEAK if split else F32_PEAK)) * 1e3
     t_h = n * byt / HBM * 1e3
     bound = max(t_m, t_h)
     tot[0] += ms; tot[1] += bound
