@@ -35,7 +35,7 @@ struct H2Cfg {
   static constexpr int BKG = BN * 16, BPL = 4 * BKG, STAGE_B = 2 * BPL;     // B stage: the linear image the DMA writes
   static constexpr int BOFF = 2 * ASTG;
   static constexpr int RING = BOFF + 2 * STAGE_B;
-  static constexpr int CTILE = 128 * (BN + 4) * 4;                          // two 128-row epilogue passes
+  static constexpr int CTILE = (BM < 128 ? BM : 128) * (BN + 4) * 4;        // 128-row epilogue passes
   static constexpr int LDS = RING > CTILE ? RING : CTILE;
   static constexpr int NW = STAGE_B / 1024 / NWV;                           // DMA instructions per wave and stage
   static constexpr int RA = BM * 8 / NTHR;                                  // A rows (16-byte loads) per thread and stage: BM / (NTHR / 8)
@@ -473,7 +473,7 @@ int launch_conv_h2(const ConvParams& p, const ConvParams* dev, hipStream_t strea
   const int bn = p.wt_split_bn;
   const int bm = p.wt_split_bm;
   ODT_CHECK(((bm == 256 && (bn >= 128 || p.wt_split_kwr)) || (bm == 128 && bn <= 128 && !p.wt_split_kwr) ||
-             (bm == 512 && bn == 64 && (!p.wt_split_kwr || p.Ho * p.Wo >= 512))) && (bn == 256 || bn == 128 || bn == 64) && p.Cin % 32 == 0 && p.kh * p.kw <= 32 && p.in_amax != nullptr &&
+             (bm == 512 && bn == 64 && (!p.wt_split_kwr || p.Ho * p.Wo >= 512)) || (bm == 64 && bn == 128 && !p.wt_split_kwr)) && (bn == 256 || bn == 128 || bn == 64) && p.Cin % 32 == 0 && p.kh * p.kw <= 32 && p.in_amax != nullptr &&
             p.h2_chinv != nullptr && (p.in2 == nullptr || (p.in2_amax != nullptr && p.Cin2 % 32 == 0)) && p.nlvl <= 1,
             "conv h2: unsupported tile / shape, or no recorded input range");
   const int sk = p.splitk > 1 ? p.splitk : 1;
@@ -490,6 +490,8 @@ int launch_conv_h2(const ConvParams& p, const ConvParams* dev, hipStream_t strea
     launch_conv_h2k(p, dev, grid, stream);
   } else if (p.f_wt != nullptr) {
     ODT_CHECK(false, "conv h2: a fused 1x1 tail needs the kw-reuse kernel");
+  } else if (bm == 64) {                     // few-row layers (b = 1 below res3): 64 x 128 tiles on two waves, three workgroups per CU, no split-K
+    hipLaunchKernelGGL((conv_h2_kernel<2, 1, false>), dim3(grid), dim3(128), 0, stream, dev);
   } else if (bn == 64 && bm == 512) {
     hipLaunchKernelGGL((conv_h2_kernel<2, 8, false, 1>), dim3(grid), dim3(512), 0, stream, dev);
   } else if (bn == 64) {

@@ -97,6 +97,10 @@ ConvPolicy conv_policy_default() {
   q.h2s_maxk = 0;         // fp16x2: reductions up to this K take the 128 x 128 two-per-CU tile (A/B knob; measured: no gain)
   q.h2_few_tiles = true;  // fp16x2: layers without enough 256-row tiles take 128 x 128 tiles instead of bf16x3 + split-K
   q.h2_n64 = true;        // fp16x2: the 64-wide layers too
+  q.fill_div = 6;         // split-K layers are taken when tiles x ranges reach min_tiles3 / fill_div workgroups (b = 1: fc6 / fc7 leave the
+                          // exact-f32 kernel: 139.4 -> 144.9 FPS same box, profiles/r04_b1_filldiv_ab.txt; ODT_CONV_SPLIT3_FILLDIV: A/B)
+  q.h2_bm64 = 1;          // fp16x2: 64 x 128 two-wave tiles instead of 128 x 128 + split-K where only those fill the chip: 0 off | 1 for
+                          // reductions up to K = 1024 (no split-K at all) | 2 also the longer ones, cut in two (ODT_CONV_H2_BM64: A/B)
   q.h2_n64_bm512 = 1;     // fp16x2 kw-reuse kernel on 64-wide layers: 512 x 64 tiles (eight waves stacked along M: 24 MFMAs per wave and
                           // stage instead of 12) where they fill the chip (res2 conv2 1.035 -> 0.897 ms, same box); 0 off, 2 wherever
                           // the shape allows, the generic kernel included (tests)
@@ -120,6 +124,8 @@ ConvPolicy conv_policy_from_env(ConvPolicy q) {
   v = q.h2_few_tiles; geti("ODT_CONV_H2_FEW_TILES", &v); q.h2_few_tiles = v != 0;
   v = q.h2_n64; geti("ODT_CONV_H2_N64", &v); q.h2_n64 = v != 0;
   v = q.h2_n64_bm512; geti("ODT_CONV_H2_N64_BM512", &v); q.h2_n64_bm512 = (int)v;
+  v = q.h2_bm64; geti("ODT_CONV_H2_BM64", &v); q.h2_bm64 = (int)v;
+  v = q.fill_div; geti("ODT_CONV_SPLIT3_FILLDIV", &v); q.fill_div = v < 1 ? 1 : (int)v;
   v = q.force_bm3; geti("ODT_CONV_SPLIT3_BM", &v); q.force_bm3 = (int)v;
   v = q.splitk_max; geti("ODT_CONV_SPLIT3_SPLITK", &v); q.splitk_max = v < 1 ? 1 : (v > 16 ? 16 : (int)v);
   v = 1; geti("ODT_CONV_SPLIT3_KWR", &v); q.kw_reuse = v != 0;
@@ -160,7 +166,7 @@ static bool split3_fit(const ConvParams& p, const ConvPolicy& q, int* bm, int* b
     int k = (int)((q.min_tiles3 + t128 - 1) / t128);
     if (k > q.splitk_max) k = q.splitk_max;
     while (k > 1 && nsteps / k < 8) --k;            // at least eight stages per range
-    if (k > 1 && t128 * k >= q.min_tiles3 / 2) { *bm = 128; *sk = k; return true; }
+    if (k > 1 && t128 * k >= q.min_tiles3 / q.fill_div) { *bm = 128; *sk = k; return true; }
   }
   return false;
 }
@@ -218,6 +224,15 @@ void conv_split_choose(ConvParams& p, const ConvPolicy& q) {
         // (two of these workgroups share a CU: the chip has twice min_tiles3 slots for them -- res4 at b=1 ran its 128 tiles
         // x 2 ranges one 4-wave workgroup per CU, a single wave per SIMD)
         int k = 1;
+        // 64 x 128 tiles (two waves, three workgroups per CU) fill the chip without cutting the reduction: no partial slabs,
+        // no combine pass (b = 1: res4 has 128 x 2 ... 8 such tiles)
+        const long t64 = ((M + 63) / 64) * (cout_padded(p.Cout) / 128);
+        // (same-box A/B at b = 1, profiles/r04_b1_bm64_ab.txt: res4 conv1, K = 1024: 62.8 -> 44.4 us per layer; the K = 2304
+        // 3x3 layers lose without split-K -- 72 serial stages: 81.7 -> 105.8 us -- and take the tiles with the reduction cut in two)
+        if (q.h2_bm64 > 0 && t128 < q.min_tiles3 && t64 >= q.min_tiles3 && q.force_splitk <= 1 && (K <= 1024 || (q.h2_bm64 > 1 && p.in2 == nullptr))) {
+          p.wt_split_kind = 2; p.wt_split_bm = 64; p.wt_split_bn = 128; p.splitk = K <= 1024 ? 1 : 2; p.wt_split_kwr = 0;
+          return;
+        }
         if (t128 < q.min_tiles3 && q.splitk_max > 1 && p.in2 == nullptr) {
           k = (int)((2 * q.min_tiles3 + t128 - 1) / t128);
           if (k > q.splitk_max) k = q.splitk_max;

@@ -844,3 +844,31 @@ def test_conv2d_fp16x2_512x64_tile_generic_kernel(backend, case, monkeypatch):
     assert np.array_equal(out["0"], out["2"])
   else:
     np.testing.assert_allclose(out["0"], out["2"], rtol=0, atol=2e-6 * float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("case", [
+    (1, 10, 15, 512, 256, 1, 1, 1, 0, 0, 10, 15, True),      # dense 1x1, M = 150: 3 x 2 tiles of 64 x 128 (res4 conv1 at b = 1)
+    (1, 10, 15, 64, 256, 3, 1, 1, 1, 1, 10, 15, True),       # 3x3 taps on the generic kernel
+    (1, 20, 15, 64, 128, 1, 2, 1, 0, 0, 10, 8, False),       # strided, one n-tile, a partial last tile (M = 80)
+])
+def test_conv2d_fp16x2_64x128_tile_without_splitk(backend, case, monkeypatch):
+  """conv_h2_kernel<2, 1>: layers whose 128 x 128 tiles cannot fill the chip but whose 64 x 128 ones can (b = 1 below res3)
+  run on two-wave 64 x 128 tiles WITHOUT split-K (no partial slabs, no combine pass); the residual path too."""
+  name, lib = backend
+  _split_env(monkeypatch, "2")
+  monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "3")     # (test sizes: t128 = 2 .. 2 < 3 <= t64)
+  B, H, W, Cin, Cout, k, stride, dil, pt, pl, Ho, Wo, relu = case
+  rng = np.random.default_rng(66)
+  x = rng.standard_normal((B, H, W, Cin)).astype(F)
+  w = (rng.standard_normal((k, k, Cin, Cout)) * 0.05).astype(F)
+  b = rng.standard_normal(Cout).astype(F)
+  res = rng.standard_normal((B, Ho, Wo, Cout)).astype(F)
+  ref = torch_conv_nhwc(x, w, b, stride, dil, pt, pl, Ho, Wo) + res
+  if relu:
+    ref = np.maximum(ref, 0)
+  out = {}
+  for mode in ("0", "1"):
+    monkeypatch.setenv("ODT_CONV_H2_BM64", mode)
+    out[mode] = ops.conv2d(x, w, b, stride, dil, pt, pl, (Ho, Wo), res=res, res_mode=1, relu=relu, lib=lib)
+    np.testing.assert_allclose(out[mode], ref, rtol=1e-4, atol=2e-4)
+  np.testing.assert_allclose(out["0"], out["1"], rtol=0, atol=3e-6 * float(np.abs(ref).max()))
