@@ -481,7 +481,8 @@ int launch_conv_h2(const ConvParams& p, const ConvParams* dev, hipStream_t strea
             "conv h2: split-K needs a partial buffer, a single source and at least one stage per range");
   const unsigned grid = (unsigned)(((M + bm - 1) / bm) * (cout_padded(p.Cout) / bn) * sk);
   if (p.wt_split_kwr) {
-    ODT_CHECK(sk == 1 && p.kw == 3 && p.stride == 1 && p.in_Wa == p.Wo && p.in2 == nullptr && 2 * p.dil <= 4, "conv h2k: unsupported shape");
+    ODT_CHECK(p.kw == 3 && p.stride == 1 && p.in_Wa == p.Wo && p.in2 == nullptr && 2 * p.dil <= 4 &&
+              (sk == 1 || (bm == 256 && bn >= 128 && p.f_wt == nullptr && p.kh * (p.Cin >> 5) >= sk)), "conv h2k: unsupported shape");
     ODT_CHECK(p.f_wt == nullptr || (bm == 256 && bn == p.Cout && (bn == 256 || bn == 128) && p.head_wt == nullptr && p.res_mode == 0 && p.relu <= 1 && p.f_cout % 32 == 0 &&
                                     p.f_cout > 0 && p.f_cout <= 1024 && p.f_out != nullptr && p.f_chinv != nullptr && p.f_bias != nullptr && p.f_out_ldc % 4 == 0 &&
                                     (p.f_res == nullptr || p.f_res_ldc % 4 == 0) && (double)M * p.f_out_ldc * 4.0 < 2147483648.0 &&

@@ -350,12 +350,19 @@ __global__ void __launch_bounds__(512, 2) conv_h2k_kernel(const ConvParams* __re
     const int nwg = (int)gridDim.x, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
   }
+  // split-K (layers of few rows: res3 / res4 conv2 at b = 1): consecutive workgroups are the ranges of one tile's (slice, kh)
+  // groups; each writes its raw partial tile, split_reduce_kernel adds them in range order
+  const int splitk = p.splitk > 1 ? p.splitk : 1;
+  const int ks = wg % splitk;
+  wg /= splitk;
   const int mt = wg / ntn, nt = wg - mt * ntn;
   const int m0 = mt * BM, n0 = nt * BN;
   const int HoWo = p.Ho * p.Wo;
   const int M = p.B * HoWo;
   const int cpt = p.Cin >> 5;
-  const int nsteps = p.kh * KW * cpt, ngroups = p.kh * cpt;
+  const int nsteps = p.kh * KW * cpt, ngroups_all = p.kh * cpt;
+  const int g_begin = (int)(((long)ngroups_all * ks) / splitk);
+  const int ngroups = (int)(((long)ngroups_all * (ks + 1)) / splitk) - g_begin;
   const int halo = (KW - 1) * p.dil;
   const int sexp = h2_in_scale_exp(p);
   const float a_scale = pow2f(sexp), h2_inv = pow2f(-sexp);
@@ -365,7 +372,7 @@ __global__ void __launch_bounds__(512, 2) conv_h2k_kernel(const ConvParams* __re
   const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.wt_split, 0, (int)((unsigned)ntn * nsteps * (unsigned)STAGE_B), 0x00020000);
 
-  unsigned l_b = (unsigned)nt * (unsigned)nsteps * (unsigned)STAGE_B;
+  unsigned l_b = ((unsigned)nt * (unsigned)nsteps + (unsigned)(g_begin * KW)) * (unsigned)STAGE_B;
   auto dma_b = [&](int boff) {
 #pragma unroll
     for (int i = 0; i < NW; ++i)
@@ -390,7 +397,7 @@ __global__ void __launch_bounds__(512, 2) conv_h2k_kernel(const ConvParams* __re
     const int pix = pr < len0 + halo ? pix0 + pr : pix1 + (pr - len0 - halo);
     a_base[j] = pr < BM + 2 * halo ? pix * pix_bytes + a_c * 16 : (int)kOOB;
   }
-  int l_cs = 0, l_kh = 0;                    // next group to fetch
+  int l_cs = g_begin / p.kh, l_kh = g_begin - (g_begin / p.kh) * p.kh;      // next group to fetch (groups: kh innermost)
   f32x4 ga[RA];
   auto load_group = [&]() {
     const int khoff = l_kh * p.dil * p.in_Wa * pix_bytes;
@@ -478,7 +485,7 @@ __global__ void __launch_bounds__(512, 2) conv_h2k_kernel(const ConvParams* __re
 
   f16x8 fa[2][2][2], fb[2][2];
   int fa_addr[2];                            // this stage's fragment addresses (A buffer + row + tap, or the zero row)
-  int c_kh = 0;                              // kh of the group being computed
+  int c_kh = g_begin - (g_begin / p.kh) * p.kh;      // kh of the group being computed
   auto tap_addr = [&](int abuf, int khh, int kww) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -504,7 +511,7 @@ __global__ void __launch_bounds__(512, 2) conv_h2k_kernel(const ConvParams* __re
   };
   int a_cur = 0, a_nxt = ABUF;
   int b_cur = BOFF, b_nxt = BOFF + STAGE_B;
-  tap_addr(a_cur, 0, 0);
+  tap_addr(a_cur, c_kh, 0);
   rdA(0, 1); rdA(0, 0);
   rdB(b_cur, 0, 0, 0);
 
@@ -582,7 +589,7 @@ __global__ void __launch_bounds__(512, 2) conv_h2k_kernel(const ConvParams* __re
 #undef ODT_MF
   stamp(2);
   if constexpr (FUSE) h2f_tail<TN, TRACE>(p, acc, lds, m0, M, wave, wm, wn, h2_inv);
-  else split3_epilogue<WM, WN, TN, G::LDS, TRACE>(p, acc, lds, m0, n0, M, HoWo, 0, 1, tid, wm, wn, fr, fg, h2_inv);
+  else split3_epilogue<WM, WN, TN, G::LDS, TRACE>(p, acc, lds, m0, n0, M, HoWo, ks, splitk, tid, wm, wn, fr, fg, h2_inv);
   stamp(5);
 }
 #undef ODT_FENCE

@@ -97,6 +97,7 @@ ConvPolicy conv_policy_default() {
   q.h2s_maxk = 0;         // fp16x2: reductions up to this K take the 128 x 128 two-per-CU tile (A/B knob; measured: no gain)
   q.h2_few_tiles = true;  // fp16x2: layers without enough 256-row tiles take 128 x 128 tiles instead of bf16x3 + split-K
   q.h2_n64 = true;        // fp16x2: the 64-wide layers too
+  q.h2k_splitk = true;    // fp16x2 kw-reuse kernel with split-K for the stride-1 KH x 3 layers of few rows (ODT_CONV_H2K_SPLITK=0: A/B)
   q.fill_div = 6;         // split-K layers are taken when tiles x ranges reach min_tiles3 / fill_div workgroups (b = 1: fc6 / fc7 leave the
                           // exact-f32 kernel: 139.4 -> 144.9 FPS same box, profiles/r04_b1_filldiv_ab.txt; ODT_CONV_SPLIT3_FILLDIV: A/B)
   q.h2_bm64 = 1;          // fp16x2: 64 x 128 two-wave tiles instead of 128 x 128 + split-K where only those fill the chip: 0 off | 1 for
@@ -125,6 +126,7 @@ ConvPolicy conv_policy_from_env(ConvPolicy q) {
   v = q.h2_n64; geti("ODT_CONV_H2_N64", &v); q.h2_n64 = v != 0;
   v = q.h2_n64_bm512; geti("ODT_CONV_H2_N64_BM512", &v); q.h2_n64_bm512 = (int)v;
   v = q.h2_bm64; geti("ODT_CONV_H2_BM64", &v); q.h2_bm64 = (int)v;
+  v = q.h2k_splitk; geti("ODT_CONV_H2K_SPLITK", &v); q.h2k_splitk = v != 0;
   v = q.fill_div; geti("ODT_CONV_SPLIT3_FILLDIV", &v); q.fill_div = v < 1 ? 1 : (int)v;
   v = q.force_bm3; geti("ODT_CONV_SPLIT3_BM", &v); q.force_bm3 = (int)v;
   v = q.splitk_max; geti("ODT_CONV_SPLIT3_SPLITK", &v); q.splitk_max = v < 1 ? 1 : (v > 16 ? 16 : (int)v);
@@ -217,6 +219,22 @@ void conv_split_choose(ConvParams& p, const ConvPolicy& q) {
         // (A/B knob, off: short reductions on 128 x 128 tiles, two workgroups per CU in different phases -- measured no gain:
         // res4 conv3 4.28 -> 4.38 ms, res2 / res3 conv3 and the laterals 3-12 % slower, profiles/r03_h2_small_tile_ab.txt)
         if (!p.wt_split_kwr && k3 == 1 && K <= q.h2s_maxk && t128 >= q.min_tiles3) { p.wt_split_bm = 128; p.wt_split_bn = 128; }
+      } else if (b3 == 128 && n3 >= 256 && q.h2k_splitk && q.kw_reuse && p.kw == 3 && p.stride == 1 && p.in_Wa == p.Wo && p.in2 == nullptr &&
+                 2 * p.dil <= 4 && p.Ho * p.Wo >= 256 && p.kh * 3 <= 30 && q.splitk_max > 1 && q.force_splitk <= 1 &&
+                 [&]() {
+                   // stride-1 KH x 3 layers of few rows (res3 / res4 conv2 at b = 1, the P5 3x3s at b = 8): the kw-reuse kernel on
+                   // 256 x 128 tiles with the (slice, kh) groups cut into ranges -- a third of the activation-side work of the
+                   // generic kernel's 128 x 128 split-K tiles (same-box A/B at b = 1, profiles/r04_b1_h2k_splitk_ab.txt: res4 conv2
+                   // 83 -> 78 us per layer; the 128-wide res3 conv2 lost, 65 -> 74 us, and keeps the generic kernel)
+                   const long t256 = ((M + 255) / 256) * (cout_padded(p.Cout) / 128);
+                   const int groups = p.kh * (p.Cin >> 5);
+                   int k = (int)((q.min_tiles3 + t256 - 1) / t256);
+                   if (k > q.splitk_max) k = q.splitk_max;
+                   while (k > 1 && groups / k < 3) --k;
+                   if (k <= 1 || t256 * k < q.min_tiles3 / 2) return false;
+                   p.wt_split_kind = 2; p.wt_split_bm = 256; p.wt_split_bn = 128; p.wt_split_kwr = 1; p.splitk = k;
+                   return true;
+                 }()) {
       } else if (b3 == 128 && n3 >= 128 && q.h2_few_tiles) {
         // too few 256-row tiles (res5, P5 at b=8; everything below res3 at b=1): 128 x 128 tiles on 4 waves -- without split-K
         // where they fill the chip (res5 conv2 0.690 -> 0.465 ms, conv1 0.338 -> 0.219, same file), else with the reduction

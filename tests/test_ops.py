@@ -872,3 +872,30 @@ def test_conv2d_fp16x2_64x128_tile_without_splitk(backend, case, monkeypatch):
     out[mode] = ops.conv2d(x, w, b, stride, dil, pt, pl, (Ho, Wo), res=res, res_mode=1, relu=relu, lib=lib)
     np.testing.assert_allclose(out[mode], ref, rtol=1e-4, atol=2e-4)
   np.testing.assert_allclose(out["0"], out["1"], rtol=0, atol=3e-6 * float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("case", [
+    (1, 20, 26, 64, 256, 3, 1, 1, 1, 1, 20, 26, True),       # M = 520: 3 x 2 tiles of 256 x 128, six (slice, kh) groups cut in two
+    (2, 17, 16, 96, 128, 3, 1, 2, 2, 2, 17, 16, False),      # dilation 2, a tile across the image boundary, nine groups cut in three
+])
+def test_conv2d_fp16x2_kw_reuse_kernel_with_splitk(backend, case, monkeypatch):
+  """conv_h2k_kernel with split-K: the stride-1 KH x 3 layers of few rows (res3 / res4 conv2 at b = 1) on 256 x 128 tiles of
+  the kw-reuse kernel, the (32-channel slice, kh) groups cut into ranges, raw partial tiles combined in range order by
+  split_reduce_kernel (which applies the scales, bias, activation and records the output's range)."""
+  name, lib = backend
+  _split_env(monkeypatch, "2")
+  B, H, W, Cin, Cout, k, stride, dil, pt, pl, Ho, Wo, relu = case
+  monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "8" if Cout == 256 else "6")
+  rng = np.random.default_rng(67)
+  x = rng.standard_normal((B, H, W, Cin)).astype(F)
+  w = (rng.standard_normal((k, k, Cin, Cout)) * 0.05).astype(F)
+  b = rng.standard_normal(Cout).astype(F)
+  ref = torch_conv_nhwc(x, w, b, stride, dil, pt, pl, Ho, Wo)
+  if relu:
+    ref = np.maximum(ref, 0)
+  out = {}
+  for mode in ("0", "1"):
+    monkeypatch.setenv("ODT_CONV_H2K_SPLITK", mode)
+    out[mode] = ops.conv2d(x, w, b, stride, dil, pt, pl, (Ho, Wo), relu=relu, lib=lib)
+    np.testing.assert_allclose(out[mode], ref, rtol=1e-4, atol=2e-4)
+  np.testing.assert_allclose(out["0"], out["1"], rtol=0, atol=3e-6 * float(np.abs(ref).max()))
