@@ -876,7 +876,7 @@ def test_conv2d_fp16x2_64x128_tile_without_splitk(backend, case, monkeypatch):
 
 @pytest.mark.parametrize("case", [
     (1, 20, 26, 64, 256, 3, 1, 1, 1, 1, 20, 26, True),       # M = 520: 3 x 2 tiles of 256 x 128, six (slice, kh) groups cut in two
-    (2, 17, 16, 96, 128, 3, 1, 2, 2, 2, 17, 16, False),      # dilation 2, a tile across the image boundary, nine groups cut in three
+    (2, 17, 16, 96, 256, 3, 1, 2, 2, 2, 17, 16, False),      # dilation 2, a tile across the image boundary, nine groups cut in two
 ])
 def test_conv2d_fp16x2_kw_reuse_kernel_with_splitk(backend, case, monkeypatch):
   """conv_h2k_kernel with split-K: the stride-1 KH x 3 layers of few rows (res3 / res4 conv2 at b = 1) on 256 x 128 tiles of
@@ -885,7 +885,7 @@ def test_conv2d_fp16x2_kw_reuse_kernel_with_splitk(backend, case, monkeypatch):
   name, lib = backend
   _split_env(monkeypatch, "2")
   B, H, W, Cin, Cout, k, stride, dil, pt, pl, Ho, Wo, relu = case
-  monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "8" if Cout == 256 else "6")
+  monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "8")
   rng = np.random.default_rng(67)
   x = rng.standard_normal((B, H, W, Cin)).astype(F)
   w = (rng.standard_normal((k, k, Cin, Cout)) * 0.05).astype(F)
