@@ -604,9 +604,7 @@ __global__ void __launch_bounds__(256) split_reduce_kernel(const ConvParams* __r
     const int m = (int)(idx / C4), col = (int)(idx - (long)m * C4) * 4;
     f32x4 v = *reinterpret_cast<const f32x4*>(p.partial + (size_t)m * Np + col);
     for (int k = 1; k < p.splitk; ++k) v += *reinterpret_cast<const f32x4*>(p.partial + (size_t)k * slab + (size_t)m * Np + col);
-    if (p.h2_chinv != nullptr) {
-      for (int e = 0; e < 4; ++e) v[e] *= p.h2_chinv[col + e] * inv;
-    }
+    if (p.h2_chinv != nullptr) v = v * (*reinterpret_cast<const f32x4*>(p.h2_chinv + col) * inv);     // ([cout_padded]: whole chunks)
     for (int e = 0; e < 4; ++e) v[e] += col + e < p.Cout ? p.bias[col + e] : 0.f;
     const int n = sfast_div(m, p.div_howo_mul, p.div_howo_sh), rr = m - n * HoWo;
     const int ho = sfast_div(rr, p.div_wo_mul, p.div_wo_sh), wo = rr - ho * p.Wo;
@@ -650,7 +648,11 @@ static void launch_split3(const ConvParams& p, const ConvParams* dev, unsigned g
 void launch_split_reduce(const ConvParams& p, const ConvParams* dev, hipStream_t stream) {
   const long chunks = (long)p.B * p.Ho * p.Wo * (cout_padded(p.Cout) / 4);
   const long blocks = (chunks + 255) / 256;
-  hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream, dev);
+  // at most two blocks per CU (grid-stride; same-box A/B at b = 1: 2048 blocks 150.4, 512 167.5, 256 166.8, 128 159.6 FPS): every block ends with a conditional atomicMax on the ONE range slot of the output,
+  // and the blocks of a short pass all find the slot empty -- 2040 same-address atomics serialised in L2 made this pass 35 us
+  // per call at b = 1 (1.2 ms of the 6.8 ms frame, profiles/r04_kernel_stats_bench_b1_single_before.txt)
+  static const long cap = []() { const char* e = getenv("ODT_SPLIT_REDUCE_BLOCKS"); return e != nullptr && atol(e) > 0 ? atol(e) : 512L; }();
+  hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, stream, dev);
 }
 
 int launch_conv_split3(const ConvParams& p, const ConvParams* dev, hipStream_t stream) {
