@@ -79,6 +79,17 @@ def test_collect_defaults_follow_the_ticket_and_read_outputs(backend):
     np.copyto(buf, fr)
     r = e.collect(e.submit(None, want_feats=False, want_pooled=True))
     assert np.array_equal(r[0], want[0]) and np.array_equal(r[5], want[5])
+    # submit(None) without a buffer handed out for THIS ticket (the slot's pinned memory holds stale frames), or after
+    # asking for the other dtype, is refused instead of silently inferring on whatever the buffer holds
+    with pytest.raises(OdtError, match="odt_ingest_buffer"):
+      e.submit(None, want_feats=False, want_pooled=True)
+    e.ingest_buffer(np.float32)
+    e._ingest_dtype = ODT_DTYPE_U8
+    with pytest.raises(OdtError, match="odt_ingest_buffer"):
+      e.submit(None, want_feats=False, want_pooled=True)
+    np.copyto(e.ingest_buffer(np.uint8), fr)                                 # (re-armed: works again)
+    r = e.collect(e.submit(None, want_feats=False, want_pooled=True))
+    assert np.array_equal(r[0], want[0])
     # read_outputs after an asynchronous forward of another batch
     fr2 = synthetic_frames(B, H, W, seed=8)
     want2 = e.forward(fr2, want_feats=True, want_pooled=True)
