@@ -216,16 +216,13 @@ __device__ __forceinline__ void h2f_tail(const ConvParams& p, f32x16 (&acc)[2][T
   // (tuning ablations, results wrong: debug bit 0x10000 drops the residual fetches, 0x20000 the stores -- ODT_FUSE_DEBUG)
   const bool has_res = p.f_res != nullptr && (p.debug & 0x10000) == 0;
   const bool no_store = (p.debug & 0x20000) != 0;
-  const bool res_plain = (p.debug & 0x40000) != 0;
-  const bool out_nt = (p.debug & 0x80000) != 0;
   const float act_lo = p.f_relu == 1 ? 0.f : -__builtin_huge_valf();
   const float* k3 = reinterpret_cast<const float*>(lds + G::F_K3OFF);      // [0] 2^-t_n, [1] bias_n of the 1x1 conv (prologue)
   auto fetch_res = [&](int cs, int s2) -> f32x4 {
     const int c = ce(cs);
-    // (read once, by this workgroup only: non-temporal, like the unfused epilogue's residual chunks; past the last chunk or
-    // without a residual: out of range, zeros)
+    // (read once, by this workgroup only: non-temporal, like the unfused epilogue's residual chunks -- plain fetches, or
+    // non-temporal stores of the result, measured 0.3 - 0.7 % slower; past the last chunk or without a residual: out of range, zeros)
     const unsigned off = has_res && c < nch && m_first + 64u * s2 < mrows ? roff0 + s2 * rstep : kOOB;
-    if (res_plain) return (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)off, c * 128, 0);      // (A/B: ODT_FUSE_DEBUG=4)
     return (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)off, c * 128, 2);
   };
   // residual chunks in flight: ra = chunk c - 1 (consumed under chunk c's MFMAs, each register refilled with chunk c + 1's
@@ -254,8 +251,7 @@ __device__ __forceinline__ void h2f_tail(const ConvParams& p, f32x16 (&acc)[2][T
     const float vm = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
     const bool ok = m_first + 64u * s2 < mrows;
     vmax = fmaxf(vmax, ok ? vm : 0.f);
-    if (out_nt) __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)(ok && !no_store ? ooff0 + s2 * ostep : kOOB), c * 128, 2);      // (A/B: ODT_FUSE_DEBUG=8)
-    else __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)(ok && !no_store ? ooff0 + s2 * ostep : kOOB), c * 128, 0);
+    __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)(ok && !no_store ? ooff0 + s2 * ostep : kOOB), c * 128, 0);
     rr = fetch_res(cs + 2, s2);
   };
   ODT_WAIT_VM_LGKM0(8);                     // (own pieces of chunks 0 / 1 have landed; the residual fetches may fly)

@@ -383,7 +383,7 @@ int fuse_bottleneck_tails(odt_model* m) {
       const char* r = getenv("ODT_FUSE_ROT");           // A/B: 0 = every workgroup walks the output column chunks in the same order
       if (r != nullptr && r[0] == '0') ap.debug |= 0x100;
       const char* d = getenv("ODT_FUSE_DEBUG");         // tuning ablations of the fused tail (1: no residual fetches, 2: no stores; results wrong)
-      if (d != nullptr) ap.debug |= (atoi(d) & 15) << 16;     // (4: residual fetches without the non-temporal hint, 8: stores with it -- results unchanged)
+      if (d != nullptr) ap.debug |= (atoi(d) & 3) << 16;
     }
     ap.out = nullptr; ap.out_amax = nullptr;
     ob.skip = true;
