@@ -433,7 +433,7 @@ const float* conv_h2f_chinv(const void* img, int Cout, int K) {
   return reinterpret_cast<const float*>(reinterpret_cast<const char*>(img) + (size_t)Cout * K * 4);
 }
 int conv_make_h2f_weights(const float* wt, int Cout, int K, void* img_dev, hipStream_t stream) {
-  ODT_CHECK((K == 256 || K == 128) && Cout % 32 == 0 && Cout > 0, "conv_make_h2f_weights: K = 128 / 256 and Cout % 32 == 0 required");
+  ODT_CHECK((K == 256 || K == 128 || K == 64) && Cout % 32 == 0 && Cout > 0, "conv_make_h2f_weights: K = 64 / 128 / 256 and Cout % 32 == 0 required");
   float* chinv = const_cast<float*>(conv_h2f_chinv(img_dev, Cout, K));
   hipLaunchKernelGGL(h2_rowscale_kernel, dim3((unsigned)Cout), dim3(256), 0, stream, wt, Cout, K, chinv);
   const long total = (long)Cout * (K >> 3);
@@ -444,11 +444,11 @@ int conv_make_h2f_weights(const float* wt, int Cout, int K, void* img_dev, hipSt
 }
 
 // may the 1x1 conv b (reading a.out and nothing else of a) run in the epilogue of the KH x 3 conv a?  a: conv_h2k_kernel on
-// 256-wide (res4) or 128-wide (res3) n-tiles = its whole Cout, plain dense output, ReLU or none; b: dense same-size 1x1, single source,
+// 256-wide (res4), 128-wide (res3) or 64-wide (res2) n-tiles = its whole Cout, plain dense output, ReLU or none; b: dense same-size 1x1, single source,
 // no residual or a same-shape one, on the fp16x2 family as well (so its consumers find a recorded range)
 bool conv_h2f_fusable(const ConvParams& a, const ConvParams& b) {
   const bool a_ok = a.wt_split != nullptr && a.wt_split_kind == 2 && a.wt_split_kwr == 1 && a.wt_split_bm == 256 &&
-                    a.wt_split_bn == a.Cout && (a.Cout == 256 || a.Cout == 128) && a.splitk <= 1 && a.head_wt == nullptr &&
+                    a.wt_split_bn == a.Cout && (a.Cout == 256 || a.Cout == 128 || a.Cout == 64) && a.splitk <= 1 && a.head_wt == nullptr &&
                     a.res_mode == 0 && a.in2 == nullptr && a.relu <= 1 && a.nlvl <= 1 && a.out_oy == 0 && a.out_ox == 0 &&
                     a.out_H == a.Ho && a.out_W == a.Wo && a.f_wt == nullptr;
   const bool b_ok = b.in == a.out && b.kh == 1 && b.kw == 1 && b.stride == 1 && b.pad_t == 0 && b.pad_l == 0 && b.Cin == a.Cout &&
@@ -483,7 +483,7 @@ int launch_conv_h2(const ConvParams& p, const ConvParams* dev, hipStream_t strea
   if (p.wt_split_kwr) {
     ODT_CHECK(p.kw == 3 && p.stride == 1 && p.in_Wa == p.Wo && p.in2 == nullptr && 2 * p.dil <= 4 &&
               (sk == 1 || (bm == 256 && bn >= 128 && p.f_wt == nullptr && p.kh * (p.Cin >> 5) >= sk)), "conv h2k: unsupported shape");
-    ODT_CHECK(p.f_wt == nullptr || (bm == 256 && bn == p.Cout && (bn == 256 || bn == 128) && p.head_wt == nullptr && p.res_mode == 0 && p.relu <= 1 && p.f_cout % 32 == 0 &&
+    ODT_CHECK(p.f_wt == nullptr || (bm == 256 && bn == p.Cout && (bn == 256 || bn == 128 || bn == 64) && p.head_wt == nullptr && p.res_mode == 0 && p.relu <= 1 && p.f_cout % 32 == 0 &&
                                     p.f_cout > 0 && p.f_cout <= 1024 && p.f_out != nullptr && p.f_chinv != nullptr && p.f_bias != nullptr && p.f_out_ldc % 4 == 0 &&
                                     (p.f_res == nullptr || p.f_res_ldc % 4 == 0) && (double)M * p.f_out_ldc * 4.0 < 2147483648.0 &&
                                     (p.f_res == nullptr || (double)M * p.f_res_ldc * 4.0 < 2147483648.0)),

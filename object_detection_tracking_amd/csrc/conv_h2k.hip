@@ -267,7 +267,7 @@ __device__ __forceinline__ void h2f_tail(const ConvParams& p, f32x16 (&acc)[2][T
 #pragma unroll
     for (int r = 0; r < 16; ++r) co[r] = 0.f;
     // half-steps u = 2 t + (0: own K half, 1: received half): the next half-step's weight fragments (hi, lo) are read under
-    // this one's three MFMAs; the previous chunk's row items go behind half-steps 1, 3, 5, 7
+    // this one's three MFMAs; the previous chunk's row items go behind half-steps 1, 3, 5, 7 (TN = 1: behind each of the four)
     f16x8 wf[2][2];
     wf[0][0] = *reinterpret_cast<const f16x8*>(wo);
     wf[0][1] = *reinterpret_cast<const f16x8*>(wo + 2 * NS * 1024);
@@ -286,7 +286,10 @@ __device__ __forceinline__ void h2f_tail(const ConvParams& p, f32x16 (&acc)[2][T
       co = ODT_MFMA_F16(wf[u & 1][0], yll, co);
       co = ODT_MFMA_F16(wf[u & 1][0], yhh, co);
       ODT_FENCE();
-      if constexpr (has_prev) { if ((u & 1) && u < 8) row_item(c - 1, u >> 1, rprev[u >> 1]); }
+      if constexpr (has_prev) {
+        if constexpr (NS >= 4) { if ((u & 1) && u < 8) row_item(c - 1, u >> 1, rprev[u >> 1]); }
+        else row_item(c - 1, u, rprev[u]);            // (64-wide producer: four half-steps, one row item behind each)
+      }
     }
     float* Cb = Cst + buf * (CBUF / 4) + cw_at;
 #pragma unroll
@@ -599,7 +602,8 @@ __global__ void __launch_bounds__(512, 2) conv_h2k_kernel(const ConvParams* __re
 void launch_conv_h2k(const ConvParams& p, const ConvParams* dev, unsigned grid, hipStream_t stream) {
   const int bn = p.wt_split_bn;
   if (p.f_wt != nullptr) {                   // fused 1x1 tail (launch_conv_h2 checked the shape)
-    if (bn == 128) hipLaunchKernelGGL((conv_h2k_kernel<2, false, true>), dim3(grid), dim3(512), 0, stream, dev);
+    if (bn == 64) hipLaunchKernelGGL((conv_h2k_kernel<1, false, true>), dim3(grid), dim3(512), 0, stream, dev);
+    else if (bn == 128) hipLaunchKernelGGL((conv_h2k_kernel<2, false, true>), dim3(grid), dim3(512), 0, stream, dev);
     else if (p.trace != nullptr) hipLaunchKernelGGL((conv_h2k_kernel<4, true, true>), dim3(grid), dim3(512), 0, stream, dev);
     else hipLaunchKernelGGL((conv_h2k_kernel<4, false, true>), dim3(grid), dim3(512), 0, stream, dev);
   } else if (bn == 256) {

@@ -196,7 +196,7 @@ int odt_op_bottleneck_tail(int device, const float* in, int B, int H, int W, int
                            int dil, const float* w3_io, const float* b3, int C3, const float* res, int relu3, int fuse,
                            float* out) {
   ODT_CHECK(in && w2_hwio && b2 && w3_io && b3 && out, "odt_op_bottleneck_tail: null argument");
-  ODT_CHECK((C == 256 || C == 128) && C3 % 64 == 0 && C3 > 0 && (dil == 1 || dil == 2), "odt_op_bottleneck_tail: C = 128 / 256, C3 % 64 == 0, dil 1 or 2");
+  ODT_CHECK((C == 256 || C == 128 || C == 64) && C3 % 64 == 0 && C3 > 0 && (dil == 1 || dil == 2), "odt_op_bottleneck_tail: C = 64 / 128 / 256, C3 % 64 == 0, dil 1 or 2");
   if (set_dev(device)) return 1;
   const size_t M = (size_t)B * H * W;
   std::vector<float> w2((size_t)C * 9 * C), w3((size_t)C3 * C);

@@ -348,16 +348,20 @@ int fuse_rpn_heads(odt_model* m) {
 // attach_split_weights, before plan_arena.
 int fuse_bottleneck_tails(odt_model* m) {
   if (m->conv_fused.size() < m->convs.size()) m->conv_fused.resize(m->convs.size(), 0);
-  const char* e = getenv("ODT_FUSE_BOTTLENECK");       // A/B: 0 off | 1 only the 256-wide blocks (res4) | otherwise every fusable block
+  const char* e = getenv("ODT_FUSE_BOTTLENECK");       // A/B: 0 off | 1 only the 256-wide blocks (res4) | 2 + the 128-wide (res3) | otherwise every fusable block
   if (e != nullptr && e[0] == '0') return 0;
-  const bool only256 = e != nullptr && e[0] == '1';
+  const int min_cout = e != nullptr && e[0] == '1' ? 256 : (e != nullptr && e[0] == '2' ? 128 : 64);
   if (m->policy.arith == 0 || m->policy.family != 2) return 0;
   std::map<const float*, const void*> made;
   for (size_t oi = 0; oi + 1 < m->ops.size(); ++oi) {
     Op& oa = m->ops[oi]; Op& ob = m->ops[oi + 1];
     if (oa.kind != OP_CONV || ob.kind != OP_CONV || oa.skip || ob.skip) continue;
     ConvOp& a = m->convs[oa.conv]; ConvOp& b = m->convs[ob.conv];
-    if (!conv_h2f_fusable(a.p, b.p) || (only256 && a.p.Cout != 256)) continue;
+    if (a.p.Cout < min_cout) continue;
+    // (a 64-wide conv2 on the kw-reuse kernel's 512 x 64 tiles: the fused tail works on 256-row tiles -- same weight image)
+    const int bm0 = a.p.wt_split_bm;
+    if (a.p.Cout == 64 && a.p.wt_split_kind == 2 && a.p.wt_split_kwr == 1 && bm0 == 512) a.p.wt_split_bm = 256;
+    if (!conv_h2f_fusable(a.p, b.p)) { a.p.wt_split_bm = bm0; continue; }
     // nothing else may read conv2's output (taps: a keep_taps handle exposes no stage tensor under this name, see add_conv)
     bool other = false;
     for (size_t k = 0; k < m->ops.size() && !other; ++k) {
@@ -365,7 +369,7 @@ int fuse_bottleneck_tails(odt_model* m) {
       visit_op_ptrs(m, k, [&](auto& ptr) { if ((const void*)ptr == (const void*)a.p.out) other = true; });
     }
     for (const auto& kv : m->taps) if (kv.second.d == a.p.out) other = true;
-    if (other) continue;
+    if (other) { a.p.wt_split_bm = bm0; continue; }
     const int K = b.p.Cin;
     auto it = made.find(b.p.wt);
     if (it == made.end()) {

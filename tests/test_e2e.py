@@ -395,13 +395,13 @@ def test_bottleneck_conv3_fused_into_conv2_kernel(backend, monkeypatch):
   name, lib = backend
   monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1"); monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "1")
   monkeypatch.setenv("ODT_CONV_SPLIT3_BM", "256")
-  # (res3's identity blocks are 128 wide: the 256 x 128 tile's tail, K halves of 64; res4's 256 wide)
-  cfg = small_config(resnet_num_block=[1, 2, 2, 1] if name == "emu" else [1, 2, 4, 3], max_size=256, short_edge_size=256)
+  # (res2's identity blocks are 64 wide: the 256 x 64 tile's tail, K halves of 32; res3's 128 wide, K halves of 64; res4's 256 wide)
+  cfg = small_config(resnet_num_block=[2, 2, 2, 1] if name == "emu" else [2, 2, 4, 3], max_size=256, short_edge_size=256)
   w = weights_for(cfg)
   H, W = 256, 256
   fr = synthetic_frames(1, H, W, seed=5)
   out = {}
-  for mode in ("0", "2"):
+  for mode in ("0", "3"):
     monkeypatch.setenv("ODT_FUSE_BOTTLENECK", mode)
     m = models.get_model(_with_taps(cfg), 0, weights=w, lib=lib)
     try:
@@ -410,17 +410,16 @@ def test_bottleneck_conv3_fused_into_conv2_kernel(backend, monkeypatch):
       out[mode] = (det, {k: e.tap(k) for k in ("c2", "c3", "c4", "c5", "p4", "rpn4")}, e.describe(), [nm for nm, _, _, _ in e.profile_layers()])
     finally:
       m.close()
-  nf = out["2"][2]["bottleneck_tails_fused"]
-  assert out["0"][2]["bottleneck_tails_fused"] == 0 and nf == (2 if name == "emu" else 4), out["2"][2]
-  assert out["2"][2]["conv_launches"] + nf == out["0"][2]["conv_launches"]
-  assert sum(1 for nm in out["2"][3] if "conv2+conv3[fp16x2]" in nm) == nf, out["2"][3]
-  assert np.array_equal(out["2"][1]["c2"], out["0"][1]["c2"])             # (nothing in front of res3 changes)
-  for k in ("c3", "c4", "c5", "p4", "rpn4"):
-    assert _rel(out["2"][1][k], out["0"][1][k]) < 1e-5, k
-  miss, extra = match_detections(out["2"][0][0], out["2"][0][1], out["2"][0][2], out["0"][0][0], out["0"][0][1], out["0"][0][2], 1e-3, 1e-4)
+  nf = out["3"][2]["bottleneck_tails_fused"]
+  assert out["0"][2]["bottleneck_tails_fused"] == 0 and nf == (3 if name == "emu" else 5), out["3"][2]
+  assert out["3"][2]["conv_launches"] + nf == out["0"][2]["conv_launches"]
+  assert sum(1 for nm in out["3"][3] if "conv2+conv3[fp16x2]" in nm) == nf, out["3"][3]
+  for k in ("c2", "c3", "c4", "c5", "p4", "rpn4"):
+    assert _rel(out["3"][1][k], out["0"][1][k]) < 1e-5, k
+  miss, extra = match_detections(out["3"][0][0], out["3"][0][1], out["3"][0][2], out["0"][0][0], out["0"][0][1], out["0"][0][2], 1e-3, 1e-4)
   assert miss + extra == 0
   if name == "hip":
-    monkeypatch.setenv("ODT_FUSE_BOTTLENECK", "2")
+    monkeypatch.setenv("ODT_FUSE_BOTTLENECK", "3")
     miss, extra = _run_single(lib, cfg, H, W)
     assert miss == 0 and extra == 0
 

@@ -738,6 +738,8 @@ def _bottleneck_ref(x, w2, b2, w3, b3, res, dil, relu3):
 BOTTLENECK_CASES = [
     # B, H, W, C3, dil, residual, relu3 (, C)
     (2, 11, 13, 128, 1, True, True, 128), # res3's shape class: 256 x 128 tile, the K halves are 64 wide
+    (1, 19, 27, 256, 1, True, True, 64),  # res2's shape class: 256 x 64 tile (K halves 32 wide: four half-steps per chunk), M = 513
+    (2, 8, 9, 64, 2, False, True, 64),    # ... dilation 2, two chunks, a tile across the image boundary, no residual
     (1, 12, 24, 64, 1, True, True),       # two tiles, the second partial
     (2, 9, 17, 128, 1, True, True),       # a tile that crosses the image boundary (two runs), odd sizes
     (1, 16, 16, 192, 2, False, False),    # dilation 2, six 32-column chunks, no residual, no activation
