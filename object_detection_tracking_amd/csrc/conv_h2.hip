@@ -469,6 +469,7 @@ int launch_tensor_amax(const float* x, size_t n, unsigned* slot, hipStream_t str
 }
 
 int launch_conv_h2(const ConvParams& p, const ConvParams* dev, hipStream_t stream) {
+  if (p.stem_pool) return launch_conv_stem(p, dev, stream);
   const long M = (long)p.B * p.Ho * p.Wo;
   const int bn = p.wt_split_bn;
   const int bm = p.wt_split_bm;

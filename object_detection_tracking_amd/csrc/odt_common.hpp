@@ -115,6 +115,9 @@ struct ConvParams {
   float* f_out;            // [M][f_out_ldc]
   unsigned* f_out_amax;    // range slot of f_out or nullptr
   int f_cout, f_out_ldc, f_res_ldc, f_relu;
+  // conv0 + pool0 in one kernel (conv_stem.hip; fuse_stem): `out` is the 3x3 / stride-2 max-pooled map [B, out_H, out_W, out_ldc]
+  // of the conv's [B, Ho, Wo, Cout] result, which is not written
+  int stem_pool;
 };
 // fills the derived fields (multiply-shift divisors); call before copying a record to the device
 void conv_prepare(ConvParams& p);
@@ -175,6 +178,8 @@ int launch_tensor_amax(const float* x, size_t n, unsigned* slot, hipStream_t str
 size_t conv_h2f_weight_bytes(int Cout, int K);
 const float* conv_h2f_chinv(const void* img, int Cout, int K);
 int conv_make_h2f_weights(const float* wt, int Cout, int K, void* img_dev, hipStream_t stream);
+bool conv_stem_fits(const ConvParams& p);          // conv_stem.hip: the plan's conv0 on the fp16x2 family
+int launch_conv_stem(const ConvParams& p, const ConvParams* dev, hipStream_t stream);
 bool conv_h2f_fusable(const ConvParams& a, const ConvParams& b);   // a: the KH x 3 producer, b: the 1x1 conv reading a.out
 size_t conv_split_partial_bytes(const ConvParams& p);   // scratch a split-K conv needs (0: none)
 

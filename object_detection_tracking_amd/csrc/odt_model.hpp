@@ -100,6 +100,7 @@ struct odt_model {
   unsigned* amax_dev = nullptr;
   int amax_used[2] = {0, 0};
   int convs_h2 = 0;                  // convs on the fp16x2 kernels
+  int stem_fused = 0;                // conv0 + pool0 run as one kernel (fuse_stem)
   int convs_h2f = 0;                 // ... of them with the following 1x1 conv folded into the kernel (fuse_bottleneck_tails)
   unsigned* pre_amax = nullptr;      // range slot of the preprocessed frames (OP_PRE records it; conv0 reads it)
   std::vector<Op> ops;
@@ -211,6 +212,7 @@ ConvPolicy resolve_conv_policy(const odt_model* m);
 int attach_split_weights(odt_model* m);
 int fuse_rpn_heads(odt_model* m);
 int fuse_bottleneck_tails(odt_model* m);
+int fuse_stem(odt_model* m);
 void find_overlap_points(odt_model* m);
 int plan_arena(odt_model* m);
 int upload_conv_records(odt_model* m);

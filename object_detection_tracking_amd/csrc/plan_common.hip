@@ -398,6 +398,38 @@ int fuse_bottleneck_tails(odt_model* m) {
   return 0;
 }
 
+// ---- conv0 + pool0 in one kernel ---------------------------------------------------------------------------------------
+// pool0 reads conv0's map and nothing else does (nn.py:860-896): where conv0 runs on the fp16x2 family the pair becomes one
+// launch of conv_stem_kernel (a 39 x 36 patch of the frame per 8 x 7 pooled pixels, split once into LDS; the [B,544,960,64] map
+// -- 1.07 GB written and read back at b=8 -- never exists).  Bit-identical.  ODT_FUSE_STEM=0 keeps the two launches (A/B).
+// Called after attach_split_weights, before plan_arena.
+int fuse_stem(odt_model* m) {
+  const char* e = getenv("ODT_FUSE_STEM");
+  if (e != nullptr && e[0] == '0') return 0;
+  if (m->policy.arith == 0 || m->policy.family != 2) return 0;
+  for (size_t oi = 0; oi + 1 < m->ops.size(); ++oi) {
+    Op& oa = m->ops[oi]; Op& ob = m->ops[oi + 1];
+    if (oa.kind != OP_CONV || ob.kind != OP_POOL || oa.skip || ob.skip) continue;
+    ConvParams& ap = m->convs[oa.conv].p;
+    if (ob.in.d != ap.out || ap.out == nullptr || !conv_stem_fits(ap) || ap.out_oy != 0 || ap.out_ox != 0 || ap.out_H != ap.Ho || ap.out_W != ap.Wo ||
+        ob.in.h != ap.Ho || ob.in.w != ap.Wo || ob.in.C != 64 || ob.out.H != (ap.Ho + 1 - 3) / 2 + 1 || ob.out.W != (ap.Wo + 1 - 3) / 2 + 1 ||
+        ob.out.C < 64 || (double)ap.B * ob.out.H * ob.out.W * ob.out.C * 4.0 >= 2147483648.0) continue;
+    bool other = false;                      // nothing else may read the conv map (a keep_taps handle exposes it as "conv0")
+    for (size_t k = 0; k < m->ops.size() && !other; ++k) {
+      if (k == oi || k == oi + 1) continue;
+      visit_op_ptrs(m, k, [&](auto& ptr) { if ((const void*)ptr == (const void*)ap.out) other = true; });
+    }
+    // (arena handles keep no stage tensor: odt_tap refuses the transient ones)
+    if (!m->arena_on) for (const auto& kv : m->taps) if (kv.second.d == ap.out) other = true;
+    if (other) continue;
+    ap.out = ob.out.d; ap.out_H = ob.out.H; ap.out_W = ob.out.W; ap.out_ldc = ob.out.C; ap.stem_pool = 1;
+    if (const char* g = getenv("ODT_STEM_GRID")) ap.debug |= (atoi(g) & 0x3ff) << 20;       // test knob: workgroups of the launch
+    ob.skip = true;
+    m->stem_fused = 1;
+  }
+  return 0;
+}
+
 // ---- activation arena -----------------------------------------------------------------------------------------------
 // ops [op_tail, end) of forward i (selection / ROIAlign / box head / NMS / features) may run on the side stream under ops
 // [0, op_first_fpn) of forward i+1 (run_plan: tail overlap); 0 / 0 when the graph has no such split

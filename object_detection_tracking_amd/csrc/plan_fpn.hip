@@ -366,6 +366,7 @@ int build_plan(odt_model* m) {
   if (attach_split_weights(m)) return 1;
   if (fuse_rpn_heads(m)) return 1;
   if (fuse_bottleneck_tails(m)) return 1;
+  if (fuse_stem(m)) return 1;
   if (plan_arena(m)) return 1;
   if (upload_conv_records(m)) return 1;
   return 0;

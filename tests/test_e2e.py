@@ -500,6 +500,47 @@ def test_cache_hints_and_record_granularity_do_not_change_results(backend, monke
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("shape", [(1, 96, 160), (2, 130, 200)])
+def test_stem_conv0_pool0_in_one_kernel(backend, shape, monkeypatch):
+  """conv0 + BN + ReLU + pool0 as ONE launch of conv_stem_kernel (a patch of the padded frame per 8 x 7 pooled pixels, split
+  once into LDS; the conv map never written): same products in the same order as conv_h2_kernel + maxpool3x3s2_kernel, so
+  every output of the forward is BIT-IDENTICAL to the two-launch form (tiles partial in x, tiles at the frame's borders,
+  several images, more workgroups than tiles and fewer); a keep_taps handle -- which exposes conv0 -- keeps the two launches."""
+  name, lib = backend
+  B, H, W = shape
+  if name == "hip":
+    H, W = 4 * H, 4 * W                     # (more tiles than CUs in the second shape: 2 x 17 x 29 tiles of 8 x 7 pooled pixels)
+  monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1"); monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "1")
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1], im_batch_size=B, rpn_test_post_nms_topk=32, max_size=max(H, W), short_edge_size=min(H, W))
+  w = weights_for(cfg)
+  fr = synthetic_frames(B, H, W, seed=11)
+  out = {}
+  if name == "emu":
+    monkeypatch.setenv("ODT_STEM_GRID", "3" if B > 1 else "2")     # (the simulator's 256 CUs: a persistent workgroup would see one tile)
+  for mode in ("0", "1"):
+    monkeypatch.setenv("ODT_FUSE_STEM", mode)
+    m = models.get_model(cfg, 0, weights=w, lib=lib, is_multi=B > 1)
+    try:
+      res = m.predict_batch(fr) if B > 1 else m.predict(fr[0])
+      e = m.engine(B, H, W)
+      out[mode] = (res, e.describe(), [nm for nm, _, _, _ in e.profile_layers()])
+    finally:
+      m.close()
+  assert out["0"][1]["stem_fused"] == 0 and out["1"][1]["stem_fused"] == 1, (out["0"][1], out["1"][1])
+  assert "conv0+pool0[fp16x2]" in out["1"][2] and "conv0[fp16x2]" in out["0"][2], out["1"][2][:3]
+  for a, b in zip(out["0"][0], out["1"][0]):
+    assert np.array_equal(a, b)
+  monkeypatch.setenv("ODT_FUSE_STEM", "1")
+  m = models.get_model(_with_taps(cfg), 0, weights=w, lib=lib, is_multi=B > 1)
+  try:
+    res = m.predict_batch(fr) if B > 1 else m.predict(fr[0])
+    assert m.engine(B, H, W).describe()["stem_fused"] == 0
+    for a, b in zip(out["1"][0], res):
+      assert np.array_equal(a, b)
+  finally:
+    m.close()
+
+
 def test_convs_cut_into_batch_ranges_are_bit_identical(backend, monkeypatch):
   """A conv whose tensors would reach 2 GiB (32-bit buffer offsets; b = 16 @1080p) runs as several launches over batch
   ranges.  With the limit lowered (test knob) a small batched plan takes that path for most layers: same bits out."""
