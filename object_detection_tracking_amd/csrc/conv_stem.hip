@@ -121,16 +121,33 @@ __global__ void __launch_bounds__(512, 2) conv_stem_kernel(const ConvParams* __r
     }
   };
 
-  // ---- fragments.  Pixels (B operand): lane (fr, fg) of row block t -> conv pixel r = wm 64 + t 32 + fr = (cyl, cxl) of the
-  // tile, k16 step s = (kh = s / 2, pixel pairs 2 (s % 2) + fg): 16 bytes at ((2 cyl + kh) PW + 2 cxl + 4 (s % 2) + 2 fg) 8
+  // ---- fragments.  Pixels (B operand): lane (fr, fg) of row block t -> a conv pixel (cyl, cxl) of the tile, k16 step s =
+  // (kh = s / 2, pixel pairs 2 (s % 2) + fg): 16 bytes at ((2 cyl + kh) PW + 2 cxl + 4 (s % 2) + 2 fg) 8
+  // Which conv pixel an MFMA row holds is free: ds_read_b128 serves a wave in 16-lane groups ({0-3, 12-15, 20-27} and
+  // {4-11, 16-19, 28-31} of each half), and with the patch rows 18 x 16 bytes apart a conv row's step is 4 sixteen-byte slots
+  // (mod 16): row-major pixels put two conv rows of a group on the same slots (2.6 LDS cycles per group).  Instead a group
+  // takes a 4 x 4 BLOCK of conv pixels -- slots 4 dy + dx: all sixteen -- for columns 0..11 of rows 0..15 (12 groups); the
+  // other four take a 4 x 3 block of columns 12..14 plus four pixels of row 16 (1.19 cycles per group on average).
   int a_base[2], c_row[2];
   bool c_in[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const int r = wm * 64 + t * 32 + fr, cyl = r / CW, cxl = r - cyl * CW;
+    const bool gb = (fr >= 4 && fr < 12) || (fr >= 16 && fr < 20) || fr >= 28;      // second lane group of the half
+    const int i = gb ? (fr < 12 ? fr - 4 : (fr < 20 ? fr - 8 : fr - 16)) : (fr < 4 ? fr : (fr < 16 ? fr - 8 : fr - 12));
+    const int g = (wm * 2 + t) * 2 + (gb ? 1 : 0);
+    int cyl, cxl;
+    if (g < 12) { cyl = 4 * (g / 3) + (i >> 2); cxl = 4 * (g % 3) + (i & 3); }
+    else if (i < 12) { cyl = 4 * (g - 12) + i / 3; cxl = 12 + i % 3; }
+    else {
+      // row 16: {3, 7, 11, -} | {0, 1, 2, 4} | {5, 6, 8, 9} | {10, 12, 13, 14} (the first set fills the slots its block leaves free)
+      const int j = i - 12;
+      cyl = 16;
+      cxl = g == 12 ? 4 * j + 3 : (g == 13 ? j + (j == 3 ? 1 : 0) : (g == 14 ? 5 + j + (j >= 2 ? 1 : 0) : (j == 0 ? 10 : 11 + j)));
+    }
+    c_in[t] = cxl < CW;                       // (group 12's fourth extra: the idle MFMA row)
+    if (!c_in[t]) cxl = 0;
     a_base[t] = POFF + ((2 * cyl) * PW + 2 * cxl + 2 * fg) * 8;
-    c_row[t] = r;
-    c_in[t] = r < G::CH * CW;
+    c_row[t] = c_in[t] ? cyl * CW + cxl : 255;
   }
   // weights (A operand): lane (fr, fg) -> column wn 32 + fr, k-group 2 (s % 2) + fg of stage s / 2
   const int b_base = G::WOFF + fg * BKG + (wn * 32 + fr) * 16;
@@ -156,7 +173,42 @@ __global__ void __launch_bounds__(512, 2) conv_stem_kernel(const ConvParams* __r
 
   float vmax = 0.f;
   float* Ct = reinterpret_cast<float*>(lds + COFF);
-  for (int t = t_begin; t < t_end; ++t) {
+  // ---- pool0: thread -> items tid, tid + 512 = (pooled pixel, 16-byte channel group) of the tile; the window's 3 x 3 conv
+  // pixels sit at (2 pyl + dy, 2 pxl + dx) of the conv tile.  A tile's pooling runs UNDER THE NEXT TILE'S MFMAs (one window
+  // element behind each of steps 1 .. 9, the stores behind step 10); the last tile's behind the loop.
+  int pl_at[2], pl_py[2], pl_px[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int item = tid + 512 * k, pix = item >> 4, c4 = item & 15, pyl = pix / PX, pxl = pix - pyl * PX;
+    const bool any = item < PY * PX * 16;    // (no such item: reads the tile's first window, stores outside every map)
+    pl_at[k] = any ? ((2 * pyl) * CW + 2 * pxl) * CS + c4 * 4 : 0;
+    pl_py[k] = pyl; pl_px[k] = any ? pxl : (1 << 20);
+  }
+  f32x4 pmx[2];
+  auto pool_read = [&](int e) {              // window element e = 3 dy + dx
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(Ct + pl_at[k] + ((e / 3) * CW + e % 3) * CS);
+      if (e == 0) pmx[k] = v;
+      else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pmx[k][c] = fmaxf(pmx[k][c], v[c]);
+      }
+    }
+  };
+  auto pool_store = [&](int n, int py0, int px0) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int py = py0 + pl_py[k], px = px0 + pl_px[k];
+      const bool ok = py < Hq && px < Wq;
+      if (ok) vmax = fmaxf(vmax, fmaxf(fmaxf(pmx[k][0], pmx[k][1]), fmaxf(pmx[k][2], pmx[k][3])));
+      const unsigned off = ok ? ((((unsigned)n * Hq + py) * Wq + px) * (unsigned)p.out_ldc + ((tid + 512 * k) & 15) * 4u) * 4u : kOOB;
+      __builtin_amdgcn_raw_buffer_store_b128((u32x4)pmx[k], rs_out, (int)off, 0, 0);
+    }
+  };
+  int pn = 0, ppy0 = 0, ppx0 = 0;            // the previous tile (whose conv tile is in LDS)
+  auto tile = [&](int t, auto HP) {
+    constexpr bool has_prev = decltype(HP)::value;
     int n, py0, px0;
     tile_at(t, n, py0, px0);
     // ---- 14 k16 steps, every operand in LDS; the next step's fragments are read under this step's MFMAs
@@ -188,8 +240,13 @@ __global__ void __launch_bounds__(512, 2) conv_stem_kernel(const ConvParams* __r
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[i] = ODT_MFMA_F16(fb[b][0], fa[b][0][i], acc[i]);      // hi * hi
       ODT_FENCE();
+      if constexpr (has_prev) {
+        if (s >= 1 && s <= 9) pool_read(s - 1);
+        if (s == 10) pool_store(pn, ppy0, ppx0);
+        ODT_FENCE();
+      }
     }
-    ODT_BARRIER_LDS();                       // every wave has read the patch (and the previous tile's conv tile)
+    ODT_BARRIER_LDS();                       // every wave has read the patch and the previous tile's conv tile
     // ---- conv0's epilogue in registers -> the conv tile; pixels outside the map (and the idle row) are zeros
     const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;
 #pragma unroll
@@ -209,31 +266,13 @@ __global__ void __launch_bounds__(512, 2) conv_stem_kernel(const ConvParams* __r
     if (t + 1 < t_end) store_patch();        // the next tile's patch (fetched under the MFMAs above)
     ODT_BARRIER_LDS();
     if (t + 2 < t_end) load_patch(t + 2);
-    // ---- pool0: thread -> (pooled pixel, 16-byte channel group); 3 x 3 conv pixels at (2 pyl + dy, 2 pxl + dx)
+    pn = n; ppy0 = py0; ppx0 = px0;
+  };
+  tile(t_begin, std::false_type{});
+  for (int t = t_begin + 1; t < t_end; ++t) tile(t, std::true_type{});
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int item = tid + 512 * k;
-      if (item < PY * PX * 16) {
-        const int pix = item >> 4, c4 = item & 15, pyl = pix / PX, pxl = pix - pyl * PX;
-        const float* cp = Ct + ((2 * pyl) * CW + 2 * pxl) * CS + c4 * 4;
-        f32x4 mx = *reinterpret_cast<const f32x4*>(cp);
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            if (dy == 0 && dx == 0) continue;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(cp + (dy * CW + dx) * CS);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) mx[e] = fmaxf(mx[e], v[e]);
-          }
-        const int py = py0 + pyl, px = px0 + pxl;
-        const bool ok = py < Hq && px < Wq;
-        if (ok) vmax = fmaxf(vmax, fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])));
-        const unsigned off = ok ? ((((unsigned)n * Hq + py) * Wq + px) * (unsigned)p.out_ldc + c4 * 4u) * 4u : kOOB;
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4)mx, rs_out, (int)off, 0, 0);
-      }
-    }
-  }
+  for (int e = 0; e < 9; ++e) pool_read(e);
+  pool_store(pn, ppy0, ppx0);
   publish_amax_wg<512>(p.out_amax, vmax, tid, lds);
 }
 

@@ -25,12 +25,13 @@ def main(path):
     split, h2 = name.endswith("[bf16x3]"), name.endswith("[fp16x2]")
     base = name.replace("[bf16x3]", "").replace("[fp16x2]", "")
     fused3 = base.endswith("+conv3")            # conv2 with the block's conv3 (1x1 to 4 N channels + shortcut) evaluated in its kernel
-    base = base.replace("+conv3", "").replace("+head", "")
+    pooled = base.endswith("+pool0")              # conv0 with pool0 evaluated in its kernel: a quarter of the map is written, the map itself never
+    base = base.replace("+conv3", "").replace("+head", "").replace("+pool0", "")
     k3 = base.endswith("conv2") or "posthoc_3x3" in base or base.startswith("rpn/conv0")
     cin_bytes = M * (K // 9 if k3 else K) * 4.0            # every input pixel once (stride-1 3x3: K/9 channels)
     if base == "conv0":
       cin_bytes = M * 4 * 4 * 4.0                             # 7x7 s2 over the 4-channel padded frame
-    byt = cin_bytes + M * N * 4.0 + N * K * 4.0
+    byt = cin_bytes + M * N * 4.0 * (0.25 if pooled else 1.0) + N * K * 4.0
     if "conv3" in base or "lateral" in base:
       byt += M * N * 4.0 * (0.25 if "lateral" in base else 1.0)   # residual (2x-upsampled: a quarter)
     flops = 2.0 * M * N * K
