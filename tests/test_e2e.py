@@ -510,13 +510,17 @@ def test_stem_conv0_pool0_in_one_kernel(backend, shape, monkeypatch):
   B, H, W = shape
   if name == "hip":
     H, W = 4 * H, 4 * W                     # (more tiles than CUs in the second shape: 2 x 17 x 29 tiles of 8 x 7 pooled pixels)
+  elif B == 1:
+    pytest.skip("simulator: the two-image shape covers it (a forward of the whole model takes half a minute there)")
+  else:
+    H, W = 64, 80                            # (simulator: 2 x 2 x 4 tiles, the last of a row partial, three workgroups)
   monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1"); monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "1")
   cfg = small_config(resnet_num_block=[1, 1, 1, 1], im_batch_size=B, rpn_test_post_nms_topk=32, max_size=max(H, W), short_edge_size=min(H, W))
   w = weights_for(cfg)
   fr = synthetic_frames(B, H, W, seed=11)
   out = {}
   if name == "emu":
-    monkeypatch.setenv("ODT_STEM_GRID", "3" if B > 1 else "2")     # (the simulator's 256 CUs: a persistent workgroup would see one tile)
+    monkeypatch.setenv("ODT_STEM_GRID", "3")     # (the simulator's 256 CUs: a persistent workgroup would see one tile)
   for mode in ("0", "1"):
     monkeypatch.setenv("ODT_FUSE_STEM", mode)
     m = models.get_model(cfg, 0, weights=w, lib=lib, is_multi=B > 1)
@@ -533,10 +537,11 @@ def test_stem_conv0_pool0_in_one_kernel(backend, shape, monkeypatch):
   monkeypatch.setenv("ODT_FUSE_STEM", "1")
   m = models.get_model(_with_taps(cfg), 0, weights=w, lib=lib, is_multi=B > 1)
   try:
-    res = m.predict_batch(fr) if B > 1 else m.predict(fr[0])
+    if name == "hip":
+      res = m.predict_batch(fr) if B > 1 else m.predict(fr[0])
+      for a, b in zip(out["1"][0], res):
+        assert np.array_equal(a, b)
     assert m.engine(B, H, W).describe()["stem_fused"] == 0
-    for a, b in zip(out["1"][0], res):
-      assert np.array_equal(a, b)
   finally:
     m.close()
 

@@ -7,7 +7,7 @@ d = [x for x in os.listdir(root) if x.startswith("pmc_SQ_LDS_BANK") and os.path.
 rows = list(csv.DictReader(open(os.path.join(root, d, "pmc_counter_collection.csv"))))
 t = collections.defaultdict(lambda: collections.defaultdict(float))
 import re
-FAMS = ("conv_h2k_kernel", "conv_h2_kernel", "conv_split3k_kernel", "conv_split3_kernel", "conv_split_kernel", "conv_igemm_kernel")
+FAMS = ("conv_stem_kernel", "conv_h2k_kernel", "conv_h2_kernel", "conv_split3k_kernel", "conv_split3_kernel", "conv_split_kernel", "conv_igemm_kernel")
 for r in rows:
   k = r["Kernel_Name"]
   for fam in FAMS:

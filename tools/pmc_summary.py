@@ -13,7 +13,7 @@ def agg(rows, pred):
     if pred(r["Kernel_Name"]):
       tot[r["Counter_Name"]] += float(r["Counter_Value"]); disp.add(r["Dispatch_Id"])
   return tot, len(disp)
-is_conv = lambda k: "conv_igemm_kernel" in k or "conv_split" in k or "conv_h2" in k
+is_conv = lambda k: "conv_igemm_kernel" in k or "conv_split" in k or "conv_h2" in k or "conv_stem_kernel" in k
 is_pre = lambda k: "preprocess_kernel" in k
 f, nconv = agg(load("FETCH_SIZE"), is_conv)
 w, _ = agg(load("WRITE_SIZE"), is_conv)
@@ -22,7 +22,7 @@ try:
   i, _ = agg(load("SQ_INSTS"), is_conv)
 except IndexError:            # optional fourth pass
   i = collections.defaultdict(float)
-is_split = lambda k: ("conv_split" in k or "conv_h2" in k) and "kernel" in k and "split_weights" not in k
+is_split = lambda k: ("conv_split" in k or "conv_h2" in k or "conv_stem" in k) and "kernel" in k and "split_weights" not in k
 fs, nsplit = agg(load("FETCH_SIZE"), is_split)
 ws, _ = agg(load("WRITE_SIZE"), is_split)
 ms, _ = agg(load("SQ_VALU_MFMA"), is_split)
@@ -47,7 +47,7 @@ res = {
           "over GRBM_GUI_ACTIVE/8 XCDs. Algorithmic conv traffic: 6.83 GB/frame * 8 = 54.6 GB/forward (27.3 read + 27.3 write).",
 }
 # per kernel family: MFMA-busy cycles against CU-busy cycles (same pass), HBM bytes per launch
-fams = {"conv_h2k_kernel": lambda k: "conv_h2k_kernel" in k, "conv_h2_kernel": lambda k: "conv_h2_kernel" in k,
+fams = {"conv_stem_kernel": lambda k: "conv_stem_kernel" in k, "conv_h2k_kernel": lambda k: "conv_h2k_kernel" in k, "conv_h2_kernel": lambda k: "conv_h2_kernel" in k,
         "conv_split3(k)_kernel": lambda k: "conv_split3" in k, "conv_split_kernel (one-stage)": lambda k: "conv_split_kernel" in k,
         "conv_igemm_kernel": lambda k: "conv_igemm_kernel" in k}
 res["by_kernel"] = {}
