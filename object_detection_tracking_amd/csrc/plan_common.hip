@@ -422,6 +422,8 @@ int fuse_stem(odt_model* m) {
     // (arena handles keep no stage tensor: odt_tap refuses the transient ones)
     if (!m->arena_on) for (const auto& kv : m->taps) if (kv.second.d == ap.out) other = true;
     if (other) continue;
+    // the conv map no longer exists: an arena handle must neither reserve memory for its stage name nor hand it out
+    for (auto it = m->taps.begin(); it != m->taps.end();) { if (it->second.d == ap.out) it = m->taps.erase(it); else ++it; }
     ap.out = ob.out.d; ap.out_H = ob.out.H; ap.out_W = ob.out.W; ap.out_ldc = ob.out.C; ap.stem_pool = 1;
     if (const char* g = getenv("ODT_STEM_GRID")) ap.debug |= (atoi(g) & 0x3ff) << 20;       // test knob: workgroups of the launch
     ob.skip = true;
