@@ -299,6 +299,12 @@ int odt_op_conv2d_cat(int device, const float* a, int B, int Ho, int Wo, int Ca,
 int odt_op_bottleneck_tail(int device, const float* in, int B, int H, int W, int C, const float* w2,
                            const float* b2, int dil, const float* w3, const float* b3, int C3,
                            const float* res, int relu3, int fuse, float* out);
+/* The ResNet stem on an already padded frame tensor (nn.py:860-896 + 784-792): conv0 7x7 stride 2 VALID over frame_pad
+ * [B,Hp,Wp,3] (+ bias, ReLU) -> 3x3 stride 2 max-pool over the top/left zero-padded map; fp16x2 arithmetic.  fuse = 1: the
+ * one launch of conv_stem_kernel, 0: the two launches it replaces.  out: [B, Hq, Wq, 64], Hq = ((Hp - 7) / 2 + 1 + 1 - 3) / 2 + 1
+ * (Wq alike).  grid > 0: that many workgroups (tests: several tiles per persistent workgroup). */
+int odt_op_stem(int device, const float* frame_pad, int B, int Hp, int Wp, const float* w_hwio, const float* bias,
+                int fuse, int grid, float* out);
 /* image preprocess (models.py:340-355) + zero pad -> [B,Hp,Wp,4] */
 int odt_op_preprocess(int device, const void* frames, int dtype, int B, int H,
                       int W, int pad_t, int pad_l, int Hp, int Wp, float* out);

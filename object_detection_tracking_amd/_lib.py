@@ -79,7 +79,7 @@ class OdtLib(object):
       "odt_forward_async", "odt_synchronize", "odt_read_outputs", "odt_describe", "odt_submit", "odt_submit_ex", "odt_collect",
       "odt_ingest_buffer", "odt_set_source_size", "odt_tap", "odt_profile_enable",
       "odt_profile_read", "odt_profile_layer", "odt_probe_mfma_bf16", "odt_nn_cosine", "odt_op_conv2d", "odt_op_conv2d_cat",
-      "odt_op_bottleneck_tail", "odt_op_preprocess",
+      "odt_op_bottleneck_tail", "odt_op_stem", "odt_op_preprocess",
       "odt_op_maxpool", "odt_op_topk", "odt_op_nms", "odt_op_proposals",
       "odt_op_roi_align", "odt_op_detections", "odt_op_class_nms", "odt_tracker_create", "odt_tracker_destroy",
       "odt_tracker_predict", "odt_tracker_update", "odt_tracker_tracks", "odt_lsap", "odt_tracker_nms",
@@ -130,6 +130,7 @@ class OdtLib(object):
         [c_float_p, c_float_p, c_float_p, C.c_int, C.c_int, c_float_p]
     d.odt_op_bottleneck_tail.argtypes = [C.c_int, c_float_p] + [C.c_int] * 4 + [c_float_p, c_float_p, C.c_int, c_float_p, c_float_p,
                                          C.c_int, c_float_p, C.c_int, C.c_int, c_float_p]
+    d.odt_op_stem.argtypes = [C.c_int, c_float_p] + [C.c_int] * 3 + [c_float_p, c_float_p, C.c_int, C.c_int, c_float_p]
     d.odt_op_preprocess.argtypes = [C.c_int, C.c_void_p] + [C.c_int] * 8 + [c_float_p]
     d.odt_op_maxpool.argtypes = [C.c_int, c_float_p] + [C.c_int] * 4 + [c_float_p]
     d.odt_op_topk.argtypes = [C.c_int, c_float_p, C.c_int, C.c_int, c_int_p]

@@ -252,6 +252,49 @@ int odt_op_bottleneck_tail(int device, const float* in, int B, int H, int W, int
   return dout.get(out, M * C3);
 }
 
+int odt_op_stem(int device, const float* frame_pad, int B, int Hp, int Wp, const float* w_hwio, const float* bias, int fuse,
+                int grid, float* out) {
+  ODT_CHECK(frame_pad && w_hwio && bias && out && B > 0 && Hp >= 11 && Wp >= 11, "odt_op_stem: null argument / frame too small");
+  if (set_dev(device)) return 1;
+  const int Ho0 = (Hp - 7) / 2 + 1, Wo0 = (Wp - 7) / 2 + 1, Wa = 2 * Wo0 + 8;      // (room for the 8th, zero-weight tap: plan_fpn.hip)
+  const int Hq = (Ho0 + 1 - 3) / 2 + 1, Wq = (Wo0 + 1 - 3) / 2 + 1;
+  // the plan's layouts: frames as [B, Hp, Wa, 4] (4th channel and the pad columns zero), conv0 as a 7 x 1 conv over 8-pixel x
+  // 4-channel rows: virtual weights [64][7][32]
+  std::vector<float> x((size_t)B * Hp * Wa * 4, 0.f), wv((size_t)64 * 7 * 32, 0.f);
+  for (int b = 0; b < B; ++b) for (int y = 0; y < Hp; ++y) for (int xx = 0; xx < Wp; ++xx) for (int c = 0; c < 3; ++c)
+    x[(((size_t)b * Hp + y) * Wa + xx) * 4 + c] = frame_pad[(((size_t)b * Hp + y) * Wp + xx) * 3 + c];
+  for (int y = 0; y < 7; ++y) for (int xx = 0; xx < 7; ++xx) for (int c = 0; c < 3; ++c) for (int o = 0; o < 64; ++o)
+    wv[((size_t)o * 7 + y) * 32 + xx * 4 + c] = w_hwio[(((size_t)y * 7 + xx) * 3 + c) * 64 + o];
+  Tmp<float> di, dw, db, dmap, dout, img;
+  Tmp<unsigned> amax;
+  Tmp<ConvParams> rec;
+  const size_t nmap = (size_t)B * Ho0 * Wo0 * 64, nout = (size_t)B * Hq * Wq * 64;
+  if (di.alloc(x.size()) || dw.alloc(wv.size()) || db.alloc(64) || dmap.alloc(nmap) || dout.alloc(nout) || dout.zero() ||
+      amax.alloc(4) || amax.zero() || rec.alloc(1)) return 1;
+  if (di.put(x.data()) || dw.put(wv.data()) || db.put(bias)) return 1;
+  if (launch_tensor_amax(di.d, x.size(), amax.d, nullptr)) return 1;
+  ConvParams p; std::memset(&p, 0, sizeof(p));
+  p.in = di.d; p.wt = dw.d; p.bias = db.d; p.out = dmap.d;
+  p.B = B; p.H = Hp; p.W = Wa; p.Cin = 32; p.in_ldc = 4; p.in_Ha = Hp; p.in_Wa = Wa; p.Ho = Ho0; p.Wo = Wo0; p.Cout = 64;
+  p.kh = 7; p.kw = 1; p.stride = 2; p.dil = 1; p.out_H = Ho0; p.out_W = Wo0; p.out_ldc = 64; p.relu = 1;
+  p.wt_split_kind = 2; p.wt_split_bm = 128; p.wt_split_bn = 64; p.splitk = 1;
+  p.in_amax = amax.d; p.out_amax = amax.d + 1;
+  conv_prepare(p);
+  if (img.alloc((conv_split_weight_bytes(64, 224) + 3) / 4) || conv_make_split_weights(p, img.d, nullptr)) return 1;
+  p.wt_split = img.d; p.h2_chinv = conv_h2_chinv(img.d, 64, 224);
+  if (fuse) {
+    ODT_CHECK(conv_stem_fits(p), "odt_op_stem: shape not taken by the stem kernel");
+    p.out = dout.d; p.out_H = Hq; p.out_W = Wq; p.stem_pool = 1;
+    if (grid > 0) p.debug |= (grid & 0x3ff) << 20;
+    if (rec.put(&p) || launch_conv_split(p, rec.d, nullptr)) return 1;
+  } else {
+    if (rec.put(&p) || launch_conv_split(p, rec.d, nullptr)) return 1;
+    if (launch_maxpool3x3s2(dmap.d, B, Ho0, Wo0, 64, dout.d, Hq, Wq, nullptr)) return 1;
+  }
+  ODT_HIP(hipDeviceSynchronize());
+  return dout.get(out, nout);
+}
+
 int odt_op_preprocess(int device, const void* frames, int dtype, int B, int H, int W, int pad_t, int pad_l,
                       int Hp, int Wp, float* out) {
   ODT_CHECK(frames && out, "odt_op_preprocess: null argument");

@@ -70,6 +70,20 @@ def bottleneck_tail(x, w2, b2, w3, b3, res=None, dil=1, relu3=True, fuse=True, l
   return out
 
 
+def stem(frame_pad, w_hwio, bias, fuse=True, grid=0, lib=None, device=0):
+  """conv0 (7x7 stride 2 VALID + bias + ReLU) -> pool0 (3x3 stride 2 max over the top/left zero-padded map) on a padded frame
+  tensor [B, Hp, Wp, 3] (reference nn.py:860-896, 784-792), fp16x2 arithmetic; fuse=True: conv_stem_kernel (one launch),
+  False: the two launches it replaces.  Returns [B, Hq, Wq, 64]."""
+  lib = _L(lib)
+  x = f32(frame_pad); w = f32(w_hwio); b = f32(bias)
+  B, Hp, Wp, _ = x.shape
+  Ho0, Wo0 = (Hp - 7) // 2 + 1, (Wp - 7) // 2 + 1
+  Hq, Wq = (Ho0 + 1 - 3) // 2 + 1, (Wo0 + 1 - 3) // 2 + 1
+  out = np.zeros((B, Hq, Wq, 64), np.float32)
+  lib.check(lib.dll.odt_op_stem(device, fptr(x), B, Hp, Wp, fptr(w), fptr(b), int(fuse), int(grid), fptr(out)))
+  return out
+
+
 def preprocess(frames, pad_t, pad_l, Hp, Wp, lib=None, device=0):
   """reference models.py:340-355 + zero pad; returns [B,Hp,Wp,4]."""
   lib = _L(lib)

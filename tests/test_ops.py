@@ -8,6 +8,7 @@ compared bit-exactly; floating point within the tolerance written in the test.
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as TF
 
 from common import torch_conv_nhwc
 from object_detection_tracking_amd import ops
@@ -733,6 +734,33 @@ def _bottleneck_ref(x, w2, b2, w3, b3, res, dil, relu3):
   if relu3:
     z = z.relu()
   return z.numpy(), mag.numpy()
+
+
+@pytest.mark.parametrize("case", [
+    (1, 75, 93, 3),       # 35 x 44 conv pixels (odd height: the last conv row lies outside every pool window), 17 x 22 pooled: tiles partial in y AND x, three workgroups
+    (2, 53, 61, 2),       # two images, 12 x 14 pooled: 2 x 2 x 2 tiles (partial in y), two workgroups: four tiles each
+    (1, 37, 140, 0),      # one tile row, odd width, one workgroup per tile
+])
+def test_stem_kernel_vs_two_launches_and_f64(backend, case):
+  """conv_stem_kernel (conv0 + ReLU + pool0 in one persistent kernel) at geometries the model never produces -- pooled sizes
+  that are not multiples of the 8 x 7 tile, odd conv maps: BIT-IDENTICAL to conv_h2_kernel + maxpool3x3s2_kernel, and both
+  at the fp16x2 error level against f64."""
+  name, lib = backend
+  B, Hp, Wp, grid = case
+  rng = np.random.default_rng(Hp * 1000 + Wp)
+  x = rng.uniform(-2.2, 2.7, (B, Hp, Wp, 3)).astype(F)         # (the normalised pixel range of build_preprocess)
+  w = (rng.standard_normal((7, 7, 3, 64)) * np.sqrt(2.0 / 147)).astype(F)
+  b = (rng.standard_normal(64) * 0.1).astype(F)
+  got = {f: ops.stem(x, w, b, fuse=f, grid=grid, lib=lib) for f in (False, True)}
+  np.testing.assert_array_equal(got[True], got[False])
+  xt = torch.from_numpy(x.astype(np.float64)).permute(0, 3, 1, 2)
+  wt = torch.from_numpy(w.astype(np.float64)).permute(3, 2, 0, 1)
+  conv = torch.relu(TF.conv2d(xt, wt, torch.from_numpy(b.astype(np.float64)), stride=2))
+  mag = TF.conv2d(xt.abs(), wt.abs(), torch.from_numpy(np.abs(b).astype(np.float64)), stride=2)
+  pool = lambda t: TF.max_pool2d(TF.pad(t, (1, 0, 1, 0)), 3, 2)
+  ref, mg = pool(conv).permute(0, 2, 3, 1).numpy(), pool(mag).permute(0, 2, 3, 1).numpy()
+  assert got[True].shape == ref.shape
+  assert np.all(np.abs(got[True] - ref) <= 4e-6 * mg + 1e-6), float(np.max(np.abs(got[True] - ref) / (mg + 1e-6)))
 
 
 BOTTLENECK_CASES = [
