@@ -15,11 +15,14 @@
 //     PERSISTENT: one per CU, a contiguous range of tiles each (neighbouring tiles share their halo in L2);
 //   * operands swapped (weights as A, pixels as B): lanes along the conv pixels, registers along the channels -- x 2^-s 2^-t_c
 //     + bias, ReLU in registers, 16-byte stores to a [256][64 + 4] f32 tile in LDS (conv pixels outside the map: zeros, which
-//     the post-ReLU maximum ignores like the reference's pad), then each thread takes the maximum of 3 x 3 x 16 bytes and
-//     stores a pooled pixel's 16 bytes.  The conv map never reaches HBM;
+//     the post-ReLU maximum ignores like the reference's pad); each thread then folds 3 x 3 x 16 bytes and stores a pooled
+//     pixel's 16 bytes -- one window element behind each of the NEXT tile's first MFMA steps.  The conv map never reaches HBM;
 //   * the next tile's patch is fetched (12 registers) under the current tile's MFMAs and split into the patch buffer behind
-//     them: two barriers per tile.
-// 149 KB of LDS.  Reference ops: as conv_split.hip, elementwise.hip (maxpool3x3s2_kernel).
+//     them: two barriers per tile;
+//   * MFMA rows take 4 x 4 blocks of conv pixels, not rows of them: the sixteen lanes of a ds_read_b128 group then touch sixteen
+//     different 16-byte slots (row-major pixels: 2.6 LDS cycles per group, the tile's LDS time equalled its MFMA time).
+// 149 KB of LDS, 207 VGPRs.  b = 8 @1080p: 0.37 ms against 0.76 + 0.31 (profiles/r04_stem_fusion_ab.txt).
+// Reference ops: as conv_split.hip, elementwise.hip (maxpool3x3s2_kernel).
 #include "conv_split_epilogue.hpp"
 
 namespace odt {
