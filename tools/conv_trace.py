@@ -10,6 +10,8 @@ shapes = {"conv3": (8, 68, 120, 256, 1024, 1, True), "conv2": (8, 68, 120, 256, 
           "conv1": (8, 68, 120, 1024, 256, 1, False), "short0": (2, 272, 480, 64, 256, 1, False),
           "conv3b1": (1, 68, 120, 256, 1024, 1, True), "conv3b2": (2, 68, 120, 256, 1024, 1, True),
           "conv3nores": (8, 68, 120, 256, 1024, 1, False),
+          "r5conv3": (8, 34, 60, 512, 2048, 1, True), "r5conv1": (8, 34, 60, 2048, 512, 1, False), "r5conv2": (8, 34, 60, 512, 512, 3, False),
+          "lat2": (8, 272, 480, 256, 256, 1, True), "r3conv1": (8, 136, 240, 512, 128, 1, False),
           "e1": (1, 32, 128, 2304, 1024, 1, False), "e2": (1, 64, 128, 2304, 1024, 1, False),
           "e3": (1, 96, 128, 2304, 1024, 1, False), "e4": (1, 128, 128, 2304, 1024, 1, False)}
 for name in sys.argv[1:]:
