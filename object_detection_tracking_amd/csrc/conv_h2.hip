@@ -474,7 +474,7 @@ int launch_conv_h2(const ConvParams& p, const ConvParams* dev, hipStream_t strea
   const int bn = p.wt_split_bn;
   const int bm = p.wt_split_bm;
   ODT_CHECK(((bm == 256 && (bn >= 128 || p.wt_split_kwr)) || (bm == 128 && bn <= 128 && !p.wt_split_kwr) ||
-             (bm == 512 && bn == 64 && (!p.wt_split_kwr || p.Ho * p.Wo >= 512)) || (bm == 64 && bn == 128 && !p.wt_split_kwr)) && (bn == 256 || bn == 128 || bn == 64) && p.Cin % 32 == 0 && p.kh * p.kw <= 32 && p.in_amax != nullptr &&
+             (bm == 512 && bn == 64 && (!p.wt_split_kwr || p.Ho * p.Wo >= 512)) || (bm == 64 && (bn == 128 || bn == 64) && !p.wt_split_kwr)) && (bn == 256 || bn == 128 || bn == 64) && p.Cin % 32 == 0 && p.kh * p.kw <= 32 && p.in_amax != nullptr &&
             p.h2_chinv != nullptr && (p.in2 == nullptr || (p.in2_amax != nullptr && p.Cin2 % 32 == 0)) && p.nlvl <= 1,
             "conv h2: unsupported tile / shape, or no recorded input range");
   const int sk = p.splitk > 1 ? p.splitk : 1;
@@ -492,6 +492,8 @@ int launch_conv_h2(const ConvParams& p, const ConvParams* dev, hipStream_t strea
     launch_conv_h2k(p, dev, grid, stream);
   } else if (p.f_wt != nullptr) {
     ODT_CHECK(false, "conv h2: a fused 1x1 tail needs the kw-reuse kernel");
+  } else if (bm == 64 && bn == 64) {         // ... 64 x 64 tiles: twice the workgroups again (latency-bound reductions at b = 1)
+    hipLaunchKernelGGL((conv_h2_kernel<1, 1, false>), dim3(grid), dim3(128), 0, stream, dev);
   } else if (bm == 64) {                     // few-row layers (b = 1 below res3): 64 x 128 tiles on two waves, three workgroups per CU, no split-K
     hipLaunchKernelGGL((conv_h2_kernel<2, 1, false>), dim3(grid), dim3(128), 0, stream, dev);
   } else if (bn == 64 && bm == 512) {

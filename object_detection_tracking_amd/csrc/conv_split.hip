@@ -100,8 +100,8 @@ ConvPolicy conv_policy_default() {
   q.h2k_splitk = true;    // fp16x2 kw-reuse kernel with split-K for the stride-1 KH x 3 layers of few rows (ODT_CONV_H2K_SPLITK=0: A/B)
   q.fill_div = 6;         // split-K layers are taken when tiles x ranges reach min_tiles3 / fill_div workgroups (b = 1: fc6 / fc7 leave the
                           // exact-f32 kernel: 139.4 -> 144.9 FPS same box, profiles/r04_b1_filldiv_ab.txt; ODT_CONV_SPLIT3_FILLDIV: A/B)
-  q.h2_bm64 = 1;          // fp16x2: 64 x 128 two-wave tiles instead of 128 x 128 + split-K where only those fill the chip: 0 off | 1 for
-                          // reductions up to K = 1024 (no split-K at all) | 2 also the longer ones, cut in two (ODT_CONV_H2_BM64: A/B)
+  q.h2_bm64 = 3;          // fp16x2: 64 x 128 two-wave tiles instead of 128 x 128 + split-K where only those fill the chip: 0 off | 1 for
+                          // reductions up to K = 1024 (no split-K at all) | 2 also the longer ones, cut in two | 3 = 1 on 64 x 64 tiles (ODT_CONV_H2_BM64: A/B)
   q.h2_n64_bm512 = 1;     // fp16x2 kw-reuse kernel on 64-wide layers: 512 x 64 tiles (eight waves stacked along M: 24 MFMAs per wave and
                           // stage instead of 12) where they fill the chip (res2 conv2 1.035 -> 0.897 ms, same box); 0 off, 2 wherever
                           // the shape allows, the generic kernel included (tests)
@@ -247,8 +247,12 @@ void conv_split_choose(ConvParams& p, const ConvPolicy& q) {
         const long t64 = ((M + 63) / 64) * (cout_padded(p.Cout) / 128);
         // (same-box A/B at b = 1, profiles/r04_b1_bm64_ab.txt: res4 conv1, K = 1024: 62.8 -> 44.4 us per layer; the K = 2304
         // 3x3 layers lose without split-K -- 72 serial stages: 81.7 -> 105.8 us -- and take the tiles with the reduction cut in two)
-        if (q.h2_bm64 > 0 && t128 < q.min_tiles3 && t64 >= q.min_tiles3 && q.force_splitk <= 1 && (K <= 1024 || (q.h2_bm64 > 1 && p.in2 == nullptr))) {
+        if (q.h2_bm64 > 0 && t128 < q.min_tiles3 && t64 >= q.min_tiles3 && q.force_splitk <= 1 && (K <= 1024 || (q.h2_bm64 == 2 && p.in2 == nullptr))) {
           p.wt_split_kind = 2; p.wt_split_bm = 64; p.wt_split_bn = 128; p.splitk = K <= 1024 ? 1 : 2; p.wt_split_kwr = 0;
+          // 64 x 64 tiles (conv_h2_kernel<1, 1>: twice the workgroups once more) for the reductions that stay whole: same box, b = 1,
+          // res4 conv1 44.0 -> 41.7 us per layer, 171.6 -> 174.3 FPS (profiles/r04_b1_tiles64_ab.txt; taking 64 x 128 tiles also
+          // where 128 x 128 ones give fewer than four workgroups per CU -- res4 conv3 -- lost: 33 -> 46 us per layer)
+          if (q.h2_bm64 == 3 && K <= 1024) p.wt_split_bn = 64;
           return;
         }
         if (t128 < q.min_tiles3 && q.splitk_max > 1 && p.in2 == nullptr) {

@@ -897,11 +897,12 @@ def test_conv2d_fp16x2_64x128_tile_without_splitk(backend, case, monkeypatch):
   if relu:
     ref = np.maximum(ref, 0)
   out = {}
-  for mode in ("0", "1"):
+  for mode in ("0", "1", "3"):              # (3: 64 x 64 tiles, conv_h2_kernel<1, 1>)
     monkeypatch.setenv("ODT_CONV_H2_BM64", mode)
     out[mode] = ops.conv2d(x, w, b, stride, dil, pt, pl, (Ho, Wo), res=res, res_mode=1, relu=relu, lib=lib)
     np.testing.assert_allclose(out[mode], ref, rtol=1e-4, atol=2e-4)
-  np.testing.assert_allclose(out["0"], out["1"], rtol=0, atol=3e-6 * float(np.abs(ref).max()))
+  for mode in ("1", "3"):
+    np.testing.assert_allclose(out["0"], out[mode], rtol=0, atol=3e-6 * float(np.abs(ref).max()))
 
 
 @pytest.mark.parametrize("case", [
