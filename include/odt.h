@@ -55,7 +55,7 @@ typedef struct odt_config {
   int32_t use_dilations;    /* model version >= 3                             */
   int32_t fpn_channels;     /* fpn_num_channel (256)                          */
   int32_t head_dim;         /* fpn_frcnn_fc_head_dim (1024)                   */
-  int32_t rpn_topk;         /* rpn_test_post_nms_topk (<= 1024)               */
+  int32_t rpn_topk;         /* rpn_test_post_nms_topk (<= 4096; script default 1000) */
   int32_t result_per_im;    /* 100                                            */
   int32_t anchor_field;     /* ceil(max_size/stride0): side of level-0 anchor grid */
   float rpn_nms_thresh;     /* rpn_proposal_nms_thres (0.7)                   */

@@ -63,9 +63,9 @@ def make_config(**overrides):
   c.tracking_objs = "Person,Vehicle"
   c.frame_gap = 8
   c.conv_arith = None             # None / "default": split arithmetic where it pays | "f32": exact-f32 MFMA everywhere | "bf16x3"
-  c.conv_split_family = 0         # 0 library default (2: fp16x2 kernels where eligible, bf16x3 elsewhere) | 3: bf16x3 only | 1
-                                  # | "auto": fp16x2, checked on the first forward(s) against a bf16x3-only twin handle; stays on
-                                  # bf16x3 when the pyramid / RPN tensors differ by more than conv_split_auto_tol (models._Engine)
+  c.conv_split_family = "auto"    # "auto" (default): fp16x2 kernels, checked on the first forward(s) against a bf16x3-only twin handle;
+                                  # the engine stays on bf16x3 when the pyramid / RPN tensors differ by more than conv_split_auto_tol
+                                  # (models._Engine) | 0 / 2: fp16x2 kernels where eligible, UNGUARDED | 3: bf16x3 only | 1
   c.conv_split_auto_frames = 1    # "auto": forwards that are checked
   c.conv_split_auto_tol = 2e-5    # "auto": largest |difference| / |max| of a pyramid / RPN tensor that counts as f32 rounding
   c.keep_taps = False             # True: dedicated buffers for every stage tensor (engine.tap() of backbone stages; ~5x the activation memory)

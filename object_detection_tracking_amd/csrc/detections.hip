@@ -94,6 +94,52 @@ __global__ void __launch_bounds__(kSelThreads) class_nms_kernel(DetectParams p) 
   if (tid == 0) p.cls_count[b * Cm1 + c] = nk;
 }
 
+// K > 1024 (select_device.hpp: paneled walk): the same candidates in the same order, any number of RoIs up to kMaxTopKBig
+struct ClassBoxAt {
+  const float* dec;      // dec_boxes of this image, class c: row stride Cm1 * 4
+  const int* roi;        // LDS: candidate position -> RoI
+  int stride;
+  __device__ __forceinline__ void operator()(int i, float* out) const {
+    const float* src = dec + (size_t)roi[i] * stride;
+    out[0] = src[0]; out[1] = src[1]; out[2] = src[2]; out[3] = src[3];
+  }
+};
+__global__ void __launch_bounds__(kSelThreads) class_nms_big_kernel(DetectParams p) {
+  __shared__ __attribute__((aligned(16))) char raw[sizeof(NmsBigScratch)];
+  __shared__ int s_roi[kMaxTopKBig];
+  __shared__ int s_ncand;
+  NmsBigScratch& s = *reinterpret_cast<NmsBigScratch*>(raw);
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(s.kbox);     // dead before the walk keeps its first box
+  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int n = p.nprops[b];
+  const int Cm1 = p.C - 1;
+  if (tid == 0) s_ncand = 0;
+  __syncthreads();
+  for (int t = tid; t < n; t += blockDim.x) {
+    const float prob = p.probs[((size_t)b * p.K + t) * p.C + c + 1];
+    const int cand = (p.graph == 0) ? (prob > p.score_thresh) : 1;
+    keys[t] = cand ? make_key64(prob, (unsigned)t) : 0ull;       // real keys are > 0 (inverted index in the low word)
+    if (cand) atomicAdd(&s_ncand, 1);
+  }
+  __syncthreads();
+  // candidates by (prob desc, roi asc)
+  for (int t = tid; t < n; t += blockDim.x) {
+    const unsigned long long my = keys[t];
+    if (my == 0ull) continue;
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += keys[j] > my ? 1 : 0;
+    s_roi[rank] = t;
+  }
+  __syncthreads();
+  const int ncand = s_ncand;
+  block_nms_paneled(ncand, p.per_im, p.nms_thresh,
+                    ClassBoxAt{p.dec_boxes + ((size_t)b * p.K * Cm1 + c) * 4, s_roi, Cm1 * 4}, s);
+  const int nk = s.nkeep;
+  int* out = p.cls_keep + ((size_t)b * Cm1 + c) * p.per_im;
+  for (int i = tid; i < nk; i += blockDim.x) out[i] = s_roi[s.keep[i]];
+  if (tid == 0) p.cls_count[b * Cm1 + c] = nk;
+}
+
 // ---- final selection: top result_per_im over the union (models.py:1288-1301 / :2959-2973) ----
 constexpr int kMaxFinal = 4096;
 __global__ void __launch_bounds__(kSelThreads) final_select_kernel(DetectParams p) {
@@ -186,22 +232,28 @@ __global__ void __launch_bounds__(kSelThreads) final_select_kernel(DetectParams 
 // the kernels behind tf.image.combined_non_max_suppression / nms_return_masks + fastrcnn_predictions, for tests that
 // feed them known-answer vectors (p.probs [B*K, C] with column 0 unused, p.dec_boxes [B*K, C-1, 4] filled)
 int launch_class_nms(const DetectParams& p, hipStream_t stream) {
-  ODT_CHECK(p.K >= 1 && p.K <= kMaxTopK, "class_nms: K must be in [1,1024]");
+  ODT_CHECK(p.K >= 1 && p.K <= kMaxTopKBig, "class_nms: K must be in [1,4096]");
   ODT_CHECK(p.C >= 2 && p.C <= 64, "class_nms: 2..64 classes");
   ODT_CHECK((p.C - 1) * p.per_im <= kMaxFinal, "class_nms: (C-1)*result_per_im too large");
-  hipLaunchKernelGGL(class_nms_kernel, dim3(p.C - 1, p.B), dim3(kSelThreads), 0, stream, p);
+  if (p.K <= kMaxTopK)
+    hipLaunchKernelGGL(class_nms_kernel, dim3(p.C - 1, p.B), dim3(kSelThreads), 0, stream, p);
+  else
+    hipLaunchKernelGGL(class_nms_big_kernel, dim3(p.C - 1, p.B), dim3(kSelThreads), 0, stream, p);
   hipLaunchKernelGGL(final_select_kernel, dim3(p.B), dim3(kSelThreads), 0, stream, p);
   ODT_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_detections(const DetectParams& p, hipStream_t stream) {
-  ODT_CHECK(p.K >= 1 && p.K <= kMaxTopK, "detections: K must be in [1,1024]");
+  ODT_CHECK(p.K >= 1 && p.K <= kMaxTopKBig, "detections: K must be in [1,4096]");
   ODT_CHECK(p.C >= 2 && p.C <= 64, "detections: 2..64 classes");
   ODT_CHECK((p.C - 1) * p.per_im <= kMaxFinal, "detections: (C-1)*result_per_im too large");
   const int rows = p.B * p.K;
   hipLaunchKernelGGL(head_post_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, p);
-  hipLaunchKernelGGL(class_nms_kernel, dim3(p.C - 1, p.B), dim3(kSelThreads), 0, stream, p);
+  if (p.K <= kMaxTopK)
+    hipLaunchKernelGGL(class_nms_kernel, dim3(p.C - 1, p.B), dim3(kSelThreads), 0, stream, p);
+  else
+    hipLaunchKernelGGL(class_nms_big_kernel, dim3(p.C - 1, p.B), dim3(kSelThreads), 0, stream, p);
   hipLaunchKernelGGL(final_select_kernel, dim3(p.B), dim3(kSelThreads), 0, stream, p);
   ODT_HIP(hipGetLastError());
   return 0;

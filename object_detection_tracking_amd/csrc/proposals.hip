@@ -7,7 +7,9 @@
 //                     area > 0 filter (reference nn.py:1406-1482, models.py:2458-2522)
 //
 // One 1024-thread workgroup per (image, level) for select + decode, one for NMS, one per image
-// for the merge; everything stays in LDS, counts stay on the device (no host sync).
+// for the merge; everything stays in LDS, counts stay on the device (no host sync).  K <= 1024 (every
+// configuration the reference ships; the script default is 1000) takes the one-candidate-per-thread
+// kernels; 1024 < K <= 4096 the same kernels in rounds of 1024 with the paneled NMS walk.
 #include "odt_common.hpp"
 #include "select_device.hpp"
 
@@ -42,8 +44,9 @@ struct RpnChunkKeyAt {
     return make_key64(base[(size_t)pix * kRpnCh + a], (unsigned)g);
   }
 };
+template <class Scratch>
 __global__ void __launch_bounds__(kSelThreads) rpn_chunk_topk_kernel(ProposalParams p, int total_chunks) {
-  __shared__ TopkScratch s;
+  __shared__ Scratch s;
   const int chunk = blockIdx.x, b = blockIdx.y;
   const ChunkMap cm = chunk_of(p, chunk);
   const RpnLevel lv = p.lvl[cm.level];
@@ -60,8 +63,10 @@ struct CandKeyAt {
 };
 
 // ---- stage A2: merge the chunk winners, decode, clip, (min-size filter), ordered compaction ---
+// (K <= 1024: one round, one candidate per thread; the *_big instantiation walks k in rounds of 1024)
+template <class Scratch>
 __global__ void __launch_bounds__(kSelThreads) rpn_select_kernel(ProposalParams p, int total_chunks) {
-  __shared__ TopkScratch s;
+  __shared__ Scratch s;
   const int l = blockIdx.x, b = blockIdx.y;
   const RpnLevel lv = p.lvl[l];
   const int n = lv.h * lv.w * 3;
@@ -74,42 +79,47 @@ __global__ void __launch_bounds__(kSelThreads) rpn_select_kernel(ProposalParams 
   block_topk_keys(ka, nc * p.K, k, s);
   const float* base = lv.rpn + (size_t)b * lv.h * lv.w * kRpnCh;
 
-  const int tid = threadIdx.x;
-  float bx[4] = {0.f, 0.f, 0.f, 0.f};
-  float score = 0.f;
-  int valid = 0;
-  if (tid < k) {
-    const unsigned long long key = s.keys_b[tid];
-    const int e = (int)key64_index(key);
-    const int pix = e / 3, a = e - pix * 3;
-    const int y = pix / lv.w, x = pix - y * lv.w;
-    const float* d = base + (size_t)pix * kRpnCh + 3 + a * 4;
-    const float* an = lv.anchors + ((size_t)(y * lv.field + x) * 3 + a) * 4;
-    score = base[(size_t)pix * kRpnCh + a];
-    // decode_bbox_target (nn.py:1518-1538), fp32, same operand order as the oracle
-    const float wa = an[2] - an[0], ha = an[3] - an[1];
-    const float xa = (an[2] + an[0]) * 0.5f, ya = (an[3] + an[1]) * 0.5f;
-    const float wb = expf(fminf(d[2], p.decode_clip)) * wa;
-    const float hb = expf(fminf(d[3], p.decode_clip)) * ha;
-    const float xb = d[0] * wa + xa, yb = d[1] * ha + ya;
-    const float fw = (float)p.img_w, fh = (float)p.img_h;
-    // clip_boxes (nn.py:1339-1346)
-    bx[0] = fminf(fmaxf(xb - wb * 0.5f, 0.f), fw);
-    bx[1] = fminf(fmaxf(yb - hb * 0.5f, 0.f), fh);
-    bx[2] = fminf(fmaxf(xb + wb * 0.5f, 0.f), fw);
-    bx[3] = fminf(fmaxf(yb + hb * 0.5f, 0.f), fh);
-    // rpn_min_size = 0 with strict > (nn.py:1377-1378); the multibatch graph has no filter
-    valid = (p.graph == 0) ? ((bx[2] - bx[0] > 0.f) && (bx[3] - bx[1] > 0.f)) : 1;
-  }
-  int total;
-  const int pos = block_scan_excl(valid, s.wave_tmp, &total);
   const size_t o = ((size_t)b * p.nlevels + l) * p.K;
-  if (valid) {
-    float* cb = p.cand_boxes + (o + pos) * 4;
-    cb[0] = bx[0]; cb[1] = bx[1]; cb[2] = bx[2]; cb[3] = bx[3];
-    p.cand_scores[o + pos] = score;
+  int run = 0;
+  for (int r0 = 0; r0 < k; r0 += kSelThreads) {
+    const int tid = r0 + (int)threadIdx.x;
+    float bx[4] = {0.f, 0.f, 0.f, 0.f};
+    float score = 0.f;
+    int valid = 0;
+    if (tid < k) {
+      const unsigned long long key = s.keys_b[tid];
+      const int e = (int)key64_index(key);
+      const int pix = e / 3, a = e - pix * 3;
+      const int y = pix / lv.w, x = pix - y * lv.w;
+      const float* d = base + (size_t)pix * kRpnCh + 3 + a * 4;
+      const float* an = lv.anchors + ((size_t)(y * lv.field + x) * 3 + a) * 4;
+      score = base[(size_t)pix * kRpnCh + a];
+      // decode_bbox_target (nn.py:1518-1538), fp32, same operand order as the oracle
+      const float wa = an[2] - an[0], ha = an[3] - an[1];
+      const float xa = (an[2] + an[0]) * 0.5f, ya = (an[3] + an[1]) * 0.5f;
+      const float wb = expf(fminf(d[2], p.decode_clip)) * wa;
+      const float hb = expf(fminf(d[3], p.decode_clip)) * ha;
+      const float xb = d[0] * wa + xa, yb = d[1] * ha + ya;
+      const float fw = (float)p.img_w, fh = (float)p.img_h;
+      // clip_boxes (nn.py:1339-1346)
+      bx[0] = fminf(fmaxf(xb - wb * 0.5f, 0.f), fw);
+      bx[1] = fminf(fmaxf(yb - hb * 0.5f, 0.f), fh);
+      bx[2] = fminf(fmaxf(xb + wb * 0.5f, 0.f), fw);
+      bx[3] = fminf(fmaxf(yb + hb * 0.5f, 0.f), fh);
+      // rpn_min_size = 0 with strict > (nn.py:1377-1378); the multibatch graph has no filter
+      valid = (p.graph == 0) ? ((bx[2] - bx[0] > 0.f) && (bx[3] - bx[1] > 0.f)) : 1;
+    }
+    int total;
+    const int pos = run + block_scan_excl(valid, s.wave_tmp, &total);
+    if (valid) {
+      float* cb = p.cand_boxes + (o + pos) * 4;
+      cb[0] = bx[0]; cb[1] = bx[1]; cb[2] = bx[2]; cb[3] = bx[3];
+      p.cand_scores[o + pos] = score;
+    }
+    run += total;
+    __syncthreads();               // wave_tmp is reused by the next round's scan
   }
-  if (tid == 0) p.cand_count[b * p.nlevels + l] = total;
+  if (threadIdx.x == 0) p.cand_count[b * p.nlevels + l] = run;
 }
 
 // ---- stage B: NMS per (image, level) ----------------------------------------------------
@@ -125,6 +135,31 @@ __global__ void __launch_bounds__(kSelThreads) rpn_nms_kernel(ProposalParams p) 
   for (int i = tid; i < nk; i += blockDim.x) {
     const int c = s.keep[i];
     const float* src = p.cand_boxes + (o + c) * 4;   // un-normalised original corners
+    float* dst = p.lvl_boxes + (o + i) * 4;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+    p.lvl_scores[o + i] = p.cand_scores[o + c];
+  }
+  if (tid == 0) p.lvl_count[b * p.nlevels + l] = nk;
+}
+
+// K > 1024: the same selection through the paneled walk (select_device.hpp); boxes are read from the workspace
+struct CandBoxAt {
+  const float* boxes;
+  __device__ __forceinline__ void operator()(int i, float* out) const {
+    out[0] = boxes[i * 4 + 0]; out[1] = boxes[i * 4 + 1]; out[2] = boxes[i * 4 + 2]; out[3] = boxes[i * 4 + 3];
+  }
+};
+__global__ void __launch_bounds__(kSelThreads) rpn_nms_big_kernel(ProposalParams p) {
+  __shared__ __attribute__((aligned(16))) char raw[sizeof(NmsBigScratch)];
+  NmsBigScratch& s = *reinterpret_cast<NmsBigScratch*>(raw);
+  const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const size_t o = ((size_t)b * p.nlevels + l) * p.K;
+  const int n = p.cand_count[b * p.nlevels + l];
+  block_nms_paneled(n, p.K, p.nms_thresh, CandBoxAt{p.cand_boxes + o * 4}, s);
+  const int nk = s.nkeep;
+  for (int i = tid; i < nk; i += blockDim.x) {
+    const int c = s.keep[i];
+    const float* src = p.cand_boxes + (o + c) * 4;
     float* dst = p.lvl_boxes + (o + i) * 4;
     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
     p.lvl_scores[o + i] = p.cand_scores[o + c];
@@ -168,8 +203,9 @@ __device__ __forceinline__ int count_greater(const MergeLists& m, int L, float s
   return total;
 }
 
+template <int CAP>
 __global__ void __launch_bounds__(kSelThreads) rpn_merge_kernel(ProposalParams p) {
-  __shared__ float s_box[kMaxTopK * 4];
+  __shared__ float s_box[CAP * 4];
   __shared__ int s_wave[kSelWaves + 1];
   const int b = blockIdx.x, tid = threadIdx.x, L = p.nlevels, K = p.K;
   MergeLists m;
@@ -201,24 +237,30 @@ __global__ void __launch_bounds__(kSelThreads) rpn_merge_kernel(ProposalParams p
   }
   __syncthreads();
   // multibatch graph: drop zero-area rows (padding) keeping order (models.py:2517-2520)
-  int keepf = 0;
-  float bx[4] = {0.f, 0.f, 0.f, 0.f};
-  if (tid < k) {
-    bx[0] = s_box[tid * 4 + 0]; bx[1] = s_box[tid * 4 + 1];
-    bx[2] = s_box[tid * 4 + 2]; bx[3] = s_box[tid * 4 + 3];
-    keepf = (p.graph == 1) ? (((bx[3] - bx[1]) * (bx[2] - bx[0])) > 0.f) : 1;
-  }
-  int total;
-  const int pos = block_scan_excl(keepf, s_wave, &total);
   float* out = p.props + (size_t)b * K * 4;
-  if (keepf) {
-    out[pos * 4 + 0] = bx[0]; out[pos * 4 + 1] = bx[1];
-    out[pos * 4 + 2] = bx[2]; out[pos * 4 + 3] = bx[3];
+  int run = 0;
+  for (int r0 = 0; r0 < k; r0 += kSelThreads) {          // (one round for K <= 1024)
+    const int t = r0 + tid;
+    int keepf = 0;
+    float bx[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t < k) {
+      bx[0] = s_box[t * 4 + 0]; bx[1] = s_box[t * 4 + 1];
+      bx[2] = s_box[t * 4 + 2]; bx[3] = s_box[t * 4 + 3];
+      keepf = (p.graph == 1) ? (((bx[3] - bx[1]) * (bx[2] - bx[0])) > 0.f) : 1;
+    }
+    int total;
+    const int pos = run + block_scan_excl(keepf, s_wave, &total);
+    if (keepf) {
+      out[pos * 4 + 0] = bx[0]; out[pos * 4 + 1] = bx[1];
+      out[pos * 4 + 2] = bx[2]; out[pos * 4 + 3] = bx[3];
+    }
+    run += total;
+    __syncthreads();
   }
-  for (int i = total + tid; i < K; i += blockDim.x) {   // deterministic tail
+  for (int i = run + tid; i < K; i += blockDim.x) {   // deterministic tail
     out[i * 4 + 0] = 0.f; out[i * 4 + 1] = 0.f; out[i * 4 + 2] = 0.f; out[i * 4 + 3] = 0.f;
   }
-  if (tid == 0) p.nprops[b] = total;
+  if (tid == 0) p.nprops[b] = run;
 }
 
 // ---- stand-alone top-k / NMS (parity entry points) ---------------------------------------
@@ -226,9 +268,10 @@ struct PlainScoreAt {
   const float* base;
   __device__ __forceinline__ float operator()(int e) const { return base[e]; }
 };
+template <class Scratch>
 __global__ void __launch_bounds__(kSelThreads) topk_kernel(const float* scores, int n, int k,
                                                            int* idx_out) {
-  __shared__ TopkScratch s;
+  __shared__ Scratch s;
   PlainScoreAt sc{scores};
   block_topk(sc, n, k, s);
   for (int t = threadIdx.x; t < k; t += blockDim.x) idx_out[t] = (int)key64_index(s.keys_b[t]);
@@ -266,6 +309,39 @@ __global__ void __launch_bounds__(kSelThreads) nms_kernel(const float* boxes, co
   if (tid == 0) *n_out = nk;
 }
 
+
+// n > 1024 candidates: rank sort into global-order indices, then the paneled walk
+struct OrderedBoxAt {
+  const float* boxes;
+  const int* order;
+  __device__ __forceinline__ void operator()(int i, float* out) const {
+    const int src = order[i];
+    out[0] = boxes[src * 4 + 0]; out[1] = boxes[src * 4 + 1]; out[2] = boxes[src * 4 + 2]; out[3] = boxes[src * 4 + 3];
+  }
+};
+__global__ void __launch_bounds__(kSelThreads) nms_big_kernel(const float* boxes, const float* scores,
+                                                              int n, int max_out, float thresh,
+                                                              int* idx_out, int* n_out) {
+  __shared__ __attribute__((aligned(16))) char raw[sizeof(NmsBigScratch)];
+  __shared__ int s_orig[kMaxTopKBig];
+  NmsBigScratch& s = *reinterpret_cast<NmsBigScratch*>(raw);
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(s.kbox);     // 32 KiB of the 64: dead before the walk
+  const int tid = threadIdx.x;
+  for (int t = tid; t < n; t += blockDim.x) keys[t] = make_key64(scores[t], (unsigned)t);
+  __syncthreads();
+  for (int t = tid; t < n; t += blockDim.x) {
+    const unsigned long long my = keys[t];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += keys[j] > my ? 1 : 0;
+    s_orig[rank] = t;
+  }
+  __syncthreads();
+  block_nms_paneled(n, max_out, thresh, OrderedBoxAt{boxes, s_orig}, s);
+  const int nk = s.nkeep;
+  for (int i = tid; i < nk; i += blockDim.x) idx_out[i] = s_orig[s.keep[i]];
+  if (tid == 0) *n_out = nk;
+}
+
 }  // namespace
 
 int proposal_total_chunks(const ProposalParams& p) {
@@ -280,30 +356,44 @@ size_t proposal_workspace_bytes(int B, int L, int K) {
 }
 
 int launch_proposals(const ProposalParams& p, hipStream_t stream) {
-  ODT_CHECK(p.K >= 1 && p.K <= kMaxTopK, "proposals: rpn_test_post_nms_topk must be in [1,1024]");
+  ODT_CHECK(p.K >= 1 && p.K <= kMaxTopKBig, "proposals: rpn_test_post_nms_topk must be in [1,4096]");
   ODT_CHECK(p.nlevels >= 1 && p.nlevels <= 5, "proposals: 1..5 levels");
   const int tc = proposal_total_chunks(p);
   ODT_CHECK(p.chunk_keys != nullptr, "proposals: chunk_keys workspace missing");
-  hipLaunchKernelGGL(rpn_chunk_topk_kernel, dim3(tc, p.B), dim3(kSelThreads), 0, stream, p, tc);
-  hipLaunchKernelGGL(rpn_select_kernel, dim3(p.nlevels, p.B), dim3(kSelThreads), 0, stream, p, tc);
-  hipLaunchKernelGGL(rpn_nms_kernel, dim3(p.nlevels, p.B), dim3(kSelThreads), 0, stream, p);
-  hipLaunchKernelGGL(rpn_merge_kernel, dim3(p.B), dim3(kSelThreads), 0, stream, p);
+  if (p.K <= kMaxTopK) {
+    hipLaunchKernelGGL(rpn_chunk_topk_kernel<TopkScratch>, dim3(tc, p.B), dim3(kSelThreads), 0, stream, p, tc);
+    hipLaunchKernelGGL(rpn_select_kernel<TopkScratch>, dim3(p.nlevels, p.B), dim3(kSelThreads), 0, stream, p, tc);
+    hipLaunchKernelGGL(rpn_nms_kernel, dim3(p.nlevels, p.B), dim3(kSelThreads), 0, stream, p);
+    hipLaunchKernelGGL(rpn_merge_kernel<kMaxTopK>, dim3(p.B), dim3(kSelThreads), 0, stream, p);
+  } else {            // the script accepts any --rpn_test_post_nms_topk (reference obj_detect_tracking.py:132)
+    hipLaunchKernelGGL(rpn_chunk_topk_kernel<TopkScratchBig>, dim3(tc, p.B), dim3(kSelThreads), 0, stream, p, tc);
+    hipLaunchKernelGGL(rpn_select_kernel<TopkScratchBig>, dim3(p.nlevels, p.B), dim3(kSelThreads), 0, stream, p, tc);
+    hipLaunchKernelGGL(rpn_nms_big_kernel, dim3(p.nlevels, p.B), dim3(kSelThreads), 0, stream, p);
+    hipLaunchKernelGGL(rpn_merge_kernel<kMaxTopKBig>, dim3(p.B), dim3(kSelThreads), 0, stream, p);
+  }
   ODT_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_topk(const float* scores, int n, int k, int* idx_out, hipStream_t stream) {
-  ODT_CHECK(k >= 1 && k <= kMaxTopK && k <= n, "topk: need 1 <= k <= min(n,1024)");
-  hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(kSelThreads), 0, stream, scores, n, k, idx_out);
+  ODT_CHECK(k >= 1 && k <= kMaxTopKBig && k <= n, "topk: need 1 <= k <= min(n,4096)");
+  if (k <= kMaxTopK)
+    hipLaunchKernelGGL(topk_kernel<TopkScratch>, dim3(1), dim3(kSelThreads), 0, stream, scores, n, k, idx_out);
+  else
+    hipLaunchKernelGGL(topk_kernel<TopkScratchBig>, dim3(1), dim3(kSelThreads), 0, stream, scores, n, k, idx_out);
   ODT_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_nms(const float* boxes, const float* scores, int n, int max_out, float thresh,
                int* idx_out, int* n_out, hipStream_t stream) {
-  ODT_CHECK(n >= 0 && n <= kMaxTopK, "nms: at most 1024 candidates");
-  hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(kSelThreads), 0, stream, boxes, scores, n, max_out,
-                     thresh, idx_out, n_out);
+  ODT_CHECK(n >= 0 && n <= kMaxTopKBig, "nms: at most 4096 candidates");
+  if (n <= kMaxTopK)
+    hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(kSelThreads), 0, stream, boxes, scores, n, max_out,
+                       thresh, idx_out, n_out);
+  else
+    hipLaunchKernelGGL(nms_big_kernel, dim3(1), dim3(kSelThreads), 0, stream, boxes, scores, n, max_out,
+                       thresh, idx_out, n_out);
   ODT_HIP(hipGetLastError());
   return 0;
 }

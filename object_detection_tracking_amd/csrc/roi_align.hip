@@ -4,9 +4,10 @@
 //
 // Restates reference models.py:439-485 (fpn_map_rois_to_levels, multilevel_roi_align),
 // nn.py:1229-1335 (crop_and_resize, roi_align[_multi]) and deep_sort/utils.py:27-28 (mean).
-// Feature maps are NHWC, so each bilinear tap is one coalesced C*4-byte row read; one thread
-// per channel, one workgroup per (RoI, output row).  fp32, operand order of TF-1.15
-// crop_and_resize_op.cc (see oracle/tfops.py); built with -ffp-contract=off.
+// Feature maps are NHWC, so each bilinear tap is one coalesced 256-byte row read; one thread
+// per channel, one workgroup per (RoI, 64 channels), the NCHW output and the mean through an LDS
+// tile.  fp32, operand order of TF-1.15 crop_and_resize_op.cc (see oracle/tfops.py); built with
+// -ffp-contract=off.
 #include "odt_common.hpp"
 
 namespace odt {
@@ -22,9 +23,20 @@ __device__ __forceinline__ int fpn_level_of(float x0, float y0, float x1, float 
   return (int)lv - 2;
 }
 
+// One workgroup per (RoI, block of 64 channels): 64 channels x 4 groups of output rows.  Every output value also goes
+// to an LDS tile [64][OUT*OUT (+1)], so that
+//   * fpn_box_feat (NCHW: this RoI's [64][OUT][OUT] block is contiguous) leaves as whole coalesced rows instead of one
+//     4-byte store per lane at a stride of 49 floats, and
+//   * the 7x7 mean (deep_sort/utils.py:27-28) is summed from the tile in the order of np.mean over (h, w) of the row-major
+//     window -- the order the former second pass (roi_pool_mean_kernel over the NCHW tensor) used: bit-identical `pooled`,
+//     without re-reading the tensor this kernel has just written and without its launch.
+constexpr int kRoiCB = 64;                              // channels per workgroup
 template <int OUT>
 __global__ void __launch_bounds__(256) roi_align_kernel(RoiAlignParams p, int B) {
-  const int r = blockIdx.x, oy = blockIdx.y;
+  constexpr int OO = OUT * OUT;
+  constexpr int LDP = (OO & 1) ? OO : OO + 1;           // odd row pitch: lanes (channels) fall on distinct banks
+  __shared__ float tile[kRoiCB * LDP];
+  const int r = blockIdx.x, cb = blockIdx.y * kRoiCB;
   int b, out_row = r;
   if (p.box_ind != nullptr) {
     b = p.box_ind[r];
@@ -67,69 +79,66 @@ __global__ void __launch_bounds__(256) roi_align_kernel(RoiAlignParams p, int B)
   // crop_and_resize_op.cc
   const float hs = (by2 - by1) * fH1 / (float)(CS - 1);
   const float ws = (bx2 - bx1) * fW1 / (float)(CS - 1);
-  float yl[2];
-  int top[2], bot[2];
-  bool vy[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const float in_y = by1 * fH1 + (float)(2 * oy + q) * hs;
-    vy[q] = !(in_y < 0.f || in_y > fH1);
-    const float iy = vy[q] ? in_y : 0.f;
-    top[q] = (int)floorf(iy);
-    bot[q] = (int)ceilf(iy);
-    yl[q] = iy - (float)top[q];
-  }
   const float* feat = fbase + (size_t)b * ah * aw * ldc;
-  for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
-    for (int ox = 0; ox < OUT; ++ox) {
-      float v[2][2];
+  const int cl = threadIdx.x & (kRoiCB - 1), c = cb + cl;
+  const int nch = p.C - cb < kRoiCB ? p.C - cb : kRoiCB;        // channels of this block
+  const bool stage = p.out_nchw != nullptr || p.pooled != nullptr;
+  if (cl < nch) {
+    for (int oy = threadIdx.x / kRoiCB; oy < OUT; oy += 256 / kRoiCB) {
+      float yl[2];
+      int top[2], bot[2];
+      bool vy[2];
 #pragma unroll
-      for (int qx = 0; qx < 2; ++qx) {
-        const float in_x = bx1 * fW1 + (float)(2 * ox + qx) * ws;
-        const bool vx = !(in_x < 0.f || in_x > fW1);
-        const float ix = vx ? in_x : 0.f;
-        const int lef = (int)floorf(ix), rig = (int)ceilf(ix);
-        const float xl = ix - (float)lef;
-#pragma unroll
-        for (int qy = 0; qy < 2; ++qy) {
-          float val = 0.f;
-          if (vx && vy[qy]) {
-            const float tl = feat[((size_t)top[qy] * aw + lef) * ldc + c];
-            const float tr = feat[((size_t)top[qy] * aw + rig) * ldc + c];
-            const float bl = feat[((size_t)bot[qy] * aw + lef) * ldc + c];
-            const float br = feat[((size_t)bot[qy] * aw + rig) * ldc + c];
-            const float t = tl + (tr - tl) * xl;
-            const float bm = bl + (br - bl) * xl;
-            val = t + (bm - t) * yl[qy];
-          }
-          v[qy][qx] = val;
-        }
+      for (int q = 0; q < 2; ++q) {
+        const float in_y = by1 * fH1 + (float)(2 * oy + q) * hs;
+        vy[q] = !(in_y < 0.f || in_y > fH1);
+        const float iy = vy[q] ? in_y : 0.f;
+        top[q] = (int)floorf(iy);
+        bot[q] = (int)ceilf(iy);
+        yl[q] = iy - (float)top[q];
       }
-      // 2x2 average pool (nn.py:1332): ((v00 + v01) + v10) + v11, * 0.25
-      const float o = (((v[0][0] + v[0][1]) + v[1][0]) + v[1][1]) * 0.25f;
-      if (p.out_nhwc) p.out_nhwc[(((size_t)out_row * OUT + oy) * OUT + ox) * p.C + c] = o;
-      if (p.out_nchw) p.out_nchw[(((size_t)out_row * p.C + c) * OUT + oy) * OUT + ox] = o;
+      for (int ox = 0; ox < OUT; ++ox) {
+        float v[2][2];
+#pragma unroll
+        for (int qx = 0; qx < 2; ++qx) {
+          const float in_x = bx1 * fW1 + (float)(2 * ox + qx) * ws;
+          const bool vx = !(in_x < 0.f || in_x > fW1);
+          const float ix = vx ? in_x : 0.f;
+          const int lef = (int)floorf(ix), rig = (int)ceilf(ix);
+          const float xl = ix - (float)lef;
+#pragma unroll
+          for (int qy = 0; qy < 2; ++qy) {
+            float val = 0.f;
+            if (vx && vy[qy]) {
+              const float tl = feat[((size_t)top[qy] * aw + lef) * ldc + c];
+              const float tr = feat[((size_t)top[qy] * aw + rig) * ldc + c];
+              const float bl = feat[((size_t)bot[qy] * aw + lef) * ldc + c];
+              const float br = feat[((size_t)bot[qy] * aw + rig) * ldc + c];
+              const float t = tl + (tr - tl) * xl;
+              const float bm = bl + (br - bl) * xl;
+              val = t + (bm - t) * yl[qy];
+            }
+            v[qy][qx] = val;
+          }
+        }
+        // 2x2 average pool (nn.py:1332): ((v00 + v01) + v10) + v11, * 0.25
+        const float o = (((v[0][0] + v[0][1]) + v[1][0]) + v[1][1]) * 0.25f;
+        if (p.out_nhwc) p.out_nhwc[(((size_t)out_row * OUT + oy) * OUT + ox) * p.C + c] = o;
+        if (stage) tile[cl * LDP + oy * OUT + ox] = o;
+      }
     }
   }
-}
-
-// mean over the 7x7 window (deep_sort/utils.py:27-28 np.mean(feat, axis=(1,2)))
-__global__ void __launch_bounds__(256) roi_pool_mean_kernel(const float* nchw, int rows_cap,
-                                                            const int* count, int per_image, int B,
-                                                            int C, float* pooled) {
-  int rows = rows_cap;
-  if (count != nullptr) {
-    rows = 0;
-    for (int q = 0; q < B; ++q) rows += count[q];
+  if (!stage) return;
+  __syncthreads();
+  if (p.out_nchw) {
+    float* dst = p.out_nchw + ((size_t)out_row * p.C + cb) * OO;          // [nch][OUT][OUT], contiguous
+    for (int i = threadIdx.x; i < nch * OO; i += 256) dst[i] = tile[(i / OO) * LDP + i % OO];
   }
-  (void)per_image;
-  const long total = (long)rows * C;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
-    const float* src = nchw + i * (kRoiOut * kRoiOut);
+  if (p.pooled && threadIdx.x < nch) {
+    // np.mean(feat, axis=(1, 2)) of the row-major window: sequential sum, then / 49
     float s = 0.f;
-    for (int q = 0; q < kRoiOut * kRoiOut; ++q) s += src[q];
-    pooled[i] = s / (float)(kRoiOut * kRoiOut);
+    for (int q = 0; q < OO; ++q) s += tile[threadIdx.x * LDP + q];
+    p.pooled[(size_t)out_row * p.C + cb + threadIdx.x] = s / (float)OO;
   }
 }
 
@@ -137,22 +146,15 @@ __global__ void __launch_bounds__(256) roi_pool_mean_kernel(const float* nchw, i
 
 int launch_roi_align(const RoiAlignParams& p, hipStream_t stream) {
   ODT_CHECK(p.R_cap > 0, "roi_align: no rows");
-  ODT_CHECK(p.pooled == nullptr || p.out_nchw != nullptr, "roi_align: pooled needs out_nchw");
   const int B = (p.box_ind == nullptr && p.per_image > 0) ? p.R_cap / p.per_image : 0;
   const int out = p.out_size == 0 ? kRoiOut : p.out_size;
   ODT_CHECK(out == kRoiOut || out == 2 * kRoiOut, "roi_align: output side must be 7 or 14");
   ODT_CHECK(out == kRoiOut || p.pooled == nullptr, "roi_align: pooled features are 7x7 only");
+  const dim3 grid(p.R_cap, (p.C + kRoiCB - 1) / kRoiCB);
   if (out == kRoiOut)
-    hipLaunchKernelGGL(roi_align_kernel<kRoiOut>, dim3(p.R_cap, kRoiOut), dim3(256), 0, stream, p, B);
+    hipLaunchKernelGGL(roi_align_kernel<kRoiOut>, grid, dim3(256), 0, stream, p, B);
   else
-    hipLaunchKernelGGL(roi_align_kernel<2 * kRoiOut>, dim3(p.R_cap, 2 * kRoiOut), dim3(256), 0, stream, p, B);
-  if (p.pooled) {
-    const long total = (long)p.R_cap * p.C;
-    unsigned g = (unsigned)((total + 255) / 256);
-    if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(roi_pool_mean_kernel, dim3(g), dim3(256), 0, stream, (const float*)p.out_nchw,
-                       p.R_cap, p.count, p.per_image, B, p.C, p.pooled);
-  }
+    hipLaunchKernelGGL(roi_align_kernel<2 * kRoiOut>, grid, dim3(256), 0, stream, p, B);
   ODT_HIP(hipGetLastError());
   return 0;
 }

@@ -249,7 +249,7 @@ int odt_create(const odt_config* cfg, int device, odt_handle* out) {
   ODT_CHECK(cfg->graph == ODT_GRAPH_SINGLE || cfg->graph == ODT_GRAPH_MULTI || cfg->graph == ODT_GRAPH_EFFNET,
             "odt_create: bad graph");
   if (cfg->graph != ODT_GRAPH_EFFNET) {
-    ODT_CHECK(cfg->rpn_topk >= 1 && cfg->rpn_topk <= kMaxTopK, "odt_create: rpn_topk must be in [1,1024]");
+    ODT_CHECK(cfg->rpn_topk >= 1 && cfg->rpn_topk <= kMaxTopKBig, "odt_create: rpn_topk must be in [1,4096]");
     ODT_CHECK(cfg->fpn_channels % 32 == 0 && cfg->head_dim % 32 == 0, "odt_create: channel counts must be multiples of 32");
     ODT_CHECK(cfg->graph == ODT_GRAPH_MULTI || cfg->batch == 1,
               "odt_create: the Mask_RCNN_FPN graph is single-image (obj_detect_tracking.py:241-242)");

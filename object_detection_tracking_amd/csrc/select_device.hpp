@@ -60,20 +60,24 @@ __device__ __forceinline__ int block_scan_excl(int v, int* s_wave, int* total) {
   return s_wave[wave] + inc - v;
 }
 
-// LDS scratch block_topk needs.
-struct TopkScratch {
+// LDS scratch block_topk needs (CAP: largest k).
+template <int CAP>
+struct TopkScratchT {
+  static constexpr int cap = CAP;
   int hist[4096];
-  unsigned long long keys_a[kMaxTopK];
-  unsigned long long keys_b[kMaxTopK];
+  unsigned long long keys_a[CAP];
+  unsigned long long keys_b[CAP];
   int wave_tmp[kSelWaves + 1];
   int misc[4];
 };
+using TopkScratch = TopkScratchT<kMaxTopK>;          // K <= 1024: the production configurations
+using TopkScratchBig = TopkScratchT<kMaxTopKBig>;    // 1024 < K <= 4096
 
-// Exact top-k (k <= kMaxTopK, k <= n) over n unique 64-bit keys key_at(0..n-1) (see make_key64:
+// Exact top-k (k <= Scratch::cap, k <= n) over n unique 64-bit keys key_at(0..n-1) (see make_key64:
 // score in the high word, inverted index in the low word).  On return s.keys_b[0..k) holds the
 // selected keys sorted descending == (score desc, index asc).  Workgroup-uniform call.
-template <class KeyAt>
-__device__ void block_topk_keys(KeyAt key_at, int n, int k, TopkScratch& s) {
+template <class KeyAt, class Scratch>
+__device__ void block_topk_keys(KeyAt key_at, int n, int k, Scratch& s) {
   const int tid = threadIdx.x, nthr = blockDim.x;
   unsigned long long prefix = 0ull, mask = 0ull;
   int need = k;
@@ -124,7 +128,7 @@ __device__ void block_topk_keys(KeyAt key_at, int n, int k, TopkScratch& s) {
     const unsigned long long key = key_at(e);
     if ((key & mask) >= prefix) {
       const int pos = atomicAdd(&s.misc[3], 1);
-      if (pos < kMaxTopK) s.keys_a[pos] = key;
+      if (pos < Scratch::cap) s.keys_a[pos] = key;
     }
   }
   __syncthreads();
@@ -146,8 +150,8 @@ struct ScoreKeyAt {
   }
 };
 // top-k of score_at(0..n-1); keys carry the element index.
-template <class ScoreAt>
-__device__ void block_topk(ScoreAt score_at, int n, int k, TopkScratch& s) {
+template <class ScoreAt, class Scratch>
+__device__ void block_topk(ScoreAt score_at, int n, int k, Scratch& s) {
   ScoreKeyAt<ScoreAt> ka{score_at};
   block_topk_keys(ka, n, k, s);
 }
@@ -218,6 +222,95 @@ __device__ inline void block_nms(int n, int max_out, float thresh, NmsScratch& s
       }
     }
     if (tid == 0) s.nkeep = nkeep;
+  }
+  __syncthreads();
+}
+
+// ---- NMS over more than kMaxTopK candidates (1024 < n <= kMaxTopKBig) ----------------------------------------------
+// The K x K / 64 bitmask of block_nms does not fit LDS beyond 1024 candidates, so the score-sorted candidates are walked
+// in panels of P: a panel's candidates are first tested against every box kept so far (one thread per candidate, the
+// kept boxes live in LDS), then the panel's own P x P / 64 upper-triangular bitmask is built and one wave walks it as
+// block_nms does.  Greedy NMS only asks "does SOME earlier kept box overlap by more than the threshold", so the result
+// (and every IoU evaluated, same operand order: earlier box first) is that of the one-panel walk: identical picks.
+constexpr int kNmsPanel = 512;
+struct NmsBigScratch {
+  unsigned long long mask[kNmsPanel * (kNmsPanel / 64)];   // 32 KiB
+  float pbox[kNmsPanel * 4];                               // the panel's boxes, normalised
+  float parea[kNmsPanel];
+  float kbox[kMaxTopKBig * 4];                             // kept boxes, normalised (64 KiB)
+  float karea[kMaxTopKBig];
+  int keep[kMaxTopKBig];
+  unsigned long long pre[kNmsPanel / 64];                  // panel candidates suppressed by earlier panels' picks
+  int nkeep;
+};
+
+// box_at(i, out[4]): corners of candidate i (0..n-1, score-descending).  Fills s.keep[0..s.nkeep).
+template <class BoxAt>
+__device__ inline void block_nms_paneled(int n, int max_out, float thresh, BoxAt box_at, NmsBigScratch& s) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  constexpr int P = kNmsPanel, PW = kNmsPanel / 64;
+  if (tid == 0) s.nkeep = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += P) {
+    const int m = n - base < P ? n - base : P;
+    const int nw = (m + 63) >> 6;
+    const int kept = s.nkeep;                    // uniform: written before the barrier that ended the last round
+    if (kept >= max_out) break;
+    if (tid < m) {
+      float b[4];
+      box_at(base + tid, b);
+      const float a0 = fminf(b[0], b[2]), a2 = fmaxf(b[0], b[2]);
+      const float a1 = fminf(b[1], b[3]), a3 = fmaxf(b[1], b[3]);
+      s.pbox[tid * 4 + 0] = a0; s.pbox[tid * 4 + 1] = a1; s.pbox[tid * 4 + 2] = a2; s.pbox[tid * 4 + 3] = a3;
+      s.parea[tid] = (a2 - a0) * (a3 - a1);
+    }
+    __syncthreads();
+    if (tid < P) {                               // whole waves: P is a multiple of 64
+      int gone = 0;
+      if (tid < m) {
+        const float* bj = &s.pbox[tid * 4];
+        const float aj = s.parea[tid];
+        for (int q = 0; q < kept && !gone; ++q) gone = iou_gt(&s.kbox[q * 4], s.karea[q], bj, aj, thresh) ? 1 : 0;
+      }
+      const unsigned long long word = __ballot(gone);
+      if ((tid & 63) == 0) s.pre[tid >> 6] = word;
+    }
+    for (int idx = tid; idx < m * nw; idx += nthr) {
+      const int i = idx / nw, w = idx - i * nw;
+      unsigned long long bits = 0ull;
+      if (w >= (i >> 6)) {
+        const float* bi = &s.pbox[i * 4];
+        const float ai = s.parea[i];
+        const int j0 = w << 6;
+        int jb = i + 1 - j0;
+        if (jb < 0) jb = 0;
+        int je = m - j0;
+        if (je > 64) je = 64;
+        for (int q = jb; q < je; ++q) {
+          const int j = j0 + q;
+          if (iou_gt(bi, ai, &s.pbox[j * 4], s.parea[j], thresh)) bits |= 1ull << q;
+        }
+      }
+      s.mask[i * PW + w] = bits;
+    }
+    __syncthreads();
+    if (tid < 64) {   // wave 0: lane w < nw owns word w of the panel's "removed" set
+      unsigned long long removed = tid < nw ? s.pre[tid] : 0ull;
+      int nkeep = kept;
+      for (int i = 0; i < m; ++i) {
+        if (nkeep >= max_out) break;
+        const unsigned long long r = __shfl(removed, i >> 6);
+        if (!((r >> (i & 63)) & 1ull)) {
+          if (tid == 0) s.keep[nkeep] = base + i;
+          if (tid < 4) s.kbox[nkeep * 4 + tid] = s.pbox[i * 4 + tid];
+          if (tid == 4) s.karea[nkeep] = s.parea[i];
+          ++nkeep;
+          if (tid < nw) removed |= s.mask[i * PW + tid];
+        }
+      }
+      if (tid == 0) s.nkeep = nkeep;
+    }
+    __syncthreads();
   }
   __syncthreads();
 }

@@ -108,16 +108,20 @@ class _Engine(object):
     # arithmetic of the conv / FC products (include/odt.h ODT_ARITH_*): None / "default" | "f32" | "bf16x3"
     arith = getattr(config, "conv_arith", None)
     c.conv_arith = {None: 0, "default": 0, "f32": _lib.ODT_ARITH_F32, "bf16x3": _lib.ODT_ARITH_BF16X3}[arith]
-    # conv_split_family: 0 library default (fp16x2 kernels where eligible) | 3 bf16x3 only | 1 | "auto": start on the fp16x2
+    # conv_split_family: "auto" (the DEFAULT, also for an args object that does not carry the field): start on the fp16x2
     # kernels, run the first forward(s) on a bf16x3-only twin as well and stay on bf16x3 when the pyramid / RPN tensors of
-    # the two differ by more than f32 rounding level (_auto_calibrate) -- the guard for models whose activations do not fit
-    # the fp16x2 kernels' per-tensor range (useful content more than 2^17 below a tensor's maximum)
-    fam = getattr(config, "conv_split_family", 0) or 0
+    # the two differ by more than f32 rounding level (_auto_calibrate) -- the guard for checkpoints whose activations do
+    # not fit the fp16x2 kernels' per-tensor range (useful content more than 2^17 below a tensor's maximum, DESIGN.md
+    # section 3.1).  Explicit: 0 / 2 the fp16x2 kernels where eligible, unguarded | 3 bf16x3 only | 1 one-stage bf16x3.
+    fam = getattr(config, "conv_split_family", "auto")
+    fam = "auto" if fam is None else fam
     self._auto = None
-    if fam == "auto":
+    self._family_requested = fam
+    if fam == "auto" and c.conv_arith == 0:
       self._auto = {"pending": int(getattr(config, "conv_split_auto_frames", 1) or 1), "chosen": 2, "checks": [],
-                    "tolerance": float(getattr(config, "conv_split_auto_tol", 2e-5)),
+                    "tolerance": float(getattr(config, "conv_split_auto_tol", 2e-5)), "deferred": 0, "incomplete": False,
                     "args": (lib, config, graph, batch, height, width, weights, device, num_class)}
+    if fam == "auto":
       fam = 2
     c.conv_split_family = int(fam)
     # debug / parity runs: every stage tensor keeps its own buffer and tap() can read it after a forward; the production
@@ -145,6 +149,10 @@ class _Engine(object):
     self._masks = np.zeros((B * P, 28, 28), np.float32) if self.add_mask else None
     self._ticket_want = {}           # ticket -> (want_feats, want_pooled) as submitted
     self._ingest_dtype = ODT_DTYPE_U8
+    self._ingest_view = None         # numpy view of the pinned buffer armed by ingest_buffer() (until the next submit)
+    self._ingest_views_out = False   # a view into this handle's pinned memory was ever handed out
+    self._retired = []               # handles replaced by the "auto" guard whose pinned memory a caller may still hold
+    self._profile_on = False
 
   def set_source_size(self, src_height, src_width):
     """Frames of [B, src_height, src_width, 3] from now on; the bilinear resize to the plan's
@@ -152,6 +160,9 @@ class _Engine(object):
     if (src_height, src_width) != (self.src_height, self.src_width):
       self.lib.check(self.lib.dll.odt_set_source_size(self.h, int(src_height), int(src_width)))
       self.src_height, self.src_width = int(src_height), int(src_width)
+      twin = (self._auto or {}).get("twin")
+      if twin is not None:
+        twin.set_source_size(src_height, src_width)
 
   def _load(self, name, arr):
     a = f32(arr)
@@ -160,9 +171,14 @@ class _Engine(object):
                                                 C.cast(shape, c_i64_p), a.ndim))
 
   def close(self):
-    a = object.__getattribute__(self, "__dict__").get("_auto")
+    d = object.__getattribute__(self, "__dict__")
+    a = d.get("_auto")
     if a is not None and "twin" in a:
       a.pop("twin").close()
+    for h in d.get("_retired", []):
+      self.lib.dll.odt_destroy(h)
+    d["_retired"] = []
+    d["_ingest_view"] = None
     if self.h is not None:
       self.lib.dll.odt_destroy(self.h)
       self.h = None
@@ -208,13 +224,37 @@ class _Engine(object):
   # ---- conv_split_family = "auto" --------------------------------------------------------------------------------------
   AUTO_TAPS = ("p2", "p3", "p4", "p5", "p6", "rpn2", "rpn3", "rpn4", "rpn5", "rpn6")      # (readable after a forward in arena mode too)
 
+  def _calibration_due(self):
+    a = self._auto
+    return a is not None and a["pending"] > 0 and a["chosen"] == 2
+
+  def _auto_finish(self, incomplete=False):
+    a = self._auto
+    twin = a.pop("twin", None)
+    if twin is not None:
+      twin.close()
+    a.pop("args", None)              # (the weights dict must not live as long as the engine)
+    if incomplete:
+      a["incomplete"] = True
+      a["pending"] = 0
+
   def _auto_calibrate(self, run):
     """One calibration forward: `run(engine)` puts the caller's input through an engine (blocking).  The fp16x2 handle
     and a bf16x3-only twin (no range assumption at all) see the same input; if any pyramid / RPN tensor differs by more
-    than the tolerance (relative to the tensor's |max|), this engine continues as the twin."""
+    than the tolerance (relative to the tensor's |max|), this engine continues as the twin.  Returns True when the
+    engine changed handles.
+
+    Never while a ticket is outstanding: the blocking forward would overwrite the single device output buffers under
+    the ticket's copy, and a ticket cannot follow the engine to another handle.  Such calls are skipped (counted in
+    describe()); after 16 of them the guard gives up loudly in describe() instead of holding the twin forever."""
     a = self._auto
-    if a is None or a["pending"] <= 0 or a["chosen"] != 2:
-      return
+    if not self._calibration_due():
+      return False
+    if self._ticket_want:
+      a["deferred"] += 1
+      if a["deferred"] >= 16:
+        self._auto_finish(incomplete=True)
+      return False
     import copy
     lib, config, graph, batch, height, width, weights, device, num_class = a["args"]
     if "twin" not in a:
@@ -238,19 +278,30 @@ class _Engine(object):
         worst, where = d, name
     a["checks"].append({"max_rel_diff": worst, "tensor": where})
     a["pending"] -= 1
+    swapped = False
     if worst > a["tolerance"]:
-      # stay on bf16x3: this engine takes over the twin's handle
-      self.h, twin.h = twin.h, self.h
+      # stay on bf16x3: this engine takes over the twin's handle.  State bound to the old handle: no tickets (checked
+      # above); pinned ingest memory a caller may still hold a view of keeps the old handle alive until close();
+      # the profiling switch follows.
+      old = self.h
+      self.h, twin.h = twin.h, None
+      if self._ingest_views_out:
+        self._retired.append(old)
+      else:
+        self.lib.dll.odt_destroy(old)
+      self._ingest_views_out = False
+      if self._profile_on:
+        self.lib.check(self.lib.dll.odt_profile_enable(self.h, 1))
       a["chosen"] = 3
+      swapped = True
     if a["chosen"] == 3 or a["pending"] <= 0:
-      twin.close()
-      a.pop("twin", None)
-      a.pop("args", None)
+      self._auto_finish()
+    return swapped
 
   def forward(self, frames, want_feats=True, want_pooled=False):
     """frames: [B,H,W,3] uint8/float32 BGR host array.  Returns fresh arrays."""
     fr, dt = self._frames(frames)
-    if self._auto is not None and self._auto["pending"] > 0 and self._auto["chosen"] == 2:
+    if self._calibration_due():
       self._auto_calibrate(lambda e: e.lib.check(e.lib.dll.odt_forward(e.h, fr.ctypes.data_as(C.c_void_p), dt, 0, None,
                                                                        C.byref(e._outputs(False, False)))))
     out = self._outputs(want_feats, want_pooled)
@@ -272,9 +323,19 @@ class _Engine(object):
     their 7x7 mean 0.8 MB)."""
     if frames is None:                # the frames were written into ingest_buffer(): no staging copy
       fr, dt = None, self._ingest_dtype
+      view = self._ingest_view        # (None: nothing armed for this ticket -- odt_submit_ex refuses below)
+      if view is not None and self._calibration_due():
+        # the zero-copy path is guarded like the others: both handles read the armed pinned buffer (a blocking forward
+        # does not touch the ingest slots); if the engine moves to the twin's handle, the frames move to ITS buffer
+        src = view.ctypes.data_as(C.c_void_p)
+        if self._auto_calibrate(lambda e: e.lib.check(e.lib.dll.odt_forward(e.h, src, dt, 0, None,
+                                                                            C.byref(e._outputs(False, False))))):
+          keep = view
+          self.ingest_buffer(np.uint8 if dt == ODT_DTYPE_U8 else np.float32)[...] = keep
+      self._ingest_view = None
     else:
       fr, dt = self._frames(frames)
-      if self._auto is not None and self._auto["pending"] > 0 and self._auto["chosen"] == 2:
+      if self._calibration_due():
         self._auto_calibrate(lambda e: e.lib.check(e.lib.dll.odt_forward(e.h, fr.ctypes.data_as(C.c_void_p), dt, 0, None,
                                                                          C.byref(e._outputs(False, False)))))
     t = C.c_int()
@@ -295,7 +356,9 @@ class _Engine(object):
     ctype = C.c_uint8 if dt == ODT_DTYPE_U8 else C.c_float
     n = nbytes.value // C.sizeof(ctype)
     arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(ctype)), shape=(n,))
-    return arr.reshape(self.batch, self.src_height, self.src_width, 3)
+    self._ingest_view = arr.reshape(self.batch, self.src_height, self.src_width, 3)
+    self._ingest_views_out = True
+    return self._ingest_view
 
   def collect(self, ticket, want_feats=None, want_pooled=None):
     """Wait for a ticket of :meth:`submit`; same return value as :meth:`forward`.  By default what comes back is what
@@ -323,7 +386,7 @@ class _Engine(object):
 
   def forward_device_async(self, dev_ptr, dtype, stream=None):
     """Enqueue one forward on frames already resident in HBM (bench path)."""
-    if self._auto is not None and self._auto["pending"] > 0 and self._auto["chosen"] == 2:
+    if self._calibration_due():
       def run(e):
         e.lib.check(e.lib.dll.odt_forward_async(e.h, C.c_void_p(dev_ptr), dtype, 1, None))
         e.lib.check(e.lib.dll.odt_synchronize(e.h))
@@ -344,7 +407,13 @@ class _Engine(object):
     if auto is not None:
       d["conv_split_family_auto"] = {"chosen": "bf16x3 (family 3)" if auto["chosen"] == 3 else "fp16x2 (family 2)",
                                      "calibration_forwards_left": max(0, auto["pending"]) if auto["chosen"] == 2 else 0,
-                                     "tolerance": auto["tolerance"], "checks": list(auto["checks"])}
+                                     "tolerance": auto["tolerance"], "checks": list(auto["checks"]),
+                                     "calls_skipped_with_tickets_outstanding": auto["deferred"],
+                                     "incomplete": bool(auto["incomplete"])}
+      d["range_guard"] = ("conv_split_family = \"auto\" (default): fp16x2 kernels checked against a bf16x3-only twin handle on the "
+                          "first forward(s)" + ("; GAVE UP: every call so far had tickets outstanding" if auto["incomplete"] else ""))
+    elif hasattr(self, "_family_requested"):
+      d["range_guard"] = "off (explicit conv_split_family = %r / conv_arith)" % (self._family_requested,)
     return d
 
   def range_report(self, names=None):
@@ -362,6 +431,7 @@ class _Engine(object):
 
   def profile(self, enable):
     self.lib.check(self.lib.dll.odt_profile_enable(self.h, int(enable)))
+    self._profile_on = bool(enable)
 
   def profile_read(self):
     ms = C.c_double(); fl = C.c_double(); n = C.c_int(); tot = C.c_double()

@@ -11,9 +11,9 @@ tests on identical inputs live in test_ops.py.
 import numpy as np
 import pytest
 
-from common import match_detections, small_config, weights_for
+from common import assert_same_detections, match_detections, small_config, weights_for
 from object_detection_tracking_amd import models
-from object_detection_tracking_amd.config import make_config
+from common import make_config
 from object_detection_tracking_amd.weights import synthetic_frames
 from oracle.graph import OracleModel
 
@@ -75,9 +75,10 @@ def _run_single(lib, cfg, H, W, tol=2e-5, box_tol=None, budget=0):
     miss, extra = match_detections(boxes, labels, probs, ref["final_boxes"], ref["final_labels"],
                                    ref["final_probs"], box_tol, 1e-4)
     assert miss + extra <= budget, (miss, extra)
-    if miss + extra == 0 and np.array_equal(labels, ref["final_labels"]):
-      np.testing.assert_allclose(boxes, ref["final_boxes"], rtol=0, atol=box_tol)
-      assert _rel(feats, ref["fpn_box_feat"]) < 10 * tol
+    if miss + extra == 0:
+      # not only as sets: pair by pair boxes / scores / appearance features, and the order up to score ties
+      assert_same_detections(boxes, labels, probs, feats, ref["final_boxes"], ref["final_labels"], ref["final_probs"],
+                             ref["fpn_box_feat"], box_tol, 1e-4, 10 * tol)
     return miss, extra
   finally:
     m.close()
@@ -121,8 +122,14 @@ def _run_multi(lib, cfg, B, H, W, tol=2e-5, w=None, info=None, budget=0):
                                      ref["final_probs"][b, :v], box_tol, 1e-4)
       tot += miss + extra
     assert tot <= budget, tot
-    if tot == 0 and np.array_equal(labels, ref["final_labels"]):
-      assert _rel(feats, ref["fpn_box_feat"]) < 10 * tol
+    if tot == 0:
+      off = 0
+      for b in range(B):
+        v = int(valid[b])
+        assert_same_detections(boxes[b, :v], labels[b, :v], probs[b, :v], feats[off:off + v],
+                               ref["final_boxes"][b, :v], ref["final_labels"][b, :v], ref["final_probs"][b, :v],
+                               ref["fpn_box_feat"][off:off + v], box_tol, 1e-4, 10 * tol)
+        off += v
     return tot
   finally:
     m.close()
@@ -167,6 +174,38 @@ def test_forward_single_r101_k1000(hip_lib):
   """The reference script's default rpn_test_post_nms_topk = 1000 (obj_detect_tracking.py:132)."""
   cfg = make_config(rpn_test_post_nms_topk=1000, max_size=640, short_edge_size=384)
   _run_single(hip_lib, cfg, 384, 640)
+
+
+@pytest.mark.gpu
+def test_forward_single_r101_1080p_k1000(hip_lib):
+  """BASELINE config #2's frame with the script's own default K = 1000 (obj_detect_tracking.py:132): 1000 RoIs through
+  ROIAlign / box head / per-class NMS at 1920x1080."""
+  cfg = make_config(rpn_test_post_nms_topk=1000)
+  _run_single(hip_lib, cfg, 1080, 1920, tol=1e-5)
+
+
+@pytest.mark.gpu
+def test_forward_single_r101_k2000(hip_lib):
+  """--rpn_test_post_nms_topk above 1024 (the reference takes any value): the selection kernels' K > 1024 path --
+  top-k in rounds of 1024, paneled NMS walk (csrc/select_device.hpp block_nms_paneled), per-class NMS over 2000 RoIs."""
+  cfg = make_config(rpn_test_post_nms_topk=2000, max_size=640, short_edge_size=384)
+  _run_single(hip_lib, cfg, 384, 640)
+
+
+@pytest.mark.gpu
+def test_forward_multi_r101_b2_k2000(hip_lib):
+  cfg = make_config(rpn_test_post_nms_topk=2000, max_size=448, short_edge_size=256, im_batch_size=2)
+  _run_multi(hip_lib, cfg, 2, 256, 448)
+
+
+def test_forward_k_above_1024_small(backend):
+  """K = 1100 on a small frame (P2 alone has 2304 anchors): both graphs through the K > 1024 selection kernels."""
+  name, lib = backend
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1], rpn_test_post_nms_topk=1100)
+  miss, extra = _run_single(lib, cfg, 96, 128)
+  assert miss == 0 and extra == 0
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1], im_batch_size=2, rpn_test_post_nms_topk=1100)
+  assert _run_multi(lib, cfg, 2, 96, 128) == 0
 
 
 @pytest.mark.gpu
@@ -674,6 +713,86 @@ def test_auto_family_guards_the_fp16x2_range_assumption(backend, monkeypatch):
         assert rep["pool0"]["frac_nonzero_below_2^-17_amax"] > 0.9 and rep["c2"]["frac_nonzero_below_2^-17_amax"] < 0.05, rep
       finally:
         m.close()
+
+
+def test_default_engine_is_guarded_on_every_entry_path(backend, monkeypatch):
+  """The PRODUCT default (the package's make_config, or an args object without the field) is conv_split_family = "auto":
+  describe() names the guard; the first forward calibrates whichever way the frames arrive -- forward(), submit(frames)
+  and the zero-copy ingest path ingest_buffer() + submit(None) (that path used to skip the guard and
+  keep the weights dict alive for ever); on the ingest path an engine that moves to the bf16x3 twin takes the armed
+  frames along, the caller's old buffer view stays valid memory until close(), and the profiling switch follows; a
+  call that finds tickets outstanding never calibrates (it would clobber the ticket's device outputs) and is counted."""
+  from object_detection_tracking_amd.config import make_config as product_make_config
+  name, lib = backend
+  monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1"); monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "1")
+  assert product_make_config().conv_split_family == "auto"
+  H, W = (64, 96) if name == "emu" else (160, 224)
+  kw = dict(resnet_num_block=[1, 1, 1, 1], rpn_test_post_nms_topk=64, max_size=256, short_edge_size=96, im_batch_size=1)
+  cfg = product_make_config(**kw)
+  class Args(object):                      # a reference-style args object: no conv_split_family attribute at all
+    pass
+  bare = Args(); bare.__dict__.update({k: v for k, v in cfg.__dict__.items() if not k.startswith("conv_split")})
+  fr = synthetic_frames(1, H, W, seed=5)
+  cfg3 = product_make_config(conv_split_family=3, **kw)
+  # (simulator: forced split kernels cost ~1 min per forward there -- the outlier case through the ingest path only)
+  for kind in (("outlier",) if name == "emu" else ("ordinary", "outlier")):
+    w = weights_for(cfg) if kind == "ordinary" else _outlier_weights(cfg)
+    m3 = models.get_model(cfg3, 0, weights=w, lib=lib, is_multi=True)
+    try:
+      want3 = m3.engine(1, H, W).forward(fr, want_feats=False, want_pooled=True)
+      assert m3.engine(1, H, W).describe()["range_guard"].startswith("off")
+    finally:
+      m3.close()
+    for path in (("ingest",) if name == "emu" else ("forward", "submit", "ingest")):
+      m = models.get_model(bare if path != "submit" else cfg, 0, weights=w, lib=lib, is_multi=True)
+      try:
+        e = m.engine(1, H, W)
+        d = e.describe()
+        assert "auto" in d["range_guard"] and d["conv_split_family_auto"]["calibration_forwards_left"] == 1, d
+        e.profile(True)
+        if path == "forward":
+          got = e.forward(fr, want_feats=False, want_pooled=True)
+        elif path == "submit":
+          got = e.collect(e.submit(fr, want_feats=False, want_pooled=True))
+        else:
+          view = e.ingest_buffer(np.uint8)
+          np.copyto(view, fr)
+          got = e.collect(e.submit(None, want_feats=False, want_pooled=True))
+          assert np.array_equal(view, fr)             # the caller's view is still readable memory, whatever the guard chose
+        auto = e.describe()["conv_split_family_auto"]
+        assert len(auto["checks"]) == 1 and auto["calibration_forwards_left"] == 0 and not auto["incomplete"], auto
+        assert "args" not in e._auto and "twin" not in e._auto          # the weights dict / twin handle are released
+        assert e.profile_read()["conv_launches"] > 0                      # profiling survived a handle change
+        if kind == "ordinary":
+          assert auto["chosen"].startswith("fp16x2"), auto
+        else:
+          assert auto["chosen"].startswith("bf16x3"), auto
+          for a, b in zip(got, want3):                                    # the engine IS the bf16x3 engine now
+            assert (a is None and b is None) or np.array_equal(a, b)
+          assert len(e._retired) == (1 if path == "ingest" else 0)
+        if path == "ingest":                                              # the next ticket uses the live handle's buffer
+          np.copyto(e.ingest_buffer(np.uint8), fr)
+          again = e.collect(e.submit(None, want_feats=False, want_pooled=True))
+          assert np.array_equal(again[0], got[0]) and np.array_equal(again[5], got[5])
+      finally:
+        m.close()
+  # tickets outstanding at every call that could calibrate: skipped, counted, and given up after 16
+  monkeypatch.delenv("ODT_CONV_SPLIT_MINTILES"); monkeypatch.delenv("ODT_CONV_SPLIT3_MINTILES")
+  cfg2 = product_make_config(conv_split_auto_frames=2, **kw)
+  m = models.get_model(cfg2, 0, weights=weights_for(cfg), lib=lib, is_multi=True)
+  try:
+    e = m.engine(1, H, W)
+    t0 = e.submit(fr, want_feats=False, want_pooled=True)               # calibrates (no ticket yet): 1 of 2 done
+    t1 = e.submit(fr, want_feats=False, want_pooled=True)               # t0 outstanding: skipped
+    a = e.describe()["conv_split_family_auto"]
+    assert len(a["checks"]) == 1 and a["calls_skipped_with_tickets_outstanding"] == 1 and a["calibration_forwards_left"] == 1, a
+    r0, r1 = e.collect(t0), e.collect(t1)
+    assert np.array_equal(r0[0], r1[0])
+    e.forward(fr)                                                         # nothing outstanding: the second check runs
+    a = e.describe()["conv_split_family_auto"]
+    assert len(a["checks"]) == 2 and a["calibration_forwards_left"] == 0 and "twin" not in e._auto, a
+  finally:
+    m.close()
 
 
 @pytest.mark.gpu

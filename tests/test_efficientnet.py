@@ -135,7 +135,7 @@ def _det_e2e(lib, model, H, W, topk, score_thr=0.02, tol_box=2e-2, src_hw=None, 
   """Full EfficientDet forward through get_model / Session.run against the oracle."""
   import torch
   from object_detection_tracking_amd import models
-  from object_detection_tracking_amd.config import make_config
+  from common import make_config
   from object_detection_tracking_amd.weights import synthetic_frames
   from oracle import effnet
   c = arch.det_config(model)
@@ -278,7 +278,7 @@ def _det_full_parity(lib, model, H, W, topk, thr, gain, stem_tol=2e-5, stage_tol
   import torch
   from common import match_detections, tie_swaps
   from object_detection_tracking_amd import models
-  from object_detection_tracking_amd.config import make_config
+  from common import make_config
   from object_detection_tracking_amd.weights import synthetic_frames
   from oracle import effnet
   c = arch.det_config(model)
@@ -355,7 +355,7 @@ def test_efficientdet_levels_merged_into_one_launch(backend, monkeypatch):
   _det_full_parity(lib, "efficientdet-d1", H, W, topk=300 if name == "emu" else 1000, thr=0.02, gain=1.0)
   # launch counts: merged vs per level
   from object_detection_tracking_amd import models
-  from object_detection_tracking_amd.config import make_config
+  from common import make_config
   from object_detection_tracking_amd.weights import synthetic_frames
   w = arch.synthetic_det_weights("efficientdet-d1", 0)
   fr = synthetic_frames(1, H, W, seed=13)[0]

@@ -261,7 +261,7 @@ def test_back_to_back_forwards_with_split_k_in_trunk_and_tail(hip_lib):
   """b=4 at 1080p: res5 (trunk) and the box-head FCs (tail) both run split-K, and the tail of forward i runs on the
   side stream under the trunk of forward i+1 -- the two groups must not share a partial-sum buffer.  Pipelined
   batches must equal the blocking forward bit for bit."""
-  from object_detection_tracking_amd.config import make_config
+  from common import make_config
   cfg = make_config(rpn_test_post_nms_topk=300, im_batch_size=4)
   m = models.get_model(cfg, 0, weights=weights_for(cfg), lib=hip_lib, is_multi=True)
   try:

@@ -44,11 +44,14 @@ def _run_conv(lib, case, rng, tile_env=None):
   w = (rng.standard_normal((k, k, Cin, Cout)) * np.sqrt(2.0 / (k * k * Cin))).astype(F)
   b = rng.standard_normal(Cout).astype(F)
   y = ops.conv2d(x, w, b, s, d, pt, pl, (Ho, Wo), relu=relu, lib=lib)
-  r = torch_conv_nhwc(x, w, b, s, d, pt, pl, Ho, Wo)
+  # against float64, relative to the magnitude the sum was formed from: |y - y64| <= 5e-6 * (sum |a||w| + |bias|) -- what
+  # the f64 tests of the split kernels justify (test_parity_report.py: 1.6e-7 ... 4.2e-7 measured); ReLU is 1-Lipschitz
+  r = torch_conv_nhwc(x, w, b, s, d, pt, pl, Ho, Wo, dtype=np.float64)
+  mag = torch_conv_nhwc(np.abs(x), np.abs(w), np.abs(b), s, d, pt, pl, Ho, Wo, dtype=np.float64)
   if relu:
     r = np.maximum(r, 0)
-  # fp32 accumulation in a different order than torch: 1e-4 absolute on O(1) outputs
-  np.testing.assert_allclose(y, r, rtol=1e-4, atol=1e-4)
+  err = np.abs(y.astype(np.float64) - r) / mag
+  assert err.max() <= 5e-6, err.max()
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
@@ -112,10 +115,11 @@ def test_maxpool_bit_exact(backend):
   assert np.array_equal(got, ref)
 
 
-@pytest.mark.parametrize("n,k", [(10, 10), (100, 7), (5000, 64), (70000, 300), (1530, 1000)])
+@pytest.mark.parametrize("n,k", [(10, 10), (100, 7), (5000, 64), (70000, 300), (1530, 1000), (6120, 2000), (4096, 4096),
+                                 (388800, 3000)])
 def test_topk_bit_exact(backend, n, k):
   name, lib = backend
-  if name == "emu" and n > 5000:
+  if name == "emu" and n > 6200:
     pytest.skip("large n only on the GPU")
   rng = np.random.default_rng(n + k)
   s = rng.standard_normal(n).astype(F)
@@ -143,10 +147,13 @@ def _random_boxes(rng, n, size=200.0, clustered=True):
 
 
 @pytest.mark.parametrize("n,max_out,thr", [(1, 5, 0.5), (50, 100, 0.7), (300, 300, 0.7),
-                                           (1000, 100, 0.5), (1024, 1024, 0.7)])
+                                           (1000, 100, 0.5), (1024, 1024, 0.7),
+                                           # more than 1024 candidates: the paneled walk (panels of 512, select_device.hpp)
+                                           (1025, 1025, 0.7), (1400, 100, 0.5), (2000, 2000, 0.7), (4096, 4096, 0.7),
+                                           (3000, 3000, 0.95)])
 def test_nms_indices_bit_exact(backend, n, max_out, thr):
   name, lib = backend
-  if name == "emu" and n > 300:
+  if name == "emu" and n > 300 and n not in (1025, 1400):
     pytest.skip("large n only on the GPU")
   rng = np.random.default_rng(n)
   b = _random_boxes(rng, n)

@@ -19,7 +19,7 @@ import pytest
 
 from common import weights_for
 from object_detection_tracking_amd import models, ops
-from object_detection_tracking_amd.config import make_config
+from common import make_config
 from object_detection_tracking_amd.weights import synthetic_frames
 from oracle.graph import OracleModel
 

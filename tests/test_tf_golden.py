@@ -144,7 +144,7 @@ def check_model(g, lib, tol_box=1e-3):
     pytest.skip("tf_ref.npz was generated without --reference: no model fixture")
   from common import match_detections
   from object_detection_tracking_amd import models
-  from object_detection_tracking_amd.config import make_config
+  from common import make_config
   from object_detection_tracking_amd.weights import synthetic_weights
   from oracle.graph import OracleModel
   H, W, topk, seed = (int(v) for v in g["model_config"])
