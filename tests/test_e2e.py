@@ -862,6 +862,92 @@ def _heavy_tailed_weights(cfg, base):
   return w
 
 
+def _trained_like_weights(cfg, base, seed=11):
+  """BatchNorm statistics with the shape of a TRAINED checkpoint instead of the near-identity synthetic ones: moving
+  variances over four decades (gamma following, so gamma / sigma keeps its level), on top of that a per-channel
+  gamma / sigma factor spanning 10^3 (log-uniform 10^-1.5 ... 10^1.5) on every BN of the backbone, a few channels another
+  10^2 up -- and READ by their consumers --, 3 % dead channels (gamma = 0, beta < 0: zero after ReLU) behind every
+  BN + ReLU.  The per-channel factors are compensated in the rows of the convs that read the tensor (as training does:
+  what one layer's BN scales up, the next layer's weights scale down), so the network still detects things; the
+  activation TENSORS -- conv0, every conv1 / conv2 output and the residual trunk of every group -- now carry channel
+  scales over five decades (2^17), which is what one power of two per tensor has to serve."""
+  w = {k: np.array(v, copy=True) for k, v in base.items()}
+  rng = np.random.default_rng(seed)
+  blocks = list(cfg.resnet_num_block)
+  def factors(n):
+    f = (10.0 ** rng.uniform(-1.5, 1.5, n)).astype(np.float32)
+    f[rng.choice(n, max(2, n // 64), replace=False)] *= np.float32(100.0)          # consumed outliers
+    return f
+  def rescale(producers, consumers, dead):
+    n = w[producers[0] + "/bn/gamma"].shape[0]
+    f = factors(n)
+    for pr in producers:
+      v = (10.0 ** rng.uniform(-2, 2, n)).astype(np.float32)
+      w[pr + "/bn/variance/EMA"] *= v
+      w[pr + "/bn/gamma"] *= np.sqrt(v) * f
+      w[pr + "/bn/beta"] *= f
+      w[pr + "/bn/mean/EMA"] *= np.sqrt(v)
+      if dead:
+        idx = rng.choice(n, max(1, n * 3 // 100), replace=False)
+        w[pr + "/bn/gamma"][idx] = 0
+        w[pr + "/bn/beta"][idx] = -np.abs(w[pr + "/bn/beta"][idx]) - np.float32(0.01)
+    for c in consumers:
+      w[c + "/W"] /= f[None, None, :, None]
+  rescale(["conv0"], ["group0/block0/conv1", "group0/block0/convshortcut"], True)
+  for g, cnt in enumerate(blocks):
+    for i in range(cnt):
+      pre = "group%d/block%d" % (g, i)
+      rescale([pre + "/conv1"], [pre + "/conv2"], True)
+      rescale([pre + "/conv2"], [pre + "/conv3"], True)
+    # the group's residual trunk: every block writes it (conv3 + shortcut), every later block, the next group and the
+    # FPN lateral read it
+    prod = ["group%d/block%d/conv3" % (g, i) for i in range(cnt)] + ["group%d/block0/convshortcut" % g]
+    cons = ["group%d/block%d/conv1" % (g, i) for i in range(1, cnt)] + ["fpn/lateral_1x1_c%d" % (g + 2)]
+    if g + 1 < len(blocks):
+      cons += ["group%d/block0/conv1" % (g + 1), "group%d/block0/convshortcut" % (g + 1)]
+    rescale(prod, cons, False)
+  return w
+
+
+@pytest.mark.gpu
+def test_trained_like_bn_statistics_b8_1080p_default_engine(hip_lib):
+  """the DEFAULT engine (the package's make_config: conv_split_family = "auto") on weights
+  with trained-checkpoint-shaped BatchNorm statistics (_trained_like_weights) at BASELINE config #3's size.  Whatever
+  the guard chooses must agree with the oracle at the usual budgets (every detection matched, boxes within 1e-3 px);
+  the choice and the measured fp16x2-vs-bf16x3 difference are reported by describe()."""
+  from object_detection_tracking_amd.config import make_config as product_make_config
+  cfg = product_make_config(rpn_test_post_nms_topk=300, im_batch_size=8)
+  assert cfg.conv_split_family == "auto"
+  H, W, B = 1080, 1920, 8
+  fr = synthetic_frames(B, H, W, seed=21)
+  w = _trained_like_weights(cfg, weights_for(cfg))
+  ref = OracleModel(cfg, w).forward_multi(fr)
+  per_ref = _split_multi_ref(ref, B)
+  assert sum(len(r[0]) for r in per_ref) >= 4 * B, "the rescaled network no longer detects anything: the test would be empty"
+  m = models.get_model(cfg, 0, weights=w, is_multi=True, lib=hip_lib)
+  try:
+    e = m.engine(B, H, W)
+    boxes, labels, probs, valid, _, _ = e.forward(fr)
+    d = e.describe()
+    auto = d["conv_split_family_auto"]
+    print("trained-like BN statistics: guard chose", auto["chosen"], auto["checks"])
+    assert "auto" in d["range_guard"] and len(auto["checks"]) == 1 and auto["calibration_forwards_left"] == 0, d
+    worst = 0.0
+    for b in range(B):
+      n = int(valid[b]); rb, rl, rp = per_ref[b]
+      assert n == len(rb), (b, n, len(rb))
+      miss, extra = match_detections(boxes[b, :n], labels[b, :n], probs[b, :n], rb, rl, rp, 1e-3, 1e-4)
+      assert miss + extra == 0, (b, miss, extra)
+    # the pyramid itself, not only what survives selection
+    for l in range(2, 7):
+      r = ref["p%d" % l]
+      t = e.tap("p%d" % l).transpose(0, 3, 1, 2)[:, :, :r.shape[2], :r.shape[3]]
+      worst = max(worst, _rel(t, r))
+    assert worst < 2e-5, worst
+  finally:
+    m.close()
+
+
 @pytest.mark.gpu
 def test_heavy_tailed_bn_gamma_1080p_auto_family(hip_lib):
   """Full size (b = 2 @1080p), activations with outlier channels 2^7 ... 2^12 above the rest (the regime of trained
