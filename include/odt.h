@@ -17,12 +17,30 @@
  * reference feeds them; outputs use the reference's layouts (boxes x1,y1,x2,y2
  * in resized-image coordinates, features NCHW [R,256,7,7]).
  *
- * Arithmetic: all tensors and accumulations are float32.  Environment knob read
- * by the library: ODT_CONV_SPLIT=1 (default) evaluates the products of the large
- * convolutions as six exact bf16 x bf16 matrix-core products of a 3-way bf16 split
- * of both float32 operands (error at the level of an f32 dot product in another
- * summation order); ODT_CONV_SPLIT=0 uses the exact-f32 matrix instruction for
- * every layer.
+ * Arithmetic: all tensors and accumulations are float32.  By default
+ * (odt_config.conv_arith = ODT_ARITH_DEFAULT, conv_split_family = 0 / 2) the large
+ * convolutions evaluate every f32 product as THREE exact f16 x f16 matrix-core
+ * products (v_mfma_f32_32x32x16_f16) of a 2-way f16 split of both operands
+ * ("fp16x2": hi*hi + hi*lo + lo*hi, 22 significand bits per operand, lo*lo <=
+ * 2^-22 |a||b| dropped), each operand carrying an exact power-of-two scale -- one
+ * per weight row, one per activation tensor from the |max| its producer recorded
+ * (per pixel row inside the fused bottleneck tails).  Error at the level of an f32
+ * dot product in another summation order PROVIDED a tensor's useful content lies
+ * within ~2^17 of its |max| (below that the low piece is an f16 subnormal: absolute
+ * instead of relative precision).  The library does not check that assumption by
+ * itself: the Python host guards it by default (models._Engine,
+ * conv_split_family = "auto": the first forward also runs on a conv_split_family = 3
+ * twin handle and the engine keeps whichever handle the comparison allows); a C
+ * caller does the same with two handles, or selects a mode without a range
+ * assumption: conv_split_family = 3 (six exact bf16 x bf16 products of a 3-way
+ * bf16 split: all 24 bits) or conv_arith = ODT_ARITH_F32 (the exact-f32 matrix
+ * instruction in every layer).  Layers the fp16x2 kernels do not take (no recorded
+ * input range, tiles that do not fit) run on bf16x3 / exact f32; odt_describe says
+ * which launches run on what.
+ *
+ * Errors: odt_last_error() is per calling thread (errno-style storage): a handle
+ * is driven by one thread at a time, so the message is that of the calling
+ * thread's last failing call -- never another handle's on another thread.
  */
 #ifndef ODT_H_
 #define ODT_H_
@@ -292,8 +310,8 @@ int odt_op_conv2d(int device, const float* in, int B, int H, int W, int Cin,
 int odt_op_conv2d_cat(int device, const float* a, int B, int Ho, int Wo, int Ca, const float* b2, int Hb,
                       int Wb, int Cb, int stride_b, const float* wa, const float* wb, const float* bias,
                       int Cout, int relu, float* out);
-/* The tail of a bottleneck block (nn.py:503-521) on the fp16x2 kernels: conv2 (3x3 stride 1, 'SAME' for dilation dil,
- * C -> C = 128 or 256, + bias, ReLU; w2 [3,3,C,C] HWIO) -> conv3 (1x1, C -> C3, + bias (+ res [B,H,W,C3]), ReLU if relu3;
+/* The tail of a bottleneck block (nn.py:503-521) on the fp16x2 kernels: conv2 (3x3 stride 1, 'SAME' for dilation dil = 1 or 2,
+ * C -> C = 64, 128 or 256 (res2 / res3 / res4 tails), C3 % 64 == 0, + bias, ReLU; w2 [3,3,C,C] HWIO) -> conv3 (1x1, C -> C3, + bias (+ res [B,H,W,C3]), ReLU if relu3;
  * w3 [C,C3]).  fuse = 1: one launch, conv3 evaluated from conv2's accumulators inside the 3x3 kernel (what the plan runs
  * for res4 at b = 8 @1080p); fuse = 0: the two launches it replaces.  in [B,H,W,C], out [B,H,W,C3]. */
 int odt_op_bottleneck_tail(int device, const float* in, int B, int H, int W, int C, const float* w2,

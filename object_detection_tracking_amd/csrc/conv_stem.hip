@@ -23,6 +23,7 @@
 //     different 16-byte slots (row-major pixels: 2.6 LDS cycles per group, the tile's LDS time equalled its MFMA time).
 // 149 KB of LDS, 207 VGPRs.  b = 8 @1080p: 0.37 ms against 0.76 + 0.31 (profiles/r04_stem_fusion_ab.txt).
 // Reference ops: as conv_split.hip, elementwise.hip (maxpool3x3s2_kernel).
+#include <atomic>
 #include "conv_split_epilogue.hpp"
 
 namespace odt {
@@ -296,13 +297,18 @@ bool conv_stem_fits(const ConvParams& p) {
 int launch_conv_stem(const ConvParams& p, const ConvParams* dev, hipStream_t stream) {
   ODT_CHECK(conv_stem_fits(p) && p.out != nullptr && p.out_H == (p.Ho + 1 - 3) / 2 + 1 && p.out_W == (p.Wo + 1 - 3) / 2 + 1 &&
             p.out_oy == 0 && p.out_ox == 0, "conv stem: unsupported shape");
-  static int ncu = 0;                        // one persistent workgroup per CU
+  // one persistent workgroup per CU of the CURRENT device (handles on different devices / partitions differ; several
+  // host threads may launch at once): a per-device table, each slot written once with a value that depends on the device
+  // only (a benign double fill writes the same number)
+  static std::atomic<int> cus[64];
+  int dev_id = 0;
+  ODT_HIP(hipGetDevice(&dev_id));
+  int ncu = dev_id >= 0 && dev_id < 64 ? cus[dev_id].load(std::memory_order_relaxed) : 0;
   if (ncu == 0) {
-    int dev_id = 0;
     hipDeviceProp_t prop;
-    ODT_HIP(hipGetDevice(&dev_id));
     ODT_HIP(hipGetDeviceProperties(&prop, dev_id));
     ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (dev_id >= 0 && dev_id < 64) cus[dev_id].store(ncu, std::memory_order_relaxed);
   }
   const long ntiles = (long)p.B * ((p.out_H + StemCfg::PY - 1) / StemCfg::PY) * ((p.out_W + StemCfg::PX - 1) / StemCfg::PX);
   const int cap = (p.debug >> 20) & 0x3ff;   // (test knob ODT_STEM_GRID through fuse_stem: fewer workgroups, several tiles each on small frames)

@@ -190,7 +190,7 @@ int odt_op_conv2d_cat(int device, const float* a, int B, int Ho, int Wo, int Ca,
 }
 
 // conv2 (3x3, stride 1, 'SAME' for dilation dil, C -> C, bias, ReLU) -> conv3 (1x1, C -> C3, bias (+ residual), ReLU?) on the
-// fp16x2 kernels, C = 256: fuse = 1 as ONE conv_h2k_kernel launch with the fused tail (the plan's fuse_bottleneck_tails),
+// fp16x2 kernels, C = 64 / 128 / 256 (dil 1 or 2, C3 % 64 == 0): fuse = 1 as ONE conv_h2k_kernel launch with the fused tail (the plan's fuse_bottleneck_tails),
 // fuse = 0 as the two launches the fused form replaces (conv_h2k_kernel -> [M,C] tensor + recorded range -> conv_h2_kernel).
 int odt_op_bottleneck_tail(int device, const float* in, int B, int H, int W, int C, const float* w2_hwio, const float* b2,
                            int dil, const float* w3_io, const float* b3, int C3, const float* res, int relu3, int fuse,

@@ -384,10 +384,12 @@ int fuse_bottleneck_tails(odt_model* m) {
     ap.f_out = b.p.out; ap.f_out_ldc = b.p.out_ldc; ap.f_cout = b.p.Cout; ap.f_relu = b.p.relu; ap.f_out_amax = b.p.out_amax;
     ap.debug |= b.p.debug & 0x400;           // the residual's non-temporal hint travels with it
     {
+      // A/B and ablation knobs: counted like the ODT_CONV_* ones, so that odt_describe / the bench line's
+      // env_overrides_applied show that this handle does not run the default code (ODT_FUSE_DEBUG makes results WRONG)
       const char* r = getenv("ODT_FUSE_ROT");           // A/B: 0 = every workgroup walks the output column chunks in the same order
-      if (r != nullptr && r[0] == '0') ap.debug |= 0x100;
+      if (r != nullptr && r[0] == '0') { ap.debug |= 0x100; ++m->policy.env_overrides; }
       const char* d = getenv("ODT_FUSE_DEBUG");         // tuning ablations of the fused tail (1: no residual fetches, 2: no stores; results wrong)
-      if (d != nullptr) ap.debug |= (atoi(d) & 3) << 16;
+      if (d != nullptr && (atoi(d) & 3) != 0) { ap.debug |= (atoi(d) & 3) << 16; ++m->policy.env_overrides; }
     }
     ap.out = nullptr; ap.out_amax = nullptr;
     ob.skip = true;
@@ -425,7 +427,7 @@ int fuse_stem(odt_model* m) {
     // the conv map no longer exists: an arena handle must neither reserve memory for its stage name nor hand it out
     for (auto it = m->taps.begin(); it != m->taps.end();) { if (it->second.d == ap.out) it = m->taps.erase(it); else ++it; }
     ap.out = ob.out.d; ap.out_H = ob.out.H; ap.out_W = ob.out.W; ap.out_ldc = ob.out.C; ap.stem_pool = 1;
-    if (const char* g = getenv("ODT_STEM_GRID")) ap.debug |= (atoi(g) & 0x3ff) << 20;       // test knob: workgroups of the launch
+    if (const char* g = getenv("ODT_STEM_GRID")) { ap.debug |= (atoi(g) & 0x3ff) << 20; ++m->policy.env_overrides; }   // test knob: workgroups of the launch
     ob.skip = true;
     m->stem_fused = 1;
   }
