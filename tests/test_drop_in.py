@@ -102,9 +102,11 @@ def test_session_shim_multi(backend):
     m.close()
 
 
-def test_plumbing_video_loop_with_tracker(emu_lib):
+def test_plumbing_video_loop_with_tracker(backend):
   """config #1: frame loop (frame_gap) -> sess.run -> create_obj_infos -> tracker NMS ->
-  Tracker.predict/update, exactly the call sequence of obj_detect_tracking.py:577-695."""
+  Tracker.predict/update, exactly the call sequence of obj_detect_tracking.py:577-695 -- on the simulator in the CPU
+  suite and on the product library under -m gpu (detector, cosine metric, native DeepSORT and TMOT cores all on hip)."""
+  emu_lib = backend[1]
   Tracker = _reference_tracker_cls()
   cfg = small_config(resnet_num_block=[1, 1, 1, 1], rpn_test_post_nms_topk=32)
   m = models.get_model(cfg, 0, weights=weights_for(cfg), lib=emu_lib)
