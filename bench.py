@@ -241,6 +241,16 @@ def main():
       # same, through the pipelined ingest (pinned double-buffered staging, H2D / D2H on copy
       # streams overlapping the forward; odt_submit / odt_collect)
       extra.update(pipelined_leg(eng, frames, B, nbatches=10))
+      if nn_match is not None:
+        # the timed region's step WITHOUT the per-frame nn_matching calls (what rounds 1-4 timed as `value`): the detector
+        # alone, same handle, same rotating batches -- the cosine kernels run on a highest-priority stream and take CUs from
+        # the one-round conv launches in flight, which is what the difference to `value` measures
+        for k in range(2 + 10):
+          if k == 2:
+            eng.synchronize(); t1 = time.perf_counter()
+          eng.forward_device_async(dev_rot[0][k % NROT].data_ptr(), ODT_DTYPE_U8)
+        eng.synchronize()
+        extra["detector_only_fps_without_nn_matching_in_the_step"] = 10 * B / (time.perf_counter() - t1)
       if NROT > 1:
         # the timed region's step with ONE resident batch replayed (rounds 1-3 timed this): what the rotation changes
         for k in range(2 + 10):

@@ -8,6 +8,8 @@
 // per channel, one workgroup per (RoI, 64 channels), the NCHW output and the mean through an LDS
 // tile.  fp32, operand order of TF-1.15 crop_and_resize_op.cc (see oracle/tfops.py); built with
 // -ffp-contract=off.
+#include <cstdint>
+
 #include "odt_common.hpp"
 
 namespace odt {
@@ -23,8 +25,10 @@ __device__ __forceinline__ int fpn_level_of(float x0, float y0, float x1, float 
   return (int)lv - 2;
 }
 
-// One workgroup per (RoI, block of 64 channels): 64 channels x 4 groups of output rows.  Every output value also goes
-// to an LDS tile [64][OUT*OUT (+1)], so that
+// One workgroup per (RoI, block of 64 channels): 16 channel quads x 16 output slots.  A thread owns four adjacent
+// channels (every bilinear tap is ONE 16-byte load; 16 lanes cover the 256 contiguous bytes of a pixel's 64 channels --
+// a quarter of the load instructions of one channel per lane, which is what bounds this gather) and takes every 16th of
+// the OUT x OUT outputs.  Every output value also goes to an LDS tile [64][OUT*OUT (+1)], so that
 //   * fpn_box_feat (NCHW: this RoI's [64][OUT][OUT] block is contiguous) leaves as whole coalesced rows instead of one
 //     4-byte store per lane at a stride of 49 floats, and
 //   * the 7x7 mean (deep_sort/utils.py:27-28) is summed from the tile in the order of np.mean over (h, w) of the row-major
@@ -34,7 +38,7 @@ constexpr int kRoiCB = 64;                              // channels per workgrou
 template <int OUT>
 __global__ void __launch_bounds__(256) roi_align_kernel(RoiAlignParams p, int B) {
   constexpr int OO = OUT * OUT;
-  constexpr int LDP = (OO & 1) ? OO : OO + 1;           // odd row pitch: lanes (channels) fall on distinct banks
+  constexpr int LDP = (OO & 1) ? OO : OO + 1;           // odd row pitch: channels fall on distinct banks
   __shared__ float tile[kRoiCB * LDP];
   const int r = blockIdx.x, cb = blockIdx.y * kRoiCB;
   int b, out_row = r;
@@ -80,51 +84,66 @@ __global__ void __launch_bounds__(256) roi_align_kernel(RoiAlignParams p, int B)
   const float hs = (by2 - by1) * fH1 / (float)(CS - 1);
   const float ws = (bx2 - bx1) * fW1 / (float)(CS - 1);
   const float* feat = fbase + (size_t)b * ah * aw * ldc;
-  const int cl = threadIdx.x & (kRoiCB - 1), c = cb + cl;
+  const int cq = threadIdx.x & 15, c = cb + cq * 4;      // first of this thread's four channels
   const int nch = p.C - cb < kRoiCB ? p.C - cb : kRoiCB;        // channels of this block
   const bool stage = p.out_nchw != nullptr || p.pooled != nullptr;
-  if (cl < nch) {
-    for (int oy = threadIdx.x / kRoiCB; oy < OUT; oy += 256 / kRoiCB) {
+  // whole quads only where the pixel row holds them (the row pitch ldc is a multiple of 4 and pad channels, if any, are
+  // readable: feature maps are allocated with ldc >= C rounded up to 4); lanes past the block's channels idle
+  const int nq = (nch + 3) >> 2;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  if (cq < nq) {
+    for (int q = threadIdx.x >> 4; q < OO; q += 16) {
+      const int oy = q / OUT, ox = q - oy * OUT;
       float yl[2];
       int top[2], bot[2];
       bool vy[2];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const float in_y = by1 * fH1 + (float)(2 * oy + q) * hs;
-        vy[q] = !(in_y < 0.f || in_y > fH1);
-        const float iy = vy[q] ? in_y : 0.f;
-        top[q] = (int)floorf(iy);
-        bot[q] = (int)ceilf(iy);
-        yl[q] = iy - (float)top[q];
+      for (int k = 0; k < 2; ++k) {
+        const float in_y = by1 * fH1 + (float)(2 * oy + k) * hs;
+        vy[k] = !(in_y < 0.f || in_y > fH1);
+        const float iy = vy[k] ? in_y : 0.f;
+        top[k] = (int)floorf(iy);
+        bot[k] = (int)ceilf(iy);
+        yl[k] = iy - (float)top[k];
       }
-      for (int ox = 0; ox < OUT; ++ox) {
-        float v[2][2];
+      f32x4 v[2][2];
 #pragma unroll
-        for (int qx = 0; qx < 2; ++qx) {
-          const float in_x = bx1 * fW1 + (float)(2 * ox + qx) * ws;
-          const bool vx = !(in_x < 0.f || in_x > fW1);
-          const float ix = vx ? in_x : 0.f;
-          const int lef = (int)floorf(ix), rig = (int)ceilf(ix);
-          const float xl = ix - (float)lef;
+      for (int qx = 0; qx < 2; ++qx) {
+        const float in_x = bx1 * fW1 + (float)(2 * ox + qx) * ws;
+        const bool vx = !(in_x < 0.f || in_x > fW1);
+        const float ix = vx ? in_x : 0.f;
+        const int lef = (int)floorf(ix), rig = (int)ceilf(ix);
+        const float xl = ix - (float)lef;
 #pragma unroll
-          for (int qy = 0; qy < 2; ++qy) {
-            float val = 0.f;
-            if (vx && vy[qy]) {
-              const float tl = feat[((size_t)top[qy] * aw + lef) * ldc + c];
-              const float tr = feat[((size_t)top[qy] * aw + rig) * ldc + c];
-              const float bl = feat[((size_t)bot[qy] * aw + lef) * ldc + c];
-              const float br = feat[((size_t)bot[qy] * aw + rig) * ldc + c];
-              const float t = tl + (tr - tl) * xl;
-              const float bm = bl + (br - bl) * xl;
-              val = t + (bm - t) * yl[qy];
-            }
-            v[qy][qx] = val;
+        for (int qy = 0; qy < 2; ++qy) {
+          f32x4 val = zero;
+          if (vx && vy[qy]) {
+            const f32x4 tl = *reinterpret_cast<const f32x4*>(feat + ((size_t)top[qy] * aw + lef) * ldc + c);
+            const f32x4 tr = *reinterpret_cast<const f32x4*>(feat + ((size_t)top[qy] * aw + rig) * ldc + c);
+            const f32x4 bl = *reinterpret_cast<const f32x4*>(feat + ((size_t)bot[qy] * aw + lef) * ldc + c);
+            const f32x4 br = *reinterpret_cast<const f32x4*>(feat + ((size_t)bot[qy] * aw + rig) * ldc + c);
+            const f32x4 t = tl + (tr - tl) * xl;
+            const f32x4 bm = bl + (br - bl) * xl;
+            val = t + (bm - t) * yl[qy];
           }
+          v[qy][qx] = val;
         }
-        // 2x2 average pool (nn.py:1332): ((v00 + v01) + v10) + v11, * 0.25
-        const float o = (((v[0][0] + v[0][1]) + v[1][0]) + v[1][1]) * 0.25f;
-        if (p.out_nhwc) p.out_nhwc[(((size_t)out_row * OUT + oy) * OUT + ox) * p.C + c] = o;
-        if (stage) tile[cl * LDP + oy * OUT + ox] = o;
+      }
+      // 2x2 average pool (nn.py:1332): ((v00 + v01) + v10) + v11, * 0.25
+      const f32x4 o = (((v[0][0] + v[0][1]) + v[1][0]) + v[1][1]) * 0.25f;
+      if (p.out_nhwc) {
+        float* dst = p.out_nhwc + (((size_t)out_row * OUT + oy) * OUT + ox) * p.C + c;
+        if (c + 4 <= p.C && (p.C & 3) == 0) {
+          *reinterpret_cast<f32x4*>(dst) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c + e < p.C) dst[e] = o[e];
+        }
+      }
+      if (stage) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[(cq * 4 + e) * LDP + q] = o[e];
       }
     }
   }
@@ -150,6 +169,8 @@ int launch_roi_align(const RoiAlignParams& p, hipStream_t stream) {
   const int out = p.out_size == 0 ? kRoiOut : p.out_size;
   ODT_CHECK(out == kRoiOut || out == 2 * kRoiOut, "roi_align: output side must be 7 or 14");
   ODT_CHECK(out == kRoiOut || p.pooled == nullptr, "roi_align: pooled features are 7x7 only");
+  for (int l = 0; l < 5; ++l)          // 16-byte taps: channel quads of a pixel row
+    ODT_CHECK(p.feat[l] == nullptr || ((p.ldc[l] & 3) == 0 && ((uintptr_t)p.feat[l] & 15) == 0), "roi_align: feature rows must be 16-byte aligned (ldc % 4 == 0)");
   const dim3 grid(p.R_cap, (p.C + kRoiCB - 1) / kRoiCB);
   if (out == kRoiOut)
     hipLaunchKernelGGL(roi_align_kernel<kRoiOut>, grid, dim3(256), 0, stream, p, B);

@@ -298,6 +298,13 @@ def test_roi_align(backend):
   ref = og.multilevel_roi_align([f.transpose(0, 3, 1, 2) for f in feats], boxes, box_ind, strides)
   np.testing.assert_allclose(out, ref, rtol=1e-5, atol=2e-6)
   np.testing.assert_allclose(pooled, ref.mean(axis=(2, 3)), rtol=1e-5, atol=2e-6)
+  # the 7x7 mean is formed INSIDE the ROIAlign kernel (round 5), in the order of the second pass it replaces: a sequential
+  # f32 sum over the row-major window, then / 49 -- bit for bit what that pass made of the kernel's own output
+  seq = np.zeros(out.shape[:2], F)
+  flat = out.reshape(out.shape[0], out.shape[1], 49)
+  for q in range(49):
+    seq = (seq + flat[:, :, q]).astype(F)
+  assert np.array_equal(pooled, (seq / F(49)).astype(F))
 
 
 def _head_inputs(rng, B, K, Cn, img_hw):
