@@ -215,6 +215,25 @@ struct DwConvParams {
 };
 int launch_dwconv(const DwConvParams& p, hipStream_t stream);
 int dwconv_splits(const DwConvParams& p);       // pixel splits launch_dwconv will use (sizes sum_part)
+// MBConv front half in one kernel (effnet_mbconv.hip): expand 1x1 + BN + swish -> depthwise k x k + BN + swish (+ squeeze
+// partial sums); the expanded tensor stays in LDS
+struct MbExpandDwParams {
+  const float* x;        // block input [B,H,W,in_ldc]; K of the expand GEMM = in_ldc (pad channels: zero weights)
+  int B, H, W, in_ldc;
+  const void* w_img;     // bf16x3 piece image of the expand weights [lmid][in_ldc] (conv_make_split_weights, kind 1, n-tile 64)
+  const float* e_bias;   // [mid] folded BN shift of the expand conv
+  int mid, lmid;         // expanded channels, their stride (multiple of 64)
+  const float* dw_wt;    // [k*k][lmid]  (BN scale folded, pad channels zero)
+  const float* dw_bias;  // [lmid]
+  float* out;            // [B,Ho,Wo,lmid]
+  int Ho, Wo, k, stride, pad_t, pad_l;
+  float* sum_part;       // [B][nsplit][lmid] per-workgroup sums of the output (squeeze-excite), or nullptr
+  int nsplit;            // tile ranges per image (0: launch_mbconv_expand_dw picks mbconv_expand_dw_splits())
+  int tiles_y, tiles_x;  // filled by the launcher
+};
+int launch_mbconv_expand_dw(const MbExpandDwParams& p, hipStream_t stream);
+int mbconv_expand_dw_splits(const MbExpandDwParams& p);
+size_t mbconv_expand_weight_bytes(int lmid, int in_ldc);
 struct FuseParams {
   const float* in[3];
   int ih[3], iw[3], mode[3];     // mode 0 same size | 1 nearest resize | 2 max-pool 3x3 s2 'SAME'

@@ -19,6 +19,13 @@ static bool eff_split_on() {        // (read per plan build: tests and A/B runs 
 }
 int r32(int c) { return eff_split_on() ? (c + 63) / 64 * 64 : (c + 31) / 32 * 32; }
 // squeeze-excite gate folded into the projection's weights at batch 1 (ODT_EFFDET_WSCALE=0: a pass over the activations)
+// MBConv front half (expand 1x1 -> depthwise) as one kernel, the expanded tensor kept in LDS (effnet_mbconv.hip):
+// ODT_EFFDET_FUSE_MB = 0 off | 1 (default) blocks whose depthwise output is at least 64 pixels on its short side (smaller
+// maps do not fill 16 x 16 patches: the halo / partial-tile recompute would cost more than the launch it saves) | 2 every block
+static int eff_fuse_mb_mode() {
+  const char* e = getenv("ODT_EFFDET_FUSE_MB");
+  return e != nullptr ? atoi(e) : 1;
+}
 static bool eff_wscale_on() {
   const char* e = getenv("ODT_EFFDET_WSCALE");
   return !(e != nullptr && e[0] == '0');
@@ -449,16 +456,22 @@ int build_plan_effnet(odt_model* m) {
     auto bname = [&]() { const std::string n = nbn == 0 ? "tpu_batch_normalization" : "tpu_batch_normalization_" + std::to_string(nbn); ++nbn; return p + n; };
     const Tensor inp = x;
     Tensor t1 = x;
-    if (b.expand != 1) {
-      const std::string cn = cname(), bn = bname();
-      if (eff_upload_pw(m, cn, bn, false, b.cin, x.C, mid, &wt, &bias)) return 1;
-      t1 = Tensor{};
-      if (add_conv(m, cn, x, x.C, wt, bias, 1, 1, mid, 1, 1, 0, 0, x.h, x.w, 0, 0, nullptr, 0, false, lmid, &t1, "")) return 1;
-      m->convs.back().p.relu = 2;
-    }
-    // depthwise + BN + swish
     int ho, wo, dpt, dpl;
     same(x.h, b.kernel, b.stride, &ho, &dpt); same(x.w, b.kernel, b.stride, &wo, &dpl);
+    const int fmode = eff_fuse_mb_mode();
+    const bool fuse_mb = b.expand != 1 && eff_split_on() && x.C % 32 == 0 && lmid % 64 == 0 && x.h == x.H && x.w == x.W &&
+                         (fmode >= 2 || (fmode == 1 && std::min(ho, wo) >= 64));
+    const float *ewt = nullptr, *ebias = nullptr;
+    if (b.expand != 1) {
+      const std::string cn = cname(), bn = bname();
+      if (eff_upload_pw(m, cn, bn, false, b.cin, x.C, mid, &ewt, &ebias)) return 1;
+      if (!fuse_mb) {
+        t1 = Tensor{};
+        if (add_conv(m, cn, x, x.C, ewt, ebias, 1, 1, mid, 1, 1, 0, 0, x.h, x.w, 0, 0, nullptr, 0, false, lmid, &t1, "")) return 1;
+        m->convs.back().p.relu = 2;
+      }
+    }
+    // depthwise + BN + swish
     Tensor t2{};
     if (make_tensor(m, "", B, ho, wo, lmid, &t2, true)) return 1;
     float* se_part = nullptr; int se_nsplit = 0;
@@ -473,19 +486,46 @@ int build_plan_effnet(odt_model* m) {
       for (int c = 0; c < mid; ++c) bv[c] = (float)shift[c];
       const float *dwt, *dbias;
       if (upload_raw(m, v, &dwt) || upload_raw(m, bv, &dbias)) return 1;
-      Op op; op.kind = OP_DW;
-      op.dw.in = t1.d; op.dw.wt = dwt; op.dw.bias = dbias; op.dw.out = t2.d;
-      op.dw.B = B; op.dw.H = t1.h; op.dw.W = t1.w; op.dw.Ho = ho; op.dw.Wo = wo; op.dw.ldc = lmid;
-      op.dw.k = b.kernel; op.dw.stride = b.stride; op.dw.pad_t = dpt; op.dw.pad_l = dpl; op.dw.act = 2;
-      // fused squeeze: the depthwise kernel also delivers per-workgroup sums of its output
-      // (sized by the split count the launcher will use: a placeholder makes dwconv_splits() take the fused-squeeze path)
-      op.dw.sum_part = reinterpret_cast<float*>(sizeof(float));
-      se_nsplit = dwconv_splits(op.dw);
-      ODT_CHECK(se_nsplit >= 1 && se_nsplit <= 1024, "dwconv_splits: bad number of partial sums");
-      se_part = m->alloc_f((size_t)B * se_nsplit * lmid, false);
-      ODT_CHECK(se_part, "device allocation failed (SE)");
-      op.dw.sum_part = se_part;
-      m->ops.push_back(op);
+      if (fuse_mb) {
+        // expand 1x1 + BN + swish -> depthwise + BN + swish in one kernel: the [h, w, mid] tensor is never written
+        Op op; op.kind = OP_MB_EXPAND_DW;
+        MbExpandDwParams& q = op.mb;
+        q.x = x.d; q.B = B; q.H = x.h; q.W = x.w; q.in_ldc = x.C;
+        q.e_bias = ebias; q.mid = mid; q.lmid = lmid; q.dw_wt = dwt; q.dw_bias = dbias; q.out = t2.d;
+        q.Ho = ho; q.Wo = wo; q.k = b.kernel; q.stride = b.stride; q.pad_t = dpt; q.pad_l = dpl;
+        {
+          // the expand weights as the bf16x3 piece image of the one-stage 256 x 64 kernel (built once, here)
+          float* img = m->alloc_f((mbconv_expand_weight_bytes(lmid, x.C) + 3) / 4, false);
+          ODT_CHECK(img != nullptr, "device allocation failed (expand weight image of " + p + ")");
+          ConvParams cp{};
+          cp.wt = ewt; cp.Cout = mid; cp.Cin = x.C; cp.kh = 1; cp.kw = 1; cp.wt_split_kind = 1; cp.wt_split_bn = 64;
+          if (conv_make_split_weights(cp, img, nullptr)) return 1;
+          ODT_HIP(hipDeviceSynchronize());
+          q.w_img = img;
+        }
+        q.nsplit = 0;
+        se_nsplit = mbconv_expand_dw_splits(q);
+        q.nsplit = se_nsplit;
+        se_part = m->alloc_f((size_t)B * se_nsplit * lmid, false);
+        ODT_CHECK(se_part, "device allocation failed (SE)");
+        q.sum_part = se_part;
+        m->ops.push_back(op);
+        ++m->mb_fused;
+      } else {
+        Op op; op.kind = OP_DW;
+        op.dw.in = t1.d; op.dw.wt = dwt; op.dw.bias = dbias; op.dw.out = t2.d;
+        op.dw.B = B; op.dw.H = t1.h; op.dw.W = t1.w; op.dw.Ho = ho; op.dw.Wo = wo; op.dw.ldc = lmid;
+        op.dw.k = b.kernel; op.dw.stride = b.stride; op.dw.pad_t = dpt; op.dw.pad_l = dpl; op.dw.act = 2;
+        // fused squeeze: the depthwise kernel also delivers per-workgroup sums of its output
+        // (sized by the split count the launcher will use: a placeholder makes dwconv_splits() take the fused-squeeze path)
+        op.dw.sum_part = reinterpret_cast<float*>(sizeof(float));
+        se_nsplit = dwconv_splits(op.dw);
+        ODT_CHECK(se_nsplit >= 1 && se_nsplit <= 1024, "dwconv_splits: bad number of partial sums");
+        se_part = m->alloc_f((size_t)B * se_nsplit * lmid, false);
+        ODT_CHECK(se_part, "device allocation failed (SE)");
+        op.dw.sum_part = se_part;
+        m->ops.push_back(op);
+      }
     }
     // squeeze-excite gate from that mean (1x1 reduce + swish -> 1x1 expand + sigmoid); the channel scale itself is folded
     // into the projection's weights at batch 1 (W diag(g) instead of a read-modify-write pass over the widest tensor of
