@@ -26,6 +26,10 @@ static int eff_fuse_mb_mode() {
   const char* e = getenv("ODT_EFFDET_FUSE_MB");
   return e != nullptr ? atoi(e) : 1;
 }
+static int eff_fuse_mb_min() {           // A/B knob: smallest short side of the depthwise output that is fused in mode 1
+  const char* e = getenv("ODT_EFFDET_FUSE_MB_MIN");
+  return e != nullptr && atoi(e) > 0 ? atoi(e) : 64;
+}
 static bool eff_wscale_on() {
   const char* e = getenv("ODT_EFFDET_WSCALE");
   return !(e != nullptr && e[0] == '0');
@@ -460,7 +464,7 @@ int build_plan_effnet(odt_model* m) {
     same(x.h, b.kernel, b.stride, &ho, &dpt); same(x.w, b.kernel, b.stride, &wo, &dpl);
     const int fmode = eff_fuse_mb_mode();
     const bool fuse_mb = b.expand != 1 && eff_split_on() && x.C % 32 == 0 && lmid % 64 == 0 && x.h == x.H && x.w == x.W &&
-                         (fmode >= 2 || (fmode == 1 && std::min(ho, wo) >= 64));
+                         (fmode >= 2 || (fmode == 1 && std::min(ho, wo) >= eff_fuse_mb_min()));
     const float *ewt = nullptr, *ebias = nullptr;
     if (b.expand != 1) {
       const std::string cn = cname(), bn = bname();
