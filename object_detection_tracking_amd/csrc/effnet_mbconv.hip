@@ -37,7 +37,18 @@ constexpr int kMbLds = kMbTileLds > kMbLoopLds ? kMbTileLds : kMbLoopLds;
 constexpr int kMbStageB = 3 * 4 * kMbBN * 16;    // bytes of pre-imaged weights per K slice of 32
 constexpr int kMbNB = kMbStageB / 4096;          // 16-byte weight chunks per thread and slice
 
-__device__ __forceinline__ float mb_swish(float v) { return v * (1.0f / (1.0f + expf(-v))); }
+// swish on the hardware transcendental units: v * rcp(1 + exp2(-v * log2 e)) -- v_exp_f32 and v_rcp_f32, 1 ulp each, i.e.
+// within ~3 ulp of the libm expf + IEEE division form the stand-alone kernels use.  This kernel evaluates 64 + ~50 swishes
+// per thread and tile and is bound by exactly that: with the libm form (~60 instructions per value) the first version
+// ran no faster than the two launches it replaces (profiles/r05_effdet_mbconv_fusion_v1_ab.txt).  Saturation: v -> +inf
+// gives exp2 -> 0, swish -> v; v < -88 gives exp2 -> inf, rcp -> 0, swish -> -0 (the exact value is a denormal there).
+#ifdef ODT_HIP_EMULATOR
+__device__ __forceinline__ float mb_swish(float v) { return v * (1.0f / (1.0f + exp2f(-v * 1.4426950408889634f))); }
+#else
+__device__ __forceinline__ float mb_swish(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-v * 1.4426950408889634f));
+}
+#endif
 
 template <int K, int S>
 __global__ void __launch_bounds__(256, 2) mbconv_expand_dw_kernel(MbExpandDwParams p) {
@@ -191,8 +202,10 @@ __global__ void __launch_bounds__(256, 2) mbconv_expand_dw_kernel(MbExpandDwPara
         const int y = iy0 + (row >> 4), x = ix0 + (row & 15);
         const bool v = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) Et[row * kMbCS + j * 32 + fr] = v ? mb_swish(acc[i][j][r] + ebias[j]) : 0.f;
-        __builtin_amdgcn_sched_barrier(0);       // (two activations at a time: 64 expf expansions in flight would spill)
+        for (int j = 0; j < 2; ++j) {
+          const float e = mb_swish(acc[i][j][r] + ebias[j]);
+          Et[row * kMbCS + j * 32 + fr] = v ? e : 0.f;
+        }
       }
     __syncthreads();
     // ---- depthwise stencil over the tile: this thread's outputs q = slot, slot + 16, ...; taps ky-major, kx inner
