@@ -280,51 +280,10 @@ __global__ void __launch_bounds__(256) se_expand_kernel(SeGateParams p) {
   p.gate[(long)b * p.ldc + c] = 1.0f / (1.0f + expf(-s));
 }
 
-// The three stages above as ONE launch (round 5): one 1024-thread workgroup per image runs fold -> reduce -> expand back
-// to back through LDS.  Every stage keeps the arithmetic of its stand-alone kernel -- the fold's four strided phases
-// combined as ((p0 + p1) + (p2 + p3)) / HW, one reduced channel per wave with the 64-lane strided partial sums and the
-// xor-shuffle tree, the expand's sum over the reduced channels in index order starting from the bias -- so the gate is
-// bit-identical to the three-launch form; what disappears is two launch boundaries per MBConv block (the stages are a
-// few microseconds each: a 45-block backbone spent ~0.9 ms in 135 of these launches).
-__global__ void __launch_bounds__(1024) se_gate_fused_kernel(SeGateParams p) {
-  __shared__ float mean[kSeMaxC];
-  __shared__ float ph4[4][256];
-  __shared__ float r[kSeMaxR];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // fold: thread = (channel c0 + (tid & 255), phase tid >> 8)
-  for (int c0 = 0; c0 < p.ldc; c0 += 256) {
-    const int cl = tid & 255, q = tid >> 8, c = c0 + cl;
-    float s = 0.f;
-    if (c < p.ldc) {
-      const float* src = p.part + (long)b * p.nsplit * p.ldc + c;
-#pragma unroll 8
-      for (int sp = q; sp < p.nsplit; sp += 4) s += src[(long)sp * p.ldc];
-    }
-    ph4[q][cl] = s;
-    __syncthreads();
-    if (q == 0 && c < p.ldc) mean[c] = ((ph4[0][cl] + ph4[1][cl]) + (ph4[2][cl] + ph4[3][cl])) / (float)p.HW;
-    __syncthreads();
-  }
-  // reduce: one reduced channel per wave and round
-  for (int j = wave; j < p.se; j += 16) {
-    const float* w = p.w1 + (long)j * p.ldc;
-    float s = 0.f;
-#pragma unroll 4
-    for (int c = lane; c < p.ldc; c += 64) s += mean[c] * w[c];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (lane == 0) { const float v = s + p.b1[j]; r[j] = v * (1.0f / (1.0f + expf(-v))); }
-  }
-  __syncthreads();
-  // expand
-  for (int c = tid; c < p.mid; c += 1024) {
-    float s = p.b2[c];
-#pragma unroll 8
-    for (int j = 0; j < p.se; ++j) s += r[j] * p.w2t[(long)j * p.ldc + c];
-    p.gate[(long)b * p.ldc + c] = 1.0f / (1.0f + expf(-s));
-  }
-}
-
+// (Round 5 measured the three stages as ONE launch -- a single 1024-thread workgroup per image running fold -> reduce ->
+// expand through LDS, bit-identical gate: 37 us per block on average against 3 x 6.4 us for the three launches, D7 68.4 ->
+// 64.5 FPS same box, profiles/r05_effdet_mbconv_fusion_ab.txt: for the wide late blocks one workgroup is too little
+// parallelism for 2 x 500 K MACs.  Not kept.)
 // x[b, :, :, c] *= s[b, c]   (squeeze-excite gate, already passed through the sigmoid)
 __global__ void __launch_bounds__(256) channel_scale_kernel(float* __restrict__ x, const float* __restrict__ s,
                                                             int B, int HW, int ldc) {
@@ -528,12 +487,6 @@ int launch_se_gate(const float* in, const SeGateParams& p0, int B, float* scratc
 int launch_se_gate_from_parts(const SeGateParams& p, int B, hipStream_t stream) {
   ODT_CHECK(p.ldc <= kSeMaxC && p.se <= kSeMaxR, "se_gate: channel count too large for the LDS staging");
   ODT_CHECK(p.part != nullptr && p.nsplit >= 1, "se_gate: partial sums missing");
-  static const bool one_launch = !(getenv("ODT_EFFDET_SE_FUSED") != nullptr && getenv("ODT_EFFDET_SE_FUSED")[0] == '0');   // A/B knob
-  if (one_launch) {
-    hipLaunchKernelGGL(se_gate_fused_kernel, dim3(B), dim3(1024), 0, stream, p);
-    ODT_HIP(hipGetLastError());
-    return 0;
-  }
   hipLaunchKernelGGL(channel_mean_fold_kernel, dim3((p.ldc + 63) / 64, B), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(se_reduce_kernel, dim3((p.se + 3) / 4, B), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(se_expand_kernel, dim3((p.mid + 255) / 256, B), dim3(256), 0, stream, p);

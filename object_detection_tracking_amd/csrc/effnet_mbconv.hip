@@ -222,11 +222,17 @@ __global__ void __launch_bounds__(256, 2) mbconv_expand_dw_kernel(MbExpandDwPara
         if (oy >= p.Ho || ox >= p.Wo) continue;
         const float* e0 = &Et[((oyl * S) * kMbP + oxl * S) * kMbCS + cq * 4];
         f32x4 a = zero;
+        // a kernel row's K reads are issued together (fenced: left alone the scheduler keeps two reads in flight and
+        // waits for each -- the loop was bound by LDS latency), then its K products, ky-major / kx inner as before
 #pragma unroll
-        for (int ky = 0; ky < K; ++ky)
+        for (int ky = 0; ky < K; ++ky) {
+          f32x4 ev[K];
 #pragma unroll
-          for (int kx = 0; kx < K; ++kx)
-            a += *reinterpret_cast<const f32x4*>(e0 + (ky * kMbP + kx) * kMbCS) * w[ky * K + kx];
+          for (int kx = 0; kx < K; ++kx) ev[kx] = *reinterpret_cast<const f32x4*>(e0 + (ky * kMbP + kx) * kMbCS);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) a += ev[kx] * w[ky * K + kx];
+        }
         f32x4 v = a + dbias;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = mb_swish(v[e]);
