@@ -673,13 +673,13 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
     if (pol.family == 2 && q.in_amax == nullptr) {      // fp16x2 pieces need the sources' |max|: nobody recorded it for a stand-alone call
       // (the scan covers the whole allocation B x in_Ha x in_Wa x in_ldc of a source: a stand-alone caller hands over
       // dense tensors -- odt_op_conv2d* -- so this is the logical view; a sliced view would have to bring its own range)
-      ODT_HIP(hipMalloc((void**)&tmp.amax, 2 * sizeof(unsigned)));
-      ODT_HIP(hipMemsetAsync(tmp.amax, 0, 2 * sizeof(unsigned), stream));
+      ODT_HIP(hipMalloc((void**)&tmp.amax, 2 * kAmaxWays * sizeof(unsigned)));
+      ODT_HIP(hipMemsetAsync(tmp.amax, 0, 2 * kAmaxWays * sizeof(unsigned), stream));
       if (launch_tensor_amax(q.in, (size_t)q.B * q.in_Ha * q.in_Wa * q.in_ldc, tmp.amax, stream)) return 1;
       q.in_amax = tmp.amax;
       if (q.in2 != nullptr) {
-        if (launch_tensor_amax(q.in2, (size_t)q.B * q.in2_Ha * q.in2_Wa * q.in2_ldc, tmp.amax + 1, stream)) return 1;
-        q.in2_amax = tmp.amax + 1;
+        if (launch_tensor_amax(q.in2, (size_t)q.B * q.in2_Ha * q.in2_Wa * q.in2_ldc, tmp.amax + kAmaxWays, stream)) return 1;
+        q.in2_amax = tmp.amax + kAmaxWays;
       }
     }
     conv_split_choose(q, pol);

@@ -631,7 +631,8 @@ __global__ void __launch_bounds__(256) split_reduce_kernel(const ConvParams* __r
     __syncthreads();
     if (threadIdx.x == 0) {
       const unsigned b = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
-      if (b > __atomic_load_n(p.out_amax, __ATOMIC_RELAXED)) atomicMax(p.out_amax, b);
+      unsigned* w = amax_way(p.out_amax);
+      if (b > __atomic_load_n(w, __ATOMIC_RELAXED)) atomicMax(w, b);
     }
   }
 }

@@ -107,10 +107,21 @@ __host__ __device__ __forceinline__ int h2_scale_exp(unsigned amax_bits) {
   const int s = 14 - (be - 127);
   return s > 100 ? 100 : (s < -100 ? -100 : s);
 }
+// A tensor's range slot is kAmaxWays words (odt_common.hpp): a producer workgroup folds its |max| into word
+// (workgroup index mod kAmaxWays), a consumer takes the maximum of all of them (uniform address: scalar loads).  Same value
+// as one word per tensor; a sixteenth of the same-address atomics when a launch's workgroups finish together (round 5: the
+// split-K combine pass at b = 1 ended in 512 of them on ONE word).
+__device__ __forceinline__ unsigned amax_read(const unsigned* slot) {
+  unsigned a = 0u;
+#pragma unroll
+  for (int w = 0; w < kAmaxWays; ++w) { const unsigned b = slot[w]; a = b > a ? b : a; }
+  return a;
+}
+__device__ __forceinline__ unsigned* amax_way(unsigned* slot) { return slot + (blockIdx.x & (unsigned)(kAmaxWays - 1)); }
 // the A-side scale exponent of a conv: from the recorded |max| of its source tensor(s)
 __device__ __forceinline__ int h2_in_scale_exp(const ConvParams& p) {
-  unsigned a = p.in_amax != nullptr ? *p.in_amax : 0u;
-  if (p.in2_amax != nullptr) { const unsigned b = *p.in2_amax; a = b > a ? b : a; }
+  unsigned a = p.in_amax != nullptr ? amax_read(p.in_amax) : 0u;
+  if (p.in2_amax != nullptr) { const unsigned b = amax_read(p.in2_amax); a = b > a ? b : a; }
   return h2_scale_exp(a);
 }
 

@@ -15,7 +15,8 @@ __device__ __forceinline__ void publish_amax(unsigned* slot, float vmax, int tid
   for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
   if ((tid & 63) == 0) {
     const unsigned b = __float_as_uint(vmax);
-    if (b > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, b);
+    unsigned* w = amax_way(slot);
+    if (b > __atomic_load_n(w, __ATOMIC_RELAXED)) atomicMax(w, b);
   }
 }
 
@@ -35,7 +36,8 @@ __device__ __forceinline__ void publish_amax_wg(unsigned* slot, float vmax, int 
 #pragma unroll
     for (int w = 1; w < NTHR / 64; ++w) m = fmaxf(m, red[w]);
     const unsigned b = __float_as_uint(m);
-    if (b > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, b);
+    unsigned* w = amax_way(slot);
+    if (b > __atomic_load_n(w, __ATOMIC_RELAXED)) atomicMax(w, b);
   }
 }
 

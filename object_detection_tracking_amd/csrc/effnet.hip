@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256) se_expand_kernel(SeGateParams p) {
 
 // (Round 5 measured the three stages as ONE launch -- a single 1024-thread workgroup per image running fold -> reduce ->
 // expand through LDS, bit-identical gate: 37 us per block on average against 3 x 6.4 us for the three launches, D7 68.4 ->
-// 64.5 FPS same box, profiles/r05_effdet_mbconv_fusion_ab.txt: for the wide late blocks one workgroup is too little
+// 64.5 FPS same box, profiles/r05_effdet_se_one_launch_ab.txt: for the wide late blocks one workgroup is too little
 // parallelism for 2 x 500 K MACs.  Not kept.)
 // x[b, :, :, c] *= s[b, c]   (squeeze-excite gate, already passed through the sigmoid)
 __global__ void __launch_bounds__(256) channel_scale_kernel(float* __restrict__ x, const float* __restrict__ s,

@@ -15,7 +15,8 @@ __device__ __forceinline__ void record_amax(unsigned* slot, float vmax) {
   for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
   if ((threadIdx.x & 63) == 0) {
     const unsigned b = __float_as_uint(vmax);
-    if (b > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, b);
+    unsigned* w = slot + (blockIdx.x & (unsigned)(kAmaxWays - 1));       // (kAmaxWays words per tensor: conv_split_common.hpp amax_read)
+    if (b > __atomic_load_n(w, __ATOMIC_RELAXED)) atomicMax(w, b);
   }
 }
 

@@ -206,7 +206,7 @@ int odt_op_bottleneck_tail(int device, const float* in, int B, int H, int W, int
   Tmp<float> di, dw2, db2, dw3, db3, dres, dmid, dout, img2, img3, imgf;
   Tmp<unsigned> amax;
   if (di.alloc(M * C) || dw2.alloc(w2.size()) || db2.alloc(C) || dw3.alloc(w3.size()) || db3.alloc(C3) || dmid.alloc(M * C) ||
-      dout.alloc(M * C3) || dout.zero() || amax.alloc(4) || amax.zero()) return 1;
+      dout.alloc(M * C3) || dout.zero() || amax.alloc(4 * kAmaxWays) || amax.zero()) return 1;
   if (di.put(in) || dw2.put(w2.data()) || db2.put(b2) || dw3.put(w3.data()) || db3.put(b3)) return 1;
   if (res) { if (dres.alloc(M * C3) || dres.put(res)) return 1; }
   if (launch_tensor_amax(di.d, M * C, amax.d, nullptr)) return 1;
@@ -216,7 +216,7 @@ int odt_op_bottleneck_tail(int device, const float* in, int B, int H, int W, int
   a.kh = 3; a.kw = 3; a.stride = 1; a.dil = dil; a.pad_t = dil; a.pad_l = dil;
   a.out_H = H; a.out_W = W; a.out_ldc = C; a.relu = 1;
   a.wt_split_kind = 2; a.wt_split_bm = 256; a.wt_split_bn = C; a.wt_split_kwr = 1; a.splitk = 1;
-  a.in_amax = amax.d; a.out_amax = amax.d + 1; a.debug = 0x400;
+  a.in_amax = amax.d; a.out_amax = amax.d + kAmaxWays; a.debug = 0x400;
   conv_prepare(a);
   if (img2.alloc((conv_split_weight_bytes(C, 9 * C) + 3) / 4) || conv_make_split_weights(a, img2.d, nullptr)) return 1;
   a.wt_split = img2.d; a.h2_chinv = conv_h2_chinv(img2.d, C, 9 * C);
@@ -228,7 +228,7 @@ int odt_op_bottleneck_tail(int device, const float* in, int B, int H, int W, int
   b.res_mode = res ? 1 : 0; b.res_H = H; b.res_W = W; b.res_ldc = C3;
   b.wt_split_kind = 2; b.wt_split_bm = 256; b.wt_split_bn = C3 % 256 == 0 ? 256 : (C3 % 128 == 0 ? 128 : 64); b.splitk = 1;
   if (b.wt_split_bn == 64) b.wt_split_bm = 128;
-  b.in_amax = amax.d + 1; b.out_amax = amax.d + 2; b.debug = 0x400;
+  b.in_amax = amax.d + kAmaxWays; b.out_amax = amax.d + 2 * kAmaxWays; b.debug = 0x400;
   conv_prepare(b);
   if (img3.alloc((conv_split_weight_bytes(C3, C) + 3) / 4) || conv_make_split_weights(b, img3.d, nullptr)) return 1;
   b.wt_split = img3.d; b.h2_chinv = conv_h2_chinv(img3.d, C3, C);
@@ -238,7 +238,7 @@ int odt_op_bottleneck_tail(int device, const float* in, int B, int H, int W, int
     ODT_CHECK(conv_h2f_fusable(a, b), "odt_op_bottleneck_tail: this pair is not fusable");
     if (imgf.alloc((conv_h2f_weight_bytes(C3, C) + 3) / 4) || conv_make_h2f_weights(dw3.d, C3, C, imgf.d, nullptr)) return 1;
     a.f_wt = imgf.d; a.f_chinv = conv_h2f_chinv(imgf.d, C3, C); a.f_bias = db3.d; a.f_res = b.res; a.f_res_ldc = C3;
-    a.f_out = dout.d; a.f_out_ldc = C3; a.f_cout = C3; a.f_relu = b.relu; a.f_out_amax = amax.d + 2;
+    a.f_out = dout.d; a.f_out_ldc = C3; a.f_cout = C3; a.f_relu = b.relu; a.f_out_amax = amax.d + 2 * kAmaxWays;
     a.out = nullptr; a.out_amax = nullptr;
     ConvParams recs[2] = {a, b};
     if (rec.put(recs)) return 1;
@@ -270,7 +270,7 @@ int odt_op_stem(int device, const float* frame_pad, int B, int Hp, int Wp, const
   Tmp<ConvParams> rec;
   const size_t nmap = (size_t)B * Ho0 * Wo0 * 64, nout = (size_t)B * Hq * Wq * 64;
   if (di.alloc(x.size()) || dw.alloc(wv.size()) || db.alloc(64) || dmap.alloc(nmap) || dout.alloc(nout) || dout.zero() ||
-      amax.alloc(4) || amax.zero() || rec.alloc(1)) return 1;
+      amax.alloc(4 * kAmaxWays) || amax.zero() || rec.alloc(1)) return 1;
   if (di.put(x.data()) || dw.put(wv.data()) || db.put(bias)) return 1;
   if (launch_tensor_amax(di.d, x.size(), amax.d, nullptr)) return 1;
   ConvParams p; std::memset(&p, 0, sizeof(p));
@@ -278,7 +278,7 @@ int odt_op_stem(int device, const float* frame_pad, int B, int Hp, int Wp, const
   p.B = B; p.H = Hp; p.W = Wa; p.Cin = 32; p.in_ldc = 4; p.in_Ha = Hp; p.in_Wa = Wa; p.Ho = Ho0; p.Wo = Wo0; p.Cout = 64;
   p.kh = 7; p.kw = 1; p.stride = 2; p.dil = 1; p.out_H = Ho0; p.out_W = Wo0; p.out_ldc = 64; p.relu = 1;
   p.wt_split_kind = 2; p.wt_split_bm = 128; p.wt_split_bn = 64; p.splitk = 1;
-  p.in_amax = amax.d; p.out_amax = amax.d + 1;
+  p.in_amax = amax.d; p.out_amax = amax.d + kAmaxWays;
   conv_prepare(p);
   if (img.alloc((conv_split_weight_bytes(64, 224) + 3) / 4) || conv_make_split_weights(p, img.d, nullptr)) return 1;
   p.wt_split = img.d; p.h2_chinv = conv_h2_chinv(img.d, 64, 224);

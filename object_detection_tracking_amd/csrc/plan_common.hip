@@ -191,7 +191,7 @@ int attach_split_weights(odt_model* m) {
   m->policy = pol;
   if (pol.arith == 0) return 0;
   find_overlap_points(m);
-  m->amax_dev = reinterpret_cast<unsigned*>(m->alloc_f(2 * odt_model::kAmaxSlots, true));
+  m->amax_dev = reinterpret_cast<unsigned*>(m->alloc_f((size_t)2 * odt_model::kAmaxSlots * kAmaxWays, true));   // kAmaxWays words per slot
   ODT_CHECK(m->amax_dev != nullptr, "device allocation failed (range slots)");
   // |max| slots: a tensor written by a split conv kernel gets one; a pooled / subsampled tensor shares its source's (its
   // values are a subset); anything else has none, and a conv reading it stays off the fp16x2 kernels.  Tail convs only
@@ -201,7 +201,7 @@ int attach_split_weights(odt_model* m) {
     auto it = t != nullptr ? slot_of.find(t) : slot_of.end();
     if (it == slot_of.end()) return nullptr;
     if (tail_reader != (it->second >= odt_model::kAmaxSlots)) return nullptr;
-    return m->amax_dev + it->second;
+    return m->amax_dev + (size_t)it->second * kAmaxWays;
   };
   std::map<std::pair<const float*, int>, const void*> made;      // the RPN conv is shared by the five levels: one image per layout
   size_t need_partial = 0;
@@ -211,7 +211,7 @@ int attach_split_weights(odt_model* m) {
     if (op.kind == OP_PRE && pol.family == 2) {        // the preprocess kernel records the range of the padded frames
       ODT_CHECK(m->amax_used[0] < odt_model::kAmaxSlots, "too many conv outputs for the range slots");
       slot_of[m->image_pad.d] = m->amax_used[0];
-      m->pre_amax = m->amax_dev + m->amax_used[0]++;
+      m->pre_amax = m->amax_dev + (size_t)(m->amax_used[0]++) * kAmaxWays;
       continue;
     }
     if (op.kind == OP_POOL || op.kind == OP_SUB2) {
@@ -265,7 +265,7 @@ int attach_split_weights(odt_model* m) {
         slot = (tail ? odt_model::kAmaxSlots : 0) + m->amax_used[tail]++;
         slot_of[c.p.out] = slot;
       }
-      c.p.out_amax = m->amax_dev + slot;
+      c.p.out_amax = m->amax_dev + (size_t)slot * kAmaxWays;
     }
   }
   if (need_partial > 0) {

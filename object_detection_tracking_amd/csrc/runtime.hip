@@ -170,7 +170,7 @@ static int finish_profile(odt_model* m, hipStream_t st) {
 // the |max| slots the split conv kernels of a group of ops fill (0: trunk, 1: tail) start a forward at zero
 static int clear_amax(odt_model* m, int group, hipStream_t st) {
   if (m->amax_dev == nullptr || m->amax_used[group] == 0) return 0;
-  ODT_HIP(hipMemsetAsync(m->amax_dev + group * odt_model::kAmaxSlots, 0, (size_t)m->amax_used[group] * sizeof(unsigned), st));
+  ODT_HIP(hipMemsetAsync(m->amax_dev + (size_t)group * odt_model::kAmaxSlots * kAmaxWays, 0, (size_t)m->amax_used[group] * kAmaxWays * sizeof(unsigned), st));
   return 0;
 }
 
