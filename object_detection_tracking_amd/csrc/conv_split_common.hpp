@@ -107,10 +107,8 @@ __host__ __device__ __forceinline__ int h2_scale_exp(unsigned amax_bits) {
   const int s = 14 - (be - 127);
   return s > 100 ? 100 : (s < -100 ? -100 : s);
 }
-// A tensor's range slot is kAmaxWays words (odt_common.hpp): a producer workgroup folds its |max| into word
-// (workgroup index mod kAmaxWays), a consumer takes the maximum of all of them (uniform address: scalar loads).  Same value
-// as one word per tensor; a sixteenth of the same-address atomics when a launch's workgroups finish together (round 5: the
-// split-K combine pass at b = 1 ended in 512 of them on ONE word).
+// A tensor's range slot is kAmaxWays words (odt_common.hpp; 1 in the product): a producer workgroup folds its |max| into word
+// (workgroup index mod kAmaxWays), a consumer takes the maximum of all of them.  Same value whatever the number of ways.
 __device__ __forceinline__ unsigned amax_read(const unsigned* slot) {
   unsigned a = 0u;
 #pragma unroll

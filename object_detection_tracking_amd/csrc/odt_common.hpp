@@ -35,9 +35,13 @@ typedef float f32x16 __attribute__((vector_size(64)));
 constexpr int kMaxTopK = 1024;   // rpn_test_post_nms_topk handled by the one-candidate-per-thread selection kernels
 constexpr int kMaxTopKBig = 4096;// rpn_test_post_nms_topk upper bound (above kMaxTopK: the *_big kernels, paneled NMS)
 #ifndef ODT_AMAX_WAYS
-#define ODT_AMAX_WAYS 16
+#define ODT_AMAX_WAYS 1
 #endif
-constexpr int kAmaxWays = ODT_AMAX_WAYS;   // words per tensor range slot (ConvParams::in_amax / out_amax): see conv_split_common.hpp amax_read (-DODT_AMAX_WAYS=1: the A/B build)
+// words per tensor range slot (ConvParams::in_amax / out_amax; conv_split_common.hpp amax_read / amax_way).  1: one word per
+// tensor.  Round 5 measured 16 (-DODT_AMAX_WAYS=16, tools/ab_build_all.sh: a sixteenth of the same-address atomics when a
+// launch's workgroups finish together): b = 8 310.0 -> 308.7 FPS, b = 1 174.0 -> 164.0 (profiles/r05_amax_ways_ab.txt) -- the
+// sixteen reads in front of every consumer's first load cost more than the atomics they spare.  Not kept.
+constexpr int kAmaxWays = ODT_AMAX_WAYS;
 constexpr int kRoiOut = 7;       // ROIAlign output side (models.py:703)
 constexpr int kRpnCh = 16;       // 3 logits + 12 deltas (+1 pad) per pixel
 constexpr int kSelChunk = 32768; // logits per workgroup in stage 1 of the RPN top-k
