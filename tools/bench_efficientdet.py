@@ -121,16 +121,19 @@ def measure(model="efficientdet-d7", size=0, frame="", steps=20, warmup=3, cpu_b
     cpu = {"value": 1.0 / cdt, "unit": "frames/s", "cores": int(_t.get_num_threads()), "kind": "port",
            "sample": "one frame through oracle.effnet (torch-CPU fp32 + numpy tail), one pass, %.1f s" % cdt}
   traffic = None
+  traffic_source = None
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  for name in ([pmc_profile] if pmc_profile else ["r04_pmc_summary_effdet_d7.json", "r03_pmc_summary_effdet_d7.json", "r02_pmc_summary_effdet_d7.json"]):
+  for name in ([pmc_profile] if pmc_profile else ["r05_pmc_summary_effdet_d7.json", "r04_pmc_summary_effdet_d7.json", "r03_pmc_summary_effdet_d7.json", "r02_pmc_summary_effdet_d7.json"]):
     pmc = os.path.join(root, "profiles", name)
     if model == "efficientdet-d7" and S == 1536 and os.path.exists(pmc):
       # HBM bytes per forward from the committed rocprofv3 --pmc passes (tools/gpurun/r2_effdet_pmc.sh), FETCH_SIZE doubled
       traffic = json.load(open(pmc))["hbm_GB_per_forward_fetch_x2"] * 1e9
+      traffic_source = ("profiles/%s: separate rocprofv3 --pmc passes of tools/bench_efficientdet.py on the builder's evidence box -- "
+                        "NOT measured by the run that prints this line" % name)
       break
   res = {"roofline": {"bound": "hbm", "kernel": "whole network (depthwise / SE / fusion kernels are HBM-bound, "
                       "the 1x1 convs small-K MFMA)", "achieved": algo_bytes / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
-                      "frac": algo_bytes / dt / 1e9 / 8000.0, "traffic": traffic,
+                      "frac": algo_bytes / dt / 1e9 / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
                       "algorithmic_bytes_per_frame": algo_bytes,
                       "fused_graph_bytes_per_frame": fused_bytes, "frac_vs_fused_graph_bytes": fused_bytes / dt / 1e9 / 8000.0,
                       "frac_measured_traffic": (traffic / dt / 1e9 / 8000.0) if traffic else None,

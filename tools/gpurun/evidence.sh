@@ -8,10 +8,11 @@
 #   probe   : what the matrix pipe of this box sustains on the kernels' MFMA mixes
 #   rocprof : rocprofv3 --kernel-trace --stats of the bench command
 #   pmc     : the separate --pmc passes of the bench command (FETCH_SIZE | WRITE_SIZE | MFMA busy | LDS / wait)
+#   d7pmc   : HBM traffic counters of the EfficientDet-D7 forward (two --pmc passes) + its kernel trace
 # Everything lands in gpurun_out/<ROUND>_*; copy what should be judged into profiles/.
 mkdir -p gpurun_out
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-N=${ROUND:-r04}
+N=${ROUND:-r05}
 PARTS=${PARTS:-"tests bench b1 layers probe rocprof pmc"}
 export TMPDIR=/tmp
 has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
@@ -64,5 +65,18 @@ if has pmc; then
   python tools/pmc_summary.py gpurun_out gpurun_out/${N}_pmc_summary_split > gpurun_out/${N}_pmc_summary.log 2>&1
   cat gpurun_out/${N}_pmc_summary_split.txt | cut -c1-200
   python tools/pmc_by_kernel.py gpurun_out > gpurun_out/${N}_pmc_lds_wait_by_kernel.txt 2>&1; cut -c1-220 gpurun_out/${N}_pmc_lds_wait_by_kernel.txt
+  find gpurun_out -name "*.csv" -size +20M -delete; find gpurun_out -name "*.db" -size +20M -delete
+fi
+if has d7pmc; then
+  cd /tmp
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf $R/gpurun_out/pmceff_$c
+    timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmceff_$c -o pmc -- python $R/tools/bench_efficientdet.py --no-cpu-baseline --steps 2 --warmup 1 > $R/gpurun_out/pmceff_$c.log 2>&1
+  done
+  rm -rf $R/gpurun_out/prof_d7
+  timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_d7 -o d7 -- python $R/tools/bench_efficientdet.py --no-cpu-baseline --steps 10 --warmup 2 > $R/gpurun_out/d7_prof.log 2>&1
+  cd $R
+  python tools/pmc_summary_effdet.py gpurun_out gpurun_out/${N}_pmc_summary_effdet_d7 2>&1 | tail -12
+  python tools/kernel_stats.py gpurun_out/prof_d7 > gpurun_out/${N}_kernel_stats_efficientdet_d7.txt 2>&1
   find gpurun_out -name "*.csv" -size +20M -delete; find gpurun_out -name "*.db" -size +20M -delete
 fi
