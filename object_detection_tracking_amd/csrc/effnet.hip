@@ -361,62 +361,7 @@ __global__ void __launch_bounds__(256) bifpn_fuse_kernel(FuseParams p) {
 }
 
 
-// BiFPN node front half in one kernel (round 5): the fused value (bifpn_fuse_at: weighted sum of the resampled inputs +
-// swish) of a 16 x 16 patch goes to an LDS tile ONCE, the node's depthwise 3 x 3 ('SAME', no BN, no activation:
-// separable_conv2d's first half) reads it from there -- the fused tensor is neither written nor read back, and the node is
-// two launches (this + the pointwise conv) instead of three.  Same arithmetic as bifpn_fuse_kernel + dwconv_kernel<3,1,.>
-// (same fused values; taps ky-major / kx inner, a patch pixel outside the map is the conv's zero padding and adds +0
-// where the stand-alone kernel skips the tap): bit-identical outputs.  Evaluating the fusion inside the stencil WITHOUT
-// the tile re-evaluated every fused value 3.75 times (round 2: 68.7 -> 51.4 FPS); this is that experiment with the tile.
-// Workgroup = (14 x 14 outputs, 32 channels): 8 channel quads x 32 pixel slots, 37 KB of LDS.
-constexpr int kFdP = 16, kFdT = 14, kFdC = 32, kFdCS = kFdC + 4;
-__global__ void __launch_bounds__(256) bifpn_fuse_dw_kernel(FuseDwParams q) {
-  __shared__ __attribute__((aligned(16))) float tile[kFdP * kFdP * kFdCS];
-  const FuseParams& p = q.f;
-  const int tid = threadIdx.x, cq = tid & 7, slot = tid >> 3;
-  const int tiles_x = (p.w + kFdT - 1) / kFdT;
-  const int ty = (int)blockIdx.x / tiles_x, tx = (int)blockIdx.x - ty * tiles_x;
-  const int c4 = (int)blockIdx.y * (kFdC / 4) + cq, b = (int)blockIdx.z;
-  const bool cok = c4 < (p.ldc >> 2);
-  const int y0 = ty * kFdT - 1, x0 = tx * kFdT - 1;
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  for (int m = slot; m < kFdP * kFdP; m += 32) {
-    const int y = y0 + (m >> 4), x = x0 + (m & 15);
-    f32x4 v = zero;
-    if (cok && (unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w) v = bifpn_fuse_at(p, b, y, x, c4);
-    *reinterpret_cast<f32x4*>(&tile[m * kFdCS + cq * 4]) = v;
-  }
-  __syncthreads();
-  if (!cok) return;
-  f32x4 w[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const f32x4*>(q.dw_wt + (long)t * p.ldc + c4 * 4);
-  const f32x4 bias = *reinterpret_cast<const f32x4*>(q.dw_bias + c4 * 4);
-  for (int o = slot; o < kFdT * kFdT; o += 32) {
-    const int oyl = o / kFdT, oxl = o - oyl * kFdT;
-    const int oy = ty * kFdT + oyl, ox = tx * kFdT + oxl;
-    if (oy >= p.h || ox >= p.w) continue;
-    const float* e0 = &tile[(oyl * kFdP + oxl) * kFdCS + cq * 4];
-    f32x4 a = zero;
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) a += *reinterpret_cast<const f32x4*>(e0 + (ky * kFdP + kx) * kFdCS) * w[ky * 3 + kx];
-    *reinterpret_cast<f32x4*>(q.out + (((long)b * p.h + oy) * p.w + ox) * p.ldc + c4 * 4) = a + bias;
-  }
-}
-
 }  // namespace
-
-int launch_bifpn_fuse_dw(const FuseDwParams& q, hipStream_t stream) {
-  const FuseParams& p = q.f;
-  ODT_CHECK(p.n >= 1 && p.n <= 3 && p.ldc % 4 == 0 && q.dw_wt != nullptr && q.dw_bias != nullptr && q.out != nullptr,
-            "bifpn_fuse_dw: bad arguments");
-  const dim3 grid(((p.h + kFdT - 1) / kFdT) * ((p.w + kFdT - 1) / kFdT), ((p.ldc >> 2) + kFdC / 4 - 1) / (kFdC / 4), p.B);
-  hipLaunchKernelGGL(bifpn_fuse_dw_kernel, grid, dim3(256), 0, stream, q);
-  ODT_HIP(hipGetLastError());
-  return 0;
-}
 
 int launch_preprocess_rgb(const void* frames, int dtype, int B, int H, int W, int pad_t, int pad_l, int Hp, int Wp,
                           float* out, hipStream_t stream) {

@@ -253,14 +253,6 @@ struct FuseParams {
   float* out;
 };
 int launch_bifpn_fuse(const FuseParams& p, hipStream_t stream);
-// fusion + the node's depthwise 3x3 'SAME' conv in one kernel (the fused tensor stays in LDS): f.out is unused
-struct FuseDwParams {
-  FuseParams f;
-  const float* dw_wt;    // [9][ldc]
-  const float* dw_bias;  // [ldc]
-  float* out;            // [B,h,w,ldc]
-};
-int launch_bifpn_fuse_dw(const FuseDwParams& p, hipStream_t stream);
 int launch_preprocess_rgb(const void* frames, int dtype, int B, int H, int W, int pad_t, int pad_l, int Hp, int Wp,
                           float* out, hipStream_t stream);
 int channel_mean_splits(int HW, int ldc, int B);

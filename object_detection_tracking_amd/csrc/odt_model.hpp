@@ -60,14 +60,13 @@ struct ConvOp {
 
 enum OpKind { OP_PRE, OP_CONV, OP_POOL, OP_SUB2, OP_PROPOSALS, OP_ROI_HEAD, OP_DETECT, OP_ROI_FINAL,
               OP_ROI_MASK, OP_MASK_SELECT, OP_PRE_RGB, OP_DW, OP_CMEAN, OP_CSCALE, OP_FUSE, OP_EFF_POST, OP_ROI_EFF, OP_SE_GATE,
-              OP_SE_GATE_MEAN, OP_WSCALE, OP_MB_EXPAND_DW, OP_FUSE_DW };
+              OP_SE_GATE_MEAN, OP_WSCALE, OP_MB_EXPAND_DW };
 struct Op {
   OpKind kind;
   int conv = -1;        // index into convs
   Tensor in, out;
   DwConvParams dw{};    // OP_DW
   MbExpandDwParams mb{};   // OP_MB_EXPAND_DW
-  FuseDwParams fdw{};      // OP_FUSE_DW
   FuseParams fuse{};    // OP_FUSE
   SeGateParams se{};    // OP_SE_GATE (aux2 = partial-sum scratch)
   float* aux = nullptr; // OP_CMEAN: means out [B,ldc]; OP_CSCALE / OP_WSCALE: gates in [B,ldc]
@@ -121,7 +120,6 @@ struct odt_model {
   Slot* d2h_slot = nullptr; int d2h_want = 0;
   ConvPolicy policy{};               // conv arithmetic / kernel-family policy of this handle (attach_split_weights)
   int mb_fused = 0;                  // EfficientNet: MBConv blocks whose expand + depthwise run as one kernel (effnet_mbconv.hip)
-  int fuse_dw_fused = 0;             // EfficientDet: BiFPN nodes whose fusion + depthwise run as one kernel (bifpn_fuse_dw_kernel)
   // tail overlap: the selection / ROIAlign / box-head / NMS kernels of forward i (a few dozen workgroups each,
   // ~2 ms per 8-frame step) run on a side stream under the backbone of forward i+1.  The next forward's FPN stage
   // (the first op that overwrites what the tail reads: P2..P5, the RPN outputs) waits for the previous tail.
@@ -248,7 +246,6 @@ void visit_op_ptrs(odt_model* m, size_t oi, F&& f) {
     case OP_MASK_SELECT: f(m->mask_sel.logits); break;
     case OP_DW: f(op.dw.in); f(op.dw.out); for (auto& p : op.dw.lin) f(p); for (auto& p : op.dw.lout) f(p); break;
     case OP_MB_EXPAND_DW: f(op.mb.x); f(op.mb.out); break;
-    case OP_FUSE_DW: for (auto& p : op.fdw.f.in) f(p); f(op.fdw.out); break;
     case OP_FUSE: for (auto& p : op.fuse.in) f(p); f(op.fuse.out); break;
     case OP_EFF_POST: for (auto& p : m->eff_post.cls) f(p); for (auto& p : m->eff_post.box) f(p); break;
     case OP_CMEAN: case OP_CSCALE: case OP_SE_GATE: case OP_SE_GATE_MEAN: case OP_WSCALE: case OP_POOL: case OP_SUB2: break;

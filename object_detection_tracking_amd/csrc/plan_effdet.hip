@@ -120,17 +120,9 @@ int eff_same(int n, int k, int s, int* before) {
   return out;
 }
 
-// BiFPN node: fusion + depthwise as one kernel (bifpn_fuse_dw_kernel); ODT_EFFDET_FUSE_BIFPN=0: the two launches (A/B)
-static bool eff_fuse_bifpn_on() {
-  const char* e = getenv("ODT_EFFDET_FUSE_BIFPN");
-  return !(e != nullptr && e[0] == '0');
-}
-
 // depthwise 3x3 'same' (no BN, no activation) + pointwise 1x1 (+bias, optional BN fold, activation)
-// fuse != nullptr: `in` is the (never materialised) result of that fusion -- only its shape is used -- and the depthwise
-// half runs inside the fusion kernel
 int eff_sepconv(odt_model* m, const std::string& scope, const std::string& bn_scope, const Tensor& in, int cin,
-                int cout, int act, const std::string& tap, Tensor* out, const FuseParams* fuse = nullptr) {
+                int cout, int act, const std::string& tap, Tensor* out) {
   const int B = in.B, ldc = in.C;
   const HostTensor* Wd = find_w(m, scope + "/depthwise_kernel");
   ODT_CHECK(Wd && Wd->data.size() == (size_t)9 * cin, "missing / bad " + scope + "/depthwise_kernel");
@@ -140,13 +132,7 @@ int eff_sepconv(odt_model* m, const std::string& scope, const std::string& bn_sc
   if (upload_raw(m, v, &dwt) || upload_raw(m, bv, &dbias)) return 1;
   Tensor t1{};
   if (make_tensor(m, "", B, in.h, in.w, ldc, &t1, false)) return 1;     // (the depthwise kernel writes every channel of the stride)
-  if (fuse != nullptr) {
-    Op op; op.kind = OP_FUSE_DW;
-    op.fdw.f = *fuse; op.fdw.f.out = nullptr;
-    op.fdw.dw_wt = dwt; op.fdw.dw_bias = dbias; op.fdw.out = t1.d;
-    m->ops.push_back(op);
-    ++m->fuse_dw_fused;
-  } else {
+  {
     Op op; op.kind = OP_DW;
     op.dw.in = in.d; op.dw.wt = dwt; op.dw.bias = dbias; op.dw.out = t1.d;
     op.dw.B = B; op.dw.H = in.h; op.dw.W = in.w; op.dw.Ho = in.h; op.dw.Wo = in.w; op.dw.ldc = ldc;
@@ -243,17 +229,11 @@ int build_effdet_heads(odt_model* m, const Tensor* red, const int* red_ch) {
       op.fuse.n = n; op.fuse.act = 2; op.fuse.B = B; op.fuse.h = th; op.fuse.w = tw; op.fuse.ldc = LF;
       const std::string q = p + "op_after_combine" + std::to_string(feats.size()) + "/";
       Tensor node{};
-      if (eff_fuse_bifpn_on()) {
-        // fusion + depthwise in one kernel: the fused tensor is never materialised (`shape` only carries its geometry)
-        Tensor shape{}; shape.B = B; shape.h = shape.H = th; shape.w = shape.W = tw; shape.C = LF;
-        if (eff_sepconv(m, q + "conv", q + "bn", shape, F, F, 0, "cell" + std::to_string(rep) + "_fnode" + std::to_string(i), &node, &op.fuse)) return 1;
-      } else {
-        Tensor fused{};
-        if (make_tensor(m, "", B, th, tw, LF, &fused, false)) return 1;     // (the fusion kernel writes every channel of the stride)
-        op.fuse.out = fused.d;
-        m->ops.push_back(op);
-        if (eff_sepconv(m, q + "conv", q + "bn", fused, F, F, 0, "cell" + std::to_string(rep) + "_fnode" + std::to_string(i), &node)) return 1;
-      }
+      Tensor fused{};
+      if (make_tensor(m, "", B, th, tw, LF, &fused, false)) return 1;     // (the fusion kernel writes every channel of the stride)
+      op.fuse.out = fused.d;
+      m->ops.push_back(op);
+      if (eff_sepconv(m, q + "conv", q + "bn", fused, F, F, 0, "cell" + std::to_string(rep) + "_fnode" + std::to_string(i), &node)) return 1;
       feats.push_back(Feat{node, F});
     }
     // next cell's inputs: the last node of every level (efficientdet_arch.py:676-682)

@@ -85,9 +85,6 @@ static int run_ops(odt_model* m, const void* src, int dtype, hipStream_t st, siz
       case OP_MB_EXPAND_DW:
         if (launch_mbconv_expand_dw(op.mb, st)) return 1;
         break;
-      case OP_FUSE_DW:
-        if (launch_bifpn_fuse_dw(op.fdw, st)) return 1;
-        break;
       case OP_CMEAN:
         if (launch_channel_mean(op.in.d, op.in.B, op.in.h * op.in.w, op.in.C, op.aux2, op.aux, st)) return 1;
         break;
@@ -620,14 +617,14 @@ int odt_describe(odt_handle h, char* buf, int cap) {
   char tmp[2048];
   std::snprintf(tmp, sizeof(tmp),
                 "{\"conv_arith\": \"%s\", \"conv_launches\": %d, \"convs_fused_into_epilogues\": %d, \"exact_f32_mfma_launches\": %d, "
-                "\"bf16x3_split_launches\": %d, \"fp16x2_split_launches\": %d, \"bottleneck_tails_fused\": %d, \"stem_fused\": %d, \"mbconv_expand_dw_fused\": %d, \"bifpn_fuse_dw_fused\": %d, \"split_launches_by_family\": {\"split3_8wave_lds_dma\": %d, "
+                "\"bf16x3_split_launches\": %d, \"fp16x2_split_launches\": %d, \"bottleneck_tails_fused\": %d, \"stem_fused\": %d, \"mbconv_expand_dw_fused\": %d, \"split_launches_by_family\": {\"split3_8wave_lds_dma\": %d, "
                 "\"one_stage_bk32\": %d, \"h2_8wave_lds_dma\": %d, \"of_split3_with_split_k\": %d}, \"policy\": {\"family\": %d, \"min_tiles\": %ld, "
                 "\"min_tiles3\": %ld, \"min_k\": %d}, \"env_overrides_applied\": %d, "
                 "\"memory\": {\"device_bytes\": %zu, \"activation_arena_bytes\": [%zu, %zu], \"arena_tensors\": %zu, "
                 "\"arena_tensor_bytes_unshared\": %zu, \"dedicated_tensor_bytes\": %zu, \"keep_taps\": %d}, \"convs_cut_into_batch_ranges\": %d}",
                 h->policy.arith != 0 && fam[2] > 0 ? "f32 through fp16x2 / bf16x3 split products"
                     : (h->policy.arith != 0 && fam[1] + fam[3] > 0 ? "f32 through bf16x3 split products" : "exact f32 MFMA"),
-                (int)h->convs.size() - nfused, nfused, fam[0], fam[1] + fam[3], fam[2], h->convs_h2f, h->stem_fused, h->mb_fused, h->fuse_dw_fused, fam[3], fam[1], fam[2], nsk, h->policy.family,
+                (int)h->convs.size() - nfused, nfused, fam[0], fam[1] + fam[3], fam[2], h->convs_h2f, h->stem_fused, h->mb_fused, fam[3], fam[1], fam[2], nsk, h->policy.family,
                 h->policy.min_tiles, h->policy.min_tiles3, h->policy.min_k, h->policy.env_overrides,
                 dev_bytes, h->arena_bytes[0], h->arena_bytes[1], h->vt.size(), h->virtual_tensor_bytes,
                 h->dedicated_tensor_bytes, h->cfg.keep_taps, h->chunked_convs);

@@ -375,35 +375,6 @@ def test_efficientdet_d7_1536_parity(hip_lib):
   _det_full_parity(hip_lib, "efficientdet-d7", 1536, 1536, topk=5000, thr=0.02, gain=arch.bench_gain("efficientdet-d7"))
 
 
-def test_bifpn_fusion_and_depthwise_in_one_kernel(backend, monkeypatch):
-  """A BiFPN node's fusion (weighted sum of resampled inputs + swish) and its depthwise 3x3 as ONE kernel with the fused
-  tile in LDS (csrc/effnet.hip bifpn_fuse_dw_kernel; reference efficientdet_arch.py:594-682): same fused values, same tap
-  order -> BIT-identical detections and stage taps to the two-launch form (ODT_EFFDET_FUSE_BIFPN=0), and parity with the
-  oracle as before."""
-  import torch
-  from object_detection_tracking_amd.efficientdet import EfficientNetBackbone, generate_anchors
-  from object_detection_tracking_amd.weights import synthetic_frames
-  name, lib = backend
-  model, H, W = ("efficientdet-d0", 128, 160) if name == "emu" else ("efficientdet-d1", 250, 333)
-  c = arch.det_config(model)
-  w = dict(arch.synthetic_det_weights(model, 0)); w["effdet/anchors"] = generate_anchors(H, W, c["anchor_scale"])
-  fr = synthetic_frames(1, H, W, seed=9)
-  got = {}
-  for mode in ("1", "0"):
-    monkeypatch.setenv("ODT_EFFDET_FUSE_BIFPN", mode)
-    net = EfficientNetBackbone(c["backbone"], w, 1, H, W, lib=lib, det=model, topk=100)
-    try:
-      assert (net.describe()["bifpn_fuse_dw_fused"] > 0) == (mode == "1")
-      net.forward_async(fr); net.synchronize()
-      got[mode] = {k: net.tap(k) for k in ["cell0_fnode0"] + ["fpn_%d" % l for l in range(3, 8)] + ["class_%d" % l for l in range(3, 8)]}
-    finally:
-      net.close()
-  for k in got["0"]:
-    assert np.array_equal(got["1"][k], got["0"][k]), k
-  monkeypatch.setenv("ODT_EFFDET_FUSE_BIFPN", "1")
-  _det_parity(lib, model, H, W)
-
-
 def test_efficientdet_levels_merged_into_one_launch(backend, monkeypatch):
   """Class / box nets with the five pyramid levels of a layer in ONE depthwise and ONE pointwise launch (batch 1, layers
   on the conv_split3 kernels: D7 by itself, here D1 -- 88 filters padded to 128 -- with the tile threshold lowered): the
