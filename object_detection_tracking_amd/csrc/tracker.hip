@@ -14,6 +14,11 @@
 // against every staged gallery row with lane-strided partial sums + a shuffle tree; min over the
 // rows, 1 - dot, one float64 store per (track, detection).  Galleries larger than the LDS chunk
 // (no budget: the gallery grows by one row per matched frame) are walked in chunks of kRows rows.
+// Next to a busy detector (round 5): the conv kernels leave neither registers nor LDS for a second resident workgroup, so
+// this kernel's workgroups take whole CUs at a kernel boundary and hold back the next conv launch's workgroups for as long
+// as they run.  Hence (i) the detections of a track are split over grid.y workgroups (four for N >= 32: a quarter of the
+// time per workgroup; the gallery rows are normalised by each -- five rows), (ii) the LDS staging is sized for the feature
+// length (D <= 256: 20 KB instead of 80 KB).
 #include <cstring>
 
 #include "odt_common.hpp"
@@ -33,14 +38,16 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+template <int DMAX>
 __global__ void __launch_bounds__(256) nn_cosine_kernel(const float* __restrict__ gal, const int* __restrict__ seg,
                                                         const float* __restrict__ det, int N, int D,
                                                         double* __restrict__ cost) {
-  __shared__ float rows[kRows * kMaxD];
-  __shared__ float dstrip[4 * kMaxD];
+  __shared__ float rows[kRows * DMAX];
+  __shared__ float dstrip[4 * DMAX];
   const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int jstep = 4 * (int)gridDim.y, j0 = wave + 4 * (int)blockIdx.y;      // this workgroup's detections: j0, j0 + jstep, ...
   const int g0 = seg[t], g1 = seg[t + 1];
-  float* mine = dstrip + wave * kMaxD;
+  float* mine = dstrip + wave * DMAX;
   for (int c0 = g0; c0 < g1; c0 += kRows) {
     const int nr = g1 - c0 < kRows ? g1 - c0 : kRows;
     if (c0 > g0) __syncthreads();                       // the previous chunk has been consumed
@@ -49,10 +56,10 @@ __global__ void __launch_bounds__(256) nn_cosine_kernel(const float* __restrict_
       float ss = 0.f;
       for (int d = lane; d < D; d += 64) ss += src[d] * src[d];
       const float nrm = sqrtf(wave_sum(ss));
-      for (int d = lane; d < D; d += 64) rows[r * kMaxD + d] = src[d] / nrm;
+      for (int d = lane; d < D; d += 64) rows[r * DMAX + d] = src[d] / nrm;
     }
     __syncthreads();
-    for (int j = wave; j < N; j += 4) {
+    for (int j = j0; j < N; j += jstep) {
       const float* dj = det + (size_t)j * D;
       float ss = 0.f;
       for (int d = lane; d < D; d += 64) ss += dj[d] * dj[d];
@@ -61,7 +68,7 @@ __global__ void __launch_bounds__(256) nn_cosine_kernel(const float* __restrict_
       float best = 3.402823466e38f;
       for (int r = 0; r < nr; ++r) {
         float dot = 0.f;
-        for (int d = lane; d < D; d += 64) dot += rows[r * kMaxD + d] * mine[d];
+        for (int d = lane; d < D; d += 64) dot += rows[r * DMAX + d] * mine[d];
         best = fminf(best, 1.0f - wave_sum(dot));
       }
       if (lane == 0) {
@@ -77,8 +84,11 @@ __global__ void __launch_bounds__(256) nn_cosine_kernel(const float* __restrict_
 int launch_nn_cosine(const float* gallery, const int* seg, int T, const float* dets, int N, int D, double* cost,
                      hipStream_t stream) {
   ODT_CHECK(D > 0 && D <= kMaxD, "nn_cosine: feature length above 1024");
-  if (T > 0 && N > 0)
-    hipLaunchKernelGGL(nn_cosine_kernel, dim3(T), dim3(256), 0, stream, gallery, seg, dets, N, D, cost);
+  if (T > 0 && N > 0) {
+    const dim3 grid(T, N >= 32 ? 4 : 1);
+    if (D <= 256) hipLaunchKernelGGL(nn_cosine_kernel<256>, grid, dim3(256), 0, stream, gallery, seg, dets, N, D, cost);
+    else hipLaunchKernelGGL(nn_cosine_kernel<kMaxD>, grid, dim3(256), 0, stream, gallery, seg, dets, N, D, cost);
+  }
   ODT_HIP(hipGetLastError());
   return 0;
 }
