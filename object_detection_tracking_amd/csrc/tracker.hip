@@ -85,7 +85,7 @@ int launch_nn_cosine(const float* gallery, const int* seg, int T, const float* d
                      hipStream_t stream) {
   ODT_CHECK(D > 0 && D <= kMaxD, "nn_cosine: feature length above 1024");
   if (T > 0 && N > 0) {
-    const dim3 grid(T, N >= 32 ? 4 : 1);
+    const dim3 grid(T, N >= 64 ? 8 : (N >= 32 ? 4 : 1));
     if (D <= 256) hipLaunchKernelGGL(nn_cosine_kernel<256>, grid, dim3(256), 0, stream, gallery, seg, dets, N, D, cost);
     else hipLaunchKernelGGL(nn_cosine_kernel<kMaxD>, grid, dim3(256), 0, stream, gallery, seg, dets, N, D, cost);
   }
