@@ -13,8 +13,8 @@
 //   * its result (+ folded BN shift, swish; ZERO at patch pixels outside the image: that is the depthwise conv's 'SAME'
 //     padding) goes to an LDS tile [256 pixels][64 channels] f32;
 //   * the depthwise stencil reads that tile: (16 - k) / s + 1 outputs per side (14 / 12 at stride 1, 7 / 6 at stride 2),
-//     thread = (channel quad, one of 16 output slots), taps ky-major / kx inner, + folded BN shift, swish -- the operand
-//     order of dwconv_kernel (a tap outside the image adds +0 there and is skipped here: the same f32 value) -- 16-byte
+//     thread = (channel quad, one of 16 output slots), taps ky-major / kx inner as in dwconv_kernel (a tap outside the
+//     image adds 0 here and is skipped there) but accumulated with fused multiply-adds, + folded BN shift, swish, 16-byte
 //     stores, and per-thread sums of what it stores for the squeeze (fixed order: tiles, then slots; a fixed tree over the
 //     slots) -> sum_part[b][split][c], which channel_mean_fold_kernel adds up as before.
 // The halo is recomputed by the neighbouring tile ((16 / 14)^2 = 1.31x the expand FLOPs at k = 3, 1.78x at k = 5): MFMA
@@ -50,13 +50,29 @@ __device__ __forceinline__ float mb_swish(float v) {
 }
 #endif
 
+// a * b + c per element with ONE rounding (v_pk_fma_f32): half the stencil's arithmetic instructions; the stand-alone
+// dwconv_kernel rounds the product and the sum separately (the build's -ffp-contract=off) -- a difference at the level of the
+// last bit of each tap, inside the tolerance the fused handle is held to against the unfused one (2e-5 of the tensor scale)
+#ifdef ODT_HIP_EMULATOR
+__device__ __forceinline__ f32x4 mb_fma4(f32x4 a, f32x4 b, f32x4 c) {
+  f32x4 r;
+  for (int e = 0; e < 4; ++e) r[e] = fmaf(a[e], b[e], c[e]);
+  return r;
+}
+#else
+__device__ __forceinline__ f32x4 mb_fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
+
 template <int K, int S>
 __global__ void __launch_bounds__(256, 2) mbconv_expand_dw_kernel(MbExpandDwParams p) {
   constexpr int TO = (kMbP - K) / S + 1;         // outputs per tile side
   constexpr int RA = 8;                          // A rows (16-byte loads) per thread and slice
-  __shared__ __attribute__((aligned(16))) unsigned char lds[kMbLds];
+  // (k = 5: the 25 tap weights of the slice live in LDS behind the tile -- 100 registers otherwise, spilled in the stencil)
+  constexpr int WL = K == 5 ? K * K * kMbBN * 4 : 0;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kMbLds + WL];
   unsigned char* const ldsB = lds + 3 * kMbAPL;
   float* const Et = reinterpret_cast<float*>(lds);
+  float* const wl = reinterpret_cast<float*>(lds + kMbLds);
 
   const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
   const int fr = lane & 31, fg = lane >> 5;
@@ -94,6 +110,13 @@ __global__ void __launch_bounds__(256, 2) mbconv_expand_dw_kernel(MbExpandDwPara
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   f32x4 sum = zero;
   const int b_st = (tid / kMbBN) * kMbBKG + (tid % kMbBN) * 16;
+  if constexpr (K == 5) {
+    for (int i = tid; i < K * K * (kMbBN / 4); i += 256) {
+      const int q = i / (kMbBN / 4), c4 = i - q * (kMbBN / 4);
+      *reinterpret_cast<f32x4*>(&wl[q * kMbBN + c4 * 4]) = *reinterpret_cast<const f32x4*>(p.dw_wt + (size_t)q * p.lmid + n0 + c4 * 4);
+    }
+    // (visible to every wave after the first barrier of the first tile's GEMM loop)
+  }
 
   for (int t = t_lo; t < t_hi; ++t) {
     const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
@@ -194,50 +217,94 @@ __global__ void __launch_bounds__(256, 2) mbconv_expand_dw_kernel(MbExpandDwPara
       __syncthreads();
     }
     // ---- BN shift + swish; pixels of the patch outside the image are the depthwise conv's zero padding
+    // (the lane's row / column base passes through an opaque asm: otherwise its 64 row numbers and LDS addresses are
+    // computed once in front of the tile loop, spilled, and reloaded per tile)
+    int rb = wm * 64 + 4 * fg, cb = fr;
+#ifdef ODT_HIP_EMULATOR
+    asm volatile("" : "+r"(rb), "+r"(cb));
+#else
+    asm volatile("" : "+v"(rb), "+v"(cb));
+#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
+        const int row = rb + i * 32 + (r & 3) + 8 * (r >> 2);
         const int y = iy0 + (row >> 4), x = ix0 + (row & 15);
         const bool v = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const float e = mb_swish(acc[i][j][r] + ebias[j]);
-          Et[row * kMbCS + j * 32 + fr] = v ? e : 0.f;
+          Et[row * kMbCS + j * 32 + cb] = v ? e : 0.f;
         }
       }
     __syncthreads();
     // ---- depthwise stencil over the tile: this thread's outputs q = slot, slot + 16, ...; taps ky-major, kx inner
     {
       asm volatile("" ::: "memory");             // (keeps the weight loads below out of the GEMM loop's register budget)
-      f32x4 w[K * K];
+      f32x4 wreg[K == 3 ? K * K : 1];
+      if constexpr (K == 3) {
 #pragma unroll
-      for (int q = 0; q < K * K; ++q) w[q] = *reinterpret_cast<const f32x4*>(p.dw_wt + (size_t)q * p.lmid + ch);
+        for (int q = 0; q < K * K; ++q) wreg[q] = *reinterpret_cast<const f32x4*>(p.dw_wt + (size_t)q * p.lmid + ch);
+      }
+      auto w_at = [&](int q) -> f32x4 {
+        if constexpr (K == 3) return wreg[q];
+        else return *reinterpret_cast<const f32x4*>(&wl[q * kMbBN + cq * 4]);
+      };
       const f32x4 dbias = *reinterpret_cast<const f32x4*>(p.dw_bias + ch);
-#pragma unroll 1
-      for (int q = slot; q < TO * TO; q += 16) {
-        const int oyl = q / TO, oxl = q - oyl * TO;
-        const int oy = ty * TO + oyl, ox = tx * TO + oxl;
-        if (oy >= p.Ho || ox >= p.Wo) continue;
-        const float* e0 = &Et[((oyl * S) * kMbP + oxl * S) * kMbCS + cq * 4];
-        f32x4 a = zero;
-        // a kernel row's K reads are issued together (fenced: left alone the scheduler keeps two reads in flight and
-        // waits for each -- the loop was bound by LDS latency), then its K products, ky-major / kx inner as before
-#pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
-          f32x4 ev[K];
-#pragma unroll
-          for (int kx = 0; kx < K; ++kx) ev[kx] = *reinterpret_cast<const f32x4*>(e0 + (ky * kMbP + kx) * kMbCS);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int kx = 0; kx < K; ++kx) a += ev[kx] * w[ky * K + kx];
-        }
+      auto finish = [&](f32x4 a, int oy, int ox) {
         f32x4 v = a + dbias;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = mb_swish(v[e]);
         *reinterpret_cast<f32x4*>(p.out + (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.lmid + ch) = v;
         sum += v;
+      };
+      if constexpr (S == 1) {
+        // stride 1: TWO horizontally adjacent outputs per iteration share K + 1 of their 2 K reads per kernel row (TO is even)
+        constexpr int PR = TO / 2;
+#pragma unroll 1
+        for (int q = slot; q < TO * PR; q += 16) {
+          const int oyl = q / PR, oxl = (q - oyl * PR) * 2;
+          const int oy = ty * TO + oyl, ox = tx * TO + oxl;
+          if (oy >= p.Ho || ox >= p.Wo) continue;
+          if constexpr (K == 5) asm volatile("" ::: "memory");      // (the LDS tap weights are re-read per iteration, not hoisted into 100 registers)
+          const float* e0 = &Et[(oyl * kMbP + oxl) * kMbCS + cq * 4];
+          f32x4 a0 = zero, a1 = zero;
+#pragma unroll
+          for (int ky = 0; ky < K; ++ky) {
+            f32x4 ev[K + 1];
+#pragma unroll
+            for (int kx = 0; kx <= K; ++kx) ev[kx] = *reinterpret_cast<const f32x4*>(e0 + (ky * kMbP + kx) * kMbCS);
+            __builtin_amdgcn_sched_barrier(0);   // (a kernel row's reads issued together, then its products: ky-major, kx inner)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+              const f32x4 wt = w_at(ky * K + kx);
+              a0 = mb_fma4(ev[kx], wt, a0);
+              a1 = mb_fma4(ev[kx + 1], wt, a1);
+            }
+          }
+          finish(a0, oy, ox);
+          if (ox + 1 < p.Wo) finish(a1, oy, ox + 1);
+        }
+      } else {
+#pragma unroll 1
+        for (int q = slot; q < TO * TO; q += 16) {
+          const int oyl = q / TO, oxl = q - oyl * TO;
+          const int oy = ty * TO + oyl, ox = tx * TO + oxl;
+          if (oy >= p.Ho || ox >= p.Wo) continue;
+          const float* e0 = &Et[((oyl * S) * kMbP + oxl * S) * kMbCS + cq * 4];
+          f32x4 a = zero;
+#pragma unroll
+          for (int ky = 0; ky < K; ++ky) {
+            f32x4 ev[K];
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) ev[kx] = *reinterpret_cast<const f32x4*>(e0 + (ky * kMbP + kx) * kMbCS);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) a = mb_fma4(ev[kx], w_at(ky * K + kx), a);
+          }
+          finish(a, oy, ox);
+        }
       }
     }
     __syncthreads();                             // the tile aliases the next patch's operand planes
