@@ -199,13 +199,16 @@ def test_forward_multi_r101_b2_k2000(hip_lib):
 
 
 def test_forward_k_above_1024_small(backend):
-  """K = 1100 on a small frame (P2 alone has 2304 anchors): both graphs through the K > 1024 selection kernels."""
+  """K = 1100 on a small frame (P2 alone has 2304 anchors): the K > 1024 selection kernels end to end -- the single-image
+  graph with 4 classes on the simulator (1024 fibres per workgroup are slow there), both graphs with 15 on the GPU."""
   name, lib = backend
-  cfg = small_config(resnet_num_block=[1, 1, 1, 1], rpn_test_post_nms_topk=1100)
+  kw = dict(num_class=4) if name == "emu" else {}
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1], rpn_test_post_nms_topk=1100, **kw)
   miss, extra = _run_single(lib, cfg, 96, 128)
   assert miss == 0 and extra == 0
-  cfg = small_config(resnet_num_block=[1, 1, 1, 1], im_batch_size=2, rpn_test_post_nms_topk=1100)
-  assert _run_multi(lib, cfg, 2, 96, 128) == 0
+  if name == "hip":
+    cfg = small_config(resnet_num_block=[1, 1, 1, 1], im_batch_size=2, rpn_test_post_nms_topk=1100)
+    assert _run_multi(lib, cfg, 2, 96, 128) == 0
 
 
 @pytest.mark.gpu
@@ -724,17 +727,24 @@ def test_default_engine_is_guarded_on_every_entry_path(backend, monkeypatch):
   call that finds tickets outstanding never calibrates (it would clobber the ticket's device outputs) and is counted."""
   from object_detection_tracking_amd.config import make_config as product_make_config
   name, lib = backend
-  monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1"); monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "1")
   assert product_make_config().conv_split_family == "auto"
   H, W = (64, 96) if name == "emu" else (160, 224)
   kw = dict(resnet_num_block=[1, 1, 1, 1], rpn_test_post_nms_topk=64, max_size=256, short_edge_size=96, im_batch_size=1)
+  if name == "hip":
+    monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1"); monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "1")
+  else:
+    # simulator: forced split kernels cost ~1 min per forward there, so the plan keeps its exact-f32 kernels at this size (both
+    # handles then agree bit for bit) and a NEGATIVE tolerance makes the guard change handles all the same -- the host logic
+    # under test (ingest buffer hand-over, retired handle, profiling switch, released twin) is what runs; the arithmetic
+    # side of the guard is test_auto_family_guards_the_fp16x2_range_assumption's
+    kw["conv_split_auto_tol"] = -1.0
   cfg = product_make_config(**kw)
   class Args(object):                      # a reference-style args object: no conv_split_family attribute at all
     pass
-  bare = Args(); bare.__dict__.update({k: v for k, v in cfg.__dict__.items() if not k.startswith("conv_split")})
+  bare = Args(); bare.__dict__.update({k: v for k, v in cfg.__dict__.items() if k != "conv_split_family"})
   fr = synthetic_frames(1, H, W, seed=5)
   cfg3 = product_make_config(conv_split_family=3, **kw)
-  # (simulator: forced split kernels cost ~1 min per forward there -- the outlier case through the ingest path only)
+  # (simulator: the handle-changing case through the ingest path only)
   for kind in (("outlier",) if name == "emu" else ("ordinary", "outlier")):
     w = weights_for(cfg) if kind == "ordinary" else _outlier_weights(cfg)
     m3 = models.get_model(cfg3, 0, weights=w, lib=lib, is_multi=True)
@@ -777,7 +787,8 @@ def test_default_engine_is_guarded_on_every_entry_path(backend, monkeypatch):
       finally:
         m.close()
   # tickets outstanding at every call that could calibrate: skipped, counted, and given up after 16
-  monkeypatch.delenv("ODT_CONV_SPLIT_MINTILES"); monkeypatch.delenv("ODT_CONV_SPLIT3_MINTILES")
+  monkeypatch.delenv("ODT_CONV_SPLIT_MINTILES", raising=False); monkeypatch.delenv("ODT_CONV_SPLIT3_MINTILES", raising=False)
+  kw.pop("conv_split_auto_tol", None)
   cfg2 = product_make_config(conv_split_auto_frames=2, **kw)
   m = models.get_model(cfg2, 0, weights=weights_for(cfg), lib=lib, is_multi=True)
   try:
