@@ -42,26 +42,14 @@ constexpr int kMbNB = kMbStageB / 4096;          // 16-byte weight chunks per th
 // per thread and tile and is bound by exactly that: with the libm form (~60 instructions per value) the first version
 // ran no faster than the two launches it replaces (profiles/r05_effdet_mbconv_fusion_v1_ab.txt).  Saturation: v -> +inf
 // gives exp2 -> 0, swish -> v; v < -88 gives exp2 -> inf, rcp -> 0, swish -> -0 (the exact value is a denormal there).
-#ifdef ODT_HIP_EMULATOR
-__device__ __forceinline__ float mb_swish(float v) { return v * (1.0f / (1.0f + exp2f(-v * 1.4426950408889634f))); }
-#else
 __device__ __forceinline__ float mb_swish(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-v * 1.4426950408889634f));
 }
-#endif
 
 // a * b + c per element with ONE rounding (v_pk_fma_f32): half the stencil's arithmetic instructions; the stand-alone
 // dwconv_kernel rounds the product and the sum separately (the build's -ffp-contract=off) -- a difference at the level of the
 // last bit of each tap, inside the tolerance the fused handle is held to against the unfused one (2e-5 of the tensor scale)
-#ifdef ODT_HIP_EMULATOR
-__device__ __forceinline__ f32x4 mb_fma4(f32x4 a, f32x4 b, f32x4 c) {
-  f32x4 r;
-  for (int e = 0; e < 4; ++e) r[e] = fmaf(a[e], b[e], c[e]);
-  return r;
-}
-#else
 __device__ __forceinline__ f32x4 mb_fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
-#endif
 
 template <int K, int S>
 __global__ void __launch_bounds__(256, 2) mbconv_expand_dw_kernel(MbExpandDwParams p) {
@@ -220,11 +208,7 @@ __global__ void __launch_bounds__(256, 2) mbconv_expand_dw_kernel(MbExpandDwPara
     // (the lane's row / column base passes through an opaque asm: otherwise its 64 row numbers and LDS addresses are
     // computed once in front of the tile loop, spilled, and reloaded per tile)
     int rb = wm * 64 + 4 * fg, cb = fr;
-#ifdef ODT_HIP_EMULATOR
-    asm volatile("" : "+r"(rb), "+r"(cb));
-#else
-    asm volatile("" : "+v"(rb), "+v"(cb));
-#endif
+    ODT_PIN2(rb, cb);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll

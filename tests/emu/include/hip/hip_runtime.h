@@ -401,6 +401,14 @@ inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
 inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
 inline float __fdividef(float a, float b) { return a / b; }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+// hardware transcendental / packed-FMA builtins (v_exp_f32, v_rcp_f32, v_pk_fma_f32) the kernels use directly
+inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+template <typename V> inline V __builtin_elementwise_fma(V a, V b, V c) {
+  V r;
+  for (unsigned e = 0; e < sizeof(V) / sizeof(float); ++e) r[e] = fmaf(a[e], b[e], c[e]);
+  return r;
+}
 
 // ---- runtime API --------------------------------------------------------------
 inline const char* hipGetErrorString(hipError_t e) { return e == 0 ? "hipSuccess(emu)" : "hipError(emu)"; }
