@@ -9,6 +9,7 @@
 #   rocprof : rocprofv3 --kernel-trace --stats of the bench command
 #   pmc     : the separate --pmc passes of the bench command (FETCH_SIZE | WRITE_SIZE | MFMA busy | LDS / wait)
 #   d7pmc   : HBM traffic counters of the EfficientDet-D7 forward (two --pmc passes) + its kernel trace
+#   n2      : the N-rank launch path on the one GPU of the box (two ranks over gloo sharing device 0)
 # Everything lands in gpurun_out/<ROUND>_*; copy what should be judged into profiles/.
 mkdir -p gpurun_out
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -79,4 +80,10 @@ if has d7pmc; then
   python tools/pmc_summary_effdet.py gpurun_out gpurun_out/${N}_pmc_summary_effdet_d7 2>&1 | tail -12
   python tools/kernel_stats.py gpurun_out/prof_d7 > gpurun_out/${N}_kernel_stats_efficientdet_d7.txt 2>&1
   find gpurun_out -name "*.csv" -size +20M -delete; find gpurun_out -name "*.db" -size +20M -delete
+fi
+if has n2; then
+  (timeout 600 python bench.py --gpus 2 --dist-backend gloo --device 0 --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-d7 2>gpurun_out/${N}_bench_n2_err.log | tail -1) > gpurun_out/${N}_bench_n2_gloo_one_gpu.json
+  python -c "
+import json; d=json.load(open('gpurun_out/${N}_bench_n2_gloo_one_gpu.json'))
+print('n_gpus %d ranks_seen %s total FPS %.2f per rank %s verified %s' % (d['n_gpus'], d['ranks_seen'], d['value'], [round(v, 1) for v in d['per_rank_fps']], d['verified']))"
 fi
