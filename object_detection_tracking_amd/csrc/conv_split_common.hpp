@@ -152,6 +152,8 @@ int launch_conv_split1(const ConvParams& p, const ConvParams* dev, hipStream_t s
 int launch_conv_split3(const ConvParams& p, const ConvParams* dev, hipStream_t stream);
 int launch_conv_h2(const ConvParams& p, const ConvParams* dev, hipStream_t stream);
 void launch_conv_h2k(const ConvParams& p, const ConvParams* dev, unsigned grid, hipStream_t stream);   // conv_h2k.hip
+bool conv_h2d_fits(const ConvParams& p);                                                               // conv_h2d.hip: double-stage two-wave tiles
+void launch_conv_h2d(const ConvParams& p, const ConvParams* dev, unsigned grid, hipStream_t stream);
 void launch_split_reduce(const ConvParams& p, const ConvParams* dev, hipStream_t stream);   // split-K combine (conv_split3.hip)
 
 }  // namespace odt

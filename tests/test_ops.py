@@ -892,6 +892,8 @@ def test_conv2d_fp16x2_512x64_tile_generic_kernel(backend, case, monkeypatch):
 
 @pytest.mark.parametrize("case", [
     (1, 10, 15, 512, 256, 1, 1, 1, 0, 0, 10, 15, True),      # dense 1x1, M = 150: 3 x 2 tiles of 64 x 128 (res4 conv1 at b = 1)
+    (1, 10, 15, 256, 512, 1, 1, 1, 0, 0, 10, 15, False),     # dense 1x1, short reduction, several n-tiles (res4 conv3 at b = 1)
+    (1, 9, 15, 64, 128, 1, 1, 1, 0, 0, 9, 15, True),         # dense 1x1 with ONE double stage (K = 64)
     (1, 10, 15, 64, 256, 3, 1, 1, 1, 1, 10, 15, True),       # 3x3 taps on the generic kernel
     (1, 20, 15, 64, 128, 1, 2, 1, 0, 0, 10, 8, False),       # strided, one n-tile, a partial last tile (M = 80)
 ])
@@ -917,6 +919,24 @@ def test_conv2d_fp16x2_64x128_tile_without_splitk(backend, case, monkeypatch):
     np.testing.assert_allclose(out[mode], ref, rtol=1e-4, atol=2e-4)
   for mode in ("1", "3"):
     np.testing.assert_allclose(out["0"], out[mode], rtol=0, atol=3e-6 * float(np.abs(ref).max()))
+  # the dense 1x1 reductions take conv_h2d_kernel (double stages: two BK = 32 sub-stages per barrier, round 5) on these tiles;
+  # ODT_CONV_H2_BK64=0 keeps conv_h2_kernel: the same products in another slice order -> equal at f32 rounding level
+  if k == 1 and stride == 1 and Cin % 64 == 0:
+    t128 = -(-(B * Ho * Wo) // 128) * -(-Cout // 128)
+    monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", str(t128 + 1))    # (the 128-row tiles do not "fill the chip", the 64-row ones do)
+    r64 = torch_conv_nhwc(x, w, b, stride, dil, pt, pl, Ho, Wo, dtype=np.float64) + res
+    if relu:
+      r64 = np.maximum(r64, 0)
+    for mode in ("1", "3"):
+      monkeypatch.setenv("ODT_CONV_H2_BM64", mode)
+      both = {}
+      for bk in ("1", "0"):
+        monkeypatch.setenv("ODT_CONV_H2_BK64", bk)
+        both[bk] = ops.conv2d(x, w, b, stride, dil, pt, pl, (Ho, Wo), res=res, res_mode=1, relu=relu, lib=lib)
+        assert np.abs(both[bk] - r64).max() <= 4e-6 * float(np.abs(r64).max()), (mode, bk)
+      np.testing.assert_allclose(both["1"], both["0"], rtol=0, atol=3e-6 * float(np.abs(ref).max()))
+      if Cin >= 256:
+        assert not np.array_equal(both["1"], both["0"]), mode   # (another summation order: the double-stage kernel really ran)
 
 
 @pytest.mark.parametrize("case", [
