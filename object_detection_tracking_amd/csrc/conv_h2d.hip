@@ -7,6 +7,7 @@
 // weight image (two consecutive stage images per double stage) and the same K-slice rotation scheme as conv_h2_kernel, in
 // units of double stages -- so a tile may start its reduction at another slice than there: the same products summed in
 // another (per tile fixed) order, i.e. results equal at f32 rounding level, deterministic run to run.
+// ("d" for double stage -- not round 3's archived conv_h2d_kernel.inc experiment, which put the activations on the LDS-DMA path.)
 // Scope: 1x1, stride 1, dense input rows, one source, no split-K, an even number of 32-channel slices; everything else
 // stays on conv_h2_kernel (launch_conv_h2 decides).  Reference ops: as conv_split.hip (nn.py:337-381, :503-521).
 #include "conv_split_epilogue.hpp"
