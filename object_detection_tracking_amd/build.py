@@ -16,8 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["runtime.hip", "plan_common.hip", "plan_fpn.hip", "plan_effdet.hip", "op_shims.hip", "conv_igemm.hip", "conv_split.hip", "conv_split1.hip", "conv_split3.hip", "conv_h2.hip", "conv_h2d.hip", "conv_h2k.hip", "conv_stem.hip", "elementwise.hip", "proposals.hip",
-           "roi_align.hip", "detections.hip", "tracker.hip", "tracker_core.cpp", "effnet.hip", "effnet_mbconv.hip", "effdet_post.hip", "probe.hip"]
-HEADERS = ["odt_common.hpp", "odt_model.hpp", "conv_split_common.hpp", "conv_split_epilogue.hpp", "select_device.hpp", os.path.join(ROOT, "include", "odt.h")]
+           "roi_align.hip", "detections.hip", "tracker.hip", "tracker_core.cpp", "knobs.cpp", "effnet.hip", "effnet_mbconv.hip", "effdet_post.hip", "probe.hip"]
+HEADERS = ["odt_common.hpp", "knobs.hpp", "odt_model.hpp", "conv_split_common.hpp", "conv_split_epilogue.hpp", "select_device.hpp", os.path.join(ROOT, "include", "odt.h")]
 LIB_HIP = os.path.join(HERE, "libodt_hip.so")
 LIB_EMU = os.path.join(ROOT, "tests", "emu", "libodt_emu.so")
 

@@ -492,7 +492,7 @@ int launch_conv_h2(const ConvParams& p, const ConvParams* dev, hipStream_t strea
     launch_conv_h2k(p, dev, grid, stream);
   } else if (p.f_wt != nullptr) {
     ODT_CHECK(false, "conv h2: a fused 1x1 tail needs the kw-reuse kernel");
-  } else if (bm == 64 && conv_h2d_fits(p) && !(getenv("ODT_CONV_H2_BK64") != nullptr && getenv("ODT_CONV_H2_BK64")[0] == '0')) {
+  } else if (bm == 64 && conv_h2d_fits(p) && !env_knob_off(K_CONV_H2_BK64)) {
     // the dense 1x1 reductions on two-wave tiles: double stages (conv_h2d.hip; ODT_CONV_H2_BK64=0: the single-stage kernel, A/B)
     launch_conv_h2d(p, dev, grid, stream);
   } else if (bm == 64 && bn == 64) {         // ... 64 x 64 tiles: twice the workgroups again (latency-bound reductions at b = 1)

@@ -638,13 +638,11 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
   const long M = (long)p.B * p.Ho * p.Wo;
   const long tiles128 = ((M + 127) / 128) * ((p.Cout + 127) / 128);
   int tile = 0;   // 0 auto | 1: 128x64 | 2: 64x64 | 3: 128x128  (ODT_CONV_TILE: tuning / test knob)
-  if (const char* e = getenv("ODT_CONV_TILE")) tile = atoi(e);
+  tile = (int)env_knob_long(K_CONV_TILE, 0);
   ConvParams q = p;
   conv_prepare(q);
   bool modified = false;
-  if (const char* e = getenv("ODT_CONV_DEBUG")) {
-    if (atoi(e) != 0) { q.debug = atoi(e); modified = true; }
-  }
+  if (env_knob(K_CONV_DEBUG).i != 0) { q.debug = (int)env_knob(K_CONV_DEBUG).i; modified = true; }
   // bf16x3 split path: plan convs carry their weight image; stand-alone calls (tests, tuning)
   // build a temporary one
   // (a plan conv without an image stays on the exact-f32 kernel: no allocation on the hot path)
@@ -700,16 +698,14 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
   // short reductions (K <= 384: EfficientNet / BiFPN 1x1 convs, the res2 / res3 1x1 layers): the
   // 64x64 tile wins -- more workgroups per CU hide the per-tile prologue / epilogue that a two-to-
   // twelve-slice main loop cannot amortise (measured per layer; ODT_CONV_SMALLK=0 for the A/B)
-  static const bool smallk = !(getenv("ODT_CONV_SMALLK") && getenv("ODT_CONV_SMALLK")[0] == '0');
+  const bool smallk = !env_knob_off(K_CONV_SMALLK);
   const int Kfull = p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0);
   if (tile == 0) tile = p.Cout <= 64 ? 1 : ((tiles128 < 384 || (smallk && Kfull <= 384)) ? 2 : 3);
   // LDS stages: the single-stage / 3-workgroups-per-CU variant wins everywhere (measured per
   // layer, profiles/) except the long 1x1 reductions on the 128x128 tile (res4 conv1, K = 1024:
   // every slice is fresh HBM data, the two-slice register+LDS prefetch of ST = 2 hides it better).
   int stages = (tile == 3 && p.kh * p.kw == 1 && p.Cin >= 1024) ? 2 : 1;
-  if (const char* e = getenv("ODT_CONV_STAGES")) {     // tuning knob: force 1 or 2
-    if (atoi(e) == 1 || atoi(e) == 2) stages = atoi(e);
-  }
+  if (env_knob(K_CONV_STAGES).i == 1 || env_knob(K_CONV_STAGES).i == 2) stages = (int)env_knob(K_CONV_STAGES).i;     // tuning knob: force 1 or 2
   // Loop style (measured per layer, profiles/r01_conv_fine_vs_coarse*.txt): the fine-grained
   // interleave keeps the matrix pipe of a CU busy when few workgroups share it (single-round
   // launches: everything at b=1) and on long reductions; on short reductions with several rounds
@@ -721,9 +717,7 @@ int launch_conv(const ConvParams& p, hipStream_t stream, const ConvParams* dev_p
   const int Kred = p.kh * p.kw * p.Cin + (p.in2 != nullptr ? p.Cin2 : 0);
   bool fine = stages == 2 || (tile != 2 && (tiles <= slots || tile == 1 || (Kred >= 1024 && tiles >= 2 * slots)));
   if (tile == 2) fine = tiles >= 384 && tiles <= slots;
-  if (const char* e = getenv("ODT_CONV_FINE")) {       // tuning knob: force 0 or 1
-    if (e[0] == '0' || e[0] == '1') fine = e[0] == '1';
-  }
+  if (env_knob(K_CONV_FINE).c0 == '0' || env_knob(K_CONV_FINE).c0 == '1') fine = env_knob(K_CONV_FINE).c0 == '1';       // tuning knob: force 0 or 1
   if (stages == 1) {
     if (tile == 1) { if (fine) launch_variant<4, 1, 1, 2, 1, true>(q, dev_params, stream); else launch_variant<4, 1, 1, 2, 1, false>(q, dev_params, stream); }
     else if (tile == 2) { if (fine) launch_variant<2, 2, 1, 1, 1, true>(q, dev_params, stream); else launch_variant<2, 2, 1, 1, 1, false>(q, dev_params, stream); }

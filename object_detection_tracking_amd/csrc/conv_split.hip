@@ -105,36 +105,36 @@ ConvPolicy conv_policy_default() {
   q.h2_n64_bm512 = 1;     // fp16x2 kw-reuse kernel on 64-wide layers: 512 x 64 tiles (eight waves stacked along M: 24 MFMAs per wave and
                           // stage instead of 12) where they fill the chip (res2 conv2 1.035 -> 0.897 ms, same box); 0 off, 2 wherever
                           // the shape allows, the generic kernel included (tests)
-  q.min_bn = 0; q.force_bm3 = 0; q.splitk_max = 8; q.force_splitk = 0; q.kw_reuse = true; q.kwr_n64 = true; q.src2 = true; q.res2 = true; q.env_overrides = 0;
+  q.min_bn = 0; q.force_bm3 = 0; q.splitk_max = 8; q.force_splitk = 0; q.kw_reuse = true; q.kwr_n64 = true; q.src2 = true; q.res2 = true;
   return q;
 }
 
 ConvPolicy conv_policy_from_env(ConvPolicy q) {
-  auto geti = [&](const char* name, long* dst) {
-    const char* e = getenv(name);
-    if (e != nullptr) { *dst = atol(e); ++q.env_overrides; }
+  auto geti = [&](Knob k, long* dst) {
+    const KnobVal& e = env_knob(k);
+    if (e.set) *dst = e.i;
   };
   long v;
-  v = q.arith; geti("ODT_CONV_SPLIT", &v); q.arith = v != 0 ? 1 : 0;
-  v = q.family; geti("ODT_CONV_SPLIT_PIPE", &v); q.family = v >= 3 ? 3 : (v == 2 ? 2 : 1);
-  geti("ODT_CONV_SPLIT_MINTILES", &q.min_tiles);
-  geti("ODT_CONV_SPLIT3_MINTILES", &q.min_tiles3);
-  v = q.min_k; geti("ODT_CONV_SPLIT_MINK", &v); q.min_k = (int)v;
-  v = q.min_bn; geti("ODT_CONV_SPLIT_MINBN", &v); q.min_bn = (int)v;
-  v = q.h2s_maxk; geti("ODT_CONV_H2S_MAXK", &v); q.h2s_maxk = (int)v;
-  v = q.h2_few_tiles; geti("ODT_CONV_H2_FEW_TILES", &v); q.h2_few_tiles = v != 0;
-  v = q.h2_n64; geti("ODT_CONV_H2_N64", &v); q.h2_n64 = v != 0;
-  v = q.h2_n64_bm512; geti("ODT_CONV_H2_N64_BM512", &v); q.h2_n64_bm512 = (int)v;
-  v = q.h2_bm64; geti("ODT_CONV_H2_BM64", &v); q.h2_bm64 = (int)v;
-  v = q.h2k_splitk; geti("ODT_CONV_H2K_SPLITK", &v); q.h2k_splitk = v != 0;
-  v = q.fill_div; geti("ODT_CONV_SPLIT3_FILLDIV", &v); q.fill_div = v < 1 ? 1 : (int)v;
-  v = q.force_bm3; geti("ODT_CONV_SPLIT3_BM", &v); q.force_bm3 = (int)v;
-  v = q.splitk_max; geti("ODT_CONV_SPLIT3_SPLITK", &v); q.splitk_max = v < 1 ? 1 : (v > 16 ? 16 : (int)v);
-  v = 1; geti("ODT_CONV_SPLIT3_KWR", &v); q.kw_reuse = v != 0;
-  v = q.kwr_n64; geti("ODT_CONV_SPLIT3_KWR_N64", &v); q.kwr_n64 = v != 0;
-  v = q.force_splitk; geti("ODT_CONV_SPLIT3_FORCE_SPLITK", &v); q.force_splitk = v < 0 ? 0 : (v > 16 ? 16 : (int)v);
-  v = 1; geti("ODT_CONV_SPLIT_SRC2", &v); q.src2 = v != 0;      // 0 keeps the fused stage-entry convs on the f32 kernel
-  v = 1; geti("ODT_CONV_SPLIT_RES2", &v); q.res2 = v != 0;      // 0 keeps the FPN laterals on the f32 kernel
+  v = q.arith; geti(K_CONV_SPLIT, &v); q.arith = v != 0 ? 1 : 0;
+  v = q.family; geti(K_CONV_SPLIT_PIPE, &v); q.family = v >= 3 ? 3 : (v == 2 ? 2 : 1);
+  geti(K_CONV_SPLIT_MINTILES, &q.min_tiles);
+  geti(K_CONV_SPLIT3_MINTILES, &q.min_tiles3);
+  v = q.min_k; geti(K_CONV_SPLIT_MINK, &v); q.min_k = (int)v;
+  v = q.min_bn; geti(K_CONV_SPLIT_MINBN, &v); q.min_bn = (int)v;
+  v = q.h2s_maxk; geti(K_CONV_H2S_MAXK, &v); q.h2s_maxk = (int)v;
+  v = q.h2_few_tiles; geti(K_CONV_H2_FEW_TILES, &v); q.h2_few_tiles = v != 0;
+  v = q.h2_n64; geti(K_CONV_H2_N64, &v); q.h2_n64 = v != 0;
+  v = q.h2_n64_bm512; geti(K_CONV_H2_N64_BM512, &v); q.h2_n64_bm512 = (int)v;
+  v = q.h2_bm64; geti(K_CONV_H2_BM64, &v); q.h2_bm64 = (int)v;
+  v = q.h2k_splitk; geti(K_CONV_H2K_SPLITK, &v); q.h2k_splitk = v != 0;
+  v = q.fill_div; geti(K_CONV_SPLIT3_FILLDIV, &v); q.fill_div = v < 1 ? 1 : (int)v;
+  v = q.force_bm3; geti(K_CONV_SPLIT3_BM, &v); q.force_bm3 = (int)v;
+  v = q.splitk_max; geti(K_CONV_SPLIT3_SPLITK, &v); q.splitk_max = v < 1 ? 1 : (v > 16 ? 16 : (int)v);
+  v = 1; geti(K_CONV_SPLIT3_KWR, &v); q.kw_reuse = v != 0;
+  v = q.kwr_n64; geti(K_CONV_SPLIT3_KWR_N64, &v); q.kwr_n64 = v != 0;
+  v = q.force_splitk; geti(K_CONV_SPLIT3_FORCE_SPLITK, &v); q.force_splitk = v < 0 ? 0 : (v > 16 ? 16 : (int)v);
+  v = 1; geti(K_CONV_SPLIT_SRC2, &v); q.src2 = v != 0;      // 0 keeps the fused stage-entry convs on the f32 kernel
+  v = 1; geti(K_CONV_SPLIT_RES2, &v); q.res2 = v != 0;      // 0 keeps the FPN laterals on the f32 kernel
   return q;
 }
 

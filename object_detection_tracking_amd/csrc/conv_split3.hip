@@ -652,7 +652,7 @@ void launch_split_reduce(const ConvParams& p, const ConvParams* dev, hipStream_t
   // at most two blocks per CU (grid-stride; same-box A/B at b = 1: 2048 blocks 150.4, 512 167.5, 256 166.8, 128 159.6 FPS): every block ends with a conditional atomicMax on the ONE range slot of the output,
   // and the blocks of a short pass all find the slot empty -- 2040 same-address atomics serialised in L2 made this pass 35 us
   // per call at b = 1 (1.2 ms of the 6.8 ms frame, profiles/r04_kernel_stats_bench_b1_single_before.txt)
-  static const long cap = []() { const char* e = getenv("ODT_SPLIT_REDUCE_BLOCKS"); return e != nullptr && atol(e) > 0 ? atol(e) : 512L; }();
+  const long capv = env_knob_long(K_SPLIT_REDUCE_BLOCKS, 512L), cap = capv > 0 ? capv : 512L;
   hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, stream, dev);
 }
 

@@ -403,10 +403,9 @@ int launch_preprocess_rgb_resize(const void* frames, int dtype, int B, int Hs, i
 namespace {
 constexpr int kDwPX2 = 2;
 // outputs per thread along x at stride 1: 8 (k = 5: 10.6 loads per output against 16.3 at 4; D7 same-box A/B 66.7 -> 67.6
-// FPS); ODT_DW_PX=4 is the A/B knob, read once
+// FPS); ODT_DW_PX=4 is the A/B knob (knobs.hpp)
 int dw_px1() {
-  static const int v = [] { const char* e = getenv("ODT_DW_PX"); return e != nullptr && atoi(e) == 4 ? 4 : 8; }();
-  return v;
+  return env_knob_long(K_DW_PX, 8) == 4 ? 4 : 8;
 }
 }  // namespace
 
@@ -417,7 +416,7 @@ int dwconv_splits(const DwConvParams& p) {
   const int px = p.stride == 1 ? dw_px1() : kDwPX2;
   const long units = (long)((p.Wo + px - 1) / px) * p.Ho;
   // (with the fused squeeze every split is a partial sum the fold kernel has to add up: at most 1024 of them)
-  static const long sumcap = [] { const char* e = getenv("ODT_DW_SUMCAP"); return e != nullptr ? atol(e) : 2048L; }();   // A/B knob (1024 ... 8192: +-0.5 %)
+  const long sumcap = env_knob_long(K_DW_SUMCAP, 2048L);   // A/B knob (1024 ... 8192: +-0.5 %)
   const long cap = std::max<long>(1, (p.sum_part != nullptr ? sumcap : 4096) / ((long)dwconv_cblocks(p) * p.B));
   return (int)std::max<long>(1, std::min(std::min<long>(cap, 1024), (units + 15) / 16));
 }
@@ -433,7 +432,7 @@ int launch_dwconv(const DwConvParams& p0, hipStream_t stream) {
     p.H = p.Ho = p.lH[big]; p.W = p.Wo = p.lW[big];
   }
   p.cqn = 16; p.nsplit = dwconv_splits(p);
-  static const bool bands = !(getenv("ODT_DW_XCD") != nullptr && getenv("ODT_DW_XCD")[0] == '0');     // A/B knob
+  const bool bands = !env_knob_off(K_DW_XCD);     // A/B knob
   p.xcd_bands = bands ? 1 : 0;
   const dim3 g(dwconv_cblocks(p), p.nsplit, p.nlvl > 0 ? p.nlvl : p.B), t(256);
   const bool wide = dw_px1() == 8;

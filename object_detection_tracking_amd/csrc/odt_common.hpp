@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <string>
 
+#include "knobs.hpp"
+
 namespace odt {
 
 void set_error(const std::string& msg);
@@ -156,7 +158,6 @@ struct ConvPolicy {
   bool kwr_n64;         // ... also for 64-wide layers (256 x 64 tile, wave tile 64 x 32)
   int force_splitk;     // 0 auto | k: force that split-K factor wherever conv_split3_kernel runs (tests)
   bool src2, res2;      // take the K-concatenated stage-entry convs / the 2x-upsampled-residual FPN laterals
-  int env_overrides;    // how many ODT_CONV_* variables were applied (recorded by odt_describe)
 };
 ConvPolicy conv_policy_default();
 ConvPolicy conv_policy_from_env(ConvPolicy q);
@@ -383,9 +384,10 @@ int launch_detections(const DetectParams& p, hipStream_t stream);
 int launch_class_nms(const DetectParams& p, hipStream_t stream);
 
 // ----------------------------------------------------------------- tracker (K15)
-// gal_n / det_n: device scratch for the L2-normalised copies ([G,D] / [N,D])
-int launch_nn_cosine(const float* gallery, const int* seg, int T, const float* dets, int N, int D, double* cost,
-                     hipStream_t stream);
+// blocks: nn_cosine_blocks' table of <= 32-row gallery blocks (device copy); any_part: a track spans several blocks
+bool nn_cosine_blocks(const int* seg, int T, std::vector<int>* blocks);
+int launch_nn_cosine(const float* gallery, const int* seg, const int* blocks, int nblocks, bool any_part, int T, const float* dets, int N,
+                     int D, double* cost, hipStream_t stream);
 // host-to-host cosine nearest-neighbour call with persistent scratch and a stream of its own (tracker.hip)
 struct CosineCtx {
   int device = -1;
@@ -393,6 +395,7 @@ struct CosineCtx {
   hipEvent_t done = nullptr;
   float* h_in = nullptr; float* d_in = nullptr; size_t cap_in = 0;        // packed [seg | gallery | detections]
   double* h_cost = nullptr; double* d_cost = nullptr; size_t cap_cost = 0;
+  std::vector<int> blocks_scratch;                   // the call's block table (host)
   std::vector<void*> retired_host, retired_dev;      // outgrown buffers: released with the context (hipFree waits for the device)
   ~CosineCtx();
   // gal_rows[G] / det_rows[N]: pointers to the D-float rows (gathered into the pinned record); seg[T+1]; cost[T*N]

@@ -123,6 +123,8 @@ struct odt_model {
   // tail overlap: the selection / ROIAlign / box-head / NMS kernels of forward i (a few dozen workgroups each,
   // ~2 ms per 8-frame step) run on a side stream under the backbone of forward i+1.  The next forward's FPN stage
   // (the first op that overwrites what the tail reads: P2..P5, the RPN outputs) waits for the previous tail.
+  std::vector<std::string> env_active;   // "ODT_NAME=value" of the overrides set when the handle's plan was built (odt_describe lists them)
+  bool knob_tail_overlap_off = false;
   int tail_overlap = -1;             // -1 undecided | 0 off | 1 on (ODT_TAIL_OVERLAP=0 disables; own stream only)
   size_t op_first_fpn = 0, op_tail = 0;
   hipStream_t tail_stream = nullptr, done_stream = nullptr;

@@ -23,6 +23,7 @@ int set_dev(int device) {
   ODT_HIP(hipGetDeviceCount(&n));
   ODT_CHECK(device >= 0 && device < n, "no such device");
   ODT_HIP(hipSetDevice(device));
+  knobs_reload();          // stand-alone ops (tests, tuning): the environment as it is at this call
   return 0;
 }
 
@@ -74,7 +75,7 @@ int odt_op_conv2d(int device, const float* in, int B, int H, int W, int Cin, con
   p.res_mode = p.res ? res_mode : 0; p.res_H = rH; p.res_W = rW; p.res_ldc = Cout; p.relu = relu;
   p.in_Ha = H; p.in_Wa = W;
   Tmp<unsigned long long> tr;
-  const bool trace = getenv("ODT_CONV_TRACE") != nullptr;
+  const bool trace = env_knob(K_CONV_TRACE).set;
   const int max_blocks = 1 << 16;
   if (trace) { if (tr.alloc((size_t)max_blocks * 16) || tr.zero()) return 1; p.trace = tr.d; }
   if (launch_conv(p, nullptr)) return 1;      // warm

@@ -164,7 +164,7 @@ int add_conv(odt_model* m, const std::string& name, const Tensor& in, int cin, c
 // stream: tools/experiments/track_stream_collision.py); streams of another priority get queues of their own.
 // ODT_SIDE_STREAM_PRIORITY=0: plain streams (A/B).
 int create_side_stream(hipStream_t* s) {
-  static const bool flat = getenv("ODT_SIDE_STREAM_PRIORITY") != nullptr && getenv("ODT_SIDE_STREAM_PRIORITY")[0] == '0';
+  const bool flat = env_knob_off(K_SIDE_STREAM_PRIORITY);
   if (flat) { ODT_HIP(hipStreamCreate(s)); return 0; }
   int least = 0, greatest = 0;
   ODT_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -241,16 +241,16 @@ int attach_split_weights(odt_model* m) {
       // A/B at b=8 1080p 30.8 -> 29.8 ms of conv time, res4 conv1 275 -> 317 TF (profiles/r03_h2_nt_ab.txt; 4: large-output
       // stores, measured no gain).  ODT_CONV_NT overrides the mask (A/B).
       int nt = 3;
-      if (const char* e = getenv("ODT_CONV_NT")) nt = atoi(e);
+      nt = (int)env_knob_long(K_CONV_NT, nt);
       c.p.debug |= (nt & 7) << 10;
     }
     {
-      const bool per_wave = getenv("ODT_AMAX_PER_WAVE") != nullptr && getenv("ODT_AMAX_PER_WAVE")[0] == '1';
+      const bool per_wave = env_knob(K_AMAX_PER_WAVE).c0 == '1';
       if (per_wave) c.p.debug |= 0x4000;      // A/B: range record per wave instead of per workgroup
     }
     if (c.p.wt_split_kind == 2) {
       c.p.h2_chinv = conv_h2_chinv(c.p.wt_split, c.p.Cout, K); ++m->convs_h2;
-      const bool norot = getenv("ODT_CONV_H2_ROT") != nullptr && getenv("ODT_CONV_H2_ROT")[0] == '0';
+      const bool norot = env_knob_off(K_CONV_H2_ROT);
       if (norot) c.p.debug |= 0x100;          // A/B: every workgroup walks the K slices in the same order
     }
     need_partial = std::max(need_partial, conv_split_partial_bytes(c.p));
@@ -303,8 +303,7 @@ int attach_split_weights(odt_model* m) {
 // ODT_FUSE_RPN_HEAD=0 keeps the two launches (A/B).  Called after attach_split_weights, before plan_arena.
 int fuse_rpn_heads(odt_model* m) {
   m->conv_fused.assign(m->convs.size(), 0);
-  const char* e = getenv("ODT_FUSE_RPN_HEAD");
-  if (e != nullptr && e[0] == '0') return 0;
+  if (env_knob_off(K_FUSE_RPN_HEAD)) return 0;
   const HostTensor* W = find_w(m, "__rpnhead/W");
   const HostTensor* Bv = find_w(m, "__rpnhead/b");
   if (W == nullptr || Bv == nullptr) return 0;
@@ -348,9 +347,9 @@ int fuse_rpn_heads(odt_model* m) {
 // attach_split_weights, before plan_arena.
 int fuse_bottleneck_tails(odt_model* m) {
   if (m->conv_fused.size() < m->convs.size()) m->conv_fused.resize(m->convs.size(), 0);
-  const char* e = getenv("ODT_FUSE_BOTTLENECK");       // A/B: 0 off | 1 only the 256-wide blocks (res4) | 2 + the 128-wide (res3) | otherwise every fusable block
-  if (e != nullptr && e[0] == '0') return 0;
-  const int min_cout = e != nullptr && e[0] == '1' ? 256 : (e != nullptr && e[0] == '2' ? 128 : 64);
+  const char e0 = env_knob(K_FUSE_BOTTLENECK).c0;      // A/B: 0 off | 1 only the 256-wide blocks (res4) | 2 + the 128-wide (res3) | otherwise every fusable block
+  if (e0 == '0') return 0;
+  const int min_cout = e0 == '1' ? 256 : (e0 == '2' ? 128 : 64);
   if (m->policy.arith == 0 || m->policy.family != 2) return 0;
   std::map<const float*, const void*> made;
   for (size_t oi = 0; oi + 1 < m->ops.size(); ++oi) {
@@ -383,14 +382,7 @@ int fuse_bottleneck_tails(odt_model* m) {
     ap.f_res = b.p.res_mode != 0 ? b.p.res : nullptr; ap.f_res_ldc = b.p.res_ldc;
     ap.f_out = b.p.out; ap.f_out_ldc = b.p.out_ldc; ap.f_cout = b.p.Cout; ap.f_relu = b.p.relu; ap.f_out_amax = b.p.out_amax;
     ap.debug |= b.p.debug & 0x400;           // the residual's non-temporal hint travels with it
-    {
-      // A/B and ablation knobs: counted like the ODT_CONV_* ones, so that odt_describe / the bench line's
-      // env_overrides_applied show that this handle does not run the default code (ODT_FUSE_DEBUG makes results WRONG)
-      const char* r = getenv("ODT_FUSE_ROT");           // A/B: 0 = every workgroup walks the output column chunks in the same order
-      if (r != nullptr && r[0] == '0') { ap.debug |= 0x100; ++m->policy.env_overrides; }
-      const char* d = getenv("ODT_FUSE_DEBUG");         // tuning ablations of the fused tail (1: no residual fetches, 2: no stores; results wrong)
-      if (d != nullptr && (atoi(d) & 3) != 0) { ap.debug |= (atoi(d) & 3) << 16; ++m->policy.env_overrides; }
-    }
+    if (env_knob_off(K_FUSE_ROT)) ap.debug |= 0x100;     // A/B: 0 = every workgroup walks the output column chunks in the same order
     ap.out = nullptr; ap.out_amax = nullptr;
     ob.skip = true;
     m->conv_fused[ob.conv] = 2;
@@ -406,8 +398,7 @@ int fuse_bottleneck_tails(odt_model* m) {
 // -- 1.07 GB written and read back at b=8 -- never exists).  Bit-identical.  ODT_FUSE_STEM=0 keeps the two launches (A/B).
 // Called after attach_split_weights, before plan_arena.
 int fuse_stem(odt_model* m) {
-  const char* e = getenv("ODT_FUSE_STEM");
-  if (e != nullptr && e[0] == '0') return 0;
+  if (env_knob_off(K_FUSE_STEM)) return 0;
   if (m->policy.arith == 0 || m->policy.family != 2) return 0;
   for (size_t oi = 0; oi + 1 < m->ops.size(); ++oi) {
     Op& oa = m->ops[oi]; Op& ob = m->ops[oi + 1];
@@ -427,7 +418,7 @@ int fuse_stem(odt_model* m) {
     // the conv map no longer exists: an arena handle must neither reserve memory for its stage name nor hand it out
     for (auto it = m->taps.begin(); it != m->taps.end();) { if (it->second.d == ap.out) it = m->taps.erase(it); else ++it; }
     ap.out = ob.out.d; ap.out_H = ob.out.H; ap.out_W = ob.out.W; ap.out_ldc = ob.out.C; ap.stem_pool = 1;
-    if (const char* g = getenv("ODT_STEM_GRID")) { ap.debug |= (atoi(g) & 0x3ff) << 20; ++m->policy.env_overrides; }   // test knob: workgroups of the launch
+    if (env_knob(K_STEM_GRID).set) ap.debug |= ((int)env_knob(K_STEM_GRID).i & 0x3ff) << 20;   // test knob: workgroups of the launch
     ob.skip = true;
     m->stem_fused = 1;
   }
@@ -554,7 +545,7 @@ static int conv_batch_chunks(const ConvParams& p, double limit) {
 
 int upload_conv_records(odt_model* m) {
   double limit = 2147483648.0;
-  if (const char* e = getenv("ODT_CONV_CHUNK_BYTES")) { if (atof(e) > 0) limit = atof(e); }
+  if (env_knob(K_CONV_CHUNK_BYTES).d > 0) limit = env_knob(K_CONV_CHUNK_BYTES).d;
   m->conv_recs.clear(); m->conv_rec0.clear(); m->conv_nrec.clear();
   for (const ConvOp& c : m->convs) {
     const ConvParams& p = c.p;

@@ -14,8 +14,7 @@ namespace odt {
 // channel stride of a tensor: padded with zero channels to a multiple of 32 -- or of 64 when the bf16x3 split kernels
 // take the 1x1 convs (their n-tile granule; conv_split.hip cout_padded)
 static bool eff_split_on() {        // (read per plan build: tests and A/B runs flip it inside one process)
-  const char* e = getenv("ODT_EFFDET_SPLIT");
-  return !(e != nullptr && e[0] == '0');
+  return !env_knob_off(K_EFFDET_SPLIT);
 }
 int r32(int c) { return eff_split_on() ? (c + 63) / 64 * 64 : (c + 31) / 32 * 32; }
 // squeeze-excite gate folded into the projection's weights at batch 1 (ODT_EFFDET_WSCALE=0: a pass over the activations)
@@ -23,16 +22,14 @@ int r32(int c) { return eff_split_on() ? (c + 63) / 64 * 64 : (c + 31) / 32 * 32
 // ODT_EFFDET_FUSE_MB = 0 off | 1 (default) blocks whose depthwise output is at least 64 pixels on its short side (smaller
 // maps do not fill 16 x 16 patches: the halo / partial-tile recompute would cost more than the launch it saves) | 2 every block
 static int eff_fuse_mb_mode() {
-  const char* e = getenv("ODT_EFFDET_FUSE_MB");
-  return e != nullptr ? atoi(e) : 1;
+  return (int)env_knob_long(K_EFFDET_FUSE_MB, 1);
 }
 static int eff_fuse_mb_min() {           // A/B knob: smallest short side of the depthwise output that is fused in mode 1
-  const char* e = getenv("ODT_EFFDET_FUSE_MB_MIN");
-  return e != nullptr && atoi(e) > 0 ? atoi(e) : 64;
+  const long v = env_knob_long(K_EFFDET_FUSE_MB_MIN, 64);
+  return v > 0 ? (int)v : 64;
 }
 static bool eff_wscale_on() {
-  const char* e = getenv("ODT_EFFDET_WSCALE");
-  return !(e != nullptr && e[0] == '0');
+  return !env_knob_off(K_EFFDET_WSCALE);
 }
 
 int eff_round_filters(int f, double width) {
@@ -255,7 +252,7 @@ int build_effdet_heads(odt_model* m, const Tensor* red, const int* red_ch) {
   for (int l = 0; l < 5; ++l) off[l + 1] = off[l] + (fh[l + 3] * fw[l + 3] + 255) / 256 * 256;
   const int Mtot = off[5];
   bool merge = B == 1 && eff_split_on();
-  if (const char* e = getenv("ODT_EFFDET_MERGE_LEVELS")) merge = merge && e[0] != '0';
+  merge = merge && !env_knob_off(K_EFFDET_MERGE_LEVELS);
   if (merge) {      // would the merged pointwise conv run on a conv_split3 kernel without split-K?
     ConvParams q; std::memset(&q, 0, sizeof(q));
     q.B = 1; q.H = Mtot / 256; q.W = 256; q.in_Ha = q.H; q.in_Wa = 256; q.Cin = LF; q.in_ldc = LF; q.Ho = q.H; q.Wo = 256; q.Cout = F;

@@ -86,7 +86,7 @@ int build_plan(odt_model* m) {
         Ho = x.h; Wo = x.w;
       }
       const std::string tap = (i == cnt - 1) ? "c" + std::to_string(g + 2) : (i == 0 ? pre : "");
-      static const bool fuse_shortcut = !(getenv("ODT_FUSE_SHORTCUT") && getenv("ODT_FUSE_SHORTCUT")[0] == '0');
+      const bool fuse_shortcut = !env_knob_off(K_FUSE_SHORTCUT);
       if (cin != ch * 4 && fuse_shortcut) {
         // stage entry: conv3(t2) + convshortcut(x[::stride]) as one K-concatenated GEMM -- saves the
         // shortcut tensor's write + read and one launch (shortcut[:, :, :-1, :-1] of nn.py:555-556

@@ -195,8 +195,7 @@ int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStre
   }
   // ---- tail overlap (own stream only: a caller's stream must see the whole forward in stream order)
   if (m->tail_overlap < 0) {
-    const char* e = getenv("ODT_TAIL_OVERLAP");
-    m->tail_overlap = (cfg.graph != ODT_GRAPH_EFFNET && !(e && e[0] == '0')) ? 1 : 0;
+    m->tail_overlap = (cfg.graph != ODT_GRAPH_EFFNET && !m->knob_tail_overlap_off) ? 1 : 0;
     find_overlap_points(m);
     if (m->op_tail == 0) m->tail_overlap = 0;
   }
@@ -261,7 +260,10 @@ int odt_create(const odt_config* cfg, int device, odt_handle* out) {
   ODT_HIP(hipGetDeviceCount(&n));
   ODT_CHECK(device >= 0 && device < n, "odt_create: no such device");
   ODT_HIP(hipSetDevice(device));
+  knobs_reload();
   std::unique_ptr<odt_model> m(new odt_model());
+  m->env_active = knobs_active();
+  m->knob_tail_overlap_off = env_knob_off(K_TAIL_OVERLAP);
   m->cfg = *cfg;
   m->device = device;
   ODT_HIP(hipStreamCreate(&m->own_stream));
@@ -308,6 +310,9 @@ int odt_finalize_weights(odt_handle h) {
   ODT_CHECK(h != nullptr, "null handle");
   ODT_CHECK(!h->finalized, "weights already finalized");
   ODT_HIP(hipSetDevice(h->device));
+  knobs_reload();          // the plan is built under the environment of THIS call (tests flip A/B knobs between handles)
+  h->env_active = knobs_active();
+  h->knob_tail_overlap_off = env_knob_off(K_TAIL_OVERLAP);
   if (build_plan(h)) return 1;
   h->conv_fused.resize(h->convs.size(), 0);
   ODT_HIP(hipDeviceSynchronize());
@@ -614,20 +619,28 @@ int odt_describe(odt_handle h, char* buf, int cap) {
   for (const auto& b : h->bufs) dev_bytes += b->bytes;
   dev_bytes += h->frames_src.bytes;
   for (const auto& sl : h->slot) dev_bytes += sl.dev_in_bytes;
-  char tmp[2048];
+  // every ODT_* override that was set when the plan was built, by name (knobs.hpp: nothing else reads the environment)
+  std::string envs;
+  for (size_t i = 0; i < h->env_active.size(); ++i) {
+    std::string e = h->env_active[i];
+    for (char& ch : e) if (ch == '"' || ch == '\\' || (unsigned char)ch < 0x20) ch = '?';
+    envs += (i ? ", \"" : "\"") + e + "\"";
+  }
+  char tmp[8192];
   std::snprintf(tmp, sizeof(tmp),
                 "{\"conv_arith\": \"%s\", \"conv_launches\": %d, \"convs_fused_into_epilogues\": %d, \"exact_f32_mfma_launches\": %d, "
                 "\"bf16x3_split_launches\": %d, \"fp16x2_split_launches\": %d, \"bottleneck_tails_fused\": %d, \"stem_fused\": %d, \"mbconv_expand_dw_fused\": %d, \"split_launches_by_family\": {\"split3_8wave_lds_dma\": %d, "
                 "\"one_stage_bk32\": %d, \"h2_8wave_lds_dma\": %d, \"of_split3_with_split_k\": %d}, \"policy\": {\"family\": %d, \"min_tiles\": %ld, "
-                "\"min_tiles3\": %ld, \"min_k\": %d}, \"env_overrides_applied\": %d, "
+                "\"min_tiles3\": %ld, \"min_k\": %d}, \"env_overrides_applied\": %d, \"env_overrides\": [%s], "
                 "\"memory\": {\"device_bytes\": %zu, \"activation_arena_bytes\": [%zu, %zu], \"arena_tensors\": %zu, "
                 "\"arena_tensor_bytes_unshared\": %zu, \"dedicated_tensor_bytes\": %zu, \"keep_taps\": %d}, \"convs_cut_into_batch_ranges\": %d}",
                 h->policy.arith != 0 && fam[2] > 0 ? "f32 through fp16x2 / bf16x3 split products"
                     : (h->policy.arith != 0 && fam[1] + fam[3] > 0 ? "f32 through bf16x3 split products" : "exact f32 MFMA"),
                 (int)h->convs.size() - nfused, nfused, fam[0], fam[1] + fam[3], fam[2], h->convs_h2f, h->stem_fused, h->mb_fused, fam[3], fam[1], fam[2], nsk, h->policy.family,
-                h->policy.min_tiles, h->policy.min_tiles3, h->policy.min_k, h->policy.env_overrides,
+                h->policy.min_tiles, h->policy.min_tiles3, h->policy.min_k, (int)h->env_active.size(), envs.c_str(),
                 dev_bytes, h->arena_bytes[0], h->arena_bytes[1], h->vt.size(), h->virtual_tensor_bytes,
                 h->dedicated_tensor_bytes, h->cfg.keep_taps, h->chunked_convs);
+  ODT_CHECK((int)std::strlen(tmp) < cap, "odt_describe: buffer too small");
   std::strncpy(buf, tmp, cap - 1); buf[cap - 1] = 0;
   return 0;
 }

@@ -429,6 +429,7 @@ int odt_tracker_create(double max_cosine_distance, int nn_budget, double max_iou
                        int n_init, int device, odt_tracker_handle* out) {
   ODT_CHECK(out != nullptr, "odt_tracker_create: null argument");
   ODT_CHECK(max_age >= 1 && n_init >= 1, "odt_tracker_create: bad parameters");
+  knobs_reload();
   odt_tracker* t = new odt_tracker();
   t->max_cos = max_cosine_distance; t->budget = nn_budget; t->max_iou = max_iou_distance;
   t->max_age = max_age; t->n_init = n_init; t->device = device;
@@ -459,7 +460,7 @@ int odt_tracker_update(odt_tracker_handle t, const double* tlwh, const double* c
     ODT_CHECK(t->D == 0 || t->D == D, "odt_tracker_update: feature dimension changed");
     t->D = D;
   }
-  static const bool timing = getenv("ODT_TRACKER_TIMING") != nullptr;     // tuning aid: where an update's wall time goes (stderr, every 160 updates)
+  static const bool timing = env_knob(K_TRACKER_TIMING).set;     // tuning aid: where an update's wall time goes (stderr, every 160 updates)
   static double tacc[4] = {0, 0, 0, 0}; static long tn = 0;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double u0 = timing ? now() : 0;

@@ -69,8 +69,8 @@ class EfficientNetBackbone(object):
   def describe(self):
     """What the handle runs (odt_describe): kernel families, launches, memory."""
     import json
-    buf = C.create_string_buffer(2048)
-    self.lib.check(self.lib.dll.odt_describe(self.h, buf, 2048))
+    buf = C.create_string_buffer(16384)
+    self.lib.check(self.lib.dll.odt_describe(self.h, buf, 16384))
     return json.loads(buf.value.decode())
 
   def tap(self, name):

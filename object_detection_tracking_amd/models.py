@@ -400,8 +400,8 @@ class _Engine(object):
   def describe(self):
     """What the handle runs (odt_describe): conv arithmetic mode, launches per kernel family, policy thresholds."""
     import json
-    buf = C.create_string_buffer(4096)
-    self.lib.check(self.lib.dll.odt_describe(self.h, buf, 4096))
+    buf = C.create_string_buffer(16384)
+    self.lib.check(self.lib.dll.odt_describe(self.h, buf, 16384))
     d = json.loads(buf.value.decode())
     auto = getattr(self, "_auto", None)      # (EfficientNetBackbone borrows this method: no auto state there)
     if auto is not None:

@@ -393,6 +393,11 @@ template <typename T> inline T atomicMin(T* p, T v) {
   T o = __atomic_load_n(p, __ATOMIC_RELAXED);
   while (o > v && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
   return o; }
+template <typename T> inline T atomicCAS(T* p, T expect, T desired) {
+  __atomic_compare_exchange_n(p, &expect, desired, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+  return expect; }
+inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }
+inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }

@@ -413,6 +413,25 @@ def test_nn_cosine(backend):
   assert ops.nn_cosine(gal, seg, np.zeros((0, D), F), lib=lib).shape == (T, 0)
 
 
+@pytest.mark.parametrize("D", [256, 132, 30])
+def test_nn_cosine_long_galleries_and_odd_lengths(backend, D):
+  """Round 6 kernel: 32-row blocks of whole tracks; a gallery of more than 32 rows (no budget: nn_matching.py:125-154 appends one
+  row per matched frame) is cut into blocks whose minima meet through an atomic min; more than 128 detections (second column of
+  workgroups); feature lengths that are not a multiple of 8 / of 4 (scalar loads)."""
+  name, lib = backend
+  rng = np.random.default_rng(14)
+  sizes = np.array([5, 70, 1, 32, 33, 2, 31, 1, 64, 3])
+  T, N = len(sizes), 150
+  seg = np.r_[0, np.cumsum(sizes)].astype(np.int32)
+  gal = rng.standard_normal((seg[-1], D)).astype(F)
+  det = rng.standard_normal((N, D)).astype(F)
+  got = ops.nn_cosine(gal, seg, det, lib=lib)
+  a = gal / np.linalg.norm(gal, axis=1, keepdims=True); b = det / np.linalg.norm(det, axis=1, keepdims=True)
+  full = 1. - a.astype(np.float64) @ b.astype(np.float64).T
+  ref = np.stack([full[seg[t]:seg[t + 1]].min(axis=0) for t in range(T)])
+  np.testing.assert_allclose(got, ref, rtol=0, atol=3e-6)
+
+
 def test_nn_cosine_scratch_growth(backend):
   """The call's persistent scratch (pinned + device, CosineCtx) starts at 2^20 floats and is doubled when outgrown;
   outgrown buffers are retired, not freed (a hipFree would wait for a detector's forward in flight).  Small call,
