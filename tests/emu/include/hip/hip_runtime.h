@@ -393,6 +393,7 @@ template <typename T> inline T atomicMin(T* p, T v) {
   T o = __atomic_load_n(p, __ATOMIC_RELAXED);
   while (o > v && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
   return o; }
+template <typename T> inline T atomicExch(T* p, T v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
 template <typename T> inline T atomicCAS(T* p, T expect, T desired) {
   __atomic_compare_exchange_n(p, &expect, desired, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
   return expect; }
