@@ -76,7 +76,7 @@ class OdtLib(object):
   SYMBOLS = [
       "odt_last_error", "odt_device_count", "odt_create", "odt_destroy",
       "odt_load_tensor", "odt_finalize_weights", "odt_forward",
-      "odt_forward_async", "odt_synchronize", "odt_read_outputs", "odt_describe", "odt_submit", "odt_submit_ex", "odt_collect",
+      "odt_forward_async", "odt_synchronize", "odt_read_outputs", "odt_describe", "odt_range_health", "odt_submit", "odt_submit_ex", "odt_collect",
       "odt_ingest_buffer", "odt_set_source_size", "odt_tap", "odt_profile_enable",
       "odt_profile_read", "odt_profile_layer", "odt_probe_mfma_bf16", "odt_nn_cosine", "odt_op_conv2d", "odt_op_conv2d_cat",
       "odt_op_bottleneck_tail", "odt_op_stem", "odt_op_preprocess",
@@ -108,6 +108,7 @@ class OdtLib(object):
     d.odt_read_outputs.argtypes = [C.c_void_p, C.POINTER(OdtOutputs)]
     d.odt_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     d.odt_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    d.odt_range_health.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     d.odt_submit_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
     d.odt_collect.argtypes = [C.c_void_p, C.c_int, C.POINTER(OdtOutputs)]
     d.odt_set_source_size.argtypes = [C.c_void_p, C.c_int, C.c_int]

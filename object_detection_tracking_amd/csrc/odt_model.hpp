@@ -100,6 +100,9 @@ struct odt_model {
   static constexpr int kAmaxSlots = 512;
   unsigned* amax_dev = nullptr;
   int amax_used[2] = {0, 0};
+  unsigned* range_host = nullptr;        // pinned, device-mapped: [|max|][non-zero][deep] x kRangeSlots of the last completed forward
+  unsigned* range_host_dev = nullptr;    // ... its device address (amax_rotate_kernel writes it)
+  std::vector<std::string> range_slot_name;
   int convs_h2 = 0;                  // convs on the fp16x2 kernels
   int stem_fused = 0;                // conv0 + pool0 run as one kernel (fuse_stem)
   int convs_h2f = 0;                 // ... of them with the following 1x1 conv folded into the kernel (fuse_bottleneck_tails)

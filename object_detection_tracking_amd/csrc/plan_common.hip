@@ -191,8 +191,17 @@ int attach_split_weights(odt_model* m) {
   m->policy = pol;
   if (pol.arith == 0) return 0;
   find_overlap_points(m);
-  m->amax_dev = reinterpret_cast<unsigned*>(m->alloc_f((size_t)2 * odt_model::kAmaxSlots * kAmaxWays, true));   // kAmaxWays words per slot
+  // [live |max|][non-zero stored][deep][previous |max|], kRangeSlots words each (odt_common.hpp: range statistics)
+  static_assert(2 * odt_model::kAmaxSlots * kAmaxWays == kRangeSlots, "range statistics are laid out for one word per slot");
+  m->amax_dev = reinterpret_cast<unsigned*>(m->alloc_f((size_t)4 * kRangeSlots, true));
   ODT_CHECK(m->amax_dev != nullptr, "device allocation failed (range slots)");
+  if (m->range_host == nullptr) {
+    // what the previous forward recorded, where the host can read it without a copy or a synchronisation (odt_range_health)
+    ODT_HIP(hipHostMalloc((void**)&m->range_host, (size_t)3 * kRangeSlots * sizeof(unsigned), hipHostMallocMapped));
+    std::memset(m->range_host, 0, (size_t)3 * kRangeSlots * sizeof(unsigned));
+    ODT_HIP(hipHostGetDevicePointer((void**)&m->range_host_dev, m->range_host, 0));
+  }
+  m->range_slot_name.assign(kRangeSlots, std::string());
   // |max| slots: a tensor written by a split conv kernel gets one; a pooled / subsampled tensor shares its source's (its
   // values are a subset); anything else has none, and a conv reading it stays off the fp16x2 kernels.  Tail convs only
   // see slots filled in the tail (the trunk group is cleared by the next forward while the tail may still be running).
@@ -266,6 +275,8 @@ int attach_split_weights(odt_model* m) {
         slot_of[c.p.out] = slot;
       }
       c.p.out_amax = m->amax_dev + (size_t)slot * kAmaxWays;
+      if (!env_knob_off(K_RANGE_STATS)) c.p.debug |= kRangeStatsBit;   // plan tensors: the producer also counts what it stores (continuous range guard; ODT_RANGE_STATS=0: A/B)
+      if (m->range_slot_name[slot].empty()) m->range_slot_name[slot] = c.name;
     }
   }
   if (need_partial > 0) {
@@ -381,7 +392,7 @@ int fuse_bottleneck_tails(odt_model* m) {
     ap.f_wt = it->second; ap.f_chinv = conv_h2f_chinv(it->second, b.p.Cout, K); ap.f_bias = b.p.bias;
     ap.f_res = b.p.res_mode != 0 ? b.p.res : nullptr; ap.f_res_ldc = b.p.res_ldc;
     ap.f_out = b.p.out; ap.f_out_ldc = b.p.out_ldc; ap.f_cout = b.p.Cout; ap.f_relu = b.p.relu; ap.f_out_amax = b.p.out_amax;
-    ap.debug |= b.p.debug & 0x400;           // the residual's non-temporal hint travels with it
+    ap.debug |= b.p.debug & (0x400 | kRangeStatsBit);      // the residual's non-temporal hint and the range statistics travel with it
     if (env_knob_off(K_FUSE_ROT)) ap.debug |= 0x100;     // A/B: 0 = every workgroup walks the output column chunks in the same order
     ap.out = nullptr; ap.out_amax = nullptr;
     ob.skip = true;

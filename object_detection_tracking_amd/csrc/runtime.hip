@@ -168,9 +168,23 @@ static int finish_profile(odt_model* m, hipStream_t st) {
 }
 
 // the |max| slots the split conv kernels of a group of ops fill (0: trunk, 1: tail) start a forward at zero
+// start of a forward (of its tail): a group's range records move on -- |max| to the "previous" row (next to it the producers'
+// counters of stored / deep elements, odt_common.hpp), all three to host-visible memory, the live words back to zero
+__global__ void __launch_bounds__(256) amax_rotate_kernel(unsigned* __restrict__ slots, int first, int n, unsigned* __restrict__ host) {
+  const int i = first + (int)(blockIdx.x * 256 + threadIdx.x);
+  if (i >= first + n) return;
+  const unsigned a = slots[i], nz = slots[kRangeSlots + i], dp = slots[2 * kRangeSlots + i];
+  slots[3 * kRangeSlots + i] = a;
+  slots[i] = 0u; slots[kRangeSlots + i] = 0u; slots[2 * kRangeSlots + i] = 0u;
+  if (host != nullptr) { host[i] = a; host[kRangeSlots + i] = nz; host[2 * kRangeSlots + i] = dp; }
+}
+
 static int clear_amax(odt_model* m, int group, hipStream_t st) {
   if (m->amax_dev == nullptr || m->amax_used[group] == 0) return 0;
-  ODT_HIP(hipMemsetAsync(m->amax_dev + (size_t)group * odt_model::kAmaxSlots * kAmaxWays, 0, (size_t)m->amax_used[group] * kAmaxWays * sizeof(unsigned), st));
+  const int n = m->amax_used[group];
+  hipLaunchKernelGGL(amax_rotate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m->amax_dev, group * odt_model::kAmaxSlots, n,
+                     m->range_host_dev);
+  ODT_HIP(hipGetLastError());
   return 0;
 }
 
@@ -285,6 +299,7 @@ int odt_destroy(odt_handle h) {
       if (q) (void)hipHostFree(q);
     for (hipEvent_t e : {sl.h2d_done, sl.fwd_done, sl.d2h_done}) if (e) (void)hipEventDestroy(e);
   }
+  if (h->range_host) (void)hipHostFree(h->range_host);
   if (h->copy_in) (void)hipStreamDestroy(h->copy_in);
   if (h->copy_out) (void)hipStreamDestroy(h->copy_out);
   if (h->tail_stream) (void)hipStreamDestroy(h->tail_stream);
@@ -481,8 +496,18 @@ int odt_submit_ex(odt_handle h, const void* frames, int dtype, int want, int* ti
             "odt_submit: frames == NULL needs odt_ingest_buffer() for this ticket and dtype first");
   sl.ingest_armed = -1;
   if (slot_prepare(h, sl, n)) return 1;
-  if (frames != nullptr) std::memcpy(sl.pin_in, frames, n);
-  ODT_HIP(hipMemcpyAsync(sl.dev_in, sl.pin_in, n, hipMemcpyHostToDevice, h->copy_in));
+  if (frames != nullptr && B > 1 && n % B == 0) {
+    // pageable source: staged and sent frame by frame -- the first frame's H2D is on its way while the second is being staged
+    // (a whole 8 x 1080p batch is 5 ms of memcpy in front of its first byte on PCIe otherwise)
+    const size_t pf = n / B;
+    for (size_t b = 0; b < B; ++b) {
+      std::memcpy(static_cast<char*>(sl.pin_in) + b * pf, static_cast<const char*>(frames) + b * pf, pf);
+      ODT_HIP(hipMemcpyAsync(static_cast<char*>(sl.dev_in) + b * pf, static_cast<char*>(sl.pin_in) + b * pf, pf, hipMemcpyHostToDevice, h->copy_in));
+    }
+  } else {
+    if (frames != nullptr) std::memcpy(sl.pin_in, frames, n);
+    ODT_HIP(hipMemcpyAsync(sl.dev_in, sl.pin_in, n, hipMemcpyHostToDevice, h->copy_in));
+  }
   ODT_HIP(hipEventRecord(sl.h2d_done, h->copy_in));
   hipStream_t st = h->own_stream;
   ODT_HIP(hipStreamWaitEvent(st, sl.h2d_done, 0));
@@ -642,6 +667,32 @@ int odt_describe(odt_handle h, char* buf, int cap) {
                 h->dedicated_tensor_bytes, h->cfg.keep_taps, h->chunked_convs);
   ODT_CHECK((int)std::strlen(tmp) < cap, "odt_describe: buffer too small");
   std::strncpy(buf, tmp, cap - 1); buf[cap - 1] = 0;
+  return 0;
+}
+
+int odt_range_health(odt_handle h, double* worst_fraction, char* tensor, int tensor_cap, double* tensor_amax, long long* tensors_seen) {
+  ODT_CHECK(h != nullptr && worst_fraction != nullptr, "odt_range_health: null argument");
+  double worst = 0.0, wamax = 0.0;
+  int wslot = -1;
+  long long seen = 0;
+  if (h->range_host != nullptr) {
+    const volatile unsigned* r = h->range_host;
+    for (int g = 0; g < 2; ++g)
+      for (int i = g * odt_model::kAmaxSlots; i < g * odt_model::kAmaxSlots + h->amax_used[g]; ++i) {
+        const unsigned nz = r[kRangeSlots + i], dp = r[2 * kRangeSlots + i];
+        if (nz < 1024u) continue;           // (too few counted elements -- one workgroup in kRangeSample counts -- to speak of a share)
+        ++seen;
+        const double f = (double)dp / (double)nz;
+        if (f > worst) { worst = f; wslot = i; unsigned a = r[i]; float fa; std::memcpy(&fa, &a, 4); wamax = fa; }
+      }
+  }
+  *worst_fraction = worst;
+  if (tensor_amax) *tensor_amax = wamax;
+  if (tensors_seen) *tensors_seen = seen;
+  if (tensor != nullptr && tensor_cap > 0) {
+    const std::string nm = wslot >= 0 && wslot < (int)h->range_slot_name.size() ? h->range_slot_name[wslot] : std::string();
+    std::strncpy(tensor, nm.c_str(), tensor_cap - 1); tensor[tensor_cap - 1] = 0;
+  }
   return 0;
 }
 

@@ -431,6 +431,8 @@ inline hipError_t hipMalloc(void** p, size_t n) {
 template <typename T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+constexpr unsigned hipHostMallocMapped = 2;
+inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned = 0) { *d = h; return hipSuccess; }
 inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = 0) {

@@ -771,7 +771,8 @@ def test_default_engine_is_guarded_on_every_entry_path(backend, monkeypatch):
           assert np.array_equal(view, fr)             # the caller's view is still readable memory, whatever the guard chose
         auto = e.describe()["conv_split_family_auto"]
         assert len(auto["checks"]) == 1 and auto["calibration_forwards_left"] == 0 and not auto["incomplete"], auto
-        assert "args" not in e._auto and "twin" not in e._auto          # the weights dict / twin handle are released
+        assert "twin" not in e._auto                                      # the twin handle is released (the weights dict is the model's own:
+        assert ("args" in e._auto) == (kind == "ordinary")                # kept while the guard watches an fp16x2 engine)
         assert e.profile_read()["conv_launches"] > 0                      # profiling survived a handle change
         if kind == "ordinary":
           assert auto["chosen"].startswith("fp16x2"), auto
@@ -992,3 +993,117 @@ def test_heavy_tailed_bn_gamma_1080p_auto_family(hip_lib):
         assert miss + extra == 0, (tag, b, miss, extra)
     finally:
       m.close()
+
+
+def _exposure_outlier_weights(cfg, exp=30):
+  """_outlier_weights whose outlier channel only fires on SATURATED frames: conv0 channel 5 averages its 7 x 7 x 3 patch of the
+  normalised frame against a BatchNorm mean of 2.0 -- frames that stay below 200 / 255 (normalised <= 1.68) leave it at zero
+  behind the ReLU, a patch of 255s (2.25 .. 2.64) gives 0.44 x 2^exp; nothing downstream reads the channel.  A stream that
+  switches from ordinary to over-exposed frames moves pool0's |max| 2^exp above its useful content MID-RUN."""
+  w = {k: np.array(v, copy=True) for k, v in weights_for(cfg).items()}
+  c = 5
+  w["conv0/W"][:, :, :, c] = np.float32(1.0 / 147.0)
+  w["conv0/bn/gamma"][c] = np.float32(2.0 ** exp)
+  w["conv0/bn/beta"][c] = 0
+  w["conv0/bn/mean/EMA"][c] = 2.0
+  w["conv0/bn/variance/EMA"][c] = 1.0
+  w["group0/block0/conv1/W"][:, :, c, :] = 0
+  w["group0/block0/convshortcut/W"][:, :, c, :] = 0
+  return w
+
+
+def _exposure_stream(B, H, W, seed):
+  """(ordinary, saturated): the same scene clipped to <= 200, and with a quarter of the frame blown out to 255."""
+  fr = np.minimum(synthetic_frames(B, H, W, seed=seed), 200).astype(np.uint8)
+  hot = fr.copy()
+  hot[:, : H // 2, : W // 2] = 255
+  return fr, hot
+
+
+def _run_exposure_switch(lib, cfg, B, H, W, multi, ordinary_frames=3, max_frames_after_cut=4):
+  import copy
+  w = _exposure_outlier_weights(cfg)
+  fr, hot = _exposure_stream(B, H, W, seed=9)
+  ca = copy.copy(cfg); ca.conv_split_family = "auto"
+  c3 = copy.copy(cfg); c3.conv_split_family = 3
+  m3 = models.get_model(c3, 0, weights=w, lib=lib, is_multi=multi)
+  try:
+    want_hot = m3.engine(B, H, W).forward(hot, want_feats=False, want_pooled=True)
+  finally:
+    m3.close()
+  m = models.get_model(ca, 0, weights=w, lib=lib, is_multi=multi)
+  try:
+    e = m.engine(B, H, W)
+    for k in range(ordinary_frames):
+      e.forward(fr, want_feats=False, want_pooled=True)
+    d = e.describe()["conv_split_family_auto"]
+    # ordinary frames: the first-forward comparison keeps fp16x2, the watch sees nothing remarkable, nothing is re-armed
+    assert d["chosen"].startswith("fp16x2") and len(d["checks"]) == 1 and d["rearmed"] == 0, d
+    assert d["watch"] is not None and d["watch"]["tensors_seen"] > 0 and d["watch"]["worst_fraction"] < 0.5, d
+    left = None
+    for k in range(max_frames_after_cut):
+      got = e.forward(hot, want_feats=False, want_pooled=True)
+      d = e.describe()["conv_split_family_auto"]
+      if d["chosen"].startswith("bf16x3"):
+        left = k + 1
+        break
+    # the scene cut: the producers' own statistics (previous |max| as the yardstick: visible from the second saturated frame
+    # on) re-arm the comparison, the twin disagrees, the engine leaves fp16x2 -- and IS the bf16x3 engine from that frame on
+    assert left is not None and left <= max_frames_after_cut, d
+    assert d["rearmed"] >= 1 and len(d["checks"]) >= 2 and d["checks"][-1]["max_rel_diff"] > d["tolerance"], d
+    for a, b in zip(got, want_hot):
+      assert (a is None and b is None) or np.array_equal(a, b)
+    return left, d
+  finally:
+    m.close()
+
+
+@pytest.mark.gpu
+def test_continuous_range_guard_leaves_fp16x2_after_a_scene_cut(hip_lib, monkeypatch):
+  """Round 6: the "auto" guard is continuous.  Small size, split kernels forced (the simulator run of this takes eight minutes:
+  the CPU suite covers the host logic with a mocked statistic below, the device counters run on the GPU)."""
+  monkeypatch.setenv("ODT_CONV_SPLIT_MINTILES", "1"); monkeypatch.setenv("ODT_CONV_SPLIT3_MINTILES", "1")
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1])
+  left, d = _run_exposure_switch(hip_lib, cfg, 1, 160, 224, multi=False)
+  assert left <= 4, (left, d)
+
+
+def test_continuous_range_guard_host_logic(emu_lib, monkeypatch):
+  """The engine's half of the continuous guard on the simulator: a range statistic above watch_fraction re-arms the fp16x2-vs-
+  bf16x3 comparison for the next forward (twin rebuilt from the model's weights), a comparison that keeps fp16x2 raises the bar
+  so that the same stream does not re-arm again, and odt_range_health answers on a handle without fp16x2 launches."""
+  import copy
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1], rpn_test_post_nms_topk=16)
+  ca = copy.copy(cfg); ca.conv_split_family = "auto"
+  fr = synthetic_frames(1, 64, 96, seed=5)
+  m = models.get_model(ca, 0, weights=weights_for(cfg), lib=emu_lib)
+  try:
+    e = m.engine(1, 64, 96)
+    e.forward(fr, want_feats=False, want_pooled=True)
+    h = e.range_health()
+    assert set(h) == {"worst_fraction", "tensor", "tensor_amax", "tensors_seen"} and h["worst_fraction"] == 0.0, h   # (exact-f32 plan at this size)
+    a = e.describe()["conv_split_family_auto"]
+    assert a["chosen"].startswith("fp16x2") and len(a["checks"]) == 1 and a["rearmed"] == 0 and "twin" not in e._auto and "args" in e._auto, a
+    fake = {"worst_fraction": 0.93, "tensor": "pool0", "tensor_amax": 1e9, "tensors_seen": 7}
+    monkeypatch.setattr(type(e), "range_health", lambda self: dict(fake))
+    e.forward(fr, want_feats=False, want_pooled=True)             # the watch behind this forward sees the signal ...
+    a = e.describe()["conv_split_family_auto"]
+    assert a["rearmed"] == 1 and a["calibration_forwards_left"] == 1 and a["watch"]["tensor"] == "pool0", a
+    e.forward(fr, want_feats=False, want_pooled=True)             # ... this one runs on a fresh twin as well
+    a = e.describe()["conv_split_family_auto"]
+    assert len(a["checks"]) == 2 and a["calibration_forwards_left"] == 0 and a["chosen"].startswith("fp16x2"), a
+    assert a["watch_fraction"] > 0.93 and "twin" not in e._auto
+    e.forward(fr, want_feats=False, want_pooled=True)             # same statistic again: below the raised bar, no re-arm
+    assert e.describe()["conv_split_family_auto"]["rearmed"] == 1
+  finally:
+    m.close()
+
+
+@pytest.mark.gpu
+def test_continuous_range_guard_1080p_stream_b2(hip_lib):
+  from object_detection_tracking_amd.config import make_config as product_make_config
+  """The same on the product default at 1080p (multi graph, b = 2): an over-exposed cut in the middle of a stream moves the
+  engine to the bf16x3 handle within four frames."""
+  cfg = product_make_config(rpn_test_post_nms_topk=300, im_batch_size=2, max_size=1920, short_edge_size=1080)
+  left, d = _run_exposure_switch(hip_lib, cfg, 2, 1080, 1920, multi=True)
+  assert left <= 4, (left, d)
