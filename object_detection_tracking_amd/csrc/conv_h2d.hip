@@ -121,10 +121,11 @@ __global__ void __launch_bounds__(128, 2) conv_h2d_kernel(const ConvParams* __re
   load_a(0); load_a(1);
 #pragma unroll
   for (int j = 0; j < RA; ++j) { store_slot(0, 0, j); store_slot(0, 1, j); }
-  if (nd > 1) { load_a(0); load_a(1); }
-  if (nd > 1) ODT_WAIT_VM_LGKM0(2 * RA); else ODT_WAIT_VM_LGKM0(0);
+  // (conv_h2d_fits: Cin >= 128, i.e. at least two double stages)
+  load_a(0); load_a(1);
+  ODT_WAIT_VM_LGKM0(2 * RA);
   __builtin_amdgcn_s_barrier();
-  if (nd > 1) { dma_b(BOFF + BSTG); dma_b(BOFF + BSTG + BSUB); }
+  dma_b(BOFF + BSTG); dma_b(BOFF + BSTG + BSUB);
 
   // fragments: fa[k-step parity][piece][t], fb[buffer][piece]
   f16x8 fa[2][2][2], fb[2][2];

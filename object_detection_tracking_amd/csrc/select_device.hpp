@@ -244,6 +244,10 @@ struct NmsBigScratch {
   int nkeep;
 };
 
+// (nms_big_kernel / class_nms_big_kernel put sizeof(int) * kMaxTopKBig of their own next to this: 154 KB of the 160 KB of LDS a
+// gfx950 workgroup can have -- a larger kMaxTopKBig or panel must fail here, not at launch)
+static_assert(sizeof(NmsBigScratch) + sizeof(int) * kMaxTopKBig + 64 <= 160 * 1024, "NmsBigScratch + the kernels' index arrays must fit 160 KB of LDS");
+
 // box_at(i, out[4]): corners of candidate i (0..n-1, score-descending).  Fills s.keep[0..s.nkeep).
 template <class BoxAt>
 __device__ inline void block_nms_paneled(int n, int max_out, float thresh, BoxAt box_at, NmsBigScratch& s) {

@@ -504,3 +504,45 @@ def test_frozen_pb_to_hip_forward_vs_oracle(hip_lib, tmp_path):
     assert list(m2.config.resnet_num_block) == [1, 2, 2, 1]
   finally:
     m2.close()
+
+
+@pytest.mark.gpu
+def test_product_default_engine_on_the_drop_in_and_ingest_paths(hip_lib):
+  """The suite-wide make_config (tests/common.py) pins conv_split_family = 0; this runs the surfaces a user touches -- the
+  session shim on both graphs, predict, the pipelined ingest with two streams' worth of tickets -- on the PRODUCT default
+  (conv_split_family = "auto": guarded, handle swap machinery armed, continuous watch) and requires the unguarded handle's
+  results bit for bit (ordinary weights: the guard stays on fp16x2)."""
+  import copy
+  base = small_config(resnet_num_block=[1, 1, 2, 3], im_batch_size=2, rpn_test_post_nms_topk=64)
+  w = weights_for(base)
+  fr = synthetic_frames(2, 160, 224, seed=21)
+  out = {}
+  for fam in (0, "auto"):
+    cfg = copy.copy(base); cfg.conv_split_family = fam
+    m1 = models.get_model(cfg, 0, weights=w, lib=hip_lib)
+    mm = models.get_model(cfg, 0, weights=w, lib=hip_lib, is_multi=True)
+    try:
+      with models.Session() as sess:
+        single = sess.run([m1.final_boxes, m1.final_labels, m1.final_probs, m1.fpn_box_feat], feed_dict=m1.get_feed_dict_forward(fr[0].astype("float32")))
+        multi = sess.run([mm.final_boxes, mm.final_labels, mm.final_probs, mm.final_valid_indices, mm.fpn_box_feat],
+                         feed_dict=mm.get_feed_dict_forward_multi([fr[0].astype("float32"), fr[1].astype("float32")]))
+      pooled = m1.predict(fr[1], pooled=True)
+      e = mm.engine(2, 160, 224)
+      stream = list(e.forward_stream([fr, fr[::-1].copy(), fr]))
+      d = e.describe()
+      if fam == "auto":
+        a = d["conv_split_family_auto"]
+        assert a["chosen"].startswith("fp16x2") and a["calibration_forwards_left"] == 0 and a["watch"] is not None, a
+      else:
+        assert d["range_guard"].startswith("off"), d
+      out[fam] = (single, multi, pooled, stream)
+    finally:
+      m1.close(); mm.close()
+  def same(a, b):
+    if isinstance(a, (list, tuple)):
+      assert len(a) == len(b)
+      for x, y in zip(a, b):
+        same(x, y)
+    else:
+      assert (a is None and b is None) or np.array_equal(a, b)
+  same(out[0], out["auto"])

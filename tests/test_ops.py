@@ -912,7 +912,8 @@ def test_conv2d_fp16x2_512x64_tile_generic_kernel(backend, case, monkeypatch):
 @pytest.mark.parametrize("case", [
     (1, 10, 15, 512, 256, 1, 1, 1, 0, 0, 10, 15, True),      # dense 1x1, M = 150: 3 x 2 tiles of 64 x 128 (res4 conv1 at b = 1)
     (1, 10, 15, 256, 512, 1, 1, 1, 0, 0, 10, 15, False),     # dense 1x1, short reduction, several n-tiles (res4 conv3 at b = 1)
-    (1, 9, 15, 64, 128, 1, 1, 1, 0, 0, 9, 15, True),         # dense 1x1 with ONE double stage (K = 64)
+    (1, 9, 15, 64, 128, 1, 1, 1, 0, 0, 9, 15, True),         # dense 1x1, K = 64: below conv_h2d_kernel's two double stages, conv_h2_kernel under both settings
+    (1, 9, 15, 128, 128, 1, 1, 1, 0, 0, 9, 15, True),        # dense 1x1, K = 128: exactly two double stages (the peeled steps only, no steady-state step)
     (1, 10, 15, 64, 256, 3, 1, 1, 1, 1, 10, 15, True),       # 3x3 taps on the generic kernel
     (1, 20, 15, 64, 128, 1, 2, 1, 0, 0, 10, 8, False),       # strided, one n-tile, a partial last tile (M = 80)
 ])
