@@ -50,6 +50,8 @@ def main():
   ap.add_argument("--no-d7", action="store_true", help="skip the EfficientDet-D7 leg of `extra` (BASELINE config #5)")
   ap.add_argument("--no-affinity", action="store_true", help="N > 1: do not pin the ranks to the CPUs next to their GPU")
   ap.add_argument("--no-extras", action="store_true", help="skip the `extra` measurements (A/B runs)")
+  ap.add_argument("--no-live-traffic", action="store_true",
+                  help="roofline.traffic from the committed counter summary instead of this run's own rocprofv3 --pmc child passes")
   ap.add_argument("--no-nn-matching", action="store_true",
                   help="A/B: leave the DeepSORT appearance matching (BASELINE config #3: T = 64 tracks x budget 5 against N = 100 "
                        "detections, once per frame) out of the timed step")
@@ -353,6 +355,8 @@ def main():
       extra["extras_failed"] = repr(ex)
   if rank == 0:
     fps = world * S * B * args.steps / dt
+    if (B, H, W) == (8, 1080, 1920) and world == 1 and not args.no_extras and not args.no_live_traffic:
+      live_pmc_traffic()
     roofline = conv_roofline(prof, sustained, (B, H, W) == (8, 1080, 1920))
     fam = prof["fam"]
     out = {
@@ -512,11 +516,60 @@ def arithmetic_of(desc):
           % (nh2 + nb3 + nf32, nh2, ntail, nb3, nf32, nfold))
 
 
+_LIVE_TRAFFIC = {}
+
+
+def live_pmc_traffic(timeout_s=150):
+  """HBM bytes per split-conv launch MEASURED BY THIS RUN (round 6): counters cannot be collected inside the timed region, so the
+  bench starts itself twice as a child under `rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE` (separate passes, as
+  MI355X_MICROARCH.md prescribes; two forwards each, no extras) and reads the counter CSVs: (2 x FETCH_SIZE + WRITE_SIZE) x 1024
+  bytes over the split-conv launches (FETCH_SIZE doubled: the guide's gfx950 correction).  Fills _LIVE_TRAFFIC; any failure --
+  no rocprofv3, a timeout -- leaves it empty and pmc_traffic() falls back to the committed summary of the builder's run."""
+  import csv, glob, shutil, subprocess, tempfile
+  exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+  if not os.path.exists(exe):
+    return
+  # (the fp16x2 kernels only -- 87 of the step's 88 split launches, 99 % of its FLOPs: the child's bring-up forward on the guard's
+  # bf16x3 twin handle runs conv_split3 kernels, which must not count)
+  is_split = lambda k: ("conv_h2" in k or "conv_stem" in k) and "kernel" in k and "split_weights" not in k
+  tot, launches = {}, None
+  t0 = time.perf_counter()
+  for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    d = tempfile.mkdtemp(prefix="odt_pmc_")
+    try:
+      cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
+             os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-d7",
+             "--profile-steps", "1", "--no-live-traffic"]
+      env = dict(os.environ); env.setdefault("TMPDIR", "/tmp")
+      subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+      files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+      v, disp = 0.0, set()
+      with open(files[0]) as fh:
+        for r in csv.DictReader(fh):
+          if r["Counter_Name"] == ctr and is_split(r["Kernel_Name"]):
+            v += float(r["Counter_Value"]); disp.add(r["Dispatch_Id"])
+      tot[ctr] = v
+      launches = len(disp) if launches is None else min(launches, len(disp))
+    except Exception as ex:
+      _LIVE_TRAFFIC["error"] = repr(ex)[:200]
+      return
+    finally:
+      shutil.rmtree(d, ignore_errors=True)
+  if launches:
+    _LIVE_TRAFFIC["split"] = ((2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / launches,
+                              "measured by this run: two child processes of this command under rocprofv3 --kernel-trace --pmc "
+                              "(FETCH_SIZE | WRITE_SIZE, separate passes, %d fp16x2 conv launches each; (2 x FETCH_SIZE + WRITE_SIZE) x "
+                              "1024 B per launch, FETCH_SIZE doubled per the gfx950 correction); %.0f s" % (launches, time.perf_counter() - t0))
+
+
 def pmc_traffic(mode):
-  """HBM bytes per conv launch from the separate rocprofv3 --pmc passes of this same command
-  (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; tools/pmc_summary.py), or None."""
-  names = ["r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"] if mode == "f32" else \
-          ["r05_pmc_summary_split.json", "r04_pmc_summary_split.json", "r03_pmc_summary_split.json", "r02_pmc_summary_split.json"]
+  """HBM bytes per conv launch: this run's own counter passes (live_pmc_traffic) where they ran, else the newest committed summary
+  of the separate rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE;
+  tools/pmc_summary.py), or None."""
+  if mode in _LIVE_TRAFFIC:
+    return _LIVE_TRAFFIC[mode]
+  names = ["r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"] if mode == "f32" else \
+          ["r06_pmc_summary_split.json", "r05_pmc_summary_split.json", "r04_pmc_summary_split.json", "r03_pmc_summary_split.json", "r02_pmc_summary_split.json"]
   for name in names:         # the newest committed summary
     try:
       with open(os.path.join(ROOT, "profiles", name)) as fh:

@@ -214,16 +214,17 @@ int odt_describe(odt_handle h, char* buf, int cap);
 int odt_tap(odt_handle h, const char* name, float* dst, size_t cap_elems,
             int64_t* shape_out, int* rank_out);
 
-/* Continuous range statistics of the fp16x2 kernels (round 6).  Those kernels scale a conv's activations by ONE power of two per
- * source tensor (from the |max| its producer recorded); content more than 2^17 below that maximum is left the f16 subnormal
- * grid -- absolute instead of relative precision.  Every producing kernel of a plan also counts, per output tensor, the
- * non-zero elements it stores and how many of them lie below 2^-17 of the tensor's |max| in the PREVIOUS forward; at the
- * start of the next forward the counts go to host-visible memory.  This call reads them (no copy, no synchronisation; the
- * numbers are one or two forwards old): the largest share over the plan's tensors, the producing layer's name and its |max|.
+/* Continuous range watch of the fp16x2 kernels (round 6).  Those kernels scale a conv's activations by ONE power of two per
+ * source tensor, taken from the |max| its producer recorded; a tensor whose maximum moves far above its useful content (an
+ * outlier channel that a scene cut or an exposure change switches on) leaves f32 level.  Every forward records those maxima
+ * anyway; at the start of the next forward they go to host-visible memory.  This call compares them (no copy, no
+ * synchronisation; the numbers are one or two forwards old) with the level the caller last accepted: *worst_growth = the
+ * largest ratio |max| now / |max| accepted over the plan's tensors, with the producing layer's name and its |max|.  A tensor
+ * seen for the first time sets its own level; rebase != 0 accepts the current maxima as the new level (after reporting).
  * The reference has no counterpart (TensorFlow computes in f32 throughout); the host side (models._Engine, the "auto"
- * conv_split_family) uses it to re-arm its fp16x2-vs-bf16x3 comparison when a video's statistics change
+ * conv_split_family) re-arms its fp16x2-vs-bf16x3 comparison when a maximum has grown past its watch ratio
  * (obj_detect_tracking.py:577-635 runs one model over a whole video).  A handle without fp16x2 launches reports 0. */
-int odt_range_health(odt_handle h, double* worst_fraction, char* tensor, int tensor_cap, double* tensor_amax,
+int odt_range_health(odt_handle h, int rebase, double* worst_growth, char* tensor, int tensor_cap, double* tensor_amax,
                      long long* tensors_seen);
 
 /* Per-launch timing of the implicit-GEMM conv kernel family, measured with

@@ -108,7 +108,7 @@ class OdtLib(object):
     d.odt_read_outputs.argtypes = [C.c_void_p, C.POINTER(OdtOutputs)]
     d.odt_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     d.odt_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
-    d.odt_range_health.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+    d.odt_range_health.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     d.odt_submit_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
     d.odt_collect.argtypes = [C.c_void_p, C.c_int, C.POINTER(OdtOutputs)]
     d.odt_set_source_size.argtypes = [C.c_void_p, C.c_int, C.c_int]

@@ -235,15 +235,8 @@ __device__ __forceinline__ void h2f_tail(const ConvParams& p, f32x16 (&acc)[2][T
   const int cw_at = (wm * 64 + wn * 32 + fr) * CS + 4 * fg;     // this lane's pixel row in the result tile
   const int cr_at = row0 * CS + c4 * 4;
   float vmax = 0.f;
-  // range statistics (non-zero | deep << 16 in one word: at most 512 elements per thread and tile).  64- / 128-wide producers count
-  // every row item; the 256-wide tile has no register to spare under its MFMAs and counts behind the last one only (below)
-  unsigned st_cnt = 0u;
-  const bool stats_loop = TN < 4 && (p.debug & kRangeStatsBit) != 0 && p.f_out_amax != nullptr && (blockIdx.x & (kRangeSample - 1)) == 0;
-  const float thr_loop = range_deep_threshold(p.f_out_amax, stats_loop);
   // one row-phase item: rows row0 + 64 s2 of chunk c's result tile -> global; the residual register is refilled for chunk c + 2
-  // (CNT: the range statistics -- on the 256-wide tile only behind the last MFMA, where registers are free: the row items of
-  // every workgroup's LAST column chunk, which the chunk rotation spreads evenly over the columns: a 1-in-nch sample)
-  auto row_item = [&](int cs, int s2, f32x4& rr, auto CNT, unsigned& cnt, float thr, bool stats) {
+  auto row_item = [&](int cs, int s2, f32x4& rr) {
     const int c = ce(cs);
     const float* Cb = Cst + (cs & 1) * (CBUF / 4);
     f32x4 v = *reinterpret_cast<const f32x4*>(Cb + cr_at + 64 * s2 * CS);
@@ -256,7 +249,6 @@ __device__ __forceinline__ void h2f_tail(const ConvParams& p, f32x16 (&acc)[2][T
     const float vm = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
     const bool ok = m_first + 64u * s2 < mrows;
     vmax = fmaxf(vmax, ok ? vm : 0.f);
-    if constexpr (decltype(CNT)::value) { if (stats && ok) range_count4_packed(v, thr, cnt); }
     __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)(ok ? ooff0 + s2 * ostep : kOOB), c * 128, 0);
     rr = fetch_res(cs + 2, s2);
   };
@@ -293,8 +285,8 @@ __device__ __forceinline__ void h2f_tail(const ConvParams& p, f32x16 (&acc)[2][T
       co = ODT_MFMA_F16(wf[u & 1][0], yhh, co);
       ODT_FENCE();
       if constexpr (has_prev) {
-        if constexpr (NS >= 4) { if ((u & 1) && u < 8) row_item(c - 1, u >> 1, rprev[u >> 1], std::integral_constant<bool, (TN < 4)>{}, st_cnt, thr_loop, stats_loop); }
-        else row_item(c - 1, u, rprev[u], std::true_type{}, st_cnt, thr_loop, stats_loop);            // (64-wide producer: four half-steps, one row item behind each)
+        if constexpr (NS >= 4) { if ((u & 1) && u < 8) row_item(c - 1, u >> 1, rprev[u >> 1]); }
+        else row_item(c - 1, u, rprev[u]);            // (64-wide producer: four half-steps, one row item behind each)
       }
     }
     float* Cb = Cst + buf * (CBUF / 4) + cw_at;
@@ -318,18 +310,15 @@ __device__ __forceinline__ void h2f_tail(const ConvParams& p, f32x16 (&acc)[2][T
     chunk(c, ra, std::true_type{});         // consumes chunk c - 1's residual (ra), refills ra with chunk c + 1's
     chunk(c + 1, rb, std::true_type{});
   }
-  const bool stats = (p.debug & kRangeStatsBit) != 0 && p.f_out_amax != nullptr && (blockIdx.x & (kRangeSample - 1)) == 0;
-  const float thr_end = range_deep_threshold(p.f_out_amax, stats);
-  unsigned cnt_end = st_cnt;
   if (c < nch) {
     chunk(c, ra, std::true_type{});
 #pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) row_item(c, s2, rb[s2], std::true_type{}, cnt_end, thr_end, stats);
+    for (int s2 = 0; s2 < 4; ++s2) row_item(c, s2, rb[s2]);
   } else {
 #pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) row_item(c - 1, s2, ra[s2], std::true_type{}, cnt_end, thr_end, stats);
+    for (int s2 = 0; s2 < 4; ++s2) row_item(c - 1, s2, ra[s2]);
   }
-  publish_range_wg<512>(p.f_out_amax, vmax, cnt_end & 0xffffu, cnt_end >> 16, stats, tid, lds);
+  publish_amax_wg<512>(p.f_out_amax, vmax, tid, lds);
 }
 
 template <int TN, bool TRACE = false, bool FUSE = false, int WN = 2>

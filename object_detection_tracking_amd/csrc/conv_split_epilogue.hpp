@@ -41,56 +41,6 @@ __device__ __forceinline__ void publish_amax_wg(unsigned* slot, float vmax, int 
   }
 }
 
-// ... and the range statistics with it (kRangeStatsBit): non-zero elements stored / of them below 2^-17 of the tensor's previous
-// |max| -- two more words through the same LDS reduction, two atomic adds per workgroup
-template <int NTHR>
-__device__ __forceinline__ void publish_range_wg(unsigned* slot, float vmax, unsigned nz, unsigned deep, bool stats, int tid, unsigned char* lds) {
-  if (slot == nullptr) return;
-  if (!stats) { publish_amax_wg<NTHR>(slot, vmax, tid, lds); return; }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    vmax = fmaxf(vmax, __shfl_xor(vmax, d));
-    nz += __shfl_xor(nz, d); deep += __shfl_xor(deep, d);
-  }
-  float* red = reinterpret_cast<float*>(lds);
-  unsigned* redu = reinterpret_cast<unsigned*>(lds) + NTHR / 64;
-  ODT_BARRIER_LDS();                                   // the last pass of the C tile has been read
-  if ((tid & 63) == 0) { red[tid >> 6] = vmax; redu[2 * (tid >> 6)] = nz; redu[2 * (tid >> 6) + 1] = deep; }
-  ODT_BARRIER_LDS();
-  if (tid == 0) {
-    float m = red[0];
-    unsigned a = redu[0], b2 = redu[1];
-#pragma unroll
-    for (int w = 1; w < NTHR / 64; ++w) { m = fmaxf(m, red[w]); a += redu[2 * w]; b2 += redu[2 * w + 1]; }
-    const unsigned b = __float_as_uint(m);
-    unsigned* w = amax_way(slot);
-    if (b > __atomic_load_n(w, __ATOMIC_RELAXED)) atomicMax(w, b);
-    if (a != 0u) atomicAdd(slot + kRangeSlots, a);
-    if (b2 != 0u) atomicAdd(slot + 2 * kRangeSlots, b2);
-  }
-}
-// the "deep" threshold of a producer: 2^-17 of the tensor's |max| in the previous forward (0: nothing counts)
-__device__ __forceinline__ float range_deep_threshold(const unsigned* slot, bool stats) {
-  return stats && slot != nullptr ? __uint_as_float(slot[3 * kRangeSlots]) * 7.62939453125e-06f : 0.f;
-}
-__device__ __forceinline__ void range_count4(const f32x4& v, float thr, unsigned& nz, unsigned& deep) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float a = fabsf(v[e]);
-    nz += a > 0.f ? 1u : 0u;
-    deep += (a > 0.f && a < thr) ? 1u : 0u;
-  }
-}
-// both counts in one register (non-zero: low half, deep: high half; at most 65535 elements per thread between two unpackings):
-// for the fused bottleneck tail, which has no register to spare
-__device__ __forceinline__ void range_count4_packed(const f32x4& v, float thr, unsigned& cnt) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float a = fabsf(v[e]);
-    cnt += a > 0.f ? (a < thr ? 0x10001u : 1u) : 0u;
-  }
-}
-
 // Epilogue shared by the conv_split3 kernels: accumulators of the 8 waves (wave tile 64 x 32 TN at (wm, wn)) -> LDS ->
 // rows of 16-byte chunks -> bias (+ residual) + activation -> global, or the raw partial tile of a split-K range.
 template <int WM, int WN, int TN, int LDSB, bool TRACE, int NTHR = 512>
@@ -234,9 +184,6 @@ __device__ __forceinline__ void split3_epilogue(const ConvParams& p, f32x16 (&ac
   }
   // (no barrier needed here: the last stage's barrier sits behind every fragment read of the ring)
   float vmax = 0.f;                          // |max| of what this thread stores (out_amax)
-  const bool stats = (p.debug & kRangeStatsBit) != 0 && p.out_amax != nullptr && (blockIdx.x & (kRangeSample - 1)) == 0;
-  const float deep_thr = range_deep_threshold(p.out_amax, stats);
-  unsigned st_nz = 0u, st_deep = 0u;
   const bool res_nt = (p.debug & 0x400) != 0;      // A/B: residual chunks (read once, by this workgroup only) with the non-temporal hint
   // A/B: outputs larger than the last-level cache (>= 128 MB: the 1024-channel res4 tensors, the res2 / P2 ones) stored non-temporally
   const bool out_nt = (p.debug & 0x1000) != 0 && (double)p.B * p.out_H * p.out_W * p.out_ldc * 4.0 >= 134217728.0;
@@ -295,10 +242,7 @@ __device__ __forceinline__ void split3_epilogue(const ConvParams& p, f32x16 (&ac
         }
         if (out_nt) __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)ooff[s2], 0, 2);
         else __builtin_amdgcn_raw_buffer_store_b128((u32x4)v, rs_out, (int)ooff[s2], 0, 0);
-        if (ooff[s2] != kOOB) {
-          vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-          if (stats) range_count4(v, deep_thr, st_nz, st_deep);
-        }
+        if (ooff[s2] != kOOB) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
       }
       if (pass == 0) ODT_STAMP(4);
     }
@@ -315,7 +259,7 @@ __device__ __forceinline__ void split3_epilogue(const ConvParams& p, f32x16 (&ac
     else run(std::integral_constant<int, 3>{}, std::false_type{});
   }
   if ((p.debug & 0x4000) != 0) publish_amax(p.out_amax, vmax, tid);       // A/B: one record per wave
-  else publish_range_wg<NTHR>(p.out_amax, vmax, st_nz, st_deep, stats, tid, lds);
+  else publish_amax_wg<NTHR>(p.out_amax, vmax, tid, lds);
 }
 
 }  // namespace

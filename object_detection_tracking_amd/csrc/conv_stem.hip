@@ -176,9 +176,6 @@ __global__ void __launch_bounds__(512, 2) conv_stem_kernel(const ConvParams* __r
   if (t_begin + 1 < t_end) load_patch(t_begin + 1);
 
   float vmax = 0.f;
-  const bool stats = (p.debug & kRangeStatsBit) != 0 && p.out_amax != nullptr && (blockIdx.x & (kRangeSample - 1)) == 0;
-  const float deep_thr = range_deep_threshold(p.out_amax, stats);
-  unsigned st_nz = 0u, st_deep = 0u;
   float* Ct = reinterpret_cast<float*>(lds + COFF);
   // ---- pool0: thread -> items tid, tid + 512 = (pooled pixel, 16-byte channel group) of the tile; the window's 3 x 3 conv
   // pixels sit at (2 pyl + dy, 2 pxl + dx) of the conv tile.  A tile's pooling runs UNDER THE NEXT TILE'S MFMAs (one window
@@ -208,10 +205,7 @@ __global__ void __launch_bounds__(512, 2) conv_stem_kernel(const ConvParams* __r
     for (int k = 0; k < 2; ++k) {
       const int py = py0 + pl_py[k], px = px0 + pl_px[k];
       const bool ok = py < Hq && px < Wq;
-      if (ok) {
-        vmax = fmaxf(vmax, fmaxf(fmaxf(pmx[k][0], pmx[k][1]), fmaxf(pmx[k][2], pmx[k][3])));
-        if (stats) range_count4(pmx[k], deep_thr, st_nz, st_deep);
-      }
+      if (ok) vmax = fmaxf(vmax, fmaxf(fmaxf(pmx[k][0], pmx[k][1]), fmaxf(pmx[k][2], pmx[k][3])));
       const unsigned off = ok ? ((((unsigned)n * Hq + py) * Wq + px) * (unsigned)p.out_ldc + ((tid + 512 * k) & 15) * 4u) * 4u : kOOB;
       __builtin_amdgcn_raw_buffer_store_b128((u32x4)pmx[k], rs_out, (int)off, 0, 0);
     }
@@ -283,7 +277,7 @@ __global__ void __launch_bounds__(512, 2) conv_stem_kernel(const ConvParams* __r
 #pragma unroll
   for (int e = 0; e < 9; ++e) pool_read(e);
   pool_store(pn, ppy0, ppx0);
-  publish_range_wg<512>(p.out_amax, vmax, st_nz, st_deep, stats, tid, lds);
+  publish_amax_wg<512>(p.out_amax, vmax, tid, lds);
 }
 
 #undef ODT_FENCE

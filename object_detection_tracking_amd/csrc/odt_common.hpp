@@ -44,18 +44,11 @@ constexpr int kMaxTopKBig = 4096;// rpn_test_post_nms_topk upper bound (above kM
 // launch's workgroups finish together): b = 8 310.0 -> 308.7 FPS, b = 1 174.0 -> 164.0 (profiles/r05_amax_ways_ab.txt) -- the
 // sixteen reads in front of every consumer's first load cost more than the atomics they spare.  Not kept.
 constexpr int kAmaxWays = ODT_AMAX_WAYS;
-// Range statistics behind the |max| slots (round 6: the continuous fp16x2 range guard).  A plan's slot array is
-//   [live |max| : kRangeSlots][non-zero elements stored][of them below 2^-17 of the tensor's PREVIOUS |max|][previous |max|]
-// (kRangeSlots words each); a producer whose parameter record carries debug bit kRangeStatsBit counts what it stores into
-// words + kRangeSlots / + 2 kRangeSlots of its out_amax pointer, against the |max| of the last forward at + 3 kRangeSlots
-// (0 on the first forward: nothing counts as "deep").  amax_rotate_kernel (runtime.hip) moves a group's records to the
-// "previous" rows and to host-visible memory at the start of the next forward.
-// Counting is SAMPLED: one workgroup in kRangeSample counts (the statistic is a share; every always-executed atomic add of a
-// launch's workgroups hits the same two words -- all workgroups counting cost 1.4 % at b = 8 and 4 % at b = 1,
-// profiles/r06_range_stats_cost_ab.txt).
+// Round 6 (the continuous fp16x2 range guard): a plan's slot array is [live |max| : kRangeSlots][previous forward's |max| : kRangeSlots];
+// amax_rotate_kernel (runtime.hip; the former memset at the start of a forward) moves a group's records to the second row and to
+// host-visible memory, where odt_range_health compares them with the values the host last accepted -- no kernel code beyond what
+// recorded the maxima all along (counters in the producers were built and cost 1 %: tools/experiments/r06_range_counters).
 constexpr int kRangeSlots = 1024;
-constexpr int kRangeStatsBit = 0x8000;
-constexpr int kRangeSample = 8;
 constexpr int kRoiOut = 7;       // ROIAlign output side (models.py:703)
 constexpr int kRpnCh = 16;       // 3 logits + 12 deltas (+1 pad) per pixel
 constexpr int kSelChunk = 32768; // logits per workgroup in stage 1 of the RPN top-k

@@ -100,7 +100,8 @@ struct odt_model {
   static constexpr int kAmaxSlots = 512;
   unsigned* amax_dev = nullptr;
   int amax_used[2] = {0, 0};
-  unsigned* range_host = nullptr;        // pinned, device-mapped: [|max|][non-zero][deep] x kRangeSlots of the last completed forward
+  unsigned* range_host = nullptr;        // pinned, device-mapped: the |max| records (kRangeSlots words) of the last completed forward
+  std::vector<float> range_baseline;     // per slot: the |max| the host last accepted (odt_range_health)
   unsigned* range_host_dev = nullptr;    // ... its device address (amax_rotate_kernel writes it)
   std::vector<std::string> range_slot_name;
   int convs_h2 = 0;                  // convs on the fp16x2 kernels

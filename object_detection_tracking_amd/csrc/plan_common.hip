@@ -191,17 +191,18 @@ int attach_split_weights(odt_model* m) {
   m->policy = pol;
   if (pol.arith == 0) return 0;
   find_overlap_points(m);
-  // [live |max|][non-zero stored][deep][previous |max|], kRangeSlots words each (odt_common.hpp: range statistics)
-  static_assert(2 * odt_model::kAmaxSlots * kAmaxWays == kRangeSlots, "range statistics are laid out for one word per slot");
-  m->amax_dev = reinterpret_cast<unsigned*>(m->alloc_f((size_t)4 * kRangeSlots, true));
+  // [live |max|][previous forward's |max|], kRangeSlots words each (odt_common.hpp)
+  static_assert(2 * odt_model::kAmaxSlots * kAmaxWays == kRangeSlots, "the range records are laid out for one word per slot");
+  m->amax_dev = reinterpret_cast<unsigned*>(m->alloc_f((size_t)2 * kRangeSlots, true));
   ODT_CHECK(m->amax_dev != nullptr, "device allocation failed (range slots)");
   if (m->range_host == nullptr) {
     // what the previous forward recorded, where the host can read it without a copy or a synchronisation (odt_range_health)
-    ODT_HIP(hipHostMalloc((void**)&m->range_host, (size_t)3 * kRangeSlots * sizeof(unsigned), hipHostMallocMapped));
-    std::memset(m->range_host, 0, (size_t)3 * kRangeSlots * sizeof(unsigned));
+    ODT_HIP(hipHostMalloc((void**)&m->range_host, (size_t)kRangeSlots * sizeof(unsigned), hipHostMallocMapped));
+    std::memset(m->range_host, 0, (size_t)kRangeSlots * sizeof(unsigned));
     ODT_HIP(hipHostGetDevicePointer((void**)&m->range_host_dev, m->range_host, 0));
   }
   m->range_slot_name.assign(kRangeSlots, std::string());
+  m->range_baseline.assign(kRangeSlots, 0.f);
   // |max| slots: a tensor written by a split conv kernel gets one; a pooled / subsampled tensor shares its source's (its
   // values are a subset); anything else has none, and a conv reading it stays off the fp16x2 kernels.  Tail convs only
   // see slots filled in the tail (the trunk group is cleared by the next forward while the tail may still be running).
@@ -220,6 +221,7 @@ int attach_split_weights(odt_model* m) {
     if (op.kind == OP_PRE && pol.family == 2) {        // the preprocess kernel records the range of the padded frames
       ODT_CHECK(m->amax_used[0] < odt_model::kAmaxSlots, "too many conv outputs for the range slots");
       slot_of[m->image_pad.d] = m->amax_used[0];
+      m->range_slot_name[m->amax_used[0]] = "preprocessed frames";
       m->pre_amax = m->amax_dev + (size_t)(m->amax_used[0]++) * kAmaxWays;
       continue;
     }
@@ -275,7 +277,6 @@ int attach_split_weights(odt_model* m) {
         slot_of[c.p.out] = slot;
       }
       c.p.out_amax = m->amax_dev + (size_t)slot * kAmaxWays;
-      if (!env_knob_off(K_RANGE_STATS)) c.p.debug |= kRangeStatsBit;   // plan tensors: the producer also counts what it stores (continuous range guard; ODT_RANGE_STATS=0: A/B)
       if (m->range_slot_name[slot].empty()) m->range_slot_name[slot] = c.name;
     }
   }
@@ -392,7 +393,7 @@ int fuse_bottleneck_tails(odt_model* m) {
     ap.f_wt = it->second; ap.f_chinv = conv_h2f_chinv(it->second, b.p.Cout, K); ap.f_bias = b.p.bias;
     ap.f_res = b.p.res_mode != 0 ? b.p.res : nullptr; ap.f_res_ldc = b.p.res_ldc;
     ap.f_out = b.p.out; ap.f_out_ldc = b.p.out_ldc; ap.f_cout = b.p.Cout; ap.f_relu = b.p.relu; ap.f_out_amax = b.p.out_amax;
-    ap.debug |= b.p.debug & (0x400 | kRangeStatsBit);      // the residual's non-temporal hint and the range statistics travel with it
+    ap.debug |= b.p.debug & 0x400;           // the residual's non-temporal hint travels with it
     if (env_knob_off(K_FUSE_ROT)) ap.debug |= 0x100;     // A/B: 0 = every workgroup walks the output column chunks in the same order
     ap.out = nullptr; ap.out_amax = nullptr;
     ob.skip = true;

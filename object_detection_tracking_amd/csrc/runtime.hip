@@ -1,5 +1,7 @@
 // Runtime of a handle behind the C ABI (include/odt.h): handle life cycle, weight ingest, the forward (op list on the
 // handle's streams, tail overlap), pipelined ingest (odt_submit_ex / odt_collect), outputs, taps, profiling, describe.
+#include <cmath>
+
 #include "odt_model.hpp"
 
 namespace odt {
@@ -168,15 +170,15 @@ static int finish_profile(odt_model* m, hipStream_t st) {
 }
 
 // the |max| slots the split conv kernels of a group of ops fill (0: trunk, 1: tail) start a forward at zero
-// start of a forward (of its tail): a group's range records move on -- |max| to the "previous" row (next to it the producers'
-// counters of stored / deep elements, odt_common.hpp), all three to host-visible memory, the live words back to zero
+// start of a forward (of its tail): a group's |max| records move to the "previous" row and to host-visible memory, the live words
+// back to zero (this was a memset)
 __global__ void __launch_bounds__(256) amax_rotate_kernel(unsigned* __restrict__ slots, int first, int n, unsigned* __restrict__ host) {
   const int i = first + (int)(blockIdx.x * 256 + threadIdx.x);
   if (i >= first + n) return;
-  const unsigned a = slots[i], nz = slots[kRangeSlots + i], dp = slots[2 * kRangeSlots + i];
-  slots[3 * kRangeSlots + i] = a;
-  slots[i] = 0u; slots[kRangeSlots + i] = 0u; slots[2 * kRangeSlots + i] = 0u;
-  if (host != nullptr) { host[i] = a; host[kRangeSlots + i] = nz; host[2 * kRangeSlots + i] = dp; }
+  const unsigned a = slots[i];
+  slots[kRangeSlots + i] = a;
+  slots[i] = 0u;
+  if (host != nullptr) host[i] = a;
 }
 
 static int clear_amax(odt_model* m, int group, hipStream_t st) {
@@ -496,18 +498,11 @@ int odt_submit_ex(odt_handle h, const void* frames, int dtype, int want, int* ti
             "odt_submit: frames == NULL needs odt_ingest_buffer() for this ticket and dtype first");
   sl.ingest_armed = -1;
   if (slot_prepare(h, sl, n)) return 1;
-  if (frames != nullptr && B > 1 && n % B == 0) {
-    // pageable source: staged and sent frame by frame -- the first frame's H2D is on its way while the second is being staged
-    // (a whole 8 x 1080p batch is 5 ms of memcpy in front of its first byte on PCIe otherwise)
-    const size_t pf = n / B;
-    for (size_t b = 0; b < B; ++b) {
-      std::memcpy(static_cast<char*>(sl.pin_in) + b * pf, static_cast<const char*>(frames) + b * pf, pf);
-      ODT_HIP(hipMemcpyAsync(static_cast<char*>(sl.dev_in) + b * pf, static_cast<char*>(sl.pin_in) + b * pf, pf, hipMemcpyHostToDevice, h->copy_in));
-    }
-  } else {
-    if (frames != nullptr) std::memcpy(sl.pin_in, frames, n);
-    ODT_HIP(hipMemcpyAsync(sl.dev_in, sl.pin_in, n, hipMemcpyHostToDevice, h->copy_in));
-  }
+  // (round 6 measured the staging frame by frame -- eight memcpy + H2D pairs instead of one: the first frame is on PCIe 4 ms
+  // earlier, and the eight copies get in the way of the tracker's small H2D / D2H copies on the copy engines: cosine calls
+  // 150 -> 500 us next to them, detect + track 284 -> 245 FPS, pipelined 311 -> 302: profiles/r06_frame_staging_ab.txt.  One copy.)
+  if (frames != nullptr) std::memcpy(sl.pin_in, frames, n);
+  ODT_HIP(hipMemcpyAsync(sl.dev_in, sl.pin_in, n, hipMemcpyHostToDevice, h->copy_in));
   ODT_HIP(hipEventRecord(sl.h2d_done, h->copy_in));
   hipStream_t st = h->own_stream;
   ODT_HIP(hipStreamWaitEvent(st, sl.h2d_done, 0));
@@ -670,23 +665,27 @@ int odt_describe(odt_handle h, char* buf, int cap) {
   return 0;
 }
 
-int odt_range_health(odt_handle h, double* worst_fraction, char* tensor, int tensor_cap, double* tensor_amax, long long* tensors_seen) {
-  ODT_CHECK(h != nullptr && worst_fraction != nullptr, "odt_range_health: null argument");
+int odt_range_health(odt_handle h, int rebase, double* worst_growth, char* tensor, int tensor_cap, double* tensor_amax, long long* tensors_seen) {
+  ODT_CHECK(h != nullptr && worst_growth != nullptr, "odt_range_health: null argument");
   double worst = 0.0, wamax = 0.0;
   int wslot = -1;
   long long seen = 0;
-  if (h->range_host != nullptr) {
+  if (h->range_host != nullptr && !h->range_baseline.empty()) {
     const volatile unsigned* r = h->range_host;
     for (int g = 0; g < 2; ++g)
       for (int i = g * odt_model::kAmaxSlots; i < g * odt_model::kAmaxSlots + h->amax_used[g]; ++i) {
-        const unsigned nz = r[kRangeSlots + i], dp = r[2 * kRangeSlots + i];
-        if (nz < 1024u) continue;           // (too few counted elements -- one workgroup in kRangeSample counts -- to speak of a share)
+        const unsigned bits = r[i];
+        float a; std::memcpy(&a, &bits, 4);
+        if (!(a > 0.f) || !std::isfinite(a)) continue;
         ++seen;
-        const double f = (double)dp / (double)nz;
-        if (f > worst) { worst = f; wslot = i; unsigned a = r[i]; float fa; std::memcpy(&fa, &a, 4); wamax = fa; }
+        float& base = h->range_baseline[i];
+        if (!(base > 0.f)) { base = a; continue; }          // first sighting: the level the next calls compare with
+        const double f = (double)a / (double)base;
+        if (f > worst) { worst = f; wslot = i; wamax = a; }
+        if (rebase) base = a;
       }
   }
-  *worst_fraction = worst;
+  *worst_growth = worst;
   if (tensor_amax) *tensor_amax = wamax;
   if (tensors_seen) *tensors_seen = seen;
   if (tensor != nullptr && tensor_cap > 0) {

@@ -118,14 +118,15 @@ class _Engine(object):
     self._auto = None
     self._family_requested = fam
     if fam == "auto" and c.conv_arith == 0:
-      # (round 6) the guard stays on watch for the whole stream: the producing kernels count, per tensor, how much of what they
-      # store lies more than 2^17 below the tensor's |max| (odt_range_health); when that share passes `watch_fraction` -- a
-      # scene cut, an exposure change: content the first frames never showed -- the comparison against the bf16x3 twin is
-      # re-armed for the next forward.  `args` therefore lives as long as the engine (the weights dict is the model's own).
+      # (round 6) the guard stays on watch for the whole stream: every forward records its tensors' |max| anyway (the fp16x2
+      # kernels scale by them); when one has grown past `watch_ratio` times the level the last comparison accepted
+      # (odt_range_health) -- a scene cut, an exposure change: an outlier the first frames never showed -- the comparison
+      # against the bf16x3 twin is re-armed for the next forward.  `args` therefore lives as long as the engine (the weights
+      # dict is the model's own).
       self._auto = {"pending": int(getattr(config, "conv_split_auto_frames", 1) or 1), "chosen": 2, "checks": [],
                     "tolerance": float(getattr(config, "conv_split_auto_tol", 2e-5)), "deferred": 0, "incomplete": False,
                     "frames": int(getattr(config, "conv_split_auto_frames", 1) or 1),
-                    "watch_fraction": float(getattr(config, "conv_split_auto_watch_fraction", 0.5)), "rearmed": 0, "watch": None,
+                    "watch_ratio": float(getattr(config, "conv_split_auto_watch_ratio", 8.0)), "rearmed": 0, "watch": None,
                     "args": (lib, config, graph, batch, height, width, weights, device, num_class)}
     if fam == "auto":
       fam = 2
@@ -303,28 +304,30 @@ class _Engine(object):
       swapped = True
     if a["chosen"] == 3 or a["pending"] <= 0:
       self._auto_finish()
+      if a["chosen"] == 2 and a.pop("rebase", False):
+        self.range_health(rebase=True)
     return swapped
 
-  def range_health(self):
-    """odt_range_health: the largest share, over the plan's tensors, of stored non-zero elements more than 2^17 below the
-    tensor's |max| (of the forward before), with the producing layer's name -- one or two forwards old, free to read."""
+  def range_health(self, rebase=False):
+    """odt_range_health: the largest growth, over the plan's tensors, of the recorded |max| against the level last accepted
+    (rebase=True accepts the current one), with the producing layer's name -- one or two forwards old, free to read."""
     f = C.c_double(); amax = C.c_double(); seen = C.c_longlong(); name = C.create_string_buffer(128)
-    self.lib.check(self.lib.dll.odt_range_health(self.h, C.byref(f), name, 128, C.byref(amax), C.byref(seen)))
-    return {"worst_fraction": f.value, "tensor": name.value.decode(), "tensor_amax": amax.value, "tensors_seen": int(seen.value)}
+    self.lib.check(self.lib.dll.odt_range_health(self.h, int(bool(rebase)), C.byref(f), name, 128, C.byref(amax), C.byref(seen)))
+    return {"worst_growth": f.value, "tensor": name.value.decode(), "tensor_amax": amax.value, "tensors_seen": int(seen.value)}
 
   def _watch(self):
-    """Continuous half of the "auto" guard: called after every forward / collect while the engine runs the fp16x2 kernels."""
+    """Continuous half of the "auto" guard: called after every forward / collect / synchronize while the engine runs the
+    fp16x2 kernels."""
     a = self._auto
     if a is None or a["chosen"] != 2 or a["pending"] > 0 or a["incomplete"] or "args" not in a:
       return
     h = self.range_health()
     a["watch"] = h
-    if h["worst_fraction"] > a["watch_fraction"]:
+    if h["worst_growth"] > a["watch_ratio"]:
       a["pending"] = a["frames"]     # the next forward also runs on a bf16x3 twin (rebuilt: _auto_calibrate)
       a["rearmed"] += 1
       a["deferred"] = 0
-      # (a comparison that keeps fp16x2 raises the bar: only a worse stream re-arms again)
-      a["watch_fraction"] = min(0.999, max(a["watch_fraction"], h["worst_fraction"] + 0.1))
+      a["rebase"] = True             # a comparison that keeps fp16x2 accepts the new maxima as the level to watch from
 
   def forward(self, frames, want_feats=True, want_pooled=False):
     """frames: [B,H,W,3] uint8/float32 BGR host array.  Returns fresh arrays."""
@@ -441,10 +444,10 @@ class _Engine(object):
                                      "tolerance": auto["tolerance"], "checks": list(auto["checks"]),
                                      "calls_skipped_with_tickets_outstanding": auto["deferred"],
                                      "incomplete": bool(auto["incomplete"]),
-                                     "watch": auto.get("watch"), "watch_fraction": auto.get("watch_fraction"),
+                                     "watch": auto.get("watch"), "watch_ratio": auto.get("watch_ratio"),
                                      "rearmed": auto.get("rearmed", 0)}
       d["range_guard"] = ("conv_split_family = \"auto\" (default): fp16x2 kernels checked against a bf16x3-only twin handle on the "
-                          "first forward(s), re-armed whenever the kernels' own range statistics (odt_range_health) pass watch_fraction" + ("; GAVE UP: every call so far had tickets outstanding" if auto["incomplete"] else ""))
+                          "first forward(s), re-armed whenever a tensor's recorded |max| has grown past watch_ratio times the accepted level (odt_range_health)" + ("; GAVE UP: every call so far had tickets outstanding" if auto["incomplete"] else ""))
     elif hasattr(self, "_family_requested"):
       d["range_guard"] = "off (explicit conv_split_family = %r / conv_arith)" % (self._family_requested,)
     return d
