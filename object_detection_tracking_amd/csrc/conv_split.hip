@@ -97,6 +97,7 @@ ConvPolicy conv_policy_default() {
   q.h2s_maxk = 0;         // fp16x2: reductions up to this K take the 128 x 128 two-per-CU tile (A/B knob; measured: no gain)
   q.h2_few_tiles = true;  // fp16x2: layers without enough 256-row tiles take 128 x 128 tiles instead of bf16x3 + split-K
   q.h2_n64 = true;        // fp16x2: the 64-wide layers too
+  q.h2k_fewrows = 1;  // fp16x2 kw-reuse kernel on 256 x 128 tiles without split-K where those fill the chip (round-6 A/B knob)
   q.h2k_splitk = true;    // fp16x2 kw-reuse kernel with split-K for the stride-1 KH x 3 layers of few rows (ODT_CONV_H2K_SPLITK=0: A/B)
   q.fill_div = 6;         // split-K layers are taken when tiles x ranges reach min_tiles3 / fill_div workgroups (b = 1: fc6 / fc7 leave the
                           // exact-f32 kernel: 139.4 -> 144.9 FPS same box, profiles/r04_b1_filldiv_ab.txt; ODT_CONV_SPLIT3_FILLDIV: A/B)
@@ -127,6 +128,7 @@ ConvPolicy conv_policy_from_env(ConvPolicy q) {
   v = q.h2_n64_bm512; geti(K_CONV_H2_N64_BM512, &v); q.h2_n64_bm512 = (int)v;
   v = q.h2_bm64; geti(K_CONV_H2_BM64, &v); q.h2_bm64 = (int)v;
   v = q.h2k_splitk; geti(K_CONV_H2K_SPLITK, &v); q.h2k_splitk = v != 0;
+  v = q.h2k_fewrows; geti(K_CONV_H2K_FEWROWS, &v); q.h2k_fewrows = (int)v;
   v = q.fill_div; geti(K_CONV_SPLIT3_FILLDIV, &v); q.fill_div = v < 1 ? 1 : (int)v;
   v = q.force_bm3; geti(K_CONV_SPLIT3_BM, &v); q.force_bm3 = (int)v;
   v = q.splitk_max; geti(K_CONV_SPLIT3_SPLITK, &v); q.splitk_max = v < 1 ? 1 : (v > 16 ? 16 : (int)v);
@@ -231,10 +233,22 @@ void conv_split_choose(ConvParams& p, const ConvPolicy& q) {
                    int k = (int)((q.min_tiles3 + t256 - 1) / t256);
                    if (k > q.splitk_max) k = q.splitk_max;
                    while (k > 1 && groups / k < 3) --k;
+                   // (round 6: the 256 x 128 kw-reuse tiles WITHOUT split-K where they alone fill the chip -- res5 conv2 at b = 8:
+                   // 64 x 4 = 256 tiles, one round, a third of the generic kernel's activation-side work -- instead of its 128 x 128
+                   // tiles: 0.503 -> 0.376 ms for the two layers, 320.3 -> 321.8 FPS same box, profiles/r06_res5_conv2_kwr_tiles_ab.txt;
+                   // ODT_CONV_H2K_FEWROWS=0: A/B)
+                   if (k <= 1 && q.h2k_fewrows && t256 >= q.min_tiles3) {
+                     p.wt_split_kind = 2; p.wt_split_bm = 256; p.wt_split_bn = 128; p.wt_split_kwr = 1; p.splitk = 1;
+                     return true;
+                   }
                    if (k <= 1 || t256 * k < q.min_tiles3 / 2) return false;
                    p.wt_split_kind = 2; p.wt_split_bm = 256; p.wt_split_bn = 128; p.wt_split_kwr = 1; p.splitk = k;
                    return true;
                  }()) {
+      } else if (b3 == 128 && n3 >= 256 && q.h2k_fewrows >= 2 && p.kh * p.kw == 1 && p.in2 == nullptr &&
+                 ((M + 255) / 256) * (cout_padded(p.Cout) / 128) >= q.min_tiles3) {
+        // (A/B, ODT_CONV_H2K_FEWROWS=2: the same for the dense 1x1 layers of few rows -- res5 conv1 -- on conv_h2_kernel<2, 4>)
+        p.wt_split_kind = 2; p.wt_split_bm = 256; p.wt_split_bn = 128; p.splitk = 1; p.wt_split_kwr = 0;
       } else if (b3 == 128 && n3 >= 128 && q.h2_few_tiles) {
         // too few 256-row tiles (res5, P5 at b=8; everything below res3 at b=1): 128 x 128 tiles on 4 waves -- without split-K
         // where they fill the chip (res5 conv2 0.690 -> 0.465 ms, conv1 0.338 -> 0.219, same file), else with the reduction

@@ -154,6 +154,7 @@ struct ConvPolicy {
   bool h2_few_tiles;    // fp16x2: 128 x 128 tiles for the layers without enough 256-row tiles
   bool h2_n64;          // fp16x2: also the 64-wide layers (128 x 64 tiles on 4 waves; the kw-reuse kernel's 256 x 64 tile)
   bool h2k_splitk;      // fp16x2: kw-reuse kernel + split-K over (slice, kh) groups for the KH x 3 layers of few rows
+  int h2k_fewrows;      // fp16x2: 1 = kw-reuse kernel on 256 x 128 tiles without split-K where those alone fill the chip; 2 (A/B): the dense 1x1 layers too
   int fill_div;         // a split-K layer is taken when tiles x ranges >= min_tiles3 / fill_div (6)
   int h2_bm64;          // fp16x2: 64 x 128 two-wave tiles for the layers of few rows: 0 off | 1 K <= 1024, no split-K | 2 + longer K cut in two | 3 = 1 on 64 x 64 tiles
   int h2_n64_bm512;     // fp16x2 kw-reuse kernel on 64-wide layers: 512 x 64 tiles -- 0 off | 1 where they fill the chip | 2 wherever valid
