@@ -13,7 +13,7 @@ namespace odt {
   X(CONV_SPLIT) X(CONV_SPLIT_PIPE) X(CONV_SPLIT_MINTILES) X(CONV_SPLIT3_MINTILES) X(CONV_SPLIT_MINK) X(CONV_SPLIT_MINBN)          \
   X(CONV_H2S_MAXK) X(CONV_H2_FEW_TILES) X(CONV_H2_N64) X(CONV_H2_N64_BM512) X(CONV_H2_BM64) X(CONV_H2K_SPLITK) X(CONV_H2K_FEWROWS) X(CONV_H2_BK64)    \
   X(CONV_H2_ROT) X(CONV_SPLIT3_FILLDIV) X(CONV_SPLIT3_BM) X(CONV_SPLIT3_SPLITK) X(CONV_SPLIT3_KWR) X(CONV_SPLIT3_KWR_N64)         \
-  X(CONV_SPLIT3_FORCE_SPLITK) X(CONV_SPLIT_SRC2) X(CONV_SPLIT_RES2) X(SPLIT_REDUCE_BLOCKS) X(CONV_NT) X(AMAX_PER_WAVE)            \
+  X(CONV_SPLIT3_FORCE_SPLITK) X(CONV_SPLIT_SRC2) X(CONV_SPLIT_RES2) X(SPLIT_REDUCE_BLOCKS) X(CONV_NT) X(AMAX_PER_WAVE) X(ROI_AMAX)            \
   X(CONV_CHUNK_BYTES) X(CONV_TILE) X(CONV_DEBUG) X(CONV_SMALLK) X(CONV_STAGES) X(CONV_FINE) X(CONV_TRACE)                         \
   X(FUSE_SHORTCUT) X(FUSE_RPN_HEAD) X(FUSE_BOTTLENECK) X(FUSE_ROT) X(FUSE_STEM) X(STEM_GRID) X(TAIL_OVERLAP)                      \
   X(SIDE_STREAM_PRIORITY) X(COSINE_STREAM_PRIORITY) X(TRACKER_TIMING)                                                             \

@@ -350,6 +350,9 @@ struct RoiAlignParams {
   int out_size;          // 0 / 7: box head + features; 14: mask head (models.py:935-936)
   int pack_rows;         // with count: 1 = output rows packed over the valid rows of all images (final features, masks);
                          // 0 = row r stays row r, rows past count[b] untouched (box head: its consumers index b * per_image + j)
+  unsigned* amax;        // optional range slot of out_nhwc (round 6: fc6 reads the RoI features on the fp16x2 kernels, which scale by the
+                         // tensor's |max|).  With it the rows past count[b] are written as zeros instead of left stale: the recorded
+                         // maximum must cover every row the consumer's GEMM reads
 };
 int launch_roi_align(const RoiAlignParams& p, hipStream_t stream);
 

@@ -225,6 +225,17 @@ int attach_split_weights(odt_model* m) {
       m->pre_amax = m->amax_dev + (size_t)(m->amax_used[0]++) * kAmaxWays;
       continue;
     }
+    if (op.kind == OP_ROI_HEAD && pol.family == 2 && m->roi_head.out_nhwc != nullptr && !env_knob_off(K_ROI_AMAX)) {
+      // the box head's RoI features: ROIAlign records their range, so that fc6 (K = 12544, a third of the box head's time on the
+      // bf16x3 kernels) can take the fp16x2 kernels like every other layer (round 6; ODT_ROI_AMAX=0: A/B)
+      const int g = tail ? 1 : 0;
+      ODT_CHECK(m->amax_used[g] < odt_model::kAmaxSlots, "too many conv outputs for the range slots");
+      const int slot = (tail ? odt_model::kAmaxSlots : 0) + m->amax_used[g]++;
+      slot_of[m->roi_head.out_nhwc] = slot;
+      m->roi_head.amax = m->amax_dev + (size_t)slot * kAmaxWays;
+      m->range_slot_name[slot] = "roi_feat";
+      continue;
+    }
     if (op.kind == OP_POOL || op.kind == OP_SUB2) {
       auto it = slot_of.find(op.in.d);
       if (it != slot_of.end()) slot_of[op.out.d] = it->second; else slot_of.erase(op.out.d);

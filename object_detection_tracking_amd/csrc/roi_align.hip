@@ -48,7 +48,13 @@ __global__ void __launch_bounds__(256) roi_align_kernel(RoiAlignParams p, int B)
     b = r / p.per_image;
     const int j = r - b * p.per_image;
     if (p.count != nullptr) {
-      if (j >= p.count[b]) return;
+      if (j >= p.count[b]) {
+        if (p.amax != nullptr && p.out_nhwc != nullptr && !p.pack_rows) {      // (see RoiAlignParams::amax)
+          const int nchz = p.C - cb < kRoiCB ? p.C - cb : kRoiCB;
+          for (int i = threadIdx.x; i < OO * nchz; i += 256) p.out_nhwc[((size_t)r * OO + i / nchz) * p.C + cb + i % nchz] = 0.f;
+        }
+        return;
+      }
       if (p.pack_rows) {           // outputs packed over the valid rows (reference [M,...]: fpn_box_feat, masks)
         int base = 0;
         for (int q = 0; q < b; ++q) base += p.count[q];
@@ -91,6 +97,7 @@ __global__ void __launch_bounds__(256) roi_align_kernel(RoiAlignParams p, int B)
   // readable: feature maps are allocated with ldc >= C rounded up to 4); lanes past the block's channels idle
   const int nq = (nch + 3) >> 2;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  float vmax = 0.f;                                      // |max| of what goes to out_nhwc (p.amax)
   if (cq < nq) {
     for (int q = threadIdx.x >> 4; q < OO; q += 16) {
       const int oy = q / OUT, ox = q - oy * OUT;
@@ -132,6 +139,7 @@ __global__ void __launch_bounds__(256) roi_align_kernel(RoiAlignParams p, int B)
       // 2x2 average pool (nn.py:1332): ((v00 + v01) + v10) + v11, * 0.25
       const f32x4 o = (((v[0][0] + v[0][1]) + v[1][0]) + v[1][1]) * 0.25f;
       if (p.out_nhwc) {
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));     // (pad channels read as stored: finite)
         float* dst = p.out_nhwc + (((size_t)out_row * OUT + oy) * OUT + ox) * p.C + c;
         if (c + 4 <= p.C && (p.C & 3) == 0) {
           *reinterpret_cast<f32x4*>(dst) = o;
@@ -145,6 +153,15 @@ __global__ void __launch_bounds__(256) roi_align_kernel(RoiAlignParams p, int B)
 #pragma unroll
         for (int e = 0; e < 4; ++e) tile[(cq * 4 + e) * LDP + q] = o[e];
       }
+    }
+  }
+  if (p.amax != nullptr) {
+    // one conditional atomic per wave (f32 bit patterns of non-negative values order like unsigned integers)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
+    if ((threadIdx.x & 63) == 0) {
+      const unsigned bits = __float_as_uint(vmax);
+      if (bits > __atomic_load_n(p.amax, __ATOMIC_RELAXED)) atomicMax(p.amax, bits);
     }
   }
   if (!stage) return;
