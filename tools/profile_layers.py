@@ -77,7 +77,7 @@ def effdet(a):
     g[0] += 1; g[1] += fl; g[2] += ms / a.steps
   print("%-60s %5s %9s %7s %7s %9s %8s %9s" % ("first layer of shape", "n", "M", "N", "K", "ms/step", "TFLOP/s", "us/launch"))
   srt = sorted(groups.items(), key=lambda kv: -kv[1][2])
-  for mnk, (n, fl, ms, name) in (srt[:a.top] if a.top else srt):
+  for (mnk, _c3, _hd), (n, fl, ms, name) in (srt[:a.top] if a.top else srt):
     tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0
     print("%-60s %5d %9d %7d %7d %9.3f %8.1f %9.1f" % (name[:60], n, mnk[0], mnk[1], mnk[2], ms, tf, ms * 1e3 / n))
   cms = tot["conv_ms"] / a.steps
