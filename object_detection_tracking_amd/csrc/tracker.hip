@@ -197,7 +197,9 @@ int CosineCtx::run(int dev, const float* const* gal_rows, int G, const int* seg,
     ODT_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
     knobs_reload();
     const bool flat = env_knob_off(K_COSINE_STREAM_PRIORITY);   // A/B knob
-    if (flat) ODT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (env_knob(K_COSINE_STREAM_PRIORITY).set && env_knob(K_COSINE_STREAM_PRIORITY).i < 0)      // A/B: the LOWEST priority (its own queues too)
+      ODT_HIP(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio_least));
+    else if (flat) ODT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     else ODT_HIP(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio_greatest));
     ODT_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
   }
