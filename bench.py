@@ -22,6 +22,12 @@ import os
 import sys
 import time
 
+# Hardware queues per stream priority (ROCclr reads it when libamdhip64 loads, i.e. before `import torch`): a handle has one
+# compute stream and three side streams, the trackers one each; with the default of 4 a second handle's streams share
+# hardware queues with the first one's and wait behind its event barriers (two streams per GPU: 309 -> 318 FPS,
+# profiles/r06_hw_queues_and_cosine_priority_ab.txt).  An explicit setting in the environment wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

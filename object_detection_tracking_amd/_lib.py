@@ -11,6 +11,10 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# (effective when this package is imported before anything has loaded libamdhip64 -- torch does: see INTEGRATION.md section 3,
+# "several streams per GPU": eight hardware queues per stream priority instead of four; an explicit setting wins)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
