@@ -1,6 +1,7 @@
 // Runtime of a handle behind the C ABI (include/odt.h): handle life cycle, weight ingest, the forward (op list on the
 // handle's streams, tail overlap), pipelined ingest (odt_submit_ex / odt_collect), outputs, taps, profiling, describe.
 #include <cmath>
+#include <thread>
 
 #include "odt_model.hpp"
 
@@ -129,6 +130,27 @@ static int run_ops(odt_model* m, const void* src, int dtype, hipStream_t st, siz
 
 static size_t input_bytes(const odt_model* m, int dtype) {
   return (size_t)m->cfg.batch * m->src_h * m->src_w * 3 * (dtype == ODT_DTYPE_U8 ? 1 : 4);
+}
+
+// pageable -> pinned staging copy of a batch of frames (odt_submit_ex): 50 MB at 8 x 1080p, on up to four threads -- the call's
+// host time 1.93 -> 1.09 ms on the evidence box's EPYC (profiles/r06_submit_host_time.txt): host time the tracking loop has
+// other uses for (detect + track through Python objects runs within 10 % of being host-bound).  Small inputs stay on the
+// calling thread (a thread costs ~30 us to start).
+static void staging_copy(void* dst, const void* src, size_t n) {
+  constexpr size_t kPerThread = (size_t)8 << 20;
+  const unsigned hw = std::thread::hardware_concurrency();
+  size_t nt = n / kPerThread;
+  if (nt > 4) nt = 4;
+  if (hw != 0 && nt > hw) nt = hw;
+  if (nt <= 1) { std::memcpy(dst, src, n); return; }
+  const size_t chunk = ((n / nt) + 4095) & ~(size_t)4095;
+  std::vector<std::thread> th;
+  for (size_t i = 1; i < nt; ++i) {
+    const size_t off = i * chunk, len = off >= n ? 0 : (i + 1 == nt ? n - off : (off + chunk > n ? n - off : chunk));
+    if (len) th.emplace_back([=] { std::memcpy(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, len); });
+  }
+  std::memcpy(dst, src, chunk < n ? chunk : n);
+  for (auto& t : th) t.join();
 }
 
 // the small outputs of a slot's forward, copied behind it on the same stream (odt_submit_ex without ODT_WANT_FEATS)
@@ -498,10 +520,10 @@ int odt_submit_ex(odt_handle h, const void* frames, int dtype, int want, int* ti
             "odt_submit: frames == NULL needs odt_ingest_buffer() for this ticket and dtype first");
   sl.ingest_armed = -1;
   if (slot_prepare(h, sl, n)) return 1;
-  // (round 6 measured the staging frame by frame -- eight memcpy + H2D pairs instead of one: the first frame is on PCIe 4 ms
+  // (round 6 measured the staging frame by frame -- eight memcpy + H2D pairs instead of one: the first frame is on PCIe
   // earlier, and the eight copies get in the way of the tracker's small H2D / D2H copies on the copy engines: cosine calls
   // 150 -> 500 us next to them, detect + track 284 -> 245 FPS, pipelined 311 -> 302: profiles/r06_frame_staging_ab.txt.  One copy.)
-  if (frames != nullptr) std::memcpy(sl.pin_in, frames, n);
+  if (frames != nullptr) staging_copy(sl.pin_in, frames, n);
   ODT_HIP(hipMemcpyAsync(sl.dev_in, sl.pin_in, n, hipMemcpyHostToDevice, h->copy_in));
   ODT_HIP(hipEventRecord(sl.h2d_done, h->copy_in));
   hipStream_t st = h->own_stream;

@@ -277,3 +277,23 @@ def test_back_to_back_forwards_with_split_k_in_trunk_and_tail(hip_lib):
       assert np.array_equal(g[5], w[5])
   finally:
     m.close()
+
+
+@pytest.mark.gpu
+def test_submit_large_batch_staged_by_several_threads(hip_lib):
+  """odt_submit_ex copies a batch of pageable frames into the slot's pinned buffer with up to four threads (round 6: 50 MB of
+  uint8 at 8 x 1080p; the call's host time 1.93 -> 1.09 ms).  2 x 1080p float32 frames = 50 MB: the chunked copy
+  must be the blocking forward's input bit for bit (odd sizes: the last chunk is shorter)."""
+  B, H, W = 2, 1080, 1920
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1], im_batch_size=B, rpn_test_post_nms_topk=32, max_size=1920, short_edge_size=1080)
+  m = models.get_model(cfg, 0, weights=weights_for(cfg), lib=hip_lib, is_multi=True)
+  try:
+    e = m.engine(B, H, W)
+    batches = [synthetic_frames(B, H, W, seed=s).astype(np.float32) for s in (11, 12)]
+    want = [e.forward(b, want_feats=False, want_pooled=True) for b in batches]
+    got = list(e.forward_stream(batches, want_feats=False, want_pooled=True))
+    for g, w in zip(got, want):
+      for a, b in zip(g, w):
+        assert (a is None and b is None) or np.array_equal(a, b)
+  finally:
+    m.close()
