@@ -525,13 +525,25 @@ def arithmetic_of(desc):
 _LIVE_TRAFFIC = {}
 
 
-def live_pmc_traffic(timeout_s=150):
+def sum_counter_csv(path, counter, pred):
+  """(sum of `counter` over the dispatches whose kernel name satisfies pred, number of such dispatches) of a rocprofv3
+  `--pmc ... --output-format csv` counter_collection file."""
+  import csv
+  v, disp = 0.0, set()
+  with open(path) as fh:
+    for r in csv.DictReader(fh):
+      if r["Counter_Name"] == counter and pred(r["Kernel_Name"]):
+        v += float(r["Counter_Value"]); disp.add(r["Dispatch_Id"])
+  return v, len(disp)
+
+
+def live_pmc_traffic(timeout_s=100):
   """HBM bytes per split-conv launch MEASURED BY THIS RUN (round 6): counters cannot be collected inside the timed region, so the
   bench starts itself twice as a child under `rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE` (separate passes, as
   MI355X_MICROARCH.md prescribes; two forwards each, no extras) and reads the counter CSVs: (2 x FETCH_SIZE + WRITE_SIZE) x 1024
   bytes over the split-conv launches (FETCH_SIZE doubled: the guide's gfx950 correction).  Fills _LIVE_TRAFFIC; any failure --
   no rocprofv3, a timeout -- leaves it empty and pmc_traffic() falls back to the committed summary of the builder's run."""
-  import csv, glob, shutil, subprocess, tempfile
+  import glob, shutil, subprocess, tempfile
   exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
   if not os.path.exists(exe):
     return
@@ -549,13 +561,9 @@ def live_pmc_traffic(timeout_s=150):
       env = dict(os.environ); env.setdefault("TMPDIR", "/tmp")
       subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
       files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-      v, disp = 0.0, set()
-      with open(files[0]) as fh:
-        for r in csv.DictReader(fh):
-          if r["Counter_Name"] == ctr and is_split(r["Kernel_Name"]):
-            v += float(r["Counter_Value"]); disp.add(r["Dispatch_Id"])
+      v, n = sum_counter_csv(files[0], ctr, is_split)
       tot[ctr] = v
-      launches = len(disp) if launches is None else min(launches, len(disp))
+      launches = n if launches is None else min(launches, n)
     except Exception as ex:
       _LIVE_TRAFFIC["error"] = repr(ex)[:200]
       return

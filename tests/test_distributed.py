@@ -132,3 +132,20 @@ def test_rank_cpu_affinity_plan(tmp_path):
   assert info["bound"] is False and os.sched_getaffinity(0) == before
   info = P.bind_rank_to_gpu_numa(5, 8, sysfs=str(tmp_path), bdfs=bdfs, apply=False)
   assert info["numa_node"] == 1 and info["bound"] is False and info["pci"] == bdfs[5]
+
+
+def test_bench_counter_csv_reader(tmp_path):
+  """bench.py's roofline.traffic comes from its own rocprofv3 --pmc child passes (round 6): the CSV reader sums one counter over
+  the fp16x2 conv dispatches only (the guard's bring-up forward on the bf16x3 twin must not count) and counts dispatches once."""
+  import bench
+  p = tmp_path / "pmc_counter_collection.csv"
+  rows = [("1", "void odt::(anonymous namespace)::conv_h2k_kernel<4, false, true, 2>(odt::ConvParams const*)", "FETCH_SIZE", "1000"),
+          ("1", "void odt::(anonymous namespace)::conv_h2k_kernel<4, false, true, 2>(odt::ConvParams const*)", "FETCH_SIZE", "24"),
+          ("2", "void odt::(anonymous namespace)::conv_split3_kernel<4, 2, 4, false>(odt::ConvParams const*)", "FETCH_SIZE", "7777"),
+          ("3", "void odt::(anonymous namespace)::conv_stem_kernel(odt::ConvParams const*)", "FETCH_SIZE", "500"),
+          ("4", "odt::(anonymous namespace)::split_weights_h2_kernel(float const*, int)", "FETCH_SIZE", "9"),
+          ("5", "void odt::(anonymous namespace)::conv_h2_kernel<4, 4, false, 2>(odt::ConvParams const*)", "WRITE_SIZE", "3")]
+  p.write_text("Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n" + "\n".join('%s,"%s",%s,%s' % r for r in rows) + "\n")
+  is_h2 = lambda k: ("conv_h2" in k or "conv_stem" in k) and "kernel" in k and "split_weights" not in k
+  assert bench.sum_counter_csv(str(p), "FETCH_SIZE", is_h2) == (1524.0, 2)
+  assert bench.sum_counter_csv(str(p), "WRITE_SIZE", is_h2) == (3.0, 1)
