@@ -382,6 +382,11 @@ int odt_forward(odt_handle h, const void* frames, int dtype, int on_device, void
   return odt_read_outputs(h, out);
 }
 
+static hipError_t d2h_on(hipStream_t st, void* dst, const void* src, size_t n, hipMemcpyKind kind) {
+  const hipError_t e = hipMemcpyAsync(dst, src, n, kind, st);
+  return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+
 int odt_read_outputs(odt_handle h, odt_outputs* out) {
   ODT_CHECK(h != nullptr && out != nullptr, "null argument");
   ODT_CHECK(h->finalized && h->forwards_enqueued > 0, "odt_read_outputs: no forward has been enqueued on this handle");
@@ -389,6 +394,9 @@ int odt_read_outputs(odt_handle h, odt_outputs* out) {
             "odt_read_outputs: the backbone-only graph has no detection outputs (odt_tap)");
   ODT_HIP(hipSetDevice(h->device));
   hipStream_t st = h->done_stream;     // (the tail may have run on the handle's side stream)
+  // (round 6) every copy below is ordered on THIS handle's stream and waited for there: a plain hipMemcpy goes through the
+  // null stream, which waits for every other blocking stream of the device -- i.e. for the forwards other handles have in
+  // flight (frames in flight on replica handles, several streams per GPU: a collect serialised them all)
   if (h->cfg.graph == ODT_GRAPH_EFFNET) {
     // EfficientDet outputs (efficientdet_wrapper.py:28-35): boxes [R,4] x1y1x2y2 (scaled), probs,
     // labels 1..90, pooled = fpn_box_feat [R, fpn_num_filters]
@@ -396,36 +404,36 @@ int odt_read_outputs(odt_handle h, odt_outputs* out) {
     const EffPostParams& ep = h->eff_post;
     const int B = ep.B, per = ep.max_out, F = h->eff_filters;
     std::vector<int> valid(B);
-    ODT_HIP(hipMemcpy(valid.data(), ep.out_valid, B * sizeof(int), hipMemcpyDeviceToHost));
+    ODT_HIP(d2h_on(st, valid.data(), ep.out_valid, B * sizeof(int), hipMemcpyDeviceToHost));
     int total = 0;
     for (int b = 0; b < B; ++b) total += valid[b];
     if (out->valid) std::memcpy(out->valid, valid.data(), B * sizeof(int));
-    if (out->boxes) ODT_HIP(hipMemcpy(out->boxes, ep.out_boxes, (size_t)B * per * 4 * sizeof(float), hipMemcpyDeviceToHost));
-    if (out->probs) ODT_HIP(hipMemcpy(out->probs, ep.out_scores, (size_t)B * per * sizeof(float), hipMemcpyDeviceToHost));
-    if (out->labels) ODT_HIP(hipMemcpy(out->labels, ep.out_labels, (size_t)B * per * sizeof(int), hipMemcpyDeviceToHost));
+    if (out->boxes) ODT_HIP(d2h_on(st, out->boxes, ep.out_boxes, (size_t)B * per * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    if (out->probs) ODT_HIP(d2h_on(st, out->probs, ep.out_scores, (size_t)B * per * sizeof(float), hipMemcpyDeviceToHost));
+    if (out->labels) ODT_HIP(d2h_on(st, out->labels, ep.out_labels, (size_t)B * per * sizeof(int), hipMemcpyDeviceToHost));
     ODT_CHECK(out->feats == nullptr && out->masks == nullptr, "odt_forward: EfficientDet returns pooled [R, filters] features only");
     if (out->pooled && total > 0)
-      ODT_HIP(hipMemcpy(out->pooled, h->final_pooled, (size_t)total * F * sizeof(float), hipMemcpyDeviceToHost));
+      ODT_HIP(d2h_on(st, out->pooled, h->final_pooled, (size_t)total * F * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
   }
   ODT_HIP(hipStreamSynchronize(st));
   const odt_config& cfg = h->cfg;
   const int B = cfg.batch, per = cfg.result_per_im, FC = cfg.fpn_channels;
   std::vector<int> valid(B);
-  ODT_HIP(hipMemcpy(valid.data(), h->det.out_valid, B * sizeof(int), hipMemcpyDeviceToHost));
+  ODT_HIP(d2h_on(st, valid.data(), h->det.out_valid, B * sizeof(int), hipMemcpyDeviceToHost));
   int total = 0;
   for (int b = 0; b < B; ++b) total += valid[b];
   if (out->valid) std::memcpy(out->valid, valid.data(), B * sizeof(int));
-  if (out->boxes) ODT_HIP(hipMemcpy(out->boxes, h->det.out_boxes, (size_t)B * per * 4 * sizeof(float), hipMemcpyDeviceToHost));
-  if (out->probs) ODT_HIP(hipMemcpy(out->probs, h->det.out_probs, (size_t)B * per * sizeof(float), hipMemcpyDeviceToHost));
-  if (out->labels) ODT_HIP(hipMemcpy(out->labels, h->det.out_labels, (size_t)B * per * sizeof(int), hipMemcpyDeviceToHost));
+  if (out->boxes) ODT_HIP(d2h_on(st, out->boxes, h->det.out_boxes, (size_t)B * per * 4 * sizeof(float), hipMemcpyDeviceToHost));
+  if (out->probs) ODT_HIP(d2h_on(st, out->probs, h->det.out_probs, (size_t)B * per * sizeof(float), hipMemcpyDeviceToHost));
+  if (out->labels) ODT_HIP(d2h_on(st, out->labels, h->det.out_labels, (size_t)B * per * sizeof(int), hipMemcpyDeviceToHost));
   if (out->feats && total > 0)
-    ODT_HIP(hipMemcpy(out->feats, h->final_feat, (size_t)total * FC * 49 * sizeof(float), hipMemcpyDeviceToHost));
+    ODT_HIP(d2h_on(st, out->feats, h->final_feat, (size_t)total * FC * 49 * sizeof(float), hipMemcpyDeviceToHost));
   if (out->pooled && total > 0)
-    ODT_HIP(hipMemcpy(out->pooled, h->final_pooled, (size_t)total * FC * sizeof(float), hipMemcpyDeviceToHost));
+    ODT_HIP(d2h_on(st, out->pooled, h->final_pooled, (size_t)total * FC * sizeof(float), hipMemcpyDeviceToHost));
   if (out->masks) {
     ODT_CHECK(h->final_masks != nullptr, "odt_forward: masks requested but the model was built without add_mask");
-    ODT_HIP(hipMemcpy(out->masks, h->final_masks, (size_t)B * per * 784 * sizeof(float), hipMemcpyDeviceToHost));
+    ODT_HIP(d2h_on(st, out->masks, h->final_masks, (size_t)B * per * 784 * sizeof(float), hipMemcpyDeviceToHost));
   }
   return 0;
 }

@@ -90,8 +90,11 @@ class EfficientDet(object):
     self.final_probs = TensorHandle(self, "final_probs")
     self.fpn_box_feat = TensorHandle(self, "fpn_box_feat")
 
-  def engine(self, src_hw=None):
-    key = tuple(src_hw) if src_hw is not None else (self.height, self.width)
+  def engine(self, src_hw=None, replica=0):
+    """The plan for frames of this size; ``replica`` > 0: a further handle of the same plan (own weights copy, arena and stream):
+    ``predict_stream`` keeps consecutive frames in flight on them."""
+    size = tuple(src_hw) if src_hw is not None else (self.height, self.width)
+    key = size if not replica else size + ("replica", int(replica))
     if key not in self._engines:
       w = dict(self.weights)
       w["effdet/anchors"] = generate_anchors(self.height, self.width, self.cfg["anchor_scale"])
@@ -102,8 +105,8 @@ class EfficientDet(object):
           score_thresh=float(getattr(self.config, "result_score_thres", 0.0)),
           per_im=int(getattr(self.config, "result_per_im", 100)),
           keep_taps=bool(getattr(self.config, "keep_taps", False)))
-      if key != (self.height, self.width):
-        e.set_source_size(*key)
+      if size != (self.height, self.width):
+        e.set_source_size(*size)
       self._engines[key] = e
     return self._engines[key]
 
@@ -133,26 +136,47 @@ class EfficientDet(object):
     r = int(valid[0])
     return boxes[0, :r].copy(), labels[0, :r].copy(), probs[0, :r].copy(), pooled[:r].copy()
 
-  def predict_async(self, frame):
-    """Enqueue the forward of one frame and return at once (odt_forward_async on the handle's stream): the host is free
-    -- e.g. to run the tracker on the PREVIOUS frame's detections (the reference's queuer loop does the detector call
-    and the tracker update back to back, obj_detect_tracking_multi_queuer_tmot.py:536-583) -- until predict_collect()."""
+  def _enqueue(self, frame, replica=0):
     import ctypes as C
     from .._lib import ODT_DTYPE_F32, ODT_DTYPE_U8
     frame = np.asarray(frame)
-    e = self.engine(frame.shape[:2])
+    e = self.engine(frame.shape[:2], replica=replica)
     fr = np.ascontiguousarray(frame[None])
     dt = ODT_DTYPE_U8 if fr.dtype == np.uint8 else ODT_DTYPE_F32
     if dt == ODT_DTYPE_F32:
       fr = np.ascontiguousarray(fr, np.float32)
     self.lib.check(self.lib.dll.odt_forward_async(e.h, fr.ctypes.data_as(C.c_void_p), dt, 0, None))
-    self._inflight = (e, fr)
+    return e, fr                      # (the frame array must outlive the asynchronous H2D copy)
+
+  def predict_async(self, frame):
+    """Enqueue the forward of one frame and return at once (odt_forward_async on the handle's stream): the host is free
+    -- e.g. to run the tracker on the PREVIOUS frame's detections (the reference's queuer loop does the detector call
+    and the tracker update back to back, obj_detect_tracking_multi_queuer_tmot.py:536-583) -- until predict_collect()."""
+    self._inflight = self._enqueue(frame)
+
+  def predict_stream(self, frames, in_flight=3):
+    """A video through the detector with ``in_flight`` consecutive frames on the GPU at once (round 6): frame t runs on handle
+    t mod in_flight, each on its own stream; results come back in frame order, as predict() would return them.  One D7 frame is
+    ~600 dependent launches of ~20 us each, most of them far too small for the chip; frames are independent: 73 -> 97 -> 106
+    frames/s with one / two / three in flight (profiles/r06_d7_frames_in_flight.txt)."""
+    import collections
+    n = max(1, int(in_flight))
+    pending = collections.deque()
+    for k, frame in enumerate(frames):
+      if len(pending) == n:
+        yield self._collect(pending.popleft()[0])
+      pending.append(self._enqueue(frame, replica=k % n))
+    while pending:
+      yield self._collect(pending.popleft()[0])
 
   def predict_collect(self):
     """Wait for the forward of predict_async() and return predict()'s tuple (odt_read_outputs)."""
-    import ctypes as C
     e, _ = self._inflight
     self._inflight = None
+    return self._collect(e)
+
+  def _collect(self, e):
+    import ctypes as C
     per = int(getattr(self.config, "result_per_im", 100))
     F_ = self.cfg["fpn_num_filters"]
     boxes = np.zeros((1, per, 4), np.float32); probs = np.zeros((1, per), np.float32)

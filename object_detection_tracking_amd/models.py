@@ -559,10 +559,14 @@ class _DetectorBase(object):
   # static plans kept per model: a plan owns its activations, a device copy of the weights and pinned staging
   # (tens of GB at 8 x 1080p), so frames of ever-changing sizes (the reference's image-list drivers) must not
   # accumulate them: least-recently-used plans beyond this many are closed
-  max_engines = 4
+  max_engines = 6
 
-  def engine(self, batch, height, width, src_hw=None):
+  def engine(self, batch, height, width, src_hw=None, replica=0):
+    """The static plan for frames of this size.  ``replica`` > 0: a further handle of the same plan (own weights copy, arena and
+    streams) -- ``predict_stream`` keeps consecutive frames in flight on them."""
     key = (batch, height, width) if src_hw is None else (batch, height, width) + tuple(src_hw)
+    if replica:
+      key = key + ("replica", int(replica))
     e = self._engines.pop(key, None)
     if e is None:
       # evict least-recently-used plans beyond the cap -- but never one with tickets in flight (its pinned results
@@ -620,6 +624,31 @@ class Mask_RCNN_FPN(_DetectorBase):
     self.last_masks = e._masks[:r].copy() if e.add_mask else None    # final_masks [R,28,28]
     return (boxes[0, :r].copy(), labels[0, :r].astype(np.int64), probs[0, :r].copy(),
             pl if pooled else feats)
+
+  def predict_stream(self, frames, in_flight=2, pooled=False):
+    """Frame-by-frame detection of a video with ``in_flight`` consecutive frames on the GPU at once (round 6): frame t runs on
+    handle t mod in_flight, each handle on its own streams, results come back in frame order.  A single 1080p frame leaves most of
+    the chip idle most of the time (each of its ~130 launches is latency-bound): two frames in flight give 185 -> 224 frames/s on
+    `Mask_RCNN_FPN` (profiles/r06_b1_frames_in_flight.txt); the reference's loop (obj_detect_tracking.py:597-635) sees the same
+    per-frame results, one frame later.  Yields what ``predict`` returns."""
+    import collections
+    n = max(1, int(in_flight))
+    pending = collections.deque()
+
+    def finish(item):
+      e, t = item
+      boxes, labels, probs, valid, feats, pl = e.collect(t)
+      r = int(valid[0])
+      return (boxes[0, :r].copy(), labels[0, :r].astype(np.int64), probs[0, :r].copy(), pl if pooled else feats)
+
+    for k, img in enumerate(frames):
+      img = np.asarray(img)
+      if len(pending) == n:
+        yield finish(pending.popleft())
+      e = self.engine(1, img.shape[0], img.shape[1], replica=k % n)
+      pending.append((e, e.submit(img[None], want_feats=not pooled, want_pooled=pooled)))
+    while pending:
+      yield finish(pending.popleft())
 
   def predict_raw(self, frame, pooled=False):
     """Decoder-sized frame [H0,W0,3] (uint8 or float32 BGR): the reference's

@@ -546,3 +546,25 @@ def test_product_default_engine_on_the_drop_in_and_ingest_paths(hip_lib):
     else:
       assert (a is None and b is None) or np.array_equal(a, b)
   same(out[0], out["auto"])
+
+
+def test_predict_stream_keeps_frames_in_flight_on_replica_handles(backend):
+  """models.predict_stream (round 6): consecutive frames on replica handles (frame t on handle t mod in_flight), results in frame
+  order and equal to predict() frame by frame; the replicas are separate handles of the same plan."""
+  name, lib = backend
+  cfg = small_config(resnet_num_block=[1, 1, 1, 1], rpn_test_post_nms_topk=32)
+  m = models.get_model(cfg, 0, weights=weights_for(cfg), lib=lib)
+  try:
+    hw = (64, 96) if name == "emu" else (96, 128)
+    frames = [synthetic_frames(1, *hw, seed=30 + i)[0] for i in range(5)]
+    want = [m.predict(f, pooled=True) for f in frames]
+    for n in (2, 3):
+      got = list(m.predict_stream(frames, in_flight=n, pooled=True))
+      assert len(got) == len(frames)
+      for g, w in zip(got, want):
+        for a, b in zip(g, w):
+          assert np.array_equal(a, b)
+    e0, e1 = m.engine(1, *hw), m.engine(1, *hw, replica=1)
+    assert e0 is not e1 and e0.h != e1.h and m.engine(1, *hw, replica=1) is e1
+  finally:
+    m.close()

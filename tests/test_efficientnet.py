@@ -407,3 +407,28 @@ def test_efficientdet_levels_merged_into_one_launch(backend, monkeypatch):
   from common import match_detections
   miss, extra = match_detections(res["1"][0][0], res["1"][0][1], res["1"][0][2], res["0"][0][0], res["0"][0][1], res["0"][0][2], 5e-2, 5e-5)
   assert miss + extra <= 2, (miss, extra)
+
+
+def test_efficientdet_predict_stream_frames_in_flight(backend):
+  """EfficientDet.predict_stream (round 6): consecutive frames on replica handles, results in frame order and equal to predict()
+  frame by frame."""
+  name, lib = backend
+  from object_detection_tracking_amd import models
+  from object_detection_tracking_amd.config import make_config
+  from object_detection_tracking_amd.weights import synthetic_frames
+  model = "efficientdet-d0"
+  S = 128 if name == "emu" else 256
+  cfg = make_config(is_efficientdet=True, efficientdet_modelname=model, efficientdet_max_detection_topk=200, short_edge_size=S, max_size=S)
+  cfg.max_size = S
+  m = models.get_model(cfg, 0, weights=arch.synthetic_det_weights(model, 0, gain=arch.bench_gain(model)), lib=lib)
+  try:
+    frames = [synthetic_frames(1, S, S, seed=40 + i)[0] for i in range(4)]
+    want = [m.predict(f) for f in frames]
+    got = list(m.predict_stream(frames, in_flight=3))
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+      for a, b in zip(g, w):
+        assert np.array_equal(a, b)
+    assert m.engine((S, S), replica=1) is not m.engine((S, S))
+  finally:
+    m.close()

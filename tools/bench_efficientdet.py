@@ -46,6 +46,38 @@ def measure(model="efficientdet-d7", size=0, frame="", steps=20, warmup=3, cpu_b
                   "what": "outputs left in HBM by the last forward of the timed loop (odt_read_outputs) == blocking odt_forward of "
                           "the same frame from host memory, all four output arrays bit for bit; detections > 0"}
   verified = all(equal.values()) and len(got[0]) > 0 and bool(np.isfinite(got[0]).all())
+  # the same video with K consecutive frames in flight (round 6: frame t on handle t mod K, one stream each -- what
+  # EfficientDet.predict_stream does; one D7 frame is ~600 dependent launches, most of them far too small for the chip, and
+  # frames are independent): device-resident like `value`, every handle's last outputs checked against the blocking forward
+  in_flight = {}
+  try:
+    engs = [e]
+    for K in (2, 3):
+      while len(engs) < K:
+        ek = m.engine((fh, fw), replica=len(engs))
+        ek.lib.check(ek.lib.dll.odt_forward_async(ek.h, dev.data_ptr(), ODT_DTYPE_U8, 1, None)); ek.synchronize()
+        engs.append(ek)
+      n = 3 * steps
+      for k in range(2 * K + n):
+        if k == 2 * K:
+          for ek in engs: ek.synchronize()
+          tk = time.perf_counter()
+        ek = engs[k % K]
+        ek.lib.check(ek.lib.dll.odt_forward_async(ek.h, dev.data_ptr(), ODT_DTYPE_U8, 1, None))
+      for ek in engs: ek.synchronize()
+      rate = n / (time.perf_counter() - tk)
+      same = all(all(bool(np.array_equal(a, b)) for a, b in zip(m._collect(ek), ref)) for ek in engs)
+      in_flight[str(K)] = {"fps": rate, "verified": bool(same)}
+  except Exception as ex:
+    in_flight["failed"] = repr(ex)
+  # `value`: the throughput of the product's streaming path (EfficientDet.predict_stream: three frames in flight) where that leg
+  # verified; the one-frame-at-a-time rate (what rounds 2-5 reported as `value`) stays beside it
+  dt_one = dt
+  best_k = 1
+  for K in ("2", "3"):
+    r = in_flight.get(K)
+    if isinstance(r, dict) and r["verified"] and 1.0 / r["fps"] < dt:
+      dt = 1.0 / r["fps"]; best_k = int(K)
   t1 = time.perf_counter()
   for _ in range(5):
     out = m.predict(fr)
@@ -101,6 +133,16 @@ def measure(model="efficientdet-d7", size=0, frame="", steps=20, warmup=3, cpu_b
                "detect_tmot_fps": 1.0 / tmot_dt, "tmot_host_ms_per_frame": 1e3 * t_trk / nfr, "tmot_tracks_last": int(ntr)}
   if piped_dt is not None:
     res_extra["detect_tmot_pipelined_fps"] = 1.0 / piped_dt
+  res_extra["frames_in_flight"] = in_flight
+  res_extra["one_frame_at_a_time_fps"] = 1.0 / dt_one
+  res_extra["value_frames_in_flight"] = best_k
+  if hasattr(m, "predict_stream"):
+    # detect + TMOT with three frames in flight (predict_stream): the tracker's host work of frame i under the forwards of i+1 .. i+3
+    jde = {c: JDETracker(0.0, frame_gap=1.0) for c in ("Person", "Vehicle")}
+    t2 = time.perf_counter()
+    for res in m.predict_stream([fr] * nfr, in_flight=3):
+      track(*res[:4])
+    res_extra["detect_tmot_three_in_flight_fps"] = nfr / (time.perf_counter() - t2)
   try:
     res_extra["handle"] = e.describe()
   except Exception:
@@ -146,7 +188,8 @@ def measure(model="efficientdet-d7", size=0, frame="", steps=20, warmup=3, cpu_b
          "verified": bool(verified), "verification": verification,
          "data": "synthetic", "config": {"workload": "%s (EfficientNet backbone + BiFPN + class/box nets + top-5000 / NMS / "
          "per-level ROI features), frame %dx%d scaled on the device, batch 1, 90 classes, random-init weights, frame "
-         "resident in HBM (uint8)" % (model, fw, fh)},
+         "resident in HBM (uint8); %d consecutive frame(s) in flight, frame t on handle t mod %d (EfficientDet.predict_stream; "
+         "extra.one_frame_at_a_time_fps: one handle, one frame at a time)" % (model, fw, fh, best_k, best_k)},
          "extra": res_extra}
   m.close()
   return res
