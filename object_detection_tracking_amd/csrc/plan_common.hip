@@ -165,10 +165,10 @@ int add_conv(odt_model* m, const std::string& name, const Tensor& in, int cin, c
 // ODT_SIDE_STREAM_PRIORITY=0: plain streams (A/B).
 int create_side_stream(hipStream_t* s) {
   const bool flat = env_knob_off(K_SIDE_STREAM_PRIORITY);
-  if (flat) { ODT_HIP(hipStreamCreate(s)); return 0; }
+  if (flat) { ODT_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking)); return 0; }
   int least = 0, greatest = 0;
   ODT_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-  ODT_HIP(hipStreamCreateWithPriority(s, hipStreamDefault, greatest));
+  ODT_HIP(hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest));
   return 0;
 }
 

@@ -304,7 +304,9 @@ int odt_create(const odt_config* cfg, int device, odt_handle* out) {
   m->knob_tail_overlap_off = env_knob_off(K_TAIL_OVERLAP);
   m->cfg = *cfg;
   m->device = device;
-  ODT_HIP(hipStreamCreate(&m->own_stream));
+  // (non-blocking, round 6: a blocking stream orders itself against every null-stream operation of the process -- another
+  // handle's synchronous copy, the host framework's default stream -- which serialises handles that should run side by side)
+  ODT_HIP(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
   *out = m.release();
   return 0;
 }
@@ -611,6 +613,7 @@ int odt_tap(odt_handle h, const char* name, float* dst, size_t cap_elems, int64_
     if (dst) {
       ODT_CHECK(cap_elems >= (size_t)h->cfg.batch, "odt_tap: buffer too small");
       std::vector<int> v(h->cfg.batch);
+      ODT_HIP(hipDeviceSynchronize());
       ODT_HIP(hipMemcpy(v.data(), h->prop.nprops, v.size() * sizeof(int), hipMemcpyDeviceToHost));
       for (size_t i = 0; i < v.size(); ++i) dst[i] = (float)v[i];
     }
