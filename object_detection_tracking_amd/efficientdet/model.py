@@ -154,11 +154,11 @@ class EfficientDet(object):
     and the tracker update back to back, obj_detect_tracking_multi_queuer_tmot.py:536-583) -- until predict_collect()."""
     self._inflight = self._enqueue(frame)
 
-  def predict_stream(self, frames, in_flight=3):
+  def predict_stream(self, frames, in_flight=4):
     """A video through the detector with ``in_flight`` consecutive frames on the GPU at once (round 6): frame t runs on handle
     t mod in_flight, each on its own stream; results come back in frame order, as predict() would return them.  One D7 frame is
-    ~600 dependent launches of ~20 us each, most of them far too small for the chip; frames are independent: 73 -> 97 -> 106
-    frames/s with one / two / three in flight (profiles/r06_d7_frames_in_flight.txt)."""
+    ~600 dependent launches of ~20 us each, most of them far too small for the chip; frames are independent: 74 -> 98 -> 106
+    -> 111 frames/s with one / two / three / four in flight, fewer again beyond (profiles/r06_d7_frames_in_flight*.txt)."""
     import collections
     n = max(1, int(in_flight))
     pending = collections.deque()

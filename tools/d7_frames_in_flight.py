@@ -16,7 +16,7 @@ w = arch.synthetic_det_weights(model, 0, gain=arch.bench_gain(model))
 fr = synthetic_frames(1, S, S)[0]
 dev = torch.from_numpy(fr[None].copy()).cuda(0)
 ms, es, out = [], [], {}
-for K in (1, 2, 3):
+for K in (1, 3, 4, 5, 6, 8):
   while len(es) < K:
     m = models.get_model(cfg, 0, weights=w); ms.append(m)
     e = m.engine((S, S)); es.append(e)
