@@ -154,11 +154,12 @@ class EfficientDet(object):
     and the tracker update back to back, obj_detect_tracking_multi_queuer_tmot.py:536-583) -- until predict_collect()."""
     self._inflight = self._enqueue(frame)
 
-  def predict_stream(self, frames, in_flight=4):
+  def predict_stream(self, frames, in_flight=3):
     """A video through the detector with ``in_flight`` consecutive frames on the GPU at once (round 6): frame t runs on handle
     t mod in_flight, each on its own stream; results come back in frame order, as predict() would return them.  One D7 frame is
     ~600 dependent launches of ~20 us each, most of them far too small for the chip; frames are independent: 74 -> 98 -> 106
-    -> 111 frames/s with one / two / three / four in flight, fewer again beyond (profiles/r06_d7_frames_in_flight*.txt)."""
+    -> 111 frames/s with one / two / three / four in flight, fewer again beyond -- and four already loses (92) when another
+    process holds hardware queues on the same GPU, hence three (profiles/r06_d7_frames_in_flight*.txt, r06_bench_n1.json)."""
     import collections
     n = max(1, int(in_flight))
     pending = collections.deque()

@@ -137,7 +137,7 @@ def measure(model="efficientdet-d7", size=0, frame="", steps=20, warmup=3, cpu_b
   res_extra["one_frame_at_a_time_fps"] = 1.0 / dt_one
   res_extra["value_frames_in_flight"] = best_k
   if hasattr(m, "predict_stream"):
-    # detect + TMOT through predict_stream (four frames in flight): the tracker's host work of frame i under the forwards of i+1 .. i+3
+    # detect + TMOT through predict_stream (three frames in flight): the tracker's host work of frame i under the forwards of i+1 .. i+3
     jde = {c: JDETracker(0.0, frame_gap=1.0) for c in ("Person", "Vehicle")}
     t2 = time.perf_counter()
     for res in m.predict_stream([fr] * nfr):
