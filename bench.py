@@ -726,38 +726,42 @@ def single_graph_leg(models, make_config, weights, topk, H, W, device, steps=20,
     equal = {n: bool(np.array_equal(a, b)) for n, a, b in zip(names, got, ref)}
     ok = all(equal.values()) and int(got[3].sum()) > 0 and bool(np.isfinite(got[0]).all())
     prof = profile_convs(e, ds[0].data_ptr(), 3)
-    # the same stream with TWO consecutive frames in flight (frame t on handle t mod 2, one stream each: what
-    # models.predict_stream does): a single 1080p frame's launches are latency-bound and leave most of the chip idle
+    roof1, arith1, handle1 = conv_roofline(prof, sustained, False), arithmetic_of(e.describe()), e.describe()
+    # the same stream with TWO consecutive frames in flight (frame t on handle t mod 2, one replica handle more: what
+    # models.predict_stream does by default): a single 1080p frame's launches are latency-bound and leave most of the chip idle.
+    # (Three / four frames on handles without side streams reach 223 / 236 FPS in a process of their own -- and 192 / 210 next to
+    # other handles' idle streams, as here: profiles/r06_b1_stream_set.txt.)
     two = {}
     try:
-      e2 = m.engine(1, H, W, replica=1)
-      e2.forward_device_async(ds[0].data_ptr(), ODT_DTYPE_U8); e2.synchronize()
-      engs2 = (e, e2)
-      n2 = 4 * steps
-      for k in range(2 * warmup + n2):
-        if k == 2 * warmup:
-          e.synchronize(); e2.synchronize(); t2 = time.perf_counter()
-        engs2[k % 2].forward_device_async(ds[k % len(ds)].data_ptr(), ODT_DTYPE_U8)
-      e.synchronize(); e2.synchronize()
-      dt2 = (time.perf_counter() - t2) / n2
-      ok2 = True
-      for j, eng in enumerate(engs2):             # the last frame each handle saw: frames k with k % 2 == j
-        kl = max(k for k in range(2 * warmup + n2) if k % 2 == j)
-        g2 = eng.read_outputs(want_feats=True, want_pooled=True)
-        r2 = eng.forward(frs[kl % len(ds)], want_feats=True, want_pooled=True)
-        ok2 = ok2 and all(bool(np.array_equal(a, b)) for a, b in zip(g2, r2)) and int(g2[3].sum()) > 0
-      two = {"two_frames_in_flight_fps": 1.0 / dt2, "two_frames_in_flight_verified": bool(ok2),
-             "two_frames_in_flight_note": "frame t on handle t mod 2 (models.predict_stream): each forward is still batch 1; results in "
-                                          "frame order, one frame later"}
+      K = 2
+      engsK = [e, m.engine(1, H, W, replica=1)]
+      engsK[1].forward_device_async(ds[0].data_ptr(), ODT_DTYPE_U8); engsK[1].synchronize()
+      nK = 4 * steps
+      for k in range(2 * K + nK):
+        if k == 2 * K:
+          for ek in engsK: ek.synchronize()
+          t2 = time.perf_counter()
+        engsK[k % K].forward_device_async(ds[k % len(ds)].data_ptr(), ODT_DTYPE_U8)
+      for ek in engsK: ek.synchronize()
+      dtK = (time.perf_counter() - t2) / nK
+      okK = True
+      for j, ek in enumerate(engsK):              # the last frame each handle saw: frames k with k % K == j
+        kl = max(k for k in range(2 * K + nK) if k % K == j)
+        gK = ek.read_outputs(want_feats=True, want_pooled=True)
+        rK = ek.forward(frs[kl % len(ds)], want_feats=True, want_pooled=True)
+        okK = okK and all(bool(np.array_equal(a, b)) for a, b in zip(gK, rK)) and int(gK[3].sum()) > 0
+      two = {"frames_in_flight_fps": 1.0 / dtK, "frames_in_flight": K, "frames_in_flight_verified": bool(okK),
+             "frames_in_flight_note": "frame t on handle t mod %d (models.predict_stream): each forward is still batch 1; results in "
+                                      "frame order, one frame later" % K}
     except Exception as ex:
-      two = {"two_frames_in_flight_fps": "failed: %r" % (ex,)}
-    return {"b1_single_graph_fps": 1.0 / dt, "b1_two_frames_in_flight_fps": two.get("two_frames_in_flight_fps"), "b1_single_graph": {"graph": "Mask_RCNN_FPN", "ms_per_frame": 1e3 * dt, "steps": steps, **two,
+      two = {"frames_in_flight_fps": "failed: %r" % (ex,)}
+    return {"b1_single_graph_fps": 1.0 / dt, "b1_frames_in_flight_fps": two.get("frames_in_flight_fps"), "b1_single_graph": {"graph": "Mask_RCNN_FPN", "ms_per_frame": 1e3 * dt, "steps": steps, **two,
                                                                "detections": int(got[3].sum()), "verified": bool(ok),
                                                                "verification": {"bit_equal_to_blocking_forward": equal,
                                                                                 "resident_frames_rotated": len(ds)},
-                                                               "roofline": conv_roofline(prof, sustained, False),
-                                                               "arithmetic": arithmetic_of(e.describe()),
-                                                               "handle": e.describe()}}
+                                                               "roofline": roof1,
+                                                               "arithmetic": arith1,
+                                                               "handle": handle1}}
   finally:
     m.close()
 

@@ -97,6 +97,10 @@ typedef struct odt_config {
                              * outlive the forward (outputs, proposals, zero-bordered buffers); 1 (debug / parity runs):
                              * every stage tensor keeps a dedicated buffer and odt_tap can read all of them after a
                              * forward (b=8 @1080p: ~25 GB instead of ~5 GB of activations) */
+  int32_t tail_overlap;     /* 0 (default): the selection / box-head / NMS tail of forward i runs on a side stream under the backbone
+                             * of forward i + 1 (one handle, forwards back to back: +1 %); -1: the whole forward stays on the compute
+                             * stream -- for handles that run consecutive frames side by side (models.predict_stream: with three b = 1
+                             * frames in flight 189 FPS with the side streams, 235 without: they compete for hardware queues) */
 } odt_config;
 
 /* conv_arith: all modes keep f32 tensors and f32 accumulation.  ODT_ARITH_F32: every product on the exact-f32 MFMA

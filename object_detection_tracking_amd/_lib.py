@@ -45,6 +45,7 @@ class OdtConfig(C.Structure):
       ("eff_backbone", C.c_int32), ("eff_det", C.c_int32), ("eff_topk", C.c_int32),
       ("eff_image_scale", C.c_float), ("conv_arith", C.c_int32), ("conv_split_family", C.c_int32),
       ("keep_taps", C.c_int32),
+      ("tail_overlap", C.c_int32),
   ]
 
 

@@ -233,7 +233,7 @@ int run_plan(odt_model* m, const void* frames, int dtype, int on_device, hipStre
   }
   // ---- tail overlap (own stream only: a caller's stream must see the whole forward in stream order)
   if (m->tail_overlap < 0) {
-    m->tail_overlap = (cfg.graph != ODT_GRAPH_EFFNET && !m->knob_tail_overlap_off) ? 1 : 0;
+    m->tail_overlap = (cfg.graph != ODT_GRAPH_EFFNET && !m->knob_tail_overlap_off && cfg.tail_overlap >= 0) ? 1 : 0;
     find_overlap_points(m);
     if (m->op_tail == 0) m->tail_overlap = 0;
   }

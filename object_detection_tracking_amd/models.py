@@ -134,6 +134,7 @@ class _Engine(object):
     # debug / parity runs: every stage tensor keeps its own buffer and tap() can read it after a forward; the production
     # default plans the activations into an arena (a stage's memory is reused once its consumers have run)
     c.keep_taps = int(bool(getattr(config, "keep_taps", False)))
+    c.tail_overlap = -1 if getattr(config, "tail_overlap", True) in (False, -1) else 0      # (False: everything on the compute stream)
     self.h = C.c_void_p()
     lib.check(lib.dll.odt_create(C.byref(c), device, C.byref(self.h)))
     try:
@@ -559,14 +560,20 @@ class _DetectorBase(object):
   # static plans kept per model: a plan owns its activations, a device copy of the weights and pinned staging
   # (tens of GB at 8 x 1080p), so frames of ever-changing sizes (the reference's image-list drivers) must not
   # accumulate them: least-recently-used plans beyond this many are closed
-  max_engines = 6
+  max_engines = 8
 
-  def engine(self, batch, height, width, src_hw=None, replica=0):
+  def engine(self, batch, height, width, src_hw=None, replica=0, stream_set=False):
     """The static plan for frames of this size.  ``replica`` > 0: a further handle of the same plan (own weights copy, arena and
     streams) -- ``predict_stream`` keeps consecutive frames in flight on them."""
     key = (batch, height, width) if src_hw is None else (batch, height, width) + tuple(src_hw)
     if replica:
       key = key + ("replica", int(replica))
+    cfg_e = self.config
+    if stream_set:
+      # handles of predict_stream: side by side, no side streams of their own (include/odt.h: tail_overlap)
+      import copy
+      key = key + ("stream",)
+      cfg_e = copy.copy(self.config); cfg_e.tail_overlap = False
     e = self._engines.pop(key, None)
     if e is None:
       # evict least-recently-used plans beyond the cap -- but never one with tickets in flight (its pinned results
@@ -578,7 +585,7 @@ class _DetectorBase(object):
         if old is None:
           break
         self._engines.pop(old).close()
-      e = _Engine(self.lib, self.config, self.graph, batch, height, width,
+      e = _Engine(self.lib, cfg_e, self.graph, batch, height, width,
                   self.weights, self.gpuid, num_class=self.head_num_class)
       if src_hw is not None:
         e.set_source_size(*src_hw)
@@ -628,8 +635,10 @@ class Mask_RCNN_FPN(_DetectorBase):
   def predict_stream(self, frames, in_flight=2, pooled=False):
     """Frame-by-frame detection of a video with ``in_flight`` consecutive frames on the GPU at once (round 6): frame t runs on
     handle t mod in_flight, each handle on its own streams, results come back in frame order.  A single 1080p frame leaves most of
-    the chip idle most of the time (each of its ~130 launches is latency-bound): two frames in flight give 185 -> 224 frames/s on
-    `Mask_RCNN_FPN` (profiles/r06_b1_frames_in_flight.txt); the reference's loop (obj_detect_tracking.py:597-635) sees the same
+    the chip idle most of the time (each of its ~130 launches is latency-bound): 181 -> 220 frames/s with two frames in flight on
+    `Mask_RCNN_FPN`.  Two is the robust default; from three on the handles are built without side streams of their own
+    (odt_config.tail_overlap = -1) -- 223 / 236 frames/s with three / four in a process that holds no other handles, but 192 / 210
+    next to an idle one (streams share hardware queues in creation order: profiles/r06_b1_stream_set.txt); the reference's loop (obj_detect_tracking.py:597-635) sees the same
     per-frame results, one frame later.  Yields what ``predict`` returns."""
     import collections
     n = max(1, int(in_flight))
@@ -645,7 +654,7 @@ class Mask_RCNN_FPN(_DetectorBase):
       img = np.asarray(img)
       if len(pending) == n:
         yield finish(pending.popleft())
-      e = self.engine(1, img.shape[0], img.shape[1], replica=k % n)
+      e = self.engine(1, img.shape[0], img.shape[1], replica=k % n, stream_set=n > 2)
       pending.append((e, e.submit(img[None], want_feats=not pooled, want_pooled=pooled)))
     while pending:
       yield finish(pending.popleft())
